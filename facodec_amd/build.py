@@ -1,0 +1,56 @@
+"""Builds libfacodec_hip.so (gfx950) in-tree with hipcc.  No torch extension glue: the library is
+a plain C-ABI shared object (include/facodec_hip.h) loaded through ctypes."""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libfacodec_hip.so")
+SOURCES = ["conv1d_mfma.hip", "pack.hip", "lstm.hip", "vq.hip", "misc.hip"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
+         "-Wno-unused-result"]
+
+
+def _hipcc():
+    for cand in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if cand and (os.path.isabs(cand) and os.path.exists(cand) or not os.path.isabs(cand)):
+            return cand
+    return "hipcc"
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    tt = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > tt for d in deps)
+
+
+def build_lib(force=False, verbose=True):
+    hipcc = _hipcc()
+    headers = [os.path.join(CSRC, "common.h"), os.path.join(HERE, "..", "include", "facodec_hip.h")]
+    objs, jobs = [], []
+    os.makedirs(os.path.join(CSRC, "build"), exist_ok=True)
+    for src in SOURCES:
+        s = os.path.join(CSRC, src)
+        o = os.path.join(CSRC, "build", src.replace(".hip", ".o"))
+        objs.append(o)
+        if force or _stale(o, [s] + headers):
+            jobs.append([hipcc, *FLAGS, "-c", s, "-o", o])
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.run(cmd, check=True)
+
+    with ThreadPoolExecutor(max_workers=min(8, max(1, len(jobs)))) as ex:
+        list(ex.map(run, jobs))
+    if force or jobs or _stale(LIB, objs):
+        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB])
+    return LIB
+
+
+if __name__ == "__main__":
+    build_lib(force="--force" in sys.argv)
+    print(LIB)

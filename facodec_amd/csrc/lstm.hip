@@ -1,0 +1,170 @@
+// K5: SLSTM recurrence (reference: dac/model/encodec.py:272-288; nn.LSTM gate order i,f,g,o,
+// zero initial state).  The input projection W_ih x_t + b runs as one big GEMM through
+// fac_conv1d_fwd; this file holds the strictly sequential part.
+//
+// Data layout is time-major with the batch innermost: h_t / y_t are (H, BP) slabs, BP = batch
+// padded to 32, so that the MFMA B operand (k = hidden index, n = batch) is a coalesced row read
+// and y[t] doubles as the h_{t} state for step t+1.
+//
+// One launch per time step.  Workgroup = 8 hidden units x 4 gates = one 32-row MFMA block for a
+// 32-wide batch block; its 8 waves split the K = H reduction, stream their slice of W_hh with
+// fully coalesced float4 loads (weights are read exactly once per step; the per-XCD L2 / MALL
+// keeps them on chip between steps), reduce through LDS and apply the cell update in place.
+#include "common.h"
+
+namespace fac {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__global__ __launch_bounds__(512) void lstm_step_kernel(const float* __restrict__ pre_t,   // (4H, BP)
+                                                        const float* __restrict__ whh,     // packed
+                                                        const float* __restrict__ h_prev,  // (H, BP) or null
+                                                        float* __restrict__ c,             // (H, BP)
+                                                        float* __restrict__ y_t,           // (H, BP)
+                                                        int H, int BP) {
+  __shared__ float red[8][32][33];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int l31 = lane & 31;
+  const int kq = lane >> 5;
+  const int ublk = blockIdx.x;
+  const int col0 = blockIdx.y * 32;
+
+  if (h_prev != nullptr) {
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const int kgs = H / 8;
+    const int per_wave = kgs / 8;  // H % 64 == 0
+    const int kg0 = wave * per_wave;
+    const float4* ap = reinterpret_cast<const float4*>(whh) + ((long long)ublk * kgs + kg0) * 64 + lane;
+    const float* bp = h_prev + (long long)(kg0 * 8 + kq) * BP + col0 + l31;
+#pragma unroll 4
+    for (int g = 0; g < per_wave; ++g) {
+      const float4 a4 = ap[(long long)g * 64];
+      const float* bq = bp + (long long)g * 8 * BP;
+      const float b0 = bq[0];
+      const float b1 = bq[2 * BP];
+      const float b2 = bq[4 * BP];
+      const float b3 = bq[6 * BP];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b0, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b1, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b2, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b3, acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * kq;
+      red[wave][row][l31] = acc[r];
+    }
+  }
+  __syncthreads();
+  if (tid < 256) {
+    const int u = tid >> 5;
+    const int col = tid & 31;
+    const int unit = ublk * 8 + u;
+    float gate[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float s = 0.f;
+      if (h_prev != nullptr) {
+#pragma unroll
+        for (int w = 0; w < 8; ++w) s += red[w][q * 8 + u][col];
+      }
+      gate[q] = pre_t[(long long)(q * H + unit) * BP + col0 + col] + s;
+    }
+    const float ig = sigmoid_f(gate[0]);
+    const float fg = sigmoid_f(gate[1]);
+    const float gg = tanhf(gate[2]);
+    const float og = sigmoid_f(gate[3]);
+    const long long o = (long long)unit * BP + col0 + col;
+    const float c_old = (h_prev != nullptr) ? c[o] : 0.f;
+    const float c_new = __fadd_rn(__fmul_rn(fg, c_old), __fmul_rn(ig, gg));
+    c[o] = c_new;
+    y_t[o] = __fmul_rn(og, tanhf(c_new));
+  }
+}
+
+// (B, H, T) -> (T, H, BP): per hidden unit, transpose the (b, t) plane through a 32x33 tile.
+__global__ __launch_bounds__(256) void to_time_major_kernel(const float* __restrict__ x,
+                                                            float* __restrict__ xT, int B, int H,
+                                                            int T, int BP) {
+  __shared__ float tile[32][33];
+  const int t0 = blockIdx.x * 32, h = blockIdx.y, b0 = blockIdx.z * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int b = b0 + ty + 8 * j, t = t0 + tx;
+    tile[ty + 8 * j][tx] = (b < B && t < T) ? x[((long long)b * H + h) * T + t] : 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int t = t0 + ty + 8 * j, b = b0 + tx;
+    if (t < T) xT[((long long)t * H + h) * BP + b] = tile[tx][ty + 8 * j];
+  }
+}
+
+__global__ __launch_bounds__(256) void from_time_major_kernel(const float* __restrict__ yT,
+                                                              const float* __restrict__ skip,
+                                                              float* __restrict__ out, int B, int H,
+                                                              int T, int BP) {
+  __shared__ float tile[32][33];
+  const int t0 = blockIdx.x * 32, h = blockIdx.y, b0 = blockIdx.z * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int t = t0 + ty + 8 * j, b = b0 + tx;
+    tile[ty + 8 * j][tx] = (t < T) ? yT[((long long)t * H + h) * BP + b] : 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int b = b0 + ty + 8 * j, t = t0 + tx;
+    if (b < B && t < T) {
+      const long long o = ((long long)b * H + h) * T + t;
+      float v = tile[tx][ty + 8 * j];
+      if (skip) v = __fadd_rn(v, skip[o]);
+      out[o] = v;
+    }
+  }
+}
+
+}  // namespace fac
+
+extern "C" int fac_lstm_to_time_major(const float* x, float* xT, int B, int H, int T,
+                                      fac_stream_t stream) {
+  using namespace fac;
+  FAC_REQUIRE(x && xT && B > 0 && H > 0 && T > 0, "lstm_to_time_major: bad arguments");
+  const int BP = fac_pad32(B);
+  dim3 grid((T + 31) / 32, H, BP / 32);
+  hipLaunchKernelGGL(to_time_major_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, xT, B, H, T, BP);
+  return check_launch("lstm_to_time_major");
+}
+
+extern "C" int fac_lstm_from_time_major(const float* yT, const float* skip, float* out, int B,
+                                        int H, int T, fac_stream_t stream) {
+  using namespace fac;
+  FAC_REQUIRE(yT && out && B > 0 && H > 0 && T > 0, "lstm_from_time_major: bad arguments");
+  const int BP = fac_pad32(B);
+  dim3 grid((T + 31) / 32, H, BP / 32);
+  hipLaunchKernelGGL(from_time_major_kernel, grid, dim3(256), 0, (hipStream_t)stream, yT, skip, out, B, H, T, BP);
+  return check_launch("lstm_from_time_major");
+}
+
+extern "C" int fac_lstm_layer_fwd(const float* pre, const float* whh_packed, float* yT, float* c,
+                                  int T, int H, int BP, fac_stream_t stream) {
+  using namespace fac;
+  FAC_REQUIRE(pre && whh_packed && yT && c, "lstm_layer_fwd: null pointer");
+  FAC_REQUIRE(T > 0 && H > 0 && H % 64 == 0, "lstm_layer_fwd: H=%d must be a multiple of 64", H);
+  FAC_REQUIRE(BP > 0 && BP % 32 == 0, "lstm_layer_fwd: BP=%d must be a multiple of 32", BP);
+  dim3 grid(H / 8, BP / 32);
+  const long long slab = (long long)H * BP;
+  for (int t = 0; t < T; ++t) {
+    const float* h_prev = t == 0 ? nullptr : yT + (long long)(t - 1) * slab;
+    hipLaunchKernelGGL(lstm_step_kernel, grid, dim3(512), 0, (hipStream_t)stream,
+                       pre + (long long)t * 4 * slab, whh_packed, h_prev, c, yT + (long long)t * slab, H, BP);
+  }
+  return check_launch("lstm_layer_fwd");
+}

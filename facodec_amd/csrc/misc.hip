@@ -1,0 +1,434 @@
+// Small HBM-bound fused ops of the quantizer front-end and the spectral losses, plus the
+// library's error plumbing.  Each kernel cites the reference op it replaces.
+#include "common.h"
+#include <string.h>
+
+namespace fac {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+constexpr int EW_THREADS = 256;
+inline int ew_grid(long long n, int per_thread = 1) {
+  long long g = (n + (long long)EW_THREADS * per_thread - 1) / ((long long)EW_THREADS * per_thread);
+  if (g > 8192) g = 8192;  // grid-stride beyond 256 CUs x 32
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+// dac/nn/layers.py:18-33
+__global__ void snake_kernel(const float* __restrict__ x, const float* __restrict__ alpha,
+                             float* __restrict__ y, int C, int T, long long n) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)((i / T) % C);
+    const float al = alpha[c];
+    y[i] = snake_apply(x[i], al, snake_inv(al));
+  }
+}
+
+// modules/commons.py:113-120
+__global__ void gate_kernel(const float* __restrict__ a, float* __restrict__ out, int C, int T,
+                            long long n) {
+  const long long ct = (long long)C * T;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (long long)gridDim.x * blockDim.x) {
+    const long long b = i / ct, r = i - b * ct;
+    const float ta = a[b * 2 * ct + r];
+    const float sa = a[b * 2 * ct + ct + r];
+    out[i] = __fmul_rn(tanhf(ta), sigmoid_f(sa));
+  }
+}
+
+// modules/style_encoder.py:26-31 (dropout is identity in eval)
+__global__ void glu_res_kernel(const float* __restrict__ a, const float* __restrict__ res,
+                               float* __restrict__ out, int C, int T, long long n) {
+  const long long ct = (long long)C * T;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (long long)gridDim.x * blockDim.x) {
+    const long long b = i / ct, r = i - b * ct;
+    const float x1 = a[b * 2 * ct + r];
+    const float x2 = a[b * 2 * ct + ct + r];
+    out[i] = __fadd_rn(res[i], __fmul_rn(x1, sigmoid_f(x2)));
+  }
+}
+
+__global__ void add_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                           float* __restrict__ out, long long n) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (long long)gridDim.x * blockDim.x)
+    out[i] = __fadd_rn(a[i], b[i]);
+}
+
+// modules/quantize.py:410  residual_feature = x - z_p - z_c
+__global__ void sub2_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                            const float* __restrict__ c, float* __restrict__ out, long long n) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (long long)gridDim.x * blockDim.x)
+    out[i] = __fsub_rn(__fsub_rn(a[i], b[i]), c[i]);
+}
+
+__global__ void mul_mask_kernel(float* __restrict__ x, const float* __restrict__ mask, int C, int T,
+                                long long n) {
+  const long long ct = (long long)C * T;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (long long)gridDim.x * blockDim.x) {
+    const long long b = i / ct;
+    const int t = (int)(i % T);
+    x[i] = __fmul_rn(x[i], mask[b * T + t]);
+  }
+}
+
+// modules/wavenet.py:159-165
+__global__ void wn_res_skip_kernel(const float* __restrict__ rs, float* __restrict__ x,
+                                   float* __restrict__ out, int C, int T, int last, long long n) {
+  const long long ct = (long long)C * T;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (long long)gridDim.x * blockDim.x) {
+    if (last) {
+      out[i] = __fadd_rn(out[i], rs[i]);
+    } else {
+      const long long b = i / ct, r = i - b * ct;
+      x[i] = __fadd_rn(x[i], rs[b * 2 * ct + r]);
+      out[i] = __fadd_rn(out[i], rs[b * 2 * ct + ct + r]);
+    }
+  }
+}
+
+// modules/attentions.py:168-199 for the StyleEncoder's 2-head self-attention: one workgroup per
+// (b, head, 16-query tile); K/V rows are streamed from L2, scores live in LDS.  ~50 MFLOP per
+// clip -- not worth MFMA plumbing.
+__global__ __launch_bounds__(256) void attention_kernel(const float* __restrict__ q,
+                                                        const float* __restrict__ k,
+                                                        const float* __restrict__ v,
+                                                        const float* __restrict__ mask,
+                                                        float* __restrict__ out, int n_heads,
+                                                        int dk, int T) {
+  extern __shared__ float sm[];
+  constexpr int QT = 16;
+  float* qs = sm;            // [dk][QT]   (pre-scaled queries)
+  float* sc = qs + dk * QT;  // [QT][T]
+  const int tq0 = blockIdx.x * QT;
+  const int h = blockIdx.y;
+  const int b = blockIdx.z;
+  const long long base = ((long long)b * n_heads + h) * dk * T;
+  const float* qg = q + base;
+  const float* kg = k + base;
+  const float* vg = v + base;
+  const float scale = sqrtf((float)dk);
+  for (int i = threadIdx.x; i < dk * QT; i += 256) {
+    const int d = i / QT, j = i - d * QT;
+    const int tq = tq0 + j;
+    qs[i] = tq < T ? __fdiv_rn(qg[(long long)d * T + tq], scale) : 0.f;
+  }
+  __syncthreads();
+  // scores[j][tk] = sum_d qs[d][j] * k[d][tk]
+  for (int tk = threadIdx.x; tk < T; tk += 256) {
+    float acc[QT];
+#pragma unroll
+    for (int j = 0; j < QT; ++j) acc[j] = 0.f;
+    for (int d = 0; d < dk; ++d) {
+      const float kv = kg[(long long)d * T + tk];
+#pragma unroll
+      for (int j = 0; j < QT; ++j) acc[j] = fmaf(qs[d * QT + j], kv, acc[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < QT; ++j) {
+      float s = acc[j];
+      const int tq = tq0 + j;
+      if (mask && tq < T) {
+        const float m = mask[(long long)b * T + tq] * mask[(long long)b * T + tk];
+        if (m == 0.f) s = -1e4f;
+      }
+      sc[j * T + tk] = s;
+    }
+  }
+  __syncthreads();
+  // softmax over tk: one wave handles 4 query rows
+  {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int j = wave; j < QT; j += 4) {
+      float mx = -INFINITY;
+      for (int tk = lane; tk < T; tk += 64) mx = fmaxf(mx, sc[j * T + tk]);
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+      float sum = 0.f;
+      for (int tk = lane; tk < T; tk += 64) {
+        const float e = expf(sc[j * T + tk] - mx);
+        sc[j * T + tk] = e;
+        sum += e;
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+      for (int tk = lane; tk < T; tk += 64) sc[j * T + tk] = __fdiv_rn(sc[j * T + tk], sum);
+    }
+  }
+  __syncthreads();
+  // out[d][tq] = sum_tk p[tq][tk] * v[d][tk]
+  for (int i = threadIdx.x; i < dk * QT; i += 256) {
+    const int d = i / QT, j = i - d * QT;
+    const int tq = tq0 + j;
+    if (tq >= T) continue;
+    const float* vr = vg + (long long)d * T;
+    const float* pr = sc + j * T;
+    float acc = 0.f;
+    for (int tk = 0; tk < T; ++tk) acc = fmaf(pr[tk], vr[tk], acc);
+    out[base + (long long)d * T + tq] = acc;
+  }
+}
+
+// modules/style_encoder.py:83-91
+__global__ __launch_bounds__(64) void masked_mean_kernel(const float* __restrict__ x,
+                                                         const float* __restrict__ mask,
+                                                         float* __restrict__ out, int C, int T) {
+  const int c = blockIdx.x, b = blockIdx.y;
+  const float* xr = x + ((long long)b * C + c) * T;
+  float s = 0.f, m = 0.f;
+  for (int t = threadIdx.x; t < T; t += 64) {
+    s += xr[t];
+    m += mask ? mask[(long long)b * T + t] : 1.0f;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    s += __shfl_down(s, o, 64);
+    m += __shfl_down(m, o, 64);
+  }
+  if (threadIdx.x == 0) out[(long long)b * C + c] = __fdiv_rn(s, m);
+}
+
+// modules/quantize.py:444-449: LayerNorm over channels (biased variance, eps 1e-5) then
+// * gamma + beta with [gamma|beta] = timbre_linear(timbre).  One workgroup per (b, 64-step tile);
+// lanes along time so the (B,C,T) reads stay coalesced; the 4 waves split C.
+__global__ __launch_bounds__(256) void layernorm_c_kernel(const float* __restrict__ x,
+                                                          const float* __restrict__ style,
+                                                          float* __restrict__ out, int C, int T) {
+  __shared__ float red[2][4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b = blockIdx.y;
+  const int t = blockIdx.x * 64 + lane;
+  const bool tv = t < T;
+  const float* xb = x + (long long)b * C * T + t;
+  float s = 0.f;
+  for (int c = wave; c < C; c += 4) s += tv ? xb[(long long)c * T] : 0.f;
+  red[0][wave][lane] = s;
+  __syncthreads();
+  const float mean = ((red[0][0][lane] + red[0][1][lane]) + (red[0][2][lane] + red[0][3][lane])) / (float)C;
+  float vs = 0.f;
+  for (int c = wave; c < C; c += 4) {
+    const float d = tv ? xb[(long long)c * T] - mean : 0.f;
+    vs = fmaf(d, d, vs);
+  }
+  red[1][wave][lane] = vs;
+  __syncthreads();
+  const float var = ((red[1][0][lane] + red[1][1][lane]) + (red[1][2][lane] + red[1][3][lane])) / (float)C;
+  const float rstd = __fdiv_rn(1.0f, sqrtf(var + 1e-5f));
+  if (!tv) return;
+  const float* gm = style + (long long)b * 2 * C;
+  float* ob = out + (long long)b * C * T + t;
+  for (int c = wave; c < C; c += 4) {
+    const float nv = __fmul_rn(xb[(long long)c * T] - mean, rstd);
+    ob[(long long)c * T] = __fadd_rn(__fmul_rn(nv, gm[c]), gm[C + c]);
+  }
+}
+
+// centre=True STFT framing (torch.stft pad_mode='reflect'): frames[b][n][f].
+__global__ void stft_frames_kernel(const float* __restrict__ wave, float* __restrict__ frames, int T,
+                                   int n_win, int n_frames, int hop, int pad, int n_off,
+                                   long long n) {
+  const long long per_b = (long long)n_win * n_frames;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (long long)gridDim.x * blockDim.x) {
+    const long long b = i / per_b;
+    const long long r = i - b * per_b;
+    const int nn = (int)(r / n_frames);
+    const int f = (int)(r - (long long)nn * n_frames);
+    int t = f * hop + nn + n_off - pad;
+    if (t < 0) t = -t;
+    if (t >= T) t = 2 * (T - 1) - t;
+    frames[i] = (t >= 0 && t < T) ? wave[b * T + t] : 0.f;
+  }
+}
+
+__global__ void spec_power_kernel(const float* __restrict__ spec, float* __restrict__ out, int F,
+                                  int n_frames, int power, long long n) {
+  const long long per_b = (long long)F * n_frames;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (long long)gridDim.x * blockDim.x) {
+    const long long b = i / per_b;
+    const long long r = i - b * per_b;
+    const float re = spec[b * 2 * per_b + r];
+    const float im = spec[b * 2 * per_b + per_b + r];
+    const float p = __fadd_rn(__fmul_rn(re, re), __fmul_rn(im, im));
+    out[i] = power == 2 ? p : sqrtf(p);
+  }
+}
+
+__device__ __forceinline__ float pair_term(float a, float b, int mode, float eps) {
+  if (mode == 0) return fabsf(a - b);
+  if (mode == 1) return fabsf(log10f(fmaxf(a, eps)) - log10f(fmaxf(b, eps)));
+  const float d = a - b;
+  return d * d;
+}
+
+__global__ __launch_bounds__(256) void reduce_pair_stage1(const float* __restrict__ a,
+                                                          const float* __restrict__ b,
+                                                          float* __restrict__ scratch, long long n,
+                                                          int mode, float eps) {
+  __shared__ float part[4];
+  float s = 0.f;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
+    s += pair_term(a[i], b[i], mode, eps);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) scratch[blockIdx.x] = (part[0] + part[1]) + (part[2] + part[3]);
+}
+
+__global__ __launch_bounds__(256) void reduce_pair_stage2(const float* __restrict__ scratch,
+                                                          float* __restrict__ out, int nblk,
+                                                          float scale, int accumulate) {
+  __shared__ float part[4];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < nblk; i += 256) s += scratch[i];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float tot = ((part[0] + part[1]) + (part[2] + part[3])) * scale;
+    out[0] = accumulate ? out[0] + tot : tot;
+  }
+}
+
+}  // namespace fac
+
+using namespace fac;
+
+extern "C" int fac_version(void) { return 1; }
+extern "C" const char* fac_last_error(void) { return fac::g_err; }
+
+#define EW_LAUNCH(kern, n, ...)                                                         \
+  hipLaunchKernelGGL(kern, dim3(ew_grid(n)), dim3(EW_THREADS), 0, (hipStream_t)stream, __VA_ARGS__)
+
+extern "C" int fac_snake_fwd(const float* x, const float* alpha, float* y, int B, int C, int T,
+                             fac_stream_t stream) {
+  FAC_REQUIRE(x && alpha && y && B > 0 && C > 0 && T > 0, "snake_fwd: bad arguments");
+  const long long n = (long long)B * C * T;
+  EW_LAUNCH(snake_kernel, n, x, alpha, y, C, T, n);
+  return check_launch("snake_fwd");
+}
+
+extern "C" int fac_gate_tanh_sigmoid(const float* a, float* out, int B, int C, int T,
+                                     fac_stream_t stream) {
+  FAC_REQUIRE(a && out && B > 0 && C > 0 && T > 0, "gate_tanh_sigmoid: bad arguments");
+  const long long n = (long long)B * C * T;
+  EW_LAUNCH(gate_kernel, n, a, out, C, T, n);
+  return check_launch("gate_tanh_sigmoid");
+}
+
+extern "C" int fac_glu_residual(const float* a, const float* res, float* out, int B, int C, int T,
+                                fac_stream_t stream) {
+  FAC_REQUIRE(a && res && out && B > 0 && C > 0 && T > 0, "glu_residual: bad arguments");
+  const long long n = (long long)B * C * T;
+  EW_LAUNCH(glu_res_kernel, n, a, res, out, C, T, n);
+  return check_launch("glu_residual");
+}
+
+extern "C" int fac_add(const float* a, const float* b, float* out, int64_t n, fac_stream_t stream) {
+  FAC_REQUIRE(a && b && out && n > 0, "add: bad arguments");
+  EW_LAUNCH(add_kernel, n, a, b, out, (long long)n);
+  return check_launch("add");
+}
+
+extern "C" int fac_sub2(const float* a, const float* b, const float* c, float* out, int64_t n,
+                        fac_stream_t stream) {
+  FAC_REQUIRE(a && b && c && out && n > 0, "sub2: bad arguments");
+  EW_LAUNCH(sub2_kernel, n, a, b, c, out, (long long)n);
+  return check_launch("sub2");
+}
+
+extern "C" int fac_mul_mask(float* x, const float* mask, int B, int C, int T, fac_stream_t stream) {
+  FAC_REQUIRE(x && mask && B > 0 && C > 0 && T > 0, "mul_mask: bad arguments");
+  const long long n = (long long)B * C * T;
+  EW_LAUNCH(mul_mask_kernel, n, x, mask, C, T, n);
+  return check_launch("mul_mask");
+}
+
+extern "C" int fac_wn_res_skip(const float* rs, float* x, float* out, int B, int C, int T, int last,
+                               fac_stream_t stream) {
+  FAC_REQUIRE(rs && out && (last || x) && B > 0 && C > 0 && T > 0, "wn_res_skip: bad arguments");
+  const long long n = (long long)B * C * T;
+  EW_LAUNCH(wn_res_skip_kernel, n, rs, x, out, C, T, last, n);
+  return check_launch("wn_res_skip");
+}
+
+extern "C" int fac_attention(const float* q, const float* k, const float* v, const float* mask,
+                             float* out, int B, int n_heads, int dk, int T, fac_stream_t stream) {
+  FAC_REQUIRE(q && k && v && out && B > 0 && n_heads > 0 && dk > 0 && T > 0, "attention: bad arguments");
+  const size_t lds = ((size_t)dk * 16 + (size_t)16 * T) * sizeof(float);
+  FAC_REQUIRE(lds <= 160 * 1024, "attention: T=%d too long for the LDS score tile", T);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attention_kernel),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  dim3 grid((T + 15) / 16, n_heads, B);
+  hipLaunchKernelGGL(attention_kernel, grid, dim3(256), lds, (hipStream_t)stream, q, k, v, mask, out,
+                     n_heads, dk, T);
+  return check_launch("attention");
+}
+
+extern "C" int fac_masked_mean(const float* x, const float* mask, float* out, int B, int C, int T,
+                               fac_stream_t stream) {
+  FAC_REQUIRE(x && out && B > 0 && C > 0 && T > 0, "masked_mean: bad arguments");
+  hipLaunchKernelGGL(masked_mean_kernel, dim3(C, B), dim3(64), 0, (hipStream_t)stream, x, mask, out, C, T);
+  return check_launch("masked_mean");
+}
+
+extern "C" int fac_layernorm_c_affine(const float* x, const float* style, float* out, int B, int C,
+                                      int T, fac_stream_t stream) {
+  FAC_REQUIRE(x && style && out && B > 0 && C > 0 && T > 0, "layernorm_c_affine: bad arguments");
+  hipLaunchKernelGGL(layernorm_c_kernel, dim3((T + 63) / 64, B), dim3(256), 0, (hipStream_t)stream, x,
+                     style, out, C, T);
+  return check_launch("layernorm_c_affine");
+}
+
+extern "C" int fac_stft_frames(const float* wave, float* frames, int B, int T, int n_win,
+                               int n_frames, int hop, int pad, int n_off, fac_stream_t stream) {
+  FAC_REQUIRE(wave && frames && B > 0 && T > 0 && n_win > 0 && n_frames > 0 && hop > 0,
+              "stft_frames: bad arguments");
+  FAC_REQUIRE(pad < T, "stft_frames: reflect pad %d needs a signal longer than %d samples", pad, T);
+  const long long n = (long long)B * n_win * n_frames;
+  EW_LAUNCH(stft_frames_kernel, n, wave, frames, T, n_win, n_frames, hop, pad, n_off, n);
+  return check_launch("stft_frames");
+}
+
+extern "C" int fac_spec_power(const float* spec, float* out, int B, int F, int n_frames, int power,
+                              fac_stream_t stream) {
+  FAC_REQUIRE(spec && out && B > 0 && F > 0 && n_frames > 0 && (power == 1 || power == 2),
+              "spec_power: bad arguments");
+  const long long n = (long long)B * F * n_frames;
+  EW_LAUNCH(spec_power_kernel, n, spec, out, F, n_frames, power, n);
+  return check_launch("spec_power");
+}
+
+extern "C" int fac_reduce_pair(const float* a, const float* b, float* out, float* scratch,
+                               int64_t n, int mode, float eps, float scale, int accumulate,
+                               fac_stream_t stream) {
+  FAC_REQUIRE(a && b && out && scratch && n > 0 && mode >= 0 && mode <= 2, "reduce_pair: bad arguments");
+  long long g = (n + 255) / 256;
+  if (g > 1024) g = 1024;
+  hipLaunchKernelGGL(reduce_pair_stage1, dim3((int)g), dim3(256), 0, (hipStream_t)stream, a, b,
+                     scratch, (long long)n, mode, eps);
+  hipLaunchKernelGGL(reduce_pair_stage2, dim3(1), dim3(256), 0, (hipStream_t)stream, scratch, out,
+                     (int)g, scale, accumulate);
+  return check_launch("reduce_pair");
+}

@@ -1,0 +1,157 @@
+// K6: weight-norm materialisation and packing into the layouts the MFMA kernels stream.
+// Replaces torch.nn.utils.weight_norm's per-forward  w = v * (g / ||v||)
+// (reference: dac/model/encodec.py:42-51 apply_parametrization_norm, dac/nn/layers.py:9-14).
+// HBM-bound: every weight element is read once and written once, coalesced on both sides
+// (the transposes go through a 32x33 LDS tile).
+#include "common.h"
+
+namespace fac {
+
+// scale[i] = g[i] / sqrt(sum v[i,:]^2); one workgroup per slice.
+__global__ __launch_bounds__(256) void wn_scale_kernel(const float* __restrict__ v,
+                                                       const float* __restrict__ g,
+                                                       float* __restrict__ scale, int slice_len) {
+  const int i = blockIdx.x;
+  if (g == nullptr) {
+    if (threadIdx.x == 0) scale[i] = 1.0f;
+    return;
+  }
+  const float* p = v + (long long)i * slice_len;
+  float s = 0.f;
+  for (int j = threadIdx.x; j < slice_len; j += 256) {
+    float x = p[j];
+    s = fmaf(x, x, s);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+  __shared__ float part[4];
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float tot = (part[0] + part[1]) + (part[2] + part[3]);
+    scale[i] = __fdiv_rn(g[i], sqrtf(tot));
+  }
+}
+
+// v (C_out, R) with R = C_in*K  ->  packed (R, C_out_pad); tiles of 32 x 32 through LDS.
+__global__ __launch_bounds__(256) void pack_conv_kernel(const float* __restrict__ v,
+                                                        const float* __restrict__ scale,
+                                                        float* __restrict__ out, int C_out, int R,
+                                                        int C_out_pad) {
+  __shared__ float tile[32][33];
+  const int r0 = blockIdx.x * 32;
+  const int c0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31;
+  const int ty = threadIdx.x >> 5;  // 0..7
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int co = c0 + ty + 8 * j;
+    const int r = r0 + tx;
+    float val = 0.f;
+    if (co < C_out && r < R) {
+      val = v[(long long)co * R + r];
+      if (scale) val = __fmul_rn(val, scale[co]);
+    }
+    tile[ty + 8 * j][tx] = val;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int r = r0 + ty + 8 * j;
+    const int co = c0 + tx;
+    if (r < R && co < C_out_pad) out[(long long)r * C_out_pad + co] = tile[tx][ty + 8 * j];
+  }
+}
+
+// ConvTranspose1d v (C_in, C_out, K=2s), scale per C_in  ->  packed[p][ci][j][co]
+//   = v[ci][co][p + s*(1-j)] * scale[ci]. One workgroup per (ci, 32-co block); K is small.
+__global__ __launch_bounds__(256) void pack_convtr_kernel(const float* __restrict__ v,
+                                                          const float* __restrict__ scale,
+                                                          float* __restrict__ out, int C_in,
+                                                          int C_out, int s, int C_out_pad) {
+  extern __shared__ float tl[];  // [32][K+1]
+  const int K = 2 * s;
+  const int ci = blockIdx.x;
+  const int c0 = blockIdx.y * 32;
+  const float sc = scale ? scale[ci] : 1.0f;
+  const float* src = v + ((long long)ci * C_out + c0) * K;
+  const int n = 32 * K;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const int co = i / K, k = i - co * K;
+    float val = 0.f;
+    if (c0 + co < C_out) val = __fmul_rn(src[i], sc);
+    tl[co * (K + 1) + k] = val;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const int co = i & 31;
+    const int pj = i >> 5;      // 0..K-1 = p*2 + j
+    const int p = pj >> 1, j = pj & 1;
+    const int k = p + s * (1 - j);
+    if (c0 + co < C_out_pad)
+      out[(((long long)p * C_in + ci) * 2 + j) * C_out_pad + c0 + co] = tl[co * (K + 1) + k];
+  }
+}
+
+// W_hh (4H, H) -> packed[ublk][kg][kq][i][4]: for unit block ublk (8 hidden units) the 32 gate
+// rows i = gate*8 + u, k = kg*8 + 2*jj + kq  (jj = 0..3 is the float4 component).
+__global__ __launch_bounds__(256) void pack_whh_kernel(const float* __restrict__ w,
+                                                       float* __restrict__ out, int H) {
+  const long long n = (long long)4 * H * H;
+  for (long long o = (long long)blockIdx.x * 256 + threadIdx.x; o < n;
+       o += (long long)gridDim.x * 256) {
+    const int jj = o & 3;
+    const int i = (o >> 2) & 31;
+    const int kq = (o >> 7) & 1;
+    const long long rest = o >> 8;
+    const int kgs = H / 8;
+    const int kg = rest % kgs;
+    const int ublk = rest / kgs;
+    const int gate = i >> 3, u = i & 7;
+    const int row = gate * H + ublk * 8 + u;
+    const int k = kg * 8 + 2 * jj + kq;
+    out[o] = w[(long long)row * H + k];
+  }
+}
+
+}  // namespace fac
+
+extern "C" int fac_wn_scale(const float* v, const float* g, float* scale, int n_slices,
+                            int slice_len, fac_stream_t stream) {
+  using namespace fac;
+  FAC_REQUIRE(scale && n_slices > 0 && slice_len > 0 && (v || !g), "wn_scale: bad arguments");
+  hipLaunchKernelGGL(wn_scale_kernel, dim3(n_slices), dim3(256), 0, (hipStream_t)stream, v, g,
+                     scale, slice_len);
+  return check_launch("wn_scale");
+}
+
+extern "C" int fac_pack_conv_w(const float* v, const float* scale, float* packed, int C_out,
+                               int C_in, int K, int C_out_pad, fac_stream_t stream) {
+  using namespace fac;
+  FAC_REQUIRE(v && packed && C_out > 0 && C_in > 0 && K > 0, "pack_conv_w: bad arguments");
+  FAC_REQUIRE(C_out_pad % 32 == 0 && C_out_pad >= C_out, "pack_conv_w: C_out_pad must be a multiple of 32");
+  const int R = C_in * K;
+  dim3 grid((R + 31) / 32, C_out_pad / 32);
+  hipLaunchKernelGGL(pack_conv_kernel, grid, dim3(256), 0, (hipStream_t)stream, v, scale, packed,
+                     C_out, R, C_out_pad);
+  return check_launch("pack_conv_w");
+}
+
+extern "C" int fac_pack_convtr_w(const float* v, const float* scale, float* packed, int C_in,
+                                 int C_out, int stride, int C_out_pad, fac_stream_t stream) {
+  using namespace fac;
+  FAC_REQUIRE(v && packed && C_out > 0 && C_in > 0 && stride > 0, "pack_convtr_w: bad arguments");
+  FAC_REQUIRE(C_out_pad % 32 == 0 && C_out_pad >= C_out, "pack_convtr_w: C_out_pad must be a multiple of 32");
+  dim3 grid(C_in, C_out_pad / 32);
+  const size_t lds = (size_t)32 * (2 * stride + 1) * sizeof(float);
+  hipLaunchKernelGGL(pack_convtr_kernel, grid, dim3(256), lds, (hipStream_t)stream, v, scale,
+                     packed, C_in, C_out, stride, C_out_pad);
+  return check_launch("pack_convtr_w");
+}
+
+extern "C" int fac_pack_lstm_whh(const float* w_hh, float* packed, int H, fac_stream_t stream) {
+  using namespace fac;
+  FAC_REQUIRE(w_hh && packed && H > 0 && H % 8 == 0, "pack_lstm_whh: H must be a multiple of 8");
+  hipLaunchKernelGGL(pack_whh_kernel, dim3(2048), dim3(256), 0, (hipStream_t)stream, w_hh, packed, H);
+  return check_launch("pack_lstm_whh");
+}

@@ -1,0 +1,317 @@
+// K7: factorized vector quantization step.
+// Reference: VectorQuantize.forward / decode_latents dac/nn/quantize.py:34-94, the residual loop of
+// ResidualVectorQuantize.forward :173-193; the search is textually the same in the (dead) named
+// variant quantize/fvq.py:101-116.
+//
+// HBM-bound (reads the (B,D,T) latent once, writes residual / accumulated output once); the
+// 1024 x 8 codebook is normalised into LDS (32 KB + 4 KB of squared norms) by every workgroup,
+// the search is a per-lane scan (lane = time step, the four waves split the codebook) with a
+// strict '>' first-index arg-max and a fixed-order cross-wave combine, so ties resolve to the
+// lowest index exactly like torch.max on CPU.
+//
+// Arithmetic follows the reference expression order:
+//   e = z_e / max(sqrt(sum z_e^2), 1e-12)               (F.normalize, true division)
+//   dist_k = (sum e^2 - (2e).c~_k) + sum c~_k^2 ; idx = first argmax(-dist)
+//   z_q = raw codebook row ; z_st = z_e + (z_q - z_e) ; out = W_out z_st + b_out
+#include "common.h"
+
+namespace fac {
+
+constexpr int VQ_TT = 64;   // time steps per workgroup
+constexpr int VQ_CD = 8;    // codebook_dim (modules/commons.py:303)
+
+struct VqArgs {
+  float* residual;
+  const float* z_in;
+  float* zq_acc;
+  float* zq_out;
+  const float* w_in;
+  const float* b_in;
+  const float* codebook;
+  const float* w_out;
+  const float* b_out;
+  const float* mask;
+  long long* codes;
+  float* z_e;
+  float* loss_part;
+  long long codes_bs;
+  int B, D, T, Kc;
+};
+
+__device__ __forceinline__ float row_norm_sq(const float* v) {
+  float s = 0.f;
+#pragma unroll
+  for (int d = 0; d < VQ_CD; ++d) s = __fadd_rn(s, __fmul_rn(v[d], v[d]));
+  return s;
+}
+
+// Normalise the codebook into LDS: cbn[k][8] and cc[k] = sum cbn[k]^2.
+__device__ __forceinline__ void load_codebook(const float* __restrict__ cb, float* cbn, float* cc,
+                                              int Kc, int tid, int nthreads) {
+  for (int k = tid; k < Kc; k += nthreads) {
+    float v[VQ_CD];
+    const float4 lo = *reinterpret_cast<const float4*>(cb + (long long)k * VQ_CD);
+    const float4 hi = *reinterpret_cast<const float4*>(cb + (long long)k * VQ_CD + 4);
+    v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w;
+    v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
+    const float nrm = fmaxf(sqrtf(row_norm_sq(v)), 1e-12f);
+#pragma unroll
+    for (int d = 0; d < VQ_CD; ++d) v[d] = __fdiv_rn(v[d], nrm);
+#pragma unroll
+    for (int d = 0; d < VQ_CD; ++d) cbn[k * VQ_CD + d] = v[d];
+    cc[k] = row_norm_sq(v);
+  }
+}
+
+// Scan codes [k_begin, k_end) for the normalised query e; returns best (-dist) and index.
+__device__ __forceinline__ void scan_codes(const float* e, float ee, const float* cbn,
+                                           const float* cc, int k_begin, int k_end, float& best,
+                                           int& best_k) {
+  float e2[VQ_CD];
+#pragma unroll
+  for (int d = 0; d < VQ_CD; ++d) e2[d] = __fmul_rn(2.0f, e[d]);
+  best = -INFINITY;
+  best_k = k_begin;
+  for (int k = k_begin; k < k_end; ++k) {
+    const float4 lo = *reinterpret_cast<const float4*>(cbn + k * VQ_CD);
+    const float4 hi = *reinterpret_cast<const float4*>(cbn + k * VQ_CD + 4);
+    float dot = __fmul_rn(e2[0], lo.x);
+    dot = fmaf(e2[1], lo.y, dot);
+    dot = fmaf(e2[2], lo.z, dot);
+    dot = fmaf(e2[3], lo.w, dot);
+    dot = fmaf(e2[4], hi.x, dot);
+    dot = fmaf(e2[5], hi.y, dot);
+    dot = fmaf(e2[6], hi.z, dot);
+    dot = fmaf(e2[7], hi.w, dot);
+    const float dist = __fadd_rn(__fsub_rn(ee, dot), cc[k]);
+    const float neg = -dist;
+    if (neg > best) {
+      best = neg;
+      best_k = k;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void vq_fwd_kernel(VqArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* cbn = sm;                              // [Kc][8]
+  float* cc = cbn + a.Kc * VQ_CD;               // [Kc]
+  float* part = cc + a.Kc;                      // [4][8][64]
+  float* zes = part + 4 * VQ_CD * VQ_TT;        // [8][64]  z_e, later z_st
+  float* bestv = zes + VQ_CD * VQ_TT;           // [4][64]
+  int* bestk = reinterpret_cast<int*>(bestv + 4 * VQ_TT);  // [4][64]
+  float* lred = reinterpret_cast<float*>(bestk + 4 * VQ_TT);  // [64]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.y;
+  const int tile = blockIdx.x;
+  const int t = tile * VQ_TT + lane;
+  const bool tv = t < a.T;
+  const long long bofs = (long long)b * a.D * a.T;
+
+  load_codebook(a.codebook, cbn, cc, a.Kc, tid, 256);
+
+  // ---- in_proj: each wave reduces a quarter of the D input channels
+  {
+    float s[VQ_CD];
+#pragma unroll
+    for (int d = 0; d < VQ_CD; ++d) s[d] = 0.f;
+    const int cper = (a.D + 3) / 4;
+    const int c_begin = wave * cper;
+    const int c_end = min(a.D, c_begin + cper);
+    const float* zp = a.z_in + bofs + t;
+    for (int c = c_begin; c < c_end; ++c) {
+      const float xv = tv ? zp[(long long)c * a.T] : 0.f;
+      const float* wr = a.w_in + (long long)c * 32;
+#pragma unroll
+      for (int d = 0; d < VQ_CD; ++d) s[d] = fmaf(wr[d], xv, s[d]);
+    }
+#pragma unroll
+    for (int d = 0; d < VQ_CD; ++d) part[(wave * VQ_CD + d) * VQ_TT + lane] = s[d];
+  }
+  __syncthreads();
+  if (wave == 0) {
+#pragma unroll
+    for (int d = 0; d < VQ_CD; ++d) {
+      float v = (part[(0 * VQ_CD + d) * VQ_TT + lane] + part[(1 * VQ_CD + d) * VQ_TT + lane]) +
+                (part[(2 * VQ_CD + d) * VQ_TT + lane] + part[(3 * VQ_CD + d) * VQ_TT + lane]);
+      v = __fadd_rn(v, a.b_in[d]);
+      zes[d * VQ_TT + lane] = v;
+      if (a.z_e && tv) a.z_e[((long long)b * VQ_CD + d) * a.T + t] = v;
+    }
+  }
+  __syncthreads();
+
+  // ---- normalise + search (every wave normalises the same query; cheap)
+  float ze[VQ_CD], e[VQ_CD];
+#pragma unroll
+  for (int d = 0; d < VQ_CD; ++d) ze[d] = zes[d * VQ_TT + lane];
+  {
+    const float nrm = fmaxf(sqrtf(row_norm_sq(ze)), 1e-12f);
+#pragma unroll
+    for (int d = 0; d < VQ_CD; ++d) e[d] = __fdiv_rn(ze[d], nrm);
+  }
+  const float ee = row_norm_sq(e);
+  {
+    const int kper = (a.Kc + 3) / 4;
+    const int k_begin = wave * kper;
+    const int k_end = min(a.Kc, k_begin + kper);
+    float bv;
+    int bk;
+    scan_codes(e, ee, cbn, cc, k_begin, k_end, bv, bk);
+    bestv[wave * VQ_TT + lane] = bv;
+    bestk[wave * VQ_TT + lane] = bk;
+  }
+  __syncthreads();
+  int idx = bestk[lane];
+  {
+    float bv = bestv[lane];
+#pragma unroll
+    for (int w = 1; w < 4; ++w) {
+      const float v = bestv[w * VQ_TT + lane];
+      if (v > bv) {
+        bv = v;
+        idx = bestk[w * VQ_TT + lane];
+      }
+    }
+  }
+
+  // ---- gather raw code, straight-through value, loss partial
+  float zst[VQ_CD];
+  float lsum = 0.f;
+  {
+    const float* cr = a.codebook + (long long)idx * VQ_CD;
+#pragma unroll
+    for (int d = 0; d < VQ_CD; ++d) {
+      const float zq = cr[d];
+      const float df = __fsub_rn(ze[d], zq);
+      lsum = __fadd_rn(lsum, __fmul_rn(df, df));
+      zst[d] = __fadd_rn(ze[d], __fsub_rn(zq, ze[d]));
+    }
+  }
+  if (wave == 0) {
+    if (tv) a.codes[(long long)b * a.codes_bs + t] = idx;
+    float l = tv ? lsum : 0.f;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) l += __shfl_down(l, o, 64);
+    if (lane == 0 && a.loss_part) a.loss_part[(long long)b * gridDim.x + tile] = l;
+  }
+
+  // ---- out_proj + residual bookkeeping: wave w handles channels w, w+4, ...
+  if (tv) {
+    const float mk = a.mask ? a.mask[b] : 1.0f;
+    for (int c = wave; c < a.D; c += 4) {
+      const float* wr = a.w_out + (long long)c * VQ_CD;
+      float o = __fmul_rn(wr[0], zst[0]);
+#pragma unroll
+      for (int d = 1; d < VQ_CD; ++d) o = fmaf(wr[d], zst[d], o);
+      o = __fadd_rn(o, a.b_out[c]);
+      const long long off = bofs + (long long)c * a.T + t;
+      if (a.zq_out) a.zq_out[off] = o;
+      if (a.zq_acc) a.zq_acc[off] = __fadd_rn(a.zq_acc[off], __fmul_rn(o, mk));
+      if (a.residual) a.residual[off] = __fsub_rn(a.z_in[off], o);
+    }
+  }
+}
+
+// Search only: latents (N, 8) row-major -> idx.
+__global__ __launch_bounds__(256) void vq_search_kernel(const float* __restrict__ lat,
+                                                        const float* __restrict__ cb,
+                                                        long long* __restrict__ idx_out,
+                                                        long long N, int Kc) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* cbn = sm;
+  float* cc = cbn + Kc * VQ_CD;
+  float* bestv = cc + Kc;
+  int* bestk = reinterpret_cast<int*>(bestv + 4 * VQ_TT);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  load_codebook(cb, cbn, cc, Kc, tid, 256);
+  __syncthreads();
+  for (long long base = (long long)blockIdx.x * VQ_TT; base < N; base += (long long)gridDim.x * VQ_TT) {
+    const long long n = base + lane;
+    const bool nv = n < N;
+    float ze[VQ_CD], e[VQ_CD];
+    if (nv) {
+      const float4 lo = *reinterpret_cast<const float4*>(lat + n * VQ_CD);
+      const float4 hi = *reinterpret_cast<const float4*>(lat + n * VQ_CD + 4);
+      ze[0] = lo.x; ze[1] = lo.y; ze[2] = lo.z; ze[3] = lo.w;
+      ze[4] = hi.x; ze[5] = hi.y; ze[6] = hi.z; ze[7] = hi.w;
+    } else {
+#pragma unroll
+      for (int d = 0; d < VQ_CD; ++d) ze[d] = 0.f;
+    }
+    const float nrm = fmaxf(sqrtf(row_norm_sq(ze)), 1e-12f);
+#pragma unroll
+    for (int d = 0; d < VQ_CD; ++d) e[d] = __fdiv_rn(ze[d], nrm);
+    const float ee = row_norm_sq(e);
+    const int kper = (Kc + 3) / 4;
+    const int k_begin = wave * kper;
+    const int k_end = min(Kc, k_begin + kper);
+    float bv;
+    int bk;
+    scan_codes(e, ee, cbn, cc, k_begin, k_end, bv, bk);
+    bestv[wave * VQ_TT + lane] = bv;
+    bestk[wave * VQ_TT + lane] = bk;
+    __syncthreads();
+    if (wave == 0 && nv) {
+      int idx = bestk[lane];
+      float b0 = bestv[lane];
+#pragma unroll
+      for (int w = 1; w < 4; ++w) {
+        const float v = bestv[w * VQ_TT + lane];
+        if (v > b0) {
+          b0 = v;
+          idx = bestk[w * VQ_TT + lane];
+        }
+      }
+      idx_out[n] = idx;
+    }
+    __syncthreads();
+  }
+}
+
+}  // namespace fac
+
+extern "C" int fac_vq_fwd(const fac_vq_desc* d, fac_stream_t stream) {
+  using namespace fac;
+  FAC_REQUIRE(d && d->z_in && d->w_in && d->b_in && d->codebook && d->w_out && d->b_out && d->codes,
+              "vq_fwd: null pointer");
+  FAC_REQUIRE(d->B > 0 && d->D > 0 && d->T > 0 && d->Kc > 0, "vq_fwd: bad shape");
+  FAC_REQUIRE(d->B <= 65535, "vq_fwd: B too large");
+  VqArgs a;
+  a.residual = d->residual; a.z_in = d->z_in; a.zq_acc = d->zq_acc; a.zq_out = d->zq_out;
+  a.w_in = d->w_in; a.b_in = d->b_in; a.codebook = d->codebook; a.w_out = d->w_out;
+  a.b_out = d->b_out; a.mask = d->mask; a.codes = (long long*)d->codes; a.z_e = d->z_e;
+  a.loss_part = d->loss_part; a.codes_bs = d->codes_bs;
+  a.B = d->B; a.D = d->D; a.T = d->T; a.Kc = d->Kc;
+  const size_t lds = ((size_t)d->Kc * (VQ_CD + 1) + 4 * VQ_CD * VQ_TT + VQ_CD * VQ_TT + 8 * VQ_TT + VQ_TT) * 4;
+  FAC_REQUIRE(lds <= 160 * 1024, "vq_fwd: codebook of %d entries does not fit LDS", d->Kc);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(vq_fwd_kernel),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  dim3 grid((d->T + VQ_TT - 1) / VQ_TT, d->B);
+  hipLaunchKernelGGL(vq_fwd_kernel, grid, dim3(256), lds, (hipStream_t)stream, a);
+  return check_launch("vq_fwd");
+}
+
+extern "C" int fac_vq_search(const float* latents, const float* codebook, int64_t* idx, int64_t N,
+                             int Kc, fac_stream_t stream) {
+  using namespace fac;
+  FAC_REQUIRE(latents && codebook && idx && N > 0 && Kc > 0, "vq_search: bad arguments");
+  const size_t lds = ((size_t)Kc * (VQ_CD + 1) + 8 * VQ_TT) * 4;
+  FAC_REQUIRE(lds <= 160 * 1024, "vq_search: codebook of %d entries does not fit LDS", Kc);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(vq_search_kernel),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  long long tiles = (N + VQ_TT - 1) / VQ_TT;
+  int grid = (int)(tiles < 2048 ? tiles : 2048);
+  hipLaunchKernelGGL(vq_search_kernel, dim3(grid), dim3(256), lds, (hipStream_t)stream, latents,
+                     codebook, (long long*)idx, (long long)N, Kc);
+  return check_launch("vq_search");
+}

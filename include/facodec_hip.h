@@ -1,0 +1,224 @@
+/*
+ * facodec_hip.h -- C ABI of libfacodec_hip.so (gfx950 / MI355X).
+ *
+ * Drop-in boundary for the FAcodec encode -> factorized-VQ -> decode (+ multi-scale
+ * spectral loss) hot path.  The reference (Plachtaa/FAcodec) is pure Python/PyTorch and has
+ * no FFI; what it binds to underneath its nn.Modules are ATen ops.  Each entry point below
+ * names the reference op (file:line under /root/reference) it replaces.  The Python host
+ * (facodec_amd/) keeps the reference's module surface (build_model / encoder / quantizer /
+ * decoder, modules/commons.py:283-348) and calls these through ctypes.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer borrowed from the caller (torch tensor storage);
+ *     dense row-major fp32 unless noted; codes are int64.
+ *   - every call is asynchronous on the hipStream_t passed as `stream` (void*); the library
+ *     never allocates, frees or synchronises device memory.
+ *   - return 0 on success, negative on error; fac_last_error() gives a thread-local message.
+ *   - activations use the reference layout (B, C, T), T contiguous.
+ */
+#ifndef FACODEC_HIP_H
+#define FACODEC_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* fac_stream_t; /* hipStream_t */
+
+#define FAC_OK 0
+#define FAC_ERR_ARG (-1)
+#define FAC_ERR_LAUNCH (-2)
+
+#define FAC_PAD_ZERO 0
+#define FAC_PAD_REFLECT 1
+
+#define FAC_ACT_NONE 0
+#define FAC_ACT_TANH 1  /* nn.Tanh, dac/model/dac.py:159 */
+#define FAC_ACT_MISH 2  /* x*tanh(softplus(x)), modules/style_encoder.py:6-10 */
+#define FAC_ACT_LOG_MEL 3 /* (log(1e-5+x)+4)/4, modules/quantize.py:241 */
+
+/* ABI version; bumped whenever a signature changes. */
+int fac_version(void);
+/* Thread-local description of the last failure (never NULL). */
+const char* fac_last_error(void);
+
+/* ------------------------------------------------------------------------------------------
+ * K6  weight-norm materialisation + packing to the GEMM-friendly layout the conv kernels read.
+ * Replaces torch.nn.utils.weight_norm's  w = v * (g / ||v||)  recomputed every forward
+ * (dac/model/encodec.py:42-51, dac/nn/layers.py:9-14).
+ * ---------------------------------------------------------------------------------------- */
+
+/* scale[i] = g[i] / ||v[i,:]||_2  for i < n_slices (slice = all dims but 0, contiguous,
+ * slice_len floats).  g == NULL -> scale[i] = 1 (plain, un-normed weight). */
+int fac_wn_scale(const float* v, const float* g, float* scale, int n_slices, int slice_len,
+                 fac_stream_t stream);
+
+/* Conv1d / Linear weight v (C_out, C_in, K) -> packed (C_in, K, C_out_pad), co fastest,
+ * packed[ci][k][co] = v[co][ci][k] * scale[co]; columns C_out..C_out_pad-1 are zero.
+ * C_out_pad must be a multiple of 32 (fac_pad32). scale may be NULL (== 1). */
+int fac_pack_conv_w(const float* v, const float* scale, float* packed, int C_out, int C_in,
+                    int K, int C_out_pad, fac_stream_t stream);
+
+/* ConvTranspose1d weight v (C_in, C_out, K = 2*stride) with weight-norm over dim 0 (= C_in,
+ * dac/model/encodec.py:163) -> `stride` polyphase 2-tap sub-filters:
+ * packed[p][ci][j][co] = v[ci][co][p + stride*(1-j)] * scale[ci],  p < stride, j in {0,1}.
+ * Output phase p of the transposed conv is then a causal 2-tap conv (see fac_conv1d_fwd). */
+int fac_pack_convtr_w(const float* v, const float* scale, float* packed, int C_in, int C_out,
+                      int stride, int C_out_pad, fac_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * K1-K4  Conv1d / polyphase ConvTranspose1d as implicit GEMM on fp32 MFMA
+ * (v_mfma_f32_32x32x2_f32), with fused Snake prologue, bias, Snake/tanh epilogue and
+ * residual add.  Replaces SConv1d.forward (dac/model/encodec.py:212-228: pad1d + F.conv1d),
+ * SConvTranspose1d.forward (:248-270), snake (dac/nn/layers.py:18-24), ResidualUnit's skip
+ * add (dac/model/dac.py:38-42) and nn.Conv1d / nn.Linear calls of the quantizer.
+ *
+ *   y[b, co, (t*y_tstride + y_toff)] = act( snake_out( bias[co] +
+ *        sum_{ci,k} w[phase][ci][k][co] * snake_in( xpad[b, ci, t*stride + k*dilation - pad_left] ) ) )
+ *        + res[b, co, ...]
+ *
+ * xpad is x extended by reflection (FAC_PAD_REFLECT: index -j -> j on the left, T-1+j -> T-1-j
+ * on the right, zero where the mirror falls outside x as pad1d :104-111 does) or zeros.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct fac_conv_desc {
+  const float* x;         /* (B, C_in, T_in); element (b,c,t) at x[b*x_bs + c*x_cs + t] */
+  const float* w;         /* packed weights, see fac_pack_conv_w / fac_pack_convtr_w */
+  const float* bias;      /* (C_out) or NULL */
+  const float* alpha_in;  /* (C_in) Snake alpha applied to x on load, or NULL */
+  const float* alpha_out; /* (C_out) Snake alpha applied after bias, or NULL */
+  const float* res;       /* residual, same indexing as y, or NULL */
+  float* y;               /* element (b,c,u) at y[b*y_bs + c*y_cs + u] */
+  int64_t x_bs, x_cs;
+  int64_t y_bs, y_cs;
+  int32_t B, C_in, T_in, C_out, C_out_pad;
+  int32_t T_out;          /* number of t positions computed per phase */
+  int32_t K, stride, dilation, pad_left, pad_mode;
+  int32_t n_phase;        /* 1 for Conv1d; = upsampling stride for polyphase ConvTranspose1d */
+  int32_t y_tstride;      /* 1 for Conv1d; = n_phase for ConvTranspose1d (y_toff = phase) */
+  int32_t act;            /* FAC_ACT_* applied last (before residual) */
+  int32_t w_batched;      /* 0: shared weights; 1: per-b weights at w + b*w_bs (attention-style) */
+  int64_t w_bs;
+} fac_conv_desc;
+
+int fac_conv1d_fwd(const fac_conv_desc* d, fac_stream_t stream);
+
+/* Standalone Snake  y = x + sin(alpha*x)^2 / (alpha + 1e-9)  (dac/nn/layers.py:18-33) for the
+ * places where it cannot be fused; alpha (C). In-place allowed. */
+int fac_snake_fwd(const float* x, const float* alpha, float* y, int B, int C, int T,
+                  fac_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * K5  SLSTM (dac/model/encodec.py:272-288): nn.LSTM(H, H, L) over time with zero initial
+ * state, gates ordered i,f,g,o, then + x (skip).
+ * Work buffers are time-major with the batch innermost and padded to a multiple of 32:
+ *   BP = fac_pad32(B);  xT/yT: (T, H, BP);  pre: (T, 4H, BP);  c: (H, BP).
+ * ---------------------------------------------------------------------------------------- */
+
+/* (B, H, T) -> (T, H, BP), zero-filling batch columns B..BP-1. */
+int fac_lstm_to_time_major(const float* x, float* xT, int B, int H, int T, fac_stream_t stream);
+/* out(B,H,T) = yT(T,H,BP) transposed back + skip(B,H,T) (skip may be NULL). */
+int fac_lstm_from_time_major(const float* yT, const float* skip, float* out, int B, int H, int T,
+                             fac_stream_t stream);
+/* W_hh (4H, H) -> layout streamed by the recurrent kernel (same element count). */
+int fac_pack_lstm_whh(const float* w_hh, float* packed, int H, fac_stream_t stream);
+/* One layer's recurrence: for t in 0..T-1:  gates = pre[t] + W_hh h_{t-1};  c,h update;
+ * yT[t] = h_t.  pre already holds W_ih x_t + b_ih + b_hh.  c is scratch (H*BP floats).
+ * H must be a multiple of 8. */
+int fac_lstm_layer_fwd(const float* pre, const float* whh_packed, float* yT, float* c, int T,
+                       int H, int BP, fac_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * K7  factorized VQ step (dac/nn/quantize.py:34-94 VectorQuantize.forward + the residual
+ * bookkeeping of ResidualVectorQuantize.forward :173-193; search identical to
+ * quantize/fvq.py:101-116):
+ *   z_e = W_in r + b_in (1x1 conv D->8); e = z_e/max(||z_e||,1e-12); c~ = cb/max(||cb||,1e-12);
+ *   idx = first argmax_k -( (||e||^2 - 2 e.c~_k) + ||c~_k||^2 );  z_q = cb[idx] (raw rows);
+ *   z_st = z_e + (z_q - z_e);  out = W_out z_st + b_out;
+ *   zq_acc += out * mask[b];  residual -= out;
+ *   loss_part[b][tile] = sum_{d,t in tile} (z_e - z_q)^2   (commitment == codebook value).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct fac_vq_desc {
+  float* residual;        /* (B, D, T) in/out: r <- r - out ; may be NULL to skip the update */
+  const float* z_in;      /* (B, D, T) the vectors to quantize (may alias residual) */
+  float* zq_acc;          /* (B, D, T) in/out: += out*mask ; NULL to skip */
+  float* zq_out;          /* (B, D, T) out (this quantizer's projected output) ; NULL to skip */
+  const float* w_in;      /* packed (D, 1, 32) from fac_pack_conv_w (C_out = 8 -> pad 32) */
+  const float* b_in;      /* (8) */
+  const float* codebook;  /* (Kc, 8) raw */
+  const float* w_out;     /* (D, 8) out_proj effective weight (row-major, [c][d]) */
+  const float* b_out;     /* (D) */
+  const float* mask;      /* (B) multiplies out in zq_acc (quantizer dropout), NULL == 1 */
+  int64_t* codes;         /* (B, T) at codes[b*codes_bs + t] */
+  float* z_e;             /* (B, 8, T) projected latents, or NULL */
+  float* loss_part;       /* (B, n_tiles) partial sums of (z_e-z_q)^2, n_tiles = ceil(T/64) */
+  int64_t codes_bs;
+  int32_t B, D, T, Kc;
+} fac_vq_desc;
+
+int fac_vq_fwd(const fac_vq_desc* d, fac_stream_t stream);
+
+/* Nearest-code search only, on already-projected latents (N, 8) row-major -> idx (N) int64.
+ * The isolated kernel of dac/nn/quantize.py:78-94 / quantize/fvq.py:101-116. */
+int fac_vq_search(const float* latents, const float* codebook, int64_t* idx, int64_t N, int Kc,
+                  fac_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Small fused elementwise / reduction ops of the quantizer (modules/quantize.py:375-454).
+ * ---------------------------------------------------------------------------------------- */
+
+/* acts = tanh(a[:, :C]) * sigmoid(a[:, C:])  (modules/commons.py:113-120), a (B,2C,T) -> (B,C,T) */
+int fac_gate_tanh_sigmoid(const float* a, float* out, int B, int C, int T, fac_stream_t stream);
+/* GLU residual: out = res + a[:, :C] * sigmoid(a[:, C:])  (modules/style_encoder.py:26-31) */
+int fac_glu_residual(const float* a, const float* res, float* out, int B, int C, int T,
+                     fac_stream_t stream);
+/* out = a + b (same shape, n elements);  out = a - b - c */
+int fac_add(const float* a, const float* b, float* out, int64_t n, fac_stream_t stream);
+int fac_sub2(const float* a, const float* b, const float* c, float* out, int64_t n,
+             fac_stream_t stream);
+/* x[b, c, t] *= mask[b, t]  in place (mask is float 0/1). */
+int fac_mul_mask(float* x, const float* mask, int B, int C, int T, fac_stream_t stream);
+/* WaveNet skip accumulation (modules/wavenet.py:160-165):
+ *   rs (B, 2C, T): x = (x + rs[:, :C]) ; out += rs[:, C:]   (last layer: rs (B,C,T): out += rs) */
+int fac_wn_res_skip(const float* rs, float* x, float* out, int B, int C, int T, int last,
+                    fac_stream_t stream);
+/* 2-head style self-attention core (modules/attentions.py:168-199) on q,k,v (B, H*dk, T):
+ * scores = (q/sqrt(dk))^T k, masked_fill(mask==0,-1e4), softmax over keys, out = p v. */
+int fac_attention(const float* q, const float* k, const float* v, const float* mask, float* out,
+                  int B, int n_heads, int dk, int T, fac_stream_t stream);
+/* masked temporal average pool (modules/style_encoder.py:83-91): out[b,c] = sum_t x / sum_t mask */
+int fac_masked_mean(const float* x, const float* mask, float* out, int B, int C, int T,
+                    fac_stream_t stream);
+/* Timbre-conditioned norm (modules/quantize.py:444-449): LayerNorm over C (eps 1e-5, no affine)
+ * per (b,t), then * gamma[b,c] + beta[b,c];  style (B, 2C) = [gamma | beta]. */
+int fac_layernorm_c_affine(const float* x, const float* style, float* out, int B, int C, int T,
+                           fac_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * K8 / K11  STFT framing + spectral losses (torchaudio MelSpectrogram in
+ * modules/quantize.py:228-242; audiotools STFT/mel in dac/nn/loss.py:203-228,294-327).
+ * The DFT itself runs through fac_conv1d_fwd as a GEMM against a windowed cos/sin basis.
+ * ---------------------------------------------------------------------------------------- */
+
+/* frames[b][n][f] = wave_reflectpad[b][f*hop + n + n_off - pad],  n < n_win, f < n_frames
+ * (centre=True framing: pad = n_fft/2, reflect; n_off = offset of the first non-zero window
+ * tap inside the n_fft frame). wave (B, T). */
+int fac_stft_frames(const float* wave, float* frames, int B, int T, int n_win, int n_frames,
+                    int hop, int pad, int n_off, fac_stream_t stream);
+/* spec (B, 2F, n_frames) rows [0,F) = Re, [F,2F) = Im  ->  out (B, F, n_frames):
+ * power == 2: re^2+im^2 ; power == 1: sqrt(re^2+im^2). */
+int fac_spec_power(const float* spec, float* out, int B, int F, int n_frames, int power,
+                   fac_stream_t stream);
+/* Deterministic two-stage reduction:  out[0] = scale * sum_i f(a_i, b_i)
+ *   mode 0: |a-b| ; mode 1: |log10(max(a,eps)) - log10(max(b,eps))| (pow folded in by caller);
+ *   mode 2: (a-b)^2.  scratch >= 1024 floats. */
+int fac_reduce_pair(const float* a, const float* b, float* out, float* scratch, int64_t n,
+                    int mode, float eps, float scale, int accumulate, fac_stream_t stream);
+
+static inline int fac_pad32(int n) { return (n + 31) & ~31; }
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FACODEC_HIP_H */
