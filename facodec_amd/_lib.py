@@ -1,0 +1,99 @@
+"""ctypes binding of libfacodec_hip.so (C ABI declared in include/facodec_hip.h).
+
+There is deliberately NO fallback: if the HIP library is missing or a call fails, the product path
+raises.  (The CPU oracle under oracle/ is test infrastructure and is never imported from here.)
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libfacodec_hip.so")
+
+PAD_ZERO, PAD_REFLECT = 0, 1
+ACT_NONE, ACT_TANH, ACT_MISH, ACT_LOG_MEL = 0, 1, 2, 3
+
+_p = C.c_void_p
+_i = C.c_int
+_i64 = C.c_int64
+_f = C.c_float
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [
+        ("x", _p), ("w", _p), ("bias", _p), ("alpha_in", _p), ("alpha_out", _p), ("res", _p), ("y", _p),
+        ("x_bs", _i64), ("x_cs", _i64), ("y_bs", _i64), ("y_cs", _i64),
+        ("B", C.c_int32), ("C_in", C.c_int32), ("T_in", C.c_int32), ("C_out", C.c_int32),
+        ("C_out_pad", C.c_int32), ("T_out", C.c_int32),
+        ("K", C.c_int32), ("stride", C.c_int32), ("dilation", C.c_int32), ("pad_left", C.c_int32),
+        ("pad_mode", C.c_int32), ("n_phase", C.c_int32), ("y_tstride", C.c_int32), ("act", C.c_int32),
+        ("w_batched", C.c_int32), ("w_bs", _i64),
+    ]
+
+
+class VqDesc(C.Structure):
+    _fields_ = [
+        ("residual", _p), ("z_in", _p), ("zq_acc", _p), ("zq_out", _p), ("w_in", _p), ("b_in", _p),
+        ("codebook", _p), ("w_out", _p), ("w_out_scale", _p), ("b_out", _p), ("mask", _p), ("codes", _p), ("z_e", _p),
+        ("loss_part", _p), ("codes_bs", _i64),
+        ("B", C.c_int32), ("D", C.c_int32), ("T", C.c_int32), ("Kc", C.c_int32),
+    ]
+
+
+# name -> (restype, argtypes); must list every symbol include/facodec_hip.h declares
+SIGNATURES = {
+    "fac_version": (_i, []),
+    "fac_last_error": (C.c_char_p, []),
+    "fac_wn_scale": (_i, [_p, _p, _p, _i, _i, _p]),
+    "fac_pack_conv_w": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
+    "fac_pack_convtr_w": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
+    "fac_conv1d_fwd": (_i, [C.POINTER(ConvDesc), _p]),
+    "fac_snake_fwd": (_i, [_p, _p, _p, _i, _i, _i, _p]),
+    "fac_lstm_to_time_major": (_i, [_p, _p, _i, _i, _i, _p]),
+    "fac_lstm_from_time_major": (_i, [_p, _p, _p, _i, _i, _i, _p]),
+    "fac_pack_lstm_whh": (_i, [_p, _p, _i, _p]),
+    "fac_lstm_layer_fwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _p]),
+    "fac_vq_fwd": (_i, [C.POINTER(VqDesc), _p]),
+    "fac_vq_search": (_i, [_p, _p, _p, _i64, _i, _p]),
+    "fac_gate_tanh_sigmoid": (_i, [_p, _p, _i, _i, _i, _p]),
+    "fac_glu_residual": (_i, [_p, _p, _p, _i, _i, _i, _p]),
+    "fac_add": (_i, [_p, _p, _p, _i64, _p]),
+    "fac_sub2": (_i, [_p, _p, _p, _p, _i64, _p]),
+    "fac_mul_mask": (_i, [_p, _p, _i, _i, _i, _p]),
+    "fac_wn_res_skip": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
+    "fac_attention": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
+    "fac_masked_mean": (_i, [_p, _p, _p, _i, _i, _i, _p]),
+    "fac_layernorm_c_affine": (_i, [_p, _p, _p, _i, _i, _i, _p]),
+    "fac_stft_frames": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "fac_spec_power": (_i, [_p, _p, _i, _i, _i, _i, _p]),
+    "fac_reduce_pair": (_i, [_p, _p, _p, _p, _i64, _i, _f, _f, _i, _p]),
+}
+
+_lib = None
+
+
+class FacodecHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Loads the shared library (once).  Raises FacodecHipError if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise FacodecHipError(
+            f"{LIB_PATH} not found: the HIP extension is required (no CPU fallback). "
+            "Build it with `python -m facodec_amd.build` (needs hipcc, cross-compiles gfx950).")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().fac_last_error().decode("utf-8", "replace")
+        raise FacodecHipError(f"{what} failed (rc={rc}): {msg}")

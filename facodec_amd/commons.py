@@ -1,0 +1,80 @@
+"""Model factory with the reference's surface (modules/commons.py:283-348, :446-479):
+
+    model = build_model(recursive_munch(config['model_params']))      # stage='codec'
+    z = model.encoder(wave); z, quantized, commit, codebook, timbre = model.quantizer(z, wave, n_c=2)
+    wave_hat = model.decoder(z)
+
+so reconstruct.py / train.py-style drivers keep working unchanged.  `munch` is not installed in this
+image, hence the small attribute-dict below (same behaviour for the keys the callers use).
+"""
+import torch
+
+
+class Munch(dict):
+    """dict with attribute access (stand-in for munch.Munch, modules/commons.py:6)."""
+
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError as e:
+            raise AttributeError(k) from e
+
+    def __setattr__(self, k, v):
+        self[k] = v
+
+
+def recursive_munch(d):
+    """modules/commons.py:473-479."""
+    if isinstance(d, dict):
+        return Munch((k, recursive_munch(v)) for k, v in d.items())
+    if isinstance(d, list):
+        return [recursive_munch(v) for v in d]
+    return d
+
+
+def build_model(args, stage="codec"):
+    """modules/commons.py:283-348.  Returns Munch(encoder, quantizer, decoder).  The reference also
+    builds `discriminator` and `fa_predictors` (train-step only); those are the next rows of the
+    scope table and are reported as missing rather than silently faked."""
+    if stage != "codec":
+        raise ValueError(f"Unknown stage: {stage}")
+    from .dac_model import Encoder, Decoder
+    from .quantize import FAquantizer
+
+    encoder = Encoder(d_model=args.DAC.encoder_dim, strides=args.DAC.encoder_rates, d_latent=1024,
+                      causal=args.causal, lstm=args.lstm)
+    quantizer = FAquantizer(in_dim=1024, n_p_codebooks=1, n_c_codebooks=args.n_c_codebooks, n_t_codebooks=2,
+                            n_r_codebooks=3, codebook_size=1024, codebook_dim=8, quantizer_dropout=0.5,
+                            causal=args.causal, separate_prosody_encoder=args.separate_prosody_encoder,
+                            timbre_norm=args.timbre_norm)
+    decoder = Decoder(input_channel=1024, channels=args.DAC.decoder_dim, rates=args.DAC.decoder_rates,
+                      causal=args.causal, lstm=args.lstm)
+    return Munch(encoder=encoder, quantizer=quantizer, decoder=decoder)
+
+
+def default_model_params():
+    """configs/config.yml:27-46 `model_params`."""
+    return recursive_munch(dict(
+        fixed=True, causal=True, lstm=2, norm_f0=True, use_gr_content_f0=False, use_gr_prosody_phone=False,
+        use_gr_timbre_prosody=False, separate_prosody_encoder=True, n_c_codebooks=2, timbre_norm=True,
+        use_gr_content_global_f0=True, w2v="w2v-ctc",
+        DAC=dict(encoder_dim=64, encoder_rates=[2, 5, 5, 6], decoder_dim=1536, decoder_rates=[6, 5, 5, 2], sr=24000)))
+
+
+def load_checkpoint(model, optimizer, path, load_only_params=True, ignore_modules=(), is_distributed=False):
+    """modules/commons.py:446-471: {'net': {key: state_dict}, ...}; strips DDP's 'module.' prefix."""
+    state = torch.load(path, map_location="cpu")
+    params = state["net"]
+    for key in model:
+        if key in params and key not in ignore_modules:
+            sd = params[key]
+            if not is_distributed:
+                sd = {(k[len("module."):] if k.startswith("module.") else k): v for k, v in sd.items()}
+            model[key].load_state_dict(sd, strict=True)
+    for key in model:
+        model[key].eval()
+    epoch, iters = state.get("epoch", 0) + 1, state.get("iters", 0)
+    if not load_only_params and optimizer is not None:
+        optimizer.load_state_dict(state["optimizer"])
+        optimizer.load_scheduler_state_dict(state["scheduler"])
+    return model, optimizer, epoch, iters

@@ -29,6 +29,7 @@ struct VqArgs {
   const float* b_in;
   const float* codebook;
   const float* w_out;
+  const float* w_out_scale;
   const float* b_out;
   const float* mask;
   long long* codes;
@@ -202,9 +203,10 @@ __global__ __launch_bounds__(256) void vq_fwd_kernel(VqArgs a) {
     const float mk = a.mask ? a.mask[b] : 1.0f;
     for (int c = wave; c < a.D; c += 4) {
       const float* wr = a.w_out + (long long)c * VQ_CD;
-      float o = __fmul_rn(wr[0], zst[0]);
+      const float sc = a.w_out_scale ? a.w_out_scale[c] : 1.0f;
+      float o = __fmul_rn(__fmul_rn(wr[0], sc), zst[0]);
 #pragma unroll
-      for (int d = 1; d < VQ_CD; ++d) o = fmaf(wr[d], zst[d], o);
+      for (int d = 1; d < VQ_CD; ++d) o = fmaf(__fmul_rn(wr[d], sc), zst[d], o);
       o = __fadd_rn(o, a.b_out[c]);
       const long long off = bofs + (long long)c * a.T + t;
       if (a.zq_out) a.zq_out[off] = o;
@@ -280,7 +282,7 @@ extern "C" int fac_vq_fwd(const fac_vq_desc* d, fac_stream_t stream) {
   FAC_REQUIRE(d->B <= 65535, "vq_fwd: B too large");
   VqArgs a;
   a.residual = d->residual; a.z_in = d->z_in; a.zq_acc = d->zq_acc; a.zq_out = d->zq_out;
-  a.w_in = d->w_in; a.b_in = d->b_in; a.codebook = d->codebook; a.w_out = d->w_out;
+  a.w_in = d->w_in; a.b_in = d->b_in; a.codebook = d->codebook; a.w_out = d->w_out; a.w_out_scale = d->w_out_scale;
   a.b_out = d->b_out; a.mask = d->mask; a.codes = (long long*)d->codes; a.z_e = d->z_e;
   a.loss_part = d->loss_part; a.codes_bs = d->codes_bs;
   a.B = d->B; a.D = d->D; a.T = d->T; a.Kc = d->Kc;

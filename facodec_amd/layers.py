@@ -1,0 +1,165 @@
+"""Parameter-holding leaf modules with the reference's state-dict names, executing on the HIP
+C ABI.  The module tree exists so that `state_dict()` / `load_state_dict()` / optimisers see exactly
+the reference's parameter names and shapes; the arithmetic lives in
+libfacodec_hip.so and is driven by the fused plans in dac_model.py / quantize.py.
+
+Reference counterparts: dac/model/encodec.py (SConv1d :192-228, SConvTranspose1d :231-270,
+SLSTM :272-288, NormConv1d :125-139), dac/nn/layers.py (Snake1d :27-33, WNConv1d :9-10).
+"""
+import math
+
+import torch
+from torch import nn
+
+from . import ops
+
+
+def _uniform_(t, bound):
+    with torch.no_grad():
+        return t.uniform_(-bound, bound)
+
+
+class ConvWeights(nn.Module):
+    """weight_g / weight_v / bias of an old-style weight-normed conv (or plain weight / bias), in
+    torch's layout: Conv1d (C_out, C_in, K); ConvTranspose1d (C_in, C_out, K) with the norm taken
+    over dim 0 = C_in.  `packed()` materialises w = g*v/||v|| straight into the MFMA kernel's layout
+    (K6); like the reference it is recomputed on every forward unless `freeze_packed` is set."""
+
+    def __init__(self, c_in, c_out, k, weight_norm=True, transposed=False, stride=1, bias=True):
+        super().__init__()
+        self.c_in, self.c_out, self.k = c_in, c_out, k
+        self.transposed, self.stride, self.weight_norm = transposed, stride, weight_norm
+        shape = (c_in, c_out, k) if transposed else (c_out, c_in, k)
+        fan_in = (c_out if transposed else c_in) * k
+        w = _uniform_(torch.empty(shape), 1.0 / math.sqrt(fan_in))
+        if weight_norm:
+            self.weight_g = nn.Parameter(w.reshape(shape[0], -1).norm(dim=1).reshape(shape[0], 1, 1))
+            self.weight_v = nn.Parameter(w)
+        else:
+            self.weight = nn.Parameter(w)
+        self.bias = nn.Parameter(_uniform_(torch.empty(c_out), 1.0 / math.sqrt(fan_in))) if bias else None
+        self._packed = None
+        self.freeze_packed = False
+
+    def packed(self):
+        if self._packed is not None and self.freeze_packed:
+            return self._packed
+        v = self.weight_v if self.weight_norm else self.weight
+        g = self.weight_g if self.weight_norm else None
+        if self.transposed:
+            self._packed = ops.pack_convtr_weight(v.detach(), g.detach() if g is not None else None, self.stride,
+                                                  out=self._packed)
+        else:
+            self._packed = ops.pack_conv_weight(v.detach(), g.detach() if g is not None else None, out=self._packed)
+        return self._packed
+
+    def _apply(self, fn, *a, **kw):
+        self._packed = None  # device / dtype moves invalidate the packed copy
+        return super()._apply(fn, *a, **kw)
+
+
+class _Norm(nn.Module):
+    """Mirrors the NormConv1d / NormConvTranspose1d naming level (`.conv` / `.convtr`)."""
+
+    def __init__(self, name, weights):
+        super().__init__()
+        setattr(self, name, weights)
+
+
+class SConv1d(nn.Module):
+    """Causal / asymmetric-padded Conv1d (dac/model/encodec.py:192-228).  State-dict keys:
+    conv.conv.{weight_g,weight_v,bias} (norm='weight_norm') or conv.conv.{weight,bias}."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, dilation=1, causal=False,
+                 norm="none", pad_mode="reflect", bias=True):
+        super().__init__()
+        self.conv = _Norm("conv", ConvWeights(in_channels, out_channels, kernel_size, norm == "weight_norm", bias=bias))
+        self.kernel_size, self.stride, self.dilation = kernel_size, stride, dilation
+        self.causal = causal
+        self.pad_mode = ops.PAD_REFLECT if pad_mode == "reflect" else ops.PAD_ZERO
+
+    @property
+    def w(self):
+        return self.conv.conv
+
+    def run(self, x, alpha_in=None, alpha_out=None, res=None, act=ops.ACT_NONE):
+        w = self.w
+        return ops.conv1d(x, w.packed(), w.c_out, self.kernel_size, bias=w.bias, stride=self.stride,
+                          dilation=self.dilation, pad_mode=self.pad_mode, alpha_in=alpha_in, alpha_out=alpha_out,
+                          res=res, act=act, causal=self.causal)
+
+    def forward(self, x):
+        return self.run(x)
+
+
+class SConvTranspose1d(nn.Module):
+    """Causal ConvTranspose1d with right trim (dac/model/encodec.py:231-270).  Keys:
+    convtr.convtr.{weight_g (C_in,1,1), weight_v (C_in,C_out,K), bias}."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, causal=False, norm="none"):
+        super().__init__()
+        if not causal:
+            raise NotImplementedError("non-causal SConvTranspose1d (redecoder path) is not built yet")
+        self.convtr = _Norm("convtr", ConvWeights(in_channels, out_channels, kernel_size, norm == "weight_norm",
+                                                  transposed=True, stride=stride))
+        self.stride = stride
+
+    @property
+    def w(self):
+        return self.convtr.convtr
+
+    def run(self, x, alpha_in=None):
+        w = self.w
+        return ops.conv_transpose1d(x, w.packed(), w.c_out, self.stride, bias=w.bias, alpha_in=alpha_in)
+
+    def forward(self, x):
+        return self.run(x)
+
+
+class Snake1d(nn.Module):
+    """alpha (1, C, 1) of dac/nn/layers.py:27-33.  Normally fused into the neighbouring conv."""
+
+    def __init__(self, channels):
+        super().__init__()
+        self.alpha = nn.Parameter(torch.ones(1, channels, 1))
+
+    def flat(self):
+        return self.alpha.detach().reshape(-1)
+
+    def forward(self, x):
+        return ops.snake(x, self.flat())
+
+
+class _LSTMParams(nn.Module):
+    """nn.LSTM's parameter names/shapes (weight_ih_l{k} (4H,H), weight_hh_l{k}, bias_ih_l{k}, bias_hh_l{k})."""
+
+    def __init__(self, hidden, num_layers):
+        super().__init__()
+        b = 1.0 / math.sqrt(hidden)
+        for l in range(num_layers):
+            for n, shp in (("weight_ih", (4 * hidden, hidden)), ("weight_hh", (4 * hidden, hidden)),
+                           ("bias_ih", (4 * hidden,)), ("bias_hh", (4 * hidden,))):
+                setattr(self, f"{n}_l{l}", nn.Parameter(_uniform_(torch.empty(shp), b)))
+
+
+class SLSTM(nn.Module):
+    """dac/model/encodec.py:272-288: multi-layer LSTM over time on (B, C, T) plus skip.
+    Input projections run as GEMMs on the MFMA conv kernel over the time-major (T, H, BP) view;
+    the recurrence is fac_lstm_layer_fwd (one launch per step)."""
+
+    def __init__(self, dimension, num_layers=2, skip=True):
+        super().__init__()
+        self.lstm = _LSTMParams(dimension, num_layers)
+        self.dimension, self.num_layers, self.skip = dimension, num_layers, skip
+
+    def forward(self, x):
+        B, H, T = x.shape
+        inp = ops.lstm_to_time_major(x)
+        for l in range(self.num_layers):
+            p = self.lstm
+            w_ih = ops.pack_conv_weight(getattr(p, f"weight_ih_l{l}").detach())
+            bias = ops.add(getattr(p, f"bias_ih_l{l}").detach(), getattr(p, f"bias_hh_l{l}").detach())
+            whh = ops.pack_lstm_whh(getattr(p, f"weight_hh_l{l}").detach())
+            pre = ops.conv1d(inp, w_ih, 4 * H, 1, bias=bias, pad_left=0, t_out=inp.shape[-1], pad_mode=ops.PAD_ZERO)
+            inp = ops.lstm_layer(pre, whh, H)
+        return ops.lstm_from_time_major(inp, x if self.skip else None, B)

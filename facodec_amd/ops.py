@@ -1,0 +1,317 @@
+"""Tensor-level wrappers over the C ABI: borrow device pointers from torch tensors, enqueue on
+torch's current HIP stream, allocate outputs with torch's caching allocator.  No arithmetic
+happens in Python / ATen here -- every op below is one or more kernels of libfacodec_hip.so.
+"""
+import ctypes as C
+import math
+
+import torch
+
+from . import _lib
+from ._lib import ConvDesc, VqDesc, PAD_REFLECT, PAD_ZERO, ACT_NONE, ACT_TANH, ACT_MISH, ACT_LOG_MEL  # noqa: F401
+
+
+def pad32(n):
+    return (n + 31) & ~31
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _dev(t, what="tensor"):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise _lib.FacodecHipError(f"{what} must live on the GPU (got {t.device}); there is no CPU path")
+    if t.dtype != torch.float32:
+        raise _lib.FacodecHipError(f"{what} must be float32 (got {t.dtype})")
+    return t if t.is_contiguous() else t.contiguous()
+
+
+# --------------------------------------------------------------------------------- weights (K6)
+def wn_scale(v, g):
+    """scale[i] = g[i]/||v[i]|| (dac/model/encodec.py:42-51)."""
+    v = _dev(v, "weight_v")
+    g = _dev(g, "weight_g")
+    n = v.shape[0]
+    scale = torch.empty(n, device=v.device, dtype=torch.float32)
+    _lib.check(_lib.load().fac_wn_scale(_ptr(v), _ptr(g), _ptr(scale), n, v.numel() // n, _stream()), "fac_wn_scale")
+    return scale
+
+
+def pack_conv_weight(v, g=None, out=None):
+    """(C_out, C_in, K) [+ weight-norm gain g (C_out,1,1)] -> packed (C_in, K, pad32(C_out))."""
+    v = _dev(v, "weight")
+    if v.dim() == 2:
+        v = v.unsqueeze(-1)
+    c_out, c_in, k = v.shape
+    cp = pad32(c_out)
+    scale = wn_scale(v, g) if g is not None else None
+    if out is None:
+        out = torch.empty(c_in, k, cp, device=v.device, dtype=torch.float32)
+    _lib.check(_lib.load().fac_pack_conv_w(_ptr(v), _ptr(scale), _ptr(out), c_out, c_in, k, cp, _stream()),
+               "fac_pack_conv_w")
+    return out
+
+
+def pack_convtr_weight(v, g, stride, out=None):
+    """ConvTranspose1d (C_in, C_out, 2*stride) -> polyphase packed (stride, C_in, 2, pad32(C_out))."""
+    v = _dev(v, "weight")
+    c_in, c_out, k = v.shape
+    if k != 2 * stride:
+        raise _lib.FacodecHipError(f"polyphase ConvTranspose1d needs kernel_size == 2*stride (got {k}, {stride})")
+    cp = pad32(c_out)
+    scale = wn_scale(v, g) if g is not None else None
+    if out is None:
+        out = torch.empty(stride, c_in, 2, cp, device=v.device, dtype=torch.float32)
+    _lib.check(_lib.load().fac_pack_convtr_w(_ptr(v), _ptr(scale), _ptr(out), c_in, c_out, stride, cp, _stream()),
+               "fac_pack_convtr_w")
+    return out
+
+
+# --------------------------------------------------------------------------------- conv (K1-K4)
+def conv_out_len(t_in, k, stride, dilation):
+    """Output length and (pad_left, extra_right) of a causal SConv1d (dac/model/encodec.py:71-78,212-222)."""
+    k_eff = (k - 1) * dilation + 1
+    padding_total = k_eff - stride
+    n_frames = (t_in - k_eff + padding_total) / stride + 1
+    ideal = (math.ceil(n_frames) - 1) * stride + (k_eff - padding_total)
+    extra = ideal - t_in
+    t_out = (t_in + padding_total + extra - k_eff) // stride + 1
+    return t_out, padding_total, extra
+
+
+def conv1d(x, w_packed, c_out, k, bias=None, stride=1, dilation=1, pad_left=None, pad_mode=PAD_REFLECT,
+           t_out=None, alpha_in=None, alpha_out=None, res=None, act=ACT_NONE, out=None, causal=True):
+    """Fused conv (see fac_conv1d_fwd).  x (B, C_in, T).  With pad_left=None the SConv1d padding
+    rule is applied (causal: everything on the left; non-causal: asymmetric split)."""
+    x = _dev(x, "x")
+    B, c_in, t_in = x.shape
+    if pad_left is None:
+        t_o, padding_total, _ = conv_out_len(t_in, k, stride, dilation)
+        pad_left = padding_total if causal else padding_total - padding_total // 2
+        if t_out is None:
+            t_out = t_o
+    if t_out is None:
+        raise ValueError("t_out required with explicit pad_left")
+    cp = w_packed.shape[-1]
+    if out is None:
+        out = torch.empty(B, c_out, t_out, device=x.device, dtype=torch.float32)
+    res = _dev(res, "res")
+    d = ConvDesc()
+    d.x, d.w, d.bias = x.data_ptr(), w_packed.data_ptr(), (bias.data_ptr() if bias is not None else None)
+    d.alpha_in = alpha_in.data_ptr() if alpha_in is not None else None
+    d.alpha_out = alpha_out.data_ptr() if alpha_out is not None else None
+    d.res = res.data_ptr() if res is not None else None
+    d.y = out.data_ptr()
+    d.x_bs, d.x_cs = c_in * t_in, t_in
+    d.y_bs, d.y_cs = c_out * t_out, t_out
+    d.B, d.C_in, d.T_in, d.C_out, d.C_out_pad, d.T_out = B, c_in, t_in, c_out, cp, t_out
+    d.K, d.stride, d.dilation, d.pad_left, d.pad_mode = k, stride, dilation, pad_left, pad_mode
+    d.n_phase, d.y_tstride, d.act, d.w_batched, d.w_bs = 1, 1, act, 0, 0
+    _lib.check(_lib.load().fac_conv1d_fwd(C.byref(d), _stream()), "fac_conv1d_fwd")
+    return out
+
+
+def conv_transpose1d(x, w_packed, c_out, stride, bias=None, alpha_in=None, out=None):
+    """Causal SConvTranspose1d (kernel 2*stride, right trim k-stride: dac/model/encodec.py:248-270)
+    as `stride` polyphase 2-tap convs: y[., t*s+p] = W[p] x[t] + W[p+s] x[t-1]."""
+    x = _dev(x, "x")
+    B, c_in, t_in = x.shape
+    t_total = t_in * stride
+    cp = w_packed.shape[-1]
+    if out is None:
+        out = torch.empty(B, c_out, t_total, device=x.device, dtype=torch.float32)
+    d = ConvDesc()
+    d.x, d.w, d.bias = x.data_ptr(), w_packed.data_ptr(), (bias.data_ptr() if bias is not None else None)
+    d.alpha_in = alpha_in.data_ptr() if alpha_in is not None else None
+    d.alpha_out, d.res, d.y = None, None, out.data_ptr()
+    d.x_bs, d.x_cs = c_in * t_in, t_in
+    d.y_bs, d.y_cs = c_out * t_total, t_total
+    d.B, d.C_in, d.T_in, d.C_out, d.C_out_pad, d.T_out = B, c_in, t_in, c_out, cp, t_in
+    d.K, d.stride, d.dilation, d.pad_left, d.pad_mode = 2, 1, 1, 1, PAD_ZERO
+    d.n_phase, d.y_tstride, d.act, d.w_batched, d.w_bs = stride, stride, ACT_NONE, 0, 0
+    _lib.check(_lib.load().fac_conv1d_fwd(C.byref(d), _stream()), "fac_conv1d_fwd(convtr)")
+    return out
+
+
+def snake(x, alpha, out=None):
+    x = _dev(x, "x")
+    B, c, t = x.shape
+    if out is None:
+        out = torch.empty_like(x)
+    _lib.check(_lib.load().fac_snake_fwd(_ptr(x), _ptr(alpha), _ptr(out), B, c, t, _stream()), "fac_snake_fwd")
+    return out
+
+
+# --------------------------------------------------------------------------------- LSTM (K5)
+def lstm_to_time_major(x):
+    x = _dev(x, "x")
+    B, H, T = x.shape
+    xT = torch.empty(T, H, pad32(B), device=x.device, dtype=torch.float32)
+    _lib.check(_lib.load().fac_lstm_to_time_major(_ptr(x), _ptr(xT), B, H, T, _stream()), "fac_lstm_to_time_major")
+    return xT
+
+
+def lstm_from_time_major(yT, skip, B):
+    T, H, BP = yT.shape
+    out = torch.empty(B, H, T, device=yT.device, dtype=torch.float32)
+    _lib.check(_lib.load().fac_lstm_from_time_major(_ptr(yT), _ptr(skip), _ptr(out), B, H, T, _stream()),
+               "fac_lstm_from_time_major")
+    return out
+
+
+def pack_lstm_whh(w_hh, out=None):
+    w_hh = _dev(w_hh, "weight_hh")
+    H = w_hh.shape[1]
+    if out is None:
+        out = torch.empty_like(w_hh)
+    _lib.check(_lib.load().fac_pack_lstm_whh(_ptr(w_hh), _ptr(out), H, _stream()), "fac_pack_lstm_whh")
+    return out
+
+
+def lstm_layer(pre, whh_packed, H):
+    """pre (T, 4H, BP) -> yT (T, H, BP)."""
+    T, _, BP = pre.shape
+    yT = torch.empty(T, H, BP, device=pre.device, dtype=torch.float32)
+    c = torch.empty(H, BP, device=pre.device, dtype=torch.float32)
+    _lib.check(_lib.load().fac_lstm_layer_fwd(_ptr(pre), _ptr(whh_packed), _ptr(yT), _ptr(c), T, H, BP, _stream()),
+               "fac_lstm_layer_fwd")
+    return yT
+
+
+# --------------------------------------------------------------------------------- VQ (K7)
+def vq_step(z_in, w_in_packed, b_in, codebook, w_out, w_out_scale, b_out, codes_out, residual=None, zq_acc=None,
+            zq_out=None, mask=None, z_e=None, loss_part=None):
+    """One VectorQuantize.forward (dac/nn/quantize.py:34-70) + RVQ bookkeeping (:173-193).
+    codes_out: int64 view (B, T) (may be a strided slice of a (B, N, T) tensor)."""
+    z_in = _dev(z_in, "z")
+    B, D, T = z_in.shape
+    assert codes_out.dtype == torch.int64 and codes_out.stride(-1) == 1
+    d = VqDesc()
+    d.residual = residual.data_ptr() if residual is not None else None
+    d.z_in = z_in.data_ptr()
+    d.zq_acc = zq_acc.data_ptr() if zq_acc is not None else None
+    d.zq_out = zq_out.data_ptr() if zq_out is not None else None
+    d.w_in, d.b_in, d.codebook = w_in_packed.data_ptr(), b_in.data_ptr(), codebook.data_ptr()
+    d.w_out, d.b_out = w_out.data_ptr(), b_out.data_ptr()
+    d.w_out_scale = w_out_scale.data_ptr() if w_out_scale is not None else None
+    d.mask = mask.data_ptr() if mask is not None else None
+    d.codes = codes_out.data_ptr()
+    d.z_e = z_e.data_ptr() if z_e is not None else None
+    d.loss_part = loss_part.data_ptr() if loss_part is not None else None
+    d.codes_bs = codes_out.stride(0)
+    d.B, d.D, d.T, d.Kc = B, D, T, codebook.shape[0]
+    _lib.check(_lib.load().fac_vq_fwd(C.byref(d), _stream()), "fac_vq_fwd")
+
+
+def vq_search(latents, codebook):
+    """latents (N, 8) -> int64 (N,) nearest normalised code (dac/nn/quantize.py:78-94)."""
+    latents = _dev(latents, "latents")
+    codebook = _dev(codebook, "codebook")
+    n = latents.shape[0]
+    idx = torch.empty(n, device=latents.device, dtype=torch.int64)
+    _lib.check(_lib.load().fac_vq_search(_ptr(latents), _ptr(codebook), _ptr(idx), n, codebook.shape[0], _stream()),
+               "fac_vq_search")
+    return idx
+
+
+# --------------------------------------------------------------------------------- small fused ops
+def gate_tanh_sigmoid(a):
+    a = _dev(a)
+    B, c2, T = a.shape
+    out = torch.empty(B, c2 // 2, T, device=a.device, dtype=torch.float32)
+    _lib.check(_lib.load().fac_gate_tanh_sigmoid(_ptr(a), _ptr(out), B, c2 // 2, T, _stream()), "fac_gate_tanh_sigmoid")
+    return out
+
+
+def glu_residual(a, res):
+    a, res = _dev(a), _dev(res)
+    B, c2, T = a.shape
+    out = torch.empty(B, c2 // 2, T, device=a.device, dtype=torch.float32)
+    _lib.check(_lib.load().fac_glu_residual(_ptr(a), _ptr(res), _ptr(out), B, c2 // 2, T, _stream()), "fac_glu_residual")
+    return out
+
+
+def add(a, b, out=None):
+    a, b = _dev(a), _dev(b)
+    if out is None:
+        out = torch.empty_like(a)
+    _lib.check(_lib.load().fac_add(_ptr(a), _ptr(b), _ptr(out), a.numel(), _stream()), "fac_add")
+    return out
+
+
+def sub2(a, b, c, out=None):
+    a, b, c = _dev(a), _dev(b), _dev(c)
+    if out is None:
+        out = torch.empty_like(a)
+    _lib.check(_lib.load().fac_sub2(_ptr(a), _ptr(b), _ptr(c), _ptr(out), a.numel(), _stream()), "fac_sub2")
+    return out
+
+
+def mul_mask_(x, mask):
+    """x (B,C,T) *= mask (B,T) in place."""
+    B, c, T = x.shape
+    _lib.check(_lib.load().fac_mul_mask(_ptr(x), _ptr(mask), B, c, T, _stream()), "fac_mul_mask")
+    return x
+
+
+def wn_res_skip_(rs, x, out, last):
+    B, c, T = out.shape
+    _lib.check(_lib.load().fac_wn_res_skip(_ptr(rs), _ptr(x), _ptr(out), B, c, T, 1 if last else 0, _stream()),
+               "fac_wn_res_skip")
+
+
+def attention(q, k, v, mask, n_heads):
+    q, k, v = _dev(q), _dev(k), _dev(v)
+    B, c, T = q.shape
+    out = torch.empty_like(q)
+    _lib.check(_lib.load().fac_attention(_ptr(q), _ptr(k), _ptr(v), _ptr(mask), _ptr(out), B, n_heads, c // n_heads, T,
+                                         _stream()), "fac_attention")
+    return out
+
+
+def masked_mean(x, mask):
+    x = _dev(x)
+    B, c, T = x.shape
+    out = torch.empty(B, c, device=x.device, dtype=torch.float32)
+    _lib.check(_lib.load().fac_masked_mean(_ptr(x), _ptr(mask), _ptr(out), B, c, T, _stream()), "fac_masked_mean")
+    return out
+
+
+def layernorm_c_affine(x, style):
+    x, style = _dev(x), _dev(style)
+    B, c, T = x.shape
+    out = torch.empty_like(x)
+    _lib.check(_lib.load().fac_layernorm_c_affine(_ptr(x), _ptr(style), _ptr(out), B, c, T, _stream()),
+               "fac_layernorm_c_affine")
+    return out
+
+
+# --------------------------------------------------------------------------------- STFT pieces
+def stft_frames(wave, n_win, n_frames, hop, pad, n_off):
+    wave = _dev(wave, "wave")
+    B, T = wave.shape
+    frames = torch.empty(B, n_win, n_frames, device=wave.device, dtype=torch.float32)
+    _lib.check(_lib.load().fac_stft_frames(_ptr(wave), _ptr(frames), B, T, n_win, n_frames, hop, pad, n_off, _stream()),
+               "fac_stft_frames")
+    return frames
+
+
+def spec_power(spec, power):
+    B, f2, nf = spec.shape
+    out = torch.empty(B, f2 // 2, nf, device=spec.device, dtype=torch.float32)
+    _lib.check(_lib.load().fac_spec_power(_ptr(spec), _ptr(out), B, f2 // 2, nf, power, _stream()), "fac_spec_power")
+    return out
+
+
+def reduce_pair(a, b, out, scratch, mode, eps=0.0, scale=1.0, accumulate=False):
+    a, b = _dev(a), _dev(b)
+    _lib.check(_lib.load().fac_reduce_pair(_ptr(a), _ptr(b), _ptr(out), _ptr(scratch), a.numel(), mode, eps, scale,
+                                           1 if accumulate else 0, _stream()), "fac_reduce_pair")
+    return out

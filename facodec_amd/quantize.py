@@ -1,0 +1,330 @@
+"""FA-quantizer (reference: modules/quantize.py:156-454 FAquantizer.forward_v2) and its parts
+(dac/nn/quantize.py VectorQuantize / ResidualVectorQuantize, modules/wavenet.py WN,
+modules/style_encoder.py StyleEncoder, modules/attentions.py MultiHeadAttention), inference
+(eval-mode) forward on the HIP C ABI.  State-dict keys follow the reference module tree.
+
+Launch plan of forward_v2 (B clips):
+  log-mel front-end: frames -> windowed-DFT GEMM (MFMA) -> |.|^2 -> mel GEMM with log epilogue,
+                     computed ONCE and shared by the 80-bin timbre and 20-bin prosody branches
+                     (the reference computes it twice, modules/quantize.py:378,385);
+  timbre:  1x1 convs (+Mish epilogue) -> 2x (conv k5 -> GLU+residual) -> QKV convs -> attention ->
+           out conv (+residual epilogue) -> fc -> masked mean;
+  prosody: 1x1 conv -> 8x (conv k5 -> tanh*sigmoid gate -> 1x1 conv -> res/skip update) -> 1x1 conv;
+  VQ:      6 fused fac_vq_fwd steps (1 prosody + 2 content + 3 residual);
+  output:  LayerNorm over channels * gamma + beta (one kernel).
+"""
+import math
+
+import numpy as np
+import torch
+from torch import nn
+
+from . import dsp, ops
+from .layers import ConvWeights, SConv1d, _uniform_
+
+
+# ------------------------------------------------------------------------------------ VQ
+class _Codebook(nn.Module):
+    def __init__(self, size, dim):
+        super().__init__()
+        self.weight = nn.Parameter(torch.randn(size, dim))
+
+
+class VectorQuantize(nn.Module):
+    """dac/nn/quantize.py:13-94.  Keys: in_proj.{weight_g,weight_v,bias}, out_proj.{...}, codebook.weight."""
+
+    def __init__(self, input_dim, codebook_size, codebook_dim):
+        super().__init__()
+        if codebook_dim != 8:
+            raise NotImplementedError("the VQ kernel is specialised for codebook_dim = 8 (modules/commons.py:303)")
+        self.codebook_size, self.codebook_dim, self.input_dim = codebook_size, codebook_dim, input_dim
+        self.in_proj = ConvWeights(input_dim, codebook_dim, 1, weight_norm=True)
+        self.out_proj = ConvWeights(codebook_dim, input_dim, 1, weight_norm=True)
+        self.codebook = _Codebook(codebook_size, codebook_dim)
+
+    def _weights(self):
+        """(packed in_proj (D,1,32), out_proj weight_v (D,8,1) as stored, its weight-norm scale (D,))."""
+        v = self.out_proj.weight_v.detach()
+        return self.in_proj.packed(), v, ops.wn_scale(v, self.out_proj.weight_g.detach())
+
+    def forward(self, z):
+        B, D, T = z.shape
+        codes = torch.empty(B, T, device=z.device, dtype=torch.int64)
+        z_e = torch.empty(B, 8, T, device=z.device, dtype=torch.float32)
+        out = torch.empty_like(z)
+        nt = (T + 63) // 64
+        lp = torch.empty(B, nt, device=z.device, dtype=torch.float32)
+        w_in, w_out, w_out_scale = self._weights()
+        ops.vq_step(z, w_in, self.in_proj.bias.detach(), self.codebook.weight.detach(), w_out, w_out_scale,
+                    self.out_proj.bias.detach(), codes, zq_out=out, z_e=z_e, loss_part=lp)
+        loss = lp.sum(1) / float(8 * T)
+        return out, loss, loss.clone(), codes, z_e
+
+
+class ResidualVectorQuantize(nn.Module):
+    """dac/nn/quantize.py:97-198 (eval-mode forward: no quantizer dropout)."""
+
+    def __init__(self, input_dim=512, n_codebooks=9, codebook_size=1024, codebook_dim=8, quantizer_dropout=0.0):
+        super().__init__()
+        self.n_codebooks, self.codebook_size, self.codebook_dim = n_codebooks, codebook_size, codebook_dim
+        self.quantizers = nn.ModuleList([VectorQuantize(input_dim, codebook_size, codebook_dim) for _ in range(n_codebooks)])
+        self.quantizer_dropout = quantizer_dropout
+
+    def forward(self, z, n_quantizers=None):
+        if self.training:
+            raise NotImplementedError("train-mode RVQ (quantizer dropout + backward) is not built yet")
+        n = self.n_codebooks if n_quantizers is None else min(int(n_quantizers), self.n_codebooks)
+        B, D, T = z.shape
+        dev = z.device
+        z_q = torch.zeros_like(z)
+        codes = torch.empty(B, n, T, device=dev, dtype=torch.int64)
+        latents = torch.empty(B, 8 * n, T, device=dev, dtype=torch.float32)
+        nt = (T + 63) // 64
+        lp = torch.empty(n, B, nt, device=dev, dtype=torch.float32)
+        residual = torch.empty_like(z) if n > 1 else None
+        src = z
+        for i in range(n):
+            q = self.quantizers[i]
+            w_in, w_out, w_out_scale = q._weights()
+            z_e_i = torch.empty(B, 8, T, device=dev, dtype=torch.float32)
+            ops.vq_step(src, w_in, q.in_proj.bias.detach(), q.codebook.weight.detach(), w_out, w_out_scale,
+                        q.out_proj.bias.detach(), codes[:, i], residual=residual if i < n - 1 else None,
+                        zq_acc=z_q, z_e=z_e_i, loss_part=lp[i])
+            latents[:, 8 * i: 8 * (i + 1)] = z_e_i
+            src = residual
+        per = lp.sum(2) / float(8 * T)       # (n, B)  mean over (8, T) per sample
+        loss = per.mean(1).sum()             # mean over batch, summed over quantizers
+        return z_q, codes, latents, loss, loss.clone()
+
+
+# ------------------------------------------------------------------------------------ WaveNet
+class WN(nn.Module):
+    """modules/wavenet.py:103-166 (g=None path).  Keys: in_layers.i.conv.conv.*, res_skip_layers.i.conv.conv.*"""
+
+    def __init__(self, hidden_channels, kernel_size, dilation_rate, n_layers, gin_channels=0, p_dropout=0, causal=False):
+        super().__init__()
+        if gin_channels != 0:
+            raise NotImplementedError("conditioned WN (redecoder) is not built yet")
+        self.hidden_channels, self.n_layers = hidden_channels, n_layers
+        self.in_layers = nn.ModuleList()
+        self.res_skip_layers = nn.ModuleList()
+        for i in range(n_layers):
+            self.in_layers.append(SConv1d(hidden_channels, 2 * hidden_channels, kernel_size,
+                                          dilation=dilation_rate ** i, norm="weight_norm", causal=causal))
+            rs = 2 * hidden_channels if i < n_layers - 1 else hidden_channels
+            self.res_skip_layers.append(SConv1d(hidden_channels, rs, 1, norm="weight_norm", causal=causal))
+
+    def forward(self, x, x_mask=None, g=None):
+        x = x.clone()
+        out = torch.zeros_like(x)
+        for i in range(self.n_layers):
+            a = self.in_layers[i].run(x)
+            acts = ops.gate_tanh_sigmoid(a)
+            rs = self.res_skip_layers[i].run(acts)
+            ops.wn_res_skip_(rs, x, out, last=(i == self.n_layers - 1))
+        return out
+
+
+# ------------------------------------------------------------------------------------ StyleEncoder
+class _PlainConv(nn.Module):
+    """nn.Conv1d parameters (weight (C_out,C_in,K), bias) + packed copy."""
+
+    def __init__(self, c_in, c_out, k):
+        super().__init__()
+        b = 1.0 / math.sqrt(c_in * k)
+        self.weight = nn.Parameter(_uniform_(torch.empty(c_out, c_in, k), b))
+        self.bias = nn.Parameter(_uniform_(torch.empty(c_out), b))
+        self.c_in, self.c_out, self.k = c_in, c_out, k
+
+    def run(self, x, pad=0, **kw):
+        return ops.conv1d(x, ops.pack_conv_weight(self.weight.detach()), self.c_out, self.k, bias=self.bias.detach(),
+                          pad_left=pad, pad_mode=ops.PAD_ZERO, t_out=x.shape[-1], **kw)
+
+
+class _Conv1dGLU(nn.Module):
+    def __init__(self, c, k):
+        super().__init__()
+        self.conv1 = _PlainConv(c, 2 * c, k)
+
+
+class MultiHeadAttention(nn.Module):
+    """modules/attentions.py:120-199 without relative window / proximal bias."""
+
+    def __init__(self, channels, out_channels, n_heads):
+        super().__init__()
+        self.n_heads = n_heads
+        self.conv_q = _PlainConv(channels, channels, 1)
+        self.conv_k = _PlainConv(channels, channels, 1)
+        self.conv_v = _PlainConv(channels, channels, 1)
+        self.conv_o = _PlainConv(channels, out_channels, 1)
+
+    def forward(self, x, mask, res=None):
+        q, k, v = self.conv_q.run(x), self.conv_k.run(x), self.conv_v.run(x)
+        o = ops.attention(q, k, v, mask, self.n_heads)
+        return self.conv_o.run(o, res=res)
+
+
+class StyleEncoder(nn.Module):
+    """modules/style_encoder.py:33-91 (eval).  Keys: spectral.{0,3}, temporal.{0,1}.conv1, slf_attn.*, fc."""
+
+    def __init__(self, in_dim=513, hidden_dim=128, out_dim=256):
+        super().__init__()
+        # indices 0 and 3 of the reference's Sequential(conv, Mish, Dropout, conv, Mish, Dropout)
+        self.spectral = nn.ModuleDict({"0": _PlainConv(in_dim, hidden_dim, 1), "3": _PlainConv(hidden_dim, hidden_dim, 1)})
+        self.temporal = nn.ModuleList([_Conv1dGLU(hidden_dim, 5), _Conv1dGLU(hidden_dim, 5)])
+        self.slf_attn = MultiHeadAttention(hidden_dim, hidden_dim, 2)
+        self.fc = _PlainConv(hidden_dim, out_dim, 1)
+
+    def forward(self, x, mask=None):
+        """x (B, in_dim, T); mask (B, T) float 0/1 or None (= all frames valid) -> (B, out_dim)."""
+        x = self.spectral["0"].run(x, act=ops.ACT_MISH)
+        x = self.spectral["3"].run(x, act=ops.ACT_MISH)
+        if mask is not None:
+            ops.mul_mask_(x, mask)
+        for glu in self.temporal:
+            a = glu.conv1.run(x, pad=2)
+            x = ops.glu_residual(a, x)
+        if mask is not None:
+            ops.mul_mask_(x, mask)
+        x = self.slf_attn(x, mask, res=x)
+        x = self.fc.run(x)
+        return ops.masked_mean(x, mask)
+
+
+# ------------------------------------------------------------------------------------ front-end
+class LogMelFrontend(nn.Module):
+    """FAquantizer.to_mel + preprocess (modules/quantize.py:219-242): torchaudio MelSpectrogram
+    (sr 24000, n_fft 2048, win 1200 periodic Hann, hop 300, centre reflect, power 2, HTK 80 mels)
+    then (log(1e-5 + mel) + 4) / 4.  Buffer names follow torchaudio so real checkpoints load."""
+
+    def __init__(self, sample_rate=24000, n_fft=2048, win_length=1200, hop_length=300, n_mels=80):
+        super().__init__()
+        self.n_fft, self.win, self.hop, self.n_mels = n_fft, win_length, hop_length, n_mels
+        self.spectrogram = nn.Module()
+        self.spectrogram.register_buffer("window", torch.from_numpy(dsp.hann_periodic(win_length)))
+        self.mel_scale = nn.Module()
+        self.mel_scale.register_buffer("fb", torch.from_numpy(dsp.mel_fbank_htk(n_fft // 2 + 1, n_mels, sample_rate)))
+        self._basis = None
+        self._fb_packed = None
+
+    def _consts(self, device):
+        if self._basis is None or self._basis.device != device:
+            win = self.spectrogram.window.detach().cpu().numpy()
+            basis, self._off = dsp.dft_basis(self.n_fft, self.win, win)
+            self._basis = ops.pack_conv_weight(torch.from_numpy(basis).to(device).unsqueeze(-1))
+            fb = self.mel_scale.fb.detach().to(device).t().contiguous()  # (n_mels, F)
+            self._fb_packed = ops.pack_conv_weight(fb.unsqueeze(-1))
+        return self._basis, self._fb_packed, self._off
+
+    def _apply(self, fn, *a, **kw):
+        self._basis = None
+        return super()._apply(fn, *a, **kw)
+
+    def forward(self, wave):
+        """wave (B, 1, T) or (B, T) -> normalised log-mel (B, n_mels, T // hop)."""
+        w = wave.reshape(wave.shape[0], wave.shape[-1])
+        B, T = w.shape
+        n_frames = T // self.hop
+        basis, fbp, off = self._consts(w.device)
+        F_ = self.n_fft // 2 + 1
+        frames = ops.stft_frames(w, self.win, n_frames, self.hop, self.n_fft // 2, off)
+        spec = ops.conv1d(frames, basis, 2 * F_, 1, pad_left=0, pad_mode=ops.PAD_ZERO, t_out=n_frames)
+        power = ops.spec_power(spec, 2)
+        return ops.conv1d(power, fbp, self.n_mels, 1, pad_left=0, pad_mode=ops.PAD_ZERO, t_out=n_frames,
+                          act=ops.ACT_LOG_MEL)
+
+
+class _Linear(nn.Module):
+    def __init__(self, c_in, c_out):
+        super().__init__()
+        b = 1.0 / math.sqrt(c_in)
+        self.weight = nn.Parameter(_uniform_(torch.empty(c_out, c_in), b))
+        self.bias = nn.Parameter(_uniform_(torch.empty(c_out), b))
+
+    def forward(self, x):
+        """x (B, C_in) -> (B, C_out) through the conv kernel on the (B, C_in, 1) view."""
+        y = ops.conv1d(x.reshape(x.shape[0], x.shape[1], 1), ops.pack_conv_weight(self.weight.detach()),
+                       self.weight.shape[0], 1, bias=self.bias.detach(), pad_left=0, pad_mode=ops.PAD_ZERO, t_out=1)
+        return y.reshape(x.shape[0], -1)
+
+
+# ------------------------------------------------------------------------------------ FAquantizer
+def sequence_mask(length, max_length=None):
+    """modules/quantize.py:127-131."""
+    if max_length is None:
+        max_length = int(length.max())
+    x = torch.arange(max_length, dtype=length.dtype, device=length.device)
+    return x.unsqueeze(0) < length.unsqueeze(1)
+
+
+class FAquantizer(nn.Module):
+    """modules/quantize.py:156-454 with timbre_norm=True / separate_prosody_encoder=True
+    (configs/config.yml:27-46); `forward` is the reference's forward_v2 (:235-237)."""
+
+    def __init__(self, in_dim=1024, n_p_codebooks=1, n_c_codebooks=2, n_t_codebooks=2, n_r_codebooks=3,
+                 codebook_size=1024, codebook_dim=8, quantizer_dropout=0.5, causal=False,
+                 separate_prosody_encoder=False, timbre_norm=False):
+        super().__init__()
+        if not (timbre_norm and separate_prosody_encoder):
+            raise NotImplementedError("only the shipped configuration (timbre_norm + separate_prosody_encoder) is built")
+        rvq = lambda n: ResidualVectorQuantize(in_dim, n, codebook_size, codebook_dim, quantizer_dropout)  # noqa: E731
+        self.prosody_quantizer = rvq(n_p_codebooks)
+        self.content_quantizer = rvq(n_c_codebooks)
+        self.timbre_encoder = StyleEncoder(in_dim=80, hidden_dim=512, out_dim=in_dim)
+        self.timbre_linear = _Linear(1024, 1024 * 2)
+        with torch.no_grad():
+            self.timbre_linear.bias[:1024] = 1
+            self.timbre_linear.bias[1024:] = 0
+        self.residual_quantizer = rvq(n_r_codebooks)
+        self.melspec_linear = SConv1d(20, 256, 1, causal=causal)
+        self.melspec_encoder = WN(hidden_channels=256, kernel_size=5, dilation_rate=1, n_layers=8, gin_channels=0,
+                                  p_dropout=0.2, causal=causal)
+        self.melspec_linear2 = SConv1d(256, 1024, 1, causal=causal)
+        self.to_mel = LogMelFrontend(24000, 2048, 1200, 300, 80)
+        self.hop_length = 300
+        self.in_dim = in_dim
+        self.is_timbre_norm = True
+        self.separate_prosody_encoder = True
+
+    def preprocess(self, wave_tensor, n_bins=20):
+        return self.to_mel(wave_tensor)[:, :n_bins]
+
+    def forward(self, x, wave_segments, n_c=1, n_t=2, full_waves=None, wave_lens=None, return_codes=False):
+        if self.training:
+            raise NotImplementedError("train-mode forward (residual mask / dropout / backward) is not built yet")
+        mel = self.to_mel(wave_segments)                      # (B, 80, F) computed once
+        if full_waves is None:
+            timbre = self.timbre_encoder(mel, None)
+        else:
+            mel_full = self.to_mel(full_waves)
+            m = sequence_mask(wave_lens // self.hop_length, mel_full.shape[-1]).to(torch.float32).contiguous()
+            timbre = self.timbre_encoder(mel_full, m)
+
+        f0 = ops.conv1d(mel[:, :20], self.melspec_linear.w.packed(), 256, 1, bias=self.melspec_linear.w.bias,
+                        pad_left=0, pad_mode=ops.PAD_ZERO, t_out=mel.shape[-1])
+        f0 = self.melspec_encoder(f0)
+        f0 = self.melspec_linear2.run(f0)
+
+        n = min(f0.shape[2], x.shape[2])
+        if f0.shape[2] != n:
+            f0 = f0[:, :, :n].contiguous()
+        if x.shape[2] != n:
+            x = x[:, :, :n].contiguous()
+
+        z_p, codes_p, _, cm_p, cb_p = self.prosody_quantizer(f0, 1)
+        z_c, codes_c, _, cm_c, cb_c = self.content_quantizer(x, n_c)
+        residual_feature = ops.sub2(x, z_p, z_c)
+        z_r, codes_r, _, cm_r, cb_r = self.residual_quantizer(residual_feature, 3)
+        outs = ops.add(ops.add(z_p, z_c), z_r)
+
+        style = self.timbre_linear(timbre)                    # (B, 2D) = [gamma | beta]
+        outs = ops.layernorm_c_affine(outs, style)
+
+        quantized = [z_p, z_c, z_r]
+        commitment = cm_p + cm_c + cm_r
+        codebook = cb_p + cb_c + cb_r
+        if return_codes:
+            return outs, quantized, commitment, codebook, timbre, [codes_p, codes_c, codes_r]
+        return outs, quantized, commitment, codebook, timbre
+
+    forward_v2 = forward

@@ -147,7 +147,8 @@ typedef struct fac_vq_desc {
   const float* w_in;      /* packed (D, 1, 32) from fac_pack_conv_w (C_out = 8 -> pad 32) */
   const float* b_in;      /* (8) */
   const float* codebook;  /* (Kc, 8) raw */
-  const float* w_out;     /* (D, 8) out_proj effective weight (row-major, [c][d]) */
+  const float* w_out;     /* (D, 8) out_proj weight_v rows ([c][d], torch layout (D,8,1)) */
+  const float* w_out_scale; /* (D) weight-norm scale g/||v|| from fac_wn_scale, or NULL (== 1) */
   const float* b_out;     /* (D) */
   const float* mask;      /* (B) multiplies out in zq_acc (quantizer dropout), NULL == 1 */
   int64_t* codes;         /* (B, T) at codes[b*codes_bs + t] */
