@@ -47,6 +47,7 @@ SIGNATURES = {
     "fac_pack_conv_w": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
     "fac_pack_convtr_w": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
     "fac_conv1d_fwd": (_i, [C.POINTER(ConvDesc), _p]),
+    "fac_conv1d_variant": (_i, [C.POINTER(ConvDesc), C.c_char_p, _i]),
     "fac_snake_fwd": (_i, [_p, _p, _p, _i, _i, _i, _p]),
     "fac_lstm_to_time_major": (_i, [_p, _p, _i, _i, _i, _p]),
     "fac_lstm_from_time_major": (_i, [_p, _p, _p, _i, _i, _i, _p]),

@@ -225,6 +225,16 @@ static int launch_cfg(ConvArgs& a, hipStream_t s) {
   return check_launch("conv1d_mfma");
 }
 
+// Tile selection: M tile by output channels, narrow-N tile for short sequences (LSTM batches).
+static int select_variant(const fac_conv_desc* d) {
+  const int co = d->C_out;
+  if (d->T_out <= 32) return 0;
+  if (co <= 32) return 1;
+  if (co <= 64) return 2;
+  if (co % 128 != 0 && co % 96 == 0) return 3;
+  return 4;
+}
+
 }  // namespace fac
 
 extern "C" int fac_conv1d_fwd(const fac_conv_desc* d, fac_stream_t stream) {
@@ -254,11 +264,22 @@ extern "C" int fac_conv1d_fwd(const fac_conv_desc* d, fac_stream_t stream) {
     a.T_ext = d->T_in > max_pad ? d->T_in : max_pad + 1;
   }
   hipStream_t s = (hipStream_t)stream;
-  const int co = d->C_out;
-  // tile selection: M tile by output channels, narrow-N tile for short sequences (LSTM batches)
-  if (d->T_out <= 32) return launch_cfg<1, 1, 4, 1>(a, s);   // 128 x 32
-  if (co <= 32) return launch_cfg<1, 2, 1, 4>(a, s);          // 32 x 256
-  if (co <= 64) return launch_cfg<2, 1, 1, 4>(a, s);          // 64 x 128
-  if (co % 128 != 0 && co % 96 == 0) return launch_cfg<3, 1, 1, 4>(a, s);  // 96 x 128
-  return launch_cfg<2, 2, 2, 2>(a, s);                        // 128 x 128
+  switch (select_variant(d)) {
+    case 0: return launch_cfg<1, 1, 4, 1>(a, s);   // 128 x 32
+    case 1: return launch_cfg<1, 2, 1, 4>(a, s);   // 32 x 256
+    case 2: return launch_cfg<2, 1, 1, 4>(a, s);   // 64 x 128
+    case 3: return launch_cfg<3, 1, 1, 4>(a, s);   // 96 x 128
+    default: return launch_cfg<2, 2, 2, 2>(a, s);  // 128 x 128
+  }
+}
+
+extern "C" int fac_conv1d_variant(const fac_conv_desc* d, char* name, int name_len) {
+  using namespace fac;
+  FAC_REQUIRE(d, "conv1d_variant: null descriptor");
+  static const char* names[] = {"conv1d_mfma_kernel<1,1,4,1> 128x32", "conv1d_mfma_kernel<1,2,1,4> 32x256",
+                                "conv1d_mfma_kernel<2,1,1,4> 64x128", "conv1d_mfma_kernel<3,1,1,4> 96x128",
+                                "conv1d_mfma_kernel<2,2,2,2> 128x128"};
+  const int v = select_variant(d);
+  if (name && name_len > 0) snprintf(name, name_len, "%s", names[v]);
+  return v;
 }

@@ -20,19 +20,22 @@ def hann_periodic(n):
 
 
 def mel_fbank_htk(n_freqs, n_mels, sample_rate, f_min=0.0, f_max=None):
-    """(n_freqs, n_mels) triangular HTK filterbank, built in float32 like torchaudio does."""
+    """(n_freqs, n_mels) triangular HTK filterbank.  Built with torch float32 tensor ops in the
+    same order torchaudio.functional.melscale_fbanks uses, because construction precision alone
+    moves these weights at the 1e-5 level."""
+    import torch
     if f_max is None:
         f_max = float(sample_rate // 2)
-    all_freqs = np.linspace(0, sample_rate // 2, n_freqs, dtype=np.float32)
+    all_freqs = torch.linspace(0, sample_rate // 2, n_freqs)
     m_min = 2595.0 * math.log10(1.0 + f_min / 700.0)
     m_max = 2595.0 * math.log10(1.0 + f_max / 700.0)
-    m_pts = np.linspace(m_min, m_max, n_mels + 2, dtype=np.float32)
-    f_pts = (np.float32(700.0) * (np.float32(10.0) ** (m_pts / np.float32(2595.0)) - np.float32(1.0))).astype(np.float32)
+    m_pts = torch.linspace(m_min, m_max, n_mels + 2)
+    f_pts = 700.0 * (10.0 ** (m_pts / 2595.0) - 1.0)
     f_diff = f_pts[1:] - f_pts[:-1]
-    slopes = f_pts[None, :] - all_freqs[:, None]
+    slopes = f_pts.unsqueeze(0) - all_freqs.unsqueeze(1)
     down = (-1.0 * slopes[:, :-2]) / f_diff[:-1]
     up = slopes[:, 2:] / f_diff[1:]
-    return np.maximum(0.0, np.minimum(down, up)).astype(np.float32)
+    return torch.clamp(torch.min(down, up), min=0.0).numpy()
 
 
 def _hz_to_mel_slaney(f):

@@ -75,6 +75,47 @@ def pack_convtr_weight(v, g, stride, out=None):
 
 
 # --------------------------------------------------------------------------------- conv (K1-K4)
+class ConvLaunchProfile:
+    """Opt-in per-launch timing of the conv kernel with HIP events recorded on the launch stream
+    (bench.py's `roofline` leg).  Collects (variant name, algorithmic FLOPs, start, end)."""
+
+    def __init__(self):
+        self.records = []
+
+    def summary(self):
+        """{variant: dict(launches, flops, ms)}; call after a device synchronise."""
+        out = {}
+        for name, flops, e0, e1 in self.records:
+            r = out.setdefault(name, dict(launches=0, flops=0.0, ms=0.0))
+            r["launches"] += 1
+            r["flops"] += flops
+            r["ms"] += e0.elapsed_time(e1)
+        return out
+
+
+_PROFILE = None
+
+
+def set_conv_profile(p):
+    global _PROFILE
+    _PROFILE = p
+
+
+def _launch_conv(d, what):
+    lib = _lib.load()
+    if _PROFILE is None:
+        _lib.check(lib.fac_conv1d_fwd(C.byref(d), _stream()), what)
+        return
+    buf = C.create_string_buffer(64)
+    lib.fac_conv1d_variant(C.byref(d), buf, 64)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    _lib.check(lib.fac_conv1d_fwd(C.byref(d), _stream()), what)
+    e1.record()
+    flops = 2.0 * d.B * d.n_phase * d.C_out * d.T_out * d.C_in * d.K
+    _PROFILE.records.append((buf.value.decode(), flops, e0, e1))
+
+
 def conv_out_len(t_in, k, stride, dilation):
     """Output length and (pad_left, extra_right) of a causal SConv1d (dac/model/encodec.py:71-78,212-222)."""
     k_eff = (k - 1) * dilation + 1
@@ -114,7 +155,7 @@ def conv1d(x, w_packed, c_out, k, bias=None, stride=1, dilation=1, pad_left=None
     d.B, d.C_in, d.T_in, d.C_out, d.C_out_pad, d.T_out = B, c_in, t_in, c_out, cp, t_out
     d.K, d.stride, d.dilation, d.pad_left, d.pad_mode = k, stride, dilation, pad_left, pad_mode
     d.n_phase, d.y_tstride, d.act, d.w_batched, d.w_bs = 1, 1, act, 0, 0
-    _lib.check(_lib.load().fac_conv1d_fwd(C.byref(d), _stream()), "fac_conv1d_fwd")
+    _launch_conv(d, "fac_conv1d_fwd")
     return out
 
 
@@ -136,7 +177,7 @@ def conv_transpose1d(x, w_packed, c_out, stride, bias=None, alpha_in=None, out=N
     d.B, d.C_in, d.T_in, d.C_out, d.C_out_pad, d.T_out = B, c_in, t_in, c_out, cp, t_in
     d.K, d.stride, d.dilation, d.pad_left, d.pad_mode = 2, 1, 1, 1, PAD_ZERO
     d.n_phase, d.y_tstride, d.act, d.w_batched, d.w_bs = stride, stride, ACT_NONE, 0, 0
-    _lib.check(_lib.load().fac_conv1d_fwd(C.byref(d), _stream()), "fac_conv1d_fwd(convtr)")
+    _launch_conv(d, "fac_conv1d_fwd(convtr)")
     return out
 
 

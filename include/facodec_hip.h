@@ -103,6 +103,10 @@ typedef struct fac_conv_desc {
 } fac_conv_desc;
 
 int fac_conv1d_fwd(const fac_conv_desc* d, fac_stream_t stream);
+/* Which kernel instantiation fac_conv1d_fwd picks for this descriptor: returns its id (>= 0) and
+ * writes a printable name; lets a profiler attribute per-launch timings without re-deriving
+ * the tile-selection rule. */
+int fac_conv1d_variant(const fac_conv_desc* d, char* name, int name_len);
 
 /* Standalone Snake  y = x + sin(alpha*x)^2 / (alpha + 1e-9)  (dac/nn/layers.py:18-33) for the
  * places where it cannot be fused; alpha (C). In-place allowed. */

@@ -1,0 +1,67 @@
+"""N>1 path on CPU: world_size-2 gloo processes exercise the bench scaffold (sharding, barrier,
+MAX-over-ranks timing, SUM of units).  The data path itself has no collective."""
+import os
+import socket
+import sys
+
+import torch
+import torch.multiprocessing as mp
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, REPO)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    import time
+    from facodec_amd import benchutil, synth
+    r, lr, w = benchutil.init_distributed("gloo")
+    lo, hi = benchutil.shard_clips(7, w, r)
+    clips = synth.synth_clips(hi - lo, 2400, seed=0, rank=r)
+    calls = []
+
+    def step():
+        calls.append(1)
+        time.sleep(0.02 * (r + 1))   # rank 1 is slower: MAX must pick it up
+
+    dt = benchutil.timed_steps(step, steps=3, warmup=1, sync_fn=lambda: None)
+    units = benchutil.aggregate_units((hi - lo) * 3)
+    q.put((r, lo, hi, len(calls), dt, units, float(clips.abs().max())))
+    torch.distributed.destroy_process_group()
+
+
+def test_two_rank_gloo_scaffold():
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (r0, lo0, hi0, c0, dt0, u0, m0), (r1, lo1, hi1, c1, dt1, u1, m1) = res
+    assert (lo0, hi0, lo1, hi1) == (0, 4, 4, 7)          # disjoint cover of the 7 clips
+    assert c0 == c1 == 4                                  # 1 warm-up + exactly 3 timed steps
+    assert abs(dt0 - dt1) < 1e-9 and dt0 >= 3 * 0.04 * 0.9   # both report the slow rank's time
+    assert u0 == u1 == 21.0                               # (4 + 3) clips x 3 steps
+    assert m0 == m1 == 1.0                                # peak-normalised clips, different per rank
+
+
+def test_shard_clips_edge_cases():
+    sys.path.insert(0, REPO)
+    from facodec_amd.benchutil import shard_clips
+    assert [shard_clips(5, 8, r) for r in range(8)] == [(0, 1), (1, 2), (2, 3), (3, 4), (4, 5), (5, 5), (5, 5), (5, 5)]
+    assert shard_clips(0, 2, 1) == (0, 0)
+    assert [shard_clips(64, 2, r) for r in range(2)] == [(0, 32), (32, 64)]

@@ -1,0 +1,324 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle on the same seeded
+inputs, and against the golden vectors produced by the real reference.
+
+Bars (BASELINE.json north_star): code indices bit-exact; waveform / latents / losses within 1e-4
+relative fp32.  Per-op tolerances below are tighter (1e-5) because single ops sit at the fp32
+noise floor.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from facodec_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OP_TOL = 1e-5
+E2E_TOL = 1e-4
+
+
+def rel(a, b):
+    a, b = torch.as_tensor(a).detach().double().cpu(), torch.as_tensor(b).detach().double().cpu()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import facodec_oracle
+    return facodec_oracle
+
+
+@pytest.fixture(scope="module")
+def ops(cuda):
+    from facodec_amd import ops as _ops
+    from facodec_amd import _lib
+    _lib.load()  # fails loudly if the extension is missing
+    return _ops
+
+
+def _g(seed=0):
+    return torch.Generator().manual_seed(seed)
+
+
+CONV_CASES = [
+    # B, Cin, Cout, T, k, stride, dil, snake_in, snake_out, res, act, pad_mode
+    (2, 64, 64, 1000, 7, 1, 1, False, False, False, 0, "reflect"),
+    (2, 128, 128, 777, 7, 1, 3, True, True, False, 0, "reflect"),
+    (1, 96, 96, 500, 7, 1, 9, True, False, False, 0, "reflect"),
+    (2, 192, 192, 300, 1, 1, 1, False, False, True, 0, "reflect"),
+    (2, 1, 64, 2400, 7, 1, 1, False, False, False, 0, "reflect"),
+    (2, 64, 128, 2400, 4, 2, 1, True, False, False, 0, "reflect"),
+    (2, 128, 256, 1201, 10, 5, 1, True, False, False, 0, "reflect"),   # ragged: extra right padding
+    (1, 512, 1024, 960, 12, 6, 1, False, False, False, 0, "reflect"),
+    (1, 1024, 1024, 160, 3, 1, 1, True, False, False, 0, "reflect"),
+    (2, 96, 1, 3000, 7, 1, 1, True, False, False, 1, "reflect"),
+    (1, 8, 16, 5, 7, 1, 1, False, False, False, 0, "reflect"),        # input shorter than the pad
+    (3, 20, 256, 33, 1, 1, 1, False, False, False, 0, "zero"),
+    (1, 1024, 1536, 160, 7, 1, 1, False, False, False, 0, "reflect"),
+    (5, 256, 512, 32, 1, 1, 1, False, False, False, 0, "reflect"),     # narrow-N tile (LSTM projections)
+    (1, 37, 45, 129, 5, 1, 2, True, True, True, 0, "reflect"),        # odd everything
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: "B%d_%dto%d_T%d_k%d_s%d_d%d" % c[:7])
+def test_conv1d_against_oracle(case, O, ops, cuda):
+    B, ci, co, T, k, s, d, sin, sout, res, act, pad_mode = case
+    g = _g(ci * 131 + co)
+    x = torch.randn(B, ci, T, generator=g)
+    w = torch.randn(co, ci, k, generator=g) / (ci * k) ** 0.5
+    b = torch.randn(co, generator=g) * 0.1
+    ai = 1 + 0.2 * torch.rand(ci, generator=g) if sin else None
+    ao = 1 + 0.2 * torch.rand(co, generator=g) if sout else None
+    xi = O.snake(x, ai.view(1, -1, 1)) if sin else x
+    y = O.sconv1d(xi, w, b, stride=s, dilation=d, causal=True, pad_mode=pad_mode)
+    if sout:
+        y = O.snake(y, ao.view(1, -1, 1))
+    if act == 1:
+        y = torch.tanh(y)
+    r = torch.randn(*y.shape, generator=g) if res else None
+    if res:
+        y = y + r
+    wp = ops.pack_conv_weight(w.to(cuda))
+    yg = ops.conv1d(x.to(cuda), wp, co, k, bias=b.to(cuda), stride=s, dilation=d,
+                    pad_mode=ops.PAD_REFLECT if pad_mode == "reflect" else ops.PAD_ZERO,
+                    alpha_in=ai.to(cuda) if sin else None, alpha_out=ao.to(cuda) if sout else None,
+                    res=r.to(cuda) if res else None, act=act)
+    assert yg.shape == y.shape
+    assert rel(yg, y) < OP_TOL
+
+
+@pytest.mark.parametrize("B,ci,co,T,s", [(2, 256, 128, 160, 6), (2, 128, 64, 333, 5), (1, 192, 96, 1000, 2), (1, 24, 12, 7, 5)])
+def test_conv_transpose_against_oracle(B, ci, co, T, s, O, ops, cuda):
+    g = _g(s)
+    x = torch.randn(B, ci, T, generator=g)
+    v = torch.randn(ci, co, 2 * s, generator=g) / (ci * 2) ** 0.5
+    gg = torch.rand(ci, 1, 1, generator=g) + 0.5
+    b = torch.randn(co, generator=g) * 0.1
+    al = 1 + 0.2 * torch.rand(ci, generator=g)
+    y = O.sconvtr1d(O.snake(x, al.view(1, -1, 1)), O.weight_norm_weight(v, gg), b, s, causal=True)
+    wp = ops.pack_convtr_weight(v.to(cuda), gg.to(cuda), s)
+    yg = ops.conv_transpose1d(x.to(cuda), wp, co, s, bias=b.to(cuda), alpha_in=al.to(cuda))
+    assert yg.shape == y.shape and rel(yg, y) < OP_TOL
+
+
+def test_conv_is_linear_in_its_input(ops, cuda):
+    """Size-independent property at a full-size layer shape: conv(a x1 + b x2) == a conv(x1) + b conv(x2)."""
+    g = _g(9)
+    w = torch.randn(192, 192, 7, generator=g).to(cuda) / 36.0
+    wp = ops.pack_conv_weight(w)
+    x1 = torch.randn(2, 192, 24000, generator=g).to(cuda)
+    x2 = torch.randn(2, 192, 24000, generator=g).to(cuda)
+    y = ops.conv1d(2.0 * x1 + 0.5 * x2, wp, 192, 7, dilation=9)
+    y12 = 2.0 * ops.conv1d(x1, wp, 192, 7, dilation=9) + 0.5 * ops.conv1d(x2, wp, 192, 7, dilation=9)
+    assert rel(y, y12) < 1e-5
+
+
+def test_weight_norm_packing(O, ops, cuda):
+    g = _g(3)
+    v = torch.randn(96, 48, 7, generator=g)
+    gg = torch.rand(96, 1, 1, generator=g) + 0.5
+    wp = ops.pack_conv_weight(v.to(cuda), gg.to(cuda))
+    assert wp.shape == (48, 7, 96)
+    assert rel(wp.permute(2, 0, 1), O.weight_norm_weight(v, gg)) < 1e-6
+    v2 = torch.randn(40, 8, 1, generator=g)                      # C_out padded 40 -> 64 with zeros
+    wp2 = ops.pack_conv_weight(v2.to(cuda))
+    assert wp2.shape == (8, 1, 64) and float(wp2[:, :, 40:].abs().max()) == 0.0
+
+
+def test_snake_standalone(O, ops, cuda):
+    g = _g(4)
+    x = torch.randn(2, 33, 777, generator=g) * 3
+    al = 1 + 0.3 * torch.rand(33, generator=g)
+    assert rel(ops.snake(x.to(cuda), al.to(cuda)), O.snake(x, al.view(1, -1, 1))) < 1e-6
+
+
+@pytest.mark.parametrize("B,H,T", [(3, 128, 20), (32, 256, 40), (2, 1024, 16), (33, 64, 5)])
+def test_slstm_against_oracle(B, H, T, O, cuda):
+    from facodec_amd.layers import SLSTM
+    m = SLSTM(H, 2)
+    sd = synth.load_synthetic(m, seed=5)
+    x = torch.randn(B, H, T, generator=_g(H))
+    y = O.slstm(x, sd, "lstm.", 2)
+    with torch.no_grad():
+        yg = m.to(cuda)(x.to(cuda))
+    assert rel(yg, y) < OP_TOL
+
+
+def test_vq_search_known_answers_and_sweep(ops, cuda, golden_dir):
+    """Bit-exact code indices on the reference's own answers: ties -> lowest index, zero latent,
+    262 144 random vectors (0 mismatches required)."""
+    d = np.load(os.path.join(golden_dir, "vq_kat.npz"))
+    cb = torch.from_numpy(d["codebook"]).to(cuda)
+    lat = torch.from_numpy(d["latents"])
+    idx = ops.vq_search(lat.permute(0, 2, 1).reshape(-1, 8).contiguous().to(cuda), cb).cpu().reshape(4, 300)
+    assert torch.equal(idx, torch.from_numpy(d["indices"].astype(np.int64)))
+    g = np.random.Generator(np.random.Philox(key=int(d["sweep_key"])))
+    g.standard_normal((1024, 8)); g.standard_normal((4, 8, 300))
+    big = torch.from_numpy(g.standard_normal((1, 8, 1 << 18)).astype(np.float32))
+    idx2 = ops.vq_search(big[0].t().contiguous().to(cuda), cb).cpu()
+    assert torch.equal(idx2, torch.from_numpy(d["sweep_indices"].astype(np.int64)))
+
+
+def test_vq_search_idempotent_on_codebook_rows(ops, cuda):
+    """Property: quantizing a codebook row returns that row's index (rows distinct)."""
+    cb = torch.randn(1024, 8, generator=_g(11)).to(cuda)
+    idx = ops.vq_search(cb * 3.7, cb).cpu()
+    assert torch.equal(idx, torch.arange(1024))
+
+
+@pytest.mark.parametrize("B,D,T,n", [(3, 256, 150, 3), (1, 64, 7, 1), (2, 1024, 160, 2)])
+def test_rvq_forward_against_oracle(B, D, T, n, O, cuda):
+    from facodec_amd.quantize import ResidualVectorQuantize
+    m = ResidualVectorQuantize(D, n, 1024, 8).eval()
+    sd = synth.load_synthetic(m, seed=2)
+    z = torch.randn(B, D, T, generator=_g(D + T))
+    zq, codes, lat, cm, cb = O.rvq_forward(z, sd, "", n, n)
+    with torch.no_grad():
+        zq_g, codes_g, lat_g, cm_g, cb_g = m.to(cuda)(z.to(cuda), n)
+    assert torch.equal(codes_g.cpu(), codes)
+    assert rel(zq_g, zq) < OP_TOL and rel(lat_g, lat) < OP_TOL
+    assert abs(float(cm_g) - float(cm)) / float(cm) < 1e-5 and abs(float(cb_g) - float(cb)) / float(cb) < 1e-5
+
+
+def test_logmel_frontend_against_oracle(O, cuda):
+    """Parity-unpinned row (torchaudio semantics restated on both sides)."""
+    from facodec_amd.quantize import LogMelFrontend
+    w = synth.synth_clips(2, 48000, seed=0)
+    ref = O.logmel_frontend(w, 80)
+    with torch.no_grad():
+        out = LogMelFrontend().to(cuda)(w.to(cuda))
+    assert out.shape == ref.shape == (2, 80, 160)
+    assert rel(out, ref) < E2E_TOL
+
+
+def test_style_encoder_and_wavenet_against_oracle(O, cuda):
+    from facodec_amd.quantize import StyleEncoder, WN
+    se = StyleEncoder(80, 512, 1024)
+    sd = synth.load_synthetic(se, seed=7)
+    mel = torch.randn(3, 80, 50, generator=_g(1))
+    mask = torch.ones(3, 50)
+    mask[1, 30:] = 0
+    mask[2, 10:] = 0
+    ref = O.style_encoder_forward(mel, sd, "", mask.unsqueeze(1))
+    with torch.no_grad():
+        out = se.to(cuda)(mel.to(cuda), mask.to(cuda))
+        out_nomask = se(mel.to(cuda), None)
+    assert rel(out, ref) < OP_TOL
+    assert rel(out_nomask, O.style_encoder_forward(mel, sd, "")) < OP_TOL
+    wn = WN(256, 5, 1, 8, causal=True)
+    sdw = synth.load_synthetic(wn, seed=8)
+    x = torch.randn(2, 256, 160, generator=_g(2))
+    refw = O.wavenet_forward(x, sdw, "", 256, 8)
+    with torch.no_grad():
+        outw = wn.to(cuda)(x.to(cuda))
+    assert rel(outw, refw) < OP_TOL
+
+
+def test_small_encoder_decoder_vs_reference_golden(cuda, golden_dir):
+    from facodec_amd.dac_model import Decoder, Encoder
+    d = np.load(os.path.join(golden_dir, "small_layers.npz"))
+    enc = Encoder(d_model=8, strides=[2, 5, 5, 6], d_latent=64, causal=True, lstm=2)
+    dec = Decoder(input_channel=64, channels=128, rates=[6, 5, 5, 2], causal=True, lstm=2)
+    synth.load_synthetic(enc, seed=1, prefix="encoder.")
+    synth.load_synthetic(dec, seed=1, prefix="decoder.")
+    with torch.no_grad():
+        z = enc.to(cuda)(torch.from_numpy(d["x"]).to(cuda))
+        y = dec.to(cuda)(torch.from_numpy(d["z"]).to(cuda))
+    assert rel(z, d["z"]) < E2E_TOL and rel(y, d["y"]) < E2E_TOL
+
+
+@pytest.fixture(scope="module")
+def full_model(cuda):
+    from facodec_amd.commons import build_model, default_model_params
+    model = build_model(default_model_params())
+    for k in model:
+        synth.load_synthetic(model[k], seed=0, prefix=k + ".")
+        model[k].eval().to(cuda)
+    return model
+
+
+def test_end_to_end_vs_reference_golden(full_model, cuda, golden_dir):
+    """configs[0]/[1] shape: 2 s clips through encoder -> FA-quantizer -> decoder with the
+    reconstruct.py call sequence (:56-61).  Codes bit-exact, everything else within 1e-4."""
+    d = np.load(os.path.join(golden_dir, "codec_e2e.npz"))
+    wave = synth.synth_clips(2, 48000, seed=0).to(cuda)
+    m = full_model
+    with torch.no_grad():
+        z = m.encoder(wave)
+        outs, quantized, commit, cbl, timbre, codes = m.quantizer(z, wave, n_c=2, return_codes=True)
+        y = m.decoder(outs)
+    assert z.shape == (2, 1024, 160) and y.shape == (2, 1, 48000)
+    for nm, c in zip(("codes_p", "codes_c", "codes_r"), codes):
+        assert c.dtype == torch.int64
+        assert torch.equal(c.cpu(), torch.from_numpy(d[nm].astype(np.int64))), nm
+    assert rel(z[:, ::8], d["z_probe"]) < E2E_TOL
+    assert rel(timbre, d["timbre"]) < E2E_TOL
+    assert rel(outs[:, ::8], d["outs_probe"]) < E2E_TOL
+    for nm, q in zip(("zq_p_probe", "zq_c_probe", "zq_r_probe"), quantized):
+        assert rel(q[:, ::16], d[nm]) < E2E_TOL
+    assert rel(y[:, 0, torch.from_numpy(d["probe_t"])], d["wave_probe"]) < E2E_TOL
+    assert abs(float(commit) - float(d["commitment"])) / float(d["commitment"]) < E2E_TOL
+    assert abs(float(cbl) - float(d["codebook"])) / float(d["codebook"]) < E2E_TOL
+
+
+def test_five_tuple_return_and_batch_independence(full_model, cuda):
+    """reconstruct.py:57-59 unpacks 5 values; clips are independent units: running a clip
+    alone or inside a batch gives the same codes and (to fp32 noise) the same waveform."""
+    m = full_model
+    wave = synth.synth_clips(3, 48000, seed=5).to(cuda)
+    with torch.no_grad():
+        z = m.encoder(wave)
+        out5 = m.quantizer(z, wave, n_c=2)
+        assert len(out5) == 5
+        outs, _, _, _, _, codes = m.quantizer(z, wave, n_c=2, return_codes=True)
+        y = m.decoder(outs)
+        z1 = m.encoder(wave[1:2])
+        o1, _, _, _, _, c1 = m.quantizer(z1, wave[1:2], n_c=2, return_codes=True)
+        y1 = m.decoder(o1)
+    for a, b in zip(codes, c1):
+        assert torch.equal(a[1:2], b)
+    assert rel(y[1:2], y1) < 1e-5
+
+
+def test_causality_of_encoder_and_decoder(full_model, cuda):
+    """perturbing samples >= 24000 changes encoder frames >= 80 only."""
+    m = full_model
+    wave = synth.synth_clips(1, 48000, seed=6).to(cuda)
+    w2 = wave.clone()
+    w2[..., 24000:] += 0.1 * torch.randn(1, 1, 24000, device=cuda)
+    with torch.no_grad():
+        za, zb = m.encoder(wave), m.encoder(w2)
+        assert float((za[..., :80] - zb[..., :80]).abs().max()) == 0.0
+        assert float((za[..., 80:] - zb[..., 80:]).abs().max()) > 0.0
+        lat = torch.randn(1, 1024, 160, device=cuda)
+        l2 = lat.clone()
+        l2[..., 80:] += 0.1
+        ya, yb = m.decoder(lat), m.decoder(l2)
+        assert float((ya[..., :24000] - yb[..., :24000]).abs().max()) == 0.0
+
+
+def test_full_waves_timbre_path(full_model, O, cuda):
+    """train.py:266-269 calls the quantizer with full_waves / wave_lens (masked timbre)."""
+    m = full_model
+    wave = synth.synth_clips(2, 24000, seed=8).to(cuda)
+    full = synth.synth_clips(2, 36000, seed=9)[:, 0].to(cuda)
+    lens = torch.tensor([36000, 21000], device=cuda)
+    sd = {k: v.detach().cpu() for k, v in m.quantizer.state_dict().items()}
+    with torch.no_grad():
+        z = m.encoder(wave)
+        outs, _, _, _, timbre, codes = m.quantizer(z, wave, n_c=2, full_waves=full, wave_lens=lens, return_codes=True)
+        ref = O.quantizer_forward(sd, z.cpu(), wave.cpu(), n_c=2, full_waves=full.cpu(), wave_lens=lens.cpu())
+    assert rel(timbre, ref[4]) < E2E_TOL and rel(outs, ref[0]) < E2E_TOL
+    for a, b in zip(codes, ref[5]):
+        assert torch.equal(a.cpu(), b)
+
+
+def test_missing_extension_fails_loudly(monkeypatch):
+    from facodec_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libfacodec_hip.so")
+    with pytest.raises(_lib.FacodecHipError):
+        _lib.load()
