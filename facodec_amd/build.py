@@ -8,7 +8,8 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libfacodec_hip.so")
-SOURCES = ["conv1d_mfma.hip", "pack.hip", "lstm.hip", "vq.hip", "misc.hip"]
+SOURCES = ["conv1d_api.hip", "conv1d_tile_128x128.hip", "conv1d_tile_96x128.hip", "conv1d_tile_64x128.hip",
+           "conv1d_tile_32x256.hip", "conv1d_tile_128x32.hip", "pack.hip", "lstm.hip", "vq.hip", "misc.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
          "-Wno-unused-result"]
 
@@ -29,7 +30,7 @@ def _stale(target, deps):
 
 def build_lib(force=False, verbose=True):
     hipcc = _hipcc()
-    headers = [os.path.join(CSRC, "common.h"), os.path.join(HERE, "..", "include", "facodec_hip.h")]
+    headers = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "conv1d_mfma.h"), os.path.join(HERE, "..", "include", "facodec_hip.h")]
     objs, jobs = [], []
     os.makedirs(os.path.join(CSRC, "build"), exist_ok=True)
     for src in SOURCES:

@@ -1,0 +1,63 @@
+// C-ABI entry points of the MFMA conv (kernel: conv1d_mfma.h; instantiations: conv1d_tile_*.hip).
+#include "conv1d_mfma.h"
+
+namespace fac {
+
+// Tile selection: M tile by output channels, narrow-N tile for short sequences (LSTM batches).
+static int select_variant(const fac_conv_desc* d) {
+  const int co = d->C_out;
+  if (d->T_out <= 32) return 0;
+  if (co <= 32) return 1;
+  if (co <= 64) return 2;
+  if (co % 128 != 0 && co % 96 == 0) return 3;
+  return 4;
+}
+
+}  // namespace fac
+
+extern "C" int fac_conv1d_fwd(const fac_conv_desc* d, fac_stream_t stream) {
+  using namespace fac;
+  FAC_REQUIRE(d && d->x && d->w && d->y, "conv1d: null pointer");
+  FAC_REQUIRE(d->B > 0 && d->C_in > 0 && d->C_out > 0 && d->T_in > 0 && d->T_out > 0,
+              "conv1d: bad shape B=%d C_in=%d C_out=%d T_in=%d T_out=%d", d->B, d->C_in, d->C_out,
+              d->T_in, d->T_out);
+  FAC_REQUIRE(d->K >= 1 && d->stride >= 1 && d->dilation >= 1 && d->pad_left >= 0,
+              "conv1d: bad K/stride/dilation/pad");
+  FAC_REQUIRE(d->C_out_pad % 32 == 0 && d->C_out_pad >= d->C_out, "conv1d: C_out_pad must be a multiple of 32");
+  FAC_REQUIRE(d->n_phase >= 1 && d->y_tstride >= 1, "conv1d: bad phase config");
+  FAC_REQUIRE((long long)d->B * d->n_phase <= 65535, "conv1d: B*n_phase too large for grid.z");
+  ConvArgs a;
+  a.x = d->x; a.w = d->w; a.bias = d->bias; a.alpha_in = d->alpha_in; a.alpha_out = d->alpha_out;
+  a.res = d->res; a.y = d->y;
+  a.x_bs = d->x_bs; a.x_cs = d->x_cs; a.y_bs = d->y_bs; a.y_cs = d->y_cs; a.w_bs = d->w_bs;
+  a.B = d->B; a.C_in = d->C_in; a.T_in = d->T_in; a.C_out = d->C_out; a.C_out_pad = d->C_out_pad;
+  a.T_out = d->T_out; a.K = d->K; a.stride = d->stride; a.dil = d->dilation;
+  a.pad_left = d->pad_left; a.pad_mode = d->pad_mode; a.n_phase = d->n_phase;
+  a.y_tstride = d->y_tstride; a.act = d->act; a.w_batched = d->w_batched;
+  // length of pad1d's temporary zero extension (only differs from T_in for inputs shorter than the pad)
+  {
+    long long last = (long long)(d->T_out - 1) * d->stride + (long long)(d->K - 1) * d->dilation - d->pad_left;
+    int pad_right = last >= d->T_in ? (int)(last - d->T_in + 1) : 0;
+    int max_pad = d->pad_left > pad_right ? d->pad_left : pad_right;
+    a.T_ext = d->T_in > max_pad ? d->T_in : max_pad + 1;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  switch (select_variant(d)) {
+    case 0: return conv_dispatch_128x32(a, s);
+    case 1: return conv_dispatch_32x256(a, s);
+    case 2: return conv_dispatch_64x128(a, s);
+    case 3: return conv_dispatch_96x128(a, s);
+    default: return conv_dispatch_128x128(a, s);
+  }
+}
+
+extern "C" int fac_conv1d_variant(const fac_conv_desc* d, char* name, int name_len) {
+  using namespace fac;
+  FAC_REQUIRE(d, "conv1d_variant: null descriptor");
+  static const char* names[] = {"conv1d_mfma_kernel<1,1,4,1,K> 128x32", "conv1d_mfma_kernel<1,2,1,4,K> 32x256",
+                                "conv1d_mfma_kernel<2,1,1,4,K> 64x128", "conv1d_mfma_kernel<3,1,1,4,K> 96x128",
+                                "conv1d_mfma_kernel<2,2,2,2,K> 128x128"};
+  const int v = select_variant(d);
+  if (name && name_len > 0) snprintf(name, name_len, "%s", names[v]);
+  return v;
+}
