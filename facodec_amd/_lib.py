@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libfacodec_hip.so")
+LIB_PATH = os.environ.get("FAC_LIB_PATH", os.path.join(_HERE, "libfacodec_hip.so"))
 
 PAD_ZERO, PAD_REFLECT = 0, 1
 ACT_NONE, ACT_TANH, ACT_MISH, ACT_LOG_MEL = 0, 1, 2, 3

@@ -10,14 +10,15 @@
 //   N = T_out (B operand: the LDS-staged receptive-field tile, time fastest)
 //   K = C_in*K taps, consumed two input channels at a time (the 32x32x2 k-pair = lanes 0-31 / 32-63)
 //
-// One workgroup (4 waves) owns a CO_TILE x T_TILE output tile of one (batch, phase) and walks C_in
-// in chunks of `cic` channels.  Per chunk:
-//   * the weight slab [cic][K][CO_TILE] goes HBM/L2 -> LDS by LDS-DMA (global_load_lds, 16 B/lane,
-//     no VGPR round trip), issued BEFORE the MFMA block of the previous chunk;
-//   * the input slab [cic][XW] (receptive field incl. halo, reflect/zero padded) is loaded into
-//     registers before that MFMA block and written to LDS after it, with Snake applied on the
-//     way (once per staged element) -- so HBM/L2 latency hides under the matrix work;
-//   * LDS is double-buffered: one barrier per chunk.
+// One workgroup = 8 waves owns a CO_TILE x T_TILE output tile of one (batch, phase) and walks C_in
+// in chunks of `cic` channels.  The waves are specialised (a wave64 is in-order: its own VALU / VMEM
+// work would stall its MFMA stream, while a DIFFERENT wave's does not -- separate pipes per SIMD):
+//   * waves 0-3 ("MFMA waves") only read fragments from LDS and issue matrix instructions;
+//   * waves 4-7 ("staging waves") fill the other LDS stage meanwhile: the weight slab
+//     [cic][K][CO_TILE] by LDS-DMA (global_load_lds, 16 B/lane, no VGPR round trip) and the input
+//     slab [cic][XW] (receptive field incl. halo, reflect/zero padded) through registers, with
+//     Snake applied on the way in (once per staged element);
+//   * LDS is double-buffered: one workgroup barrier per chunk.
 // The tap loop is a compile-time unroll (template KT) so every LDS read has an immediate offset
 // and the compiler can run the ds_reads ahead of the MFMAs.
 #pragma once
@@ -29,7 +30,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(1))) const void glb_void_t;
 
-constexpr int CONV_XMAX = 14;  // staged input dwords held in registers per thread
+constexpr int CONV_XMAX = 6;   // staged input float4s held in registers per staging thread
 
 struct ConvArgs {
   const float* x;
@@ -47,47 +48,184 @@ struct ConvArgs {
   int XW;   // staged input width = (T_TILE-1)*stride + (K-1)*dil + 1
   int XB;   // 64-wide column blocks per staged row = ceil(XW/64)
   int XQ, XR;  // 4 / XB, 4 % XB: (row, block) advance of one wave per staging iteration
+  int n_t_tiles;
+  int x_off;   // columns staged to the left of the receptive field so that the slab starts 16-B aligned
 };
 
 template <int KT>
 struct ConvUnroll {
   static constexpr int UC = (KT == 1) ? 4 : ((KT == 2 || KT == 3) ? 2 : 1);  // channel pairs per unrolled body
+  // input channels per LDS stage when the tap count is a compile-time constant (0: chosen at run time)
+  static constexpr int CIC = KT == 1 ? 24 : (KT == 2 || KT == 3) ? 16 : (KT >= 4 && KT <= 7) ? 8 : (KT > 7 ? 4 : 0);
 };
 
+#ifndef FAC_CONV_WPE
+#define FAC_CONV_WPE 4
+#endif
 template <int MB, int NB, int WM, int WN, int KT>
-__global__ __launch_bounds__(256) void conv1d_mfma_kernel(ConvArgs a) {
+__global__ __launch_bounds__(512, FAC_CONV_WPE) void conv1d_mfma_kernel(ConvArgs a) {
   constexpr int CO_TILE = 32 * MB * WM;
   constexpr int T_TILE = 32 * NB * WN;
   constexpr int CO4 = CO_TILE / 4;
-  constexpr int UC = ConvUnroll<KT>::UC;
   extern __shared__ __attribute__((aligned(16))) float smem[];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int l31 = lane & 31;
-  const int kq = lane >> 5;
-  const int wm = wave / WN;
-  const int wn = wave % WN;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // 0-3: MFMA waves, 4-7: staging waves
 
-  const int t0 = blockIdx.x * T_TILE;
-  const int co0 = blockIdx.y * CO_TILE;
-  const int b = blockIdx.z / a.n_phase;
-  const int phase = blockIdx.z - b * a.n_phase;
+  // Work decode.  Workgroups are dispatched round-robin over the 8 XCDs (observed: block i -> XCD
+  // i % 8, speed only, never correctness): remap so that each XCD walks a CONTIGUOUS range of the tile
+  // list ordered (co-tile slowest, then batch/phase, then time tile).  The workgroups resident on one
+  // XCD then share one C_out tile, i.e. stream the same weight slabs through that XCD's private L2.
+  int t0, co0, b, phase;
+  {
+    const int n = gridDim.x;
+    const int q8 = n >> 3, r8 = n & 7;
+    const int xcd = blockIdx.x & 7, within = blockIdx.x >> 3;
+    const int id = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + within;
+    const int nt = a.n_t_tiles, nbp = a.B * a.n_phase;
+    const int tt = id % nt;
+    const int rest = id / nt;
+    const int bp = rest % nbp;
+    const int ct = rest / nbp;
+    t0 = tt * T_TILE;
+    co0 = ct * CO_TILE;
+    b = bp / a.n_phase;
+    phase = bp - b * a.n_phase;
+  }
 
   const int K = KT > 0 ? KT : a.K;
-  const int cic = a.cic, XW = a.XW, XB = a.XB;
+  const int cic = KT > 0 ? ConvUnroll<KT>::CIC : a.cic;
+  const int XW = a.XW, XB = a.XB;
   const int w_stage = cic * K * CO_TILE;  // floats
   const int x_stage = cic * XW;
   float* Wbuf = smem;                 // [2][cic][K][CO_TILE]
   float* Xbuf = smem + 2 * w_stage;   // [2][cic][XW]
-
-  const float* xg = a.x + (long long)b * a.x_bs;
-  const float* wg = a.w + (long long)phase * a.C_in * K * a.C_out_pad +
-                    (a.w_batched ? (long long)b * a.w_bs : 0ll);
-  const int tin0 = t0 * a.stride - a.pad_left;
   const int n_chunks = (a.C_in + cic - 1) / cic;
-  const int w_rows_total = a.C_in * K;
+
+  if (wave >= 4) {
+    // ===================== staging waves: HBM/L2 -> LDS for chunk c+1 while chunk c is multiplied
+    const int lw = wave - 4;
+    const float* xg = a.x + (long long)b * a.x_bs;
+    const float* wg = a.w + (long long)phase * a.C_in * K * a.C_out_pad +
+                      (a.w_batched ? (long long)b * a.w_bs : 0ll);
+    const int tin0 = t0 * a.stride - a.pad_left - a.x_off;   // multiple of 4 by construction
+    const int w_rows_total = a.C_in * K;
+    // float4 global loads need 16-B aligned rows: base pointer, batch and channel strides
+    const bool vec_ok = ((a.x_cs | a.x_bs) & 3) == 0 && ((reinterpret_cast<unsigned long long>(a.x) & 15) == 0);
+    const int r_first = lw / XB, cb_first = lw - r_first * XB;
+
+    auto stage = [&](int chunk, int buf) {
+      // weight slab by LDS-DMA: flat float4 index q -> (row, col4); 64 lanes = 1 KiB contiguous in
+      // LDS.  Rows past C_in*K and columns past C_out_pad are CLAMPED to valid (finite) weights: the
+      // former meet zero-filled input rows, the latter only feed output rows that are never stored.
+      {
+        const int n4 = cic * K * CO4;
+        const int row_base = chunk * cic * K;
+        float* dst0 = Wbuf + buf * w_stage;
+        for (int i = lw; i * 64 < n4; i += 4) {
+          const int q = i * 64 + lane;
+          if (q < n4) {
+            const int row = q / CO4;
+            const int c4 = q - row * CO4;
+            int grow = row_base + row;
+            grow = grow < w_rows_total ? grow : w_rows_total - 1;
+            int co = co0 + 4 * c4;
+            co = co < a.C_out_pad ? co : a.C_out_pad - 4;
+            const float* src = wg + (long long)grow * a.C_out_pad + co;
+            __builtin_amdgcn_global_load_lds((glb_void_t*)src, (lds_void_t*)(dst0 + i * 256), 16, 0, 0);
+          }
+        }
+      }
+      // input slab: slot j of this wave covers row r, float4 column cb*64 + lane; all loads are
+      // issued first, then Snake is applied on the way into LDS (once per staged element).
+      // Interior + 16-B aligned rows move as float4; edges (reflection / zero padding / ragged ends)
+      // fall back to per-element indexing.
+      const int ci0 = chunk * cic;
+      const int XW4 = XW >> 2;
+      float4 xr[CONV_XMAX];
+      float xal[CONV_XMAX];
+      {
+        int r = r_first, cb = cb_first;
+#pragma unroll
+        for (int j = 0; j < CONV_XMAX; ++j) {
+          float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+          float al = 0.f;
+          const int c4 = cb * 64 + lane;
+          const int ci = ci0 + r;
+          if (r < cic && c4 < XW4 && ci < a.C_in) {
+            const int tin = tin0 + 4 * c4;
+            const float* xrow = xg + (long long)ci * a.x_cs;
+            if (vec_ok && tin >= 0 && tin + 3 < a.T_in) {
+              v = *reinterpret_cast<const float4*>(xrow + tin);
+            } else {
+              float e[4];
+#pragma unroll
+              for (int u = 0; u < 4; ++u) {
+                int idx;
+                if (a.pad_mode == FAC_PAD_REFLECT) idx = reflect_index(tin + u, a.T_in, a.T_ext);
+                else idx = (tin + u >= 0 && tin + u < a.T_in) ? tin + u : -1;
+                e[u] = idx >= 0 ? xrow[idx] : 0.f;
+              }
+              v = make_float4(e[0], e[1], e[2], e[3]);
+            }
+            if (a.alpha_in != nullptr) al = a.alpha_in[ci];
+          }
+          xr[j] = v;
+          xal[j] = al;
+          r += a.XQ;
+          cb += a.XR;
+          if (cb >= XB) { cb -= XB; ++r; }
+        }
+      }
+      {
+        float* dst = Xbuf + buf * x_stage;
+        int r = r_first, cb = cb_first;
+#pragma unroll
+        for (int j = 0; j < CONV_XMAX; ++j) {
+          const int c4 = cb * 64 + lane;
+          if (r < cic && c4 < XW4) {
+            float4 v = xr[j];
+            if (a.alpha_in != nullptr) {   // snake(0) == 0 keeps the zero fill
+              const float al = xal[j], inv = snake_inv(al);
+              v.x = snake_apply(v.x, al, inv);
+              v.y = snake_apply(v.y, al, inv);
+              v.z = snake_apply(v.z, al, inv);
+              v.w = snake_apply(v.w, al, inv);
+            }
+            *reinterpret_cast<float4*>(dst + r * XW + 4 * c4) = v;
+          }
+          r += a.XQ;
+          cb += a.XR;
+          if (cb >= XB) { cb -= XB; ++r; }
+        }
+      }
+    };
+
+    stage(0, 0);
+    __syncthreads();   // the barrier's release also drains the LDS-DMA (vmcnt(0))
+    for (int chunk = 0; chunk < n_chunks; ++chunk) {
+#ifndef FAC_ABL_NOSTAGE
+      if (chunk + 1 < n_chunks) stage(chunk + 1, (chunk & 1) ^ 1);
+#endif
+#ifndef FAC_ABL_NOBAR
+      __syncthreads();
+#endif
+    }
+    return;
+  }
+
+  // ========================= MFMA waves
+  // Both roles share each SIMD's issue logic: without a priority the staging waves' VALU stream
+  // (index math, Snake) delays MFMA issue by ~25 % (ablation in profiles/).  MFMA waves therefore run
+  // at raised priority for their whole life; the staging waves fill the 64-cycle MFMA shadows.
+#ifndef FAC_ABL_NOPRIO
+  __builtin_amdgcn_s_setprio(3);
+#endif
+  const int l31 = lane & 31;
+  const int kq = lane >> 5;
+  const int wm = wave / WN;
+  const int wn = wave % WN;
 
   f32x16 acc[MB][NB];
 #pragma unroll
@@ -97,114 +235,54 @@ __global__ __launch_bounds__(256) void conv1d_mfma_kernel(ConvArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
 
-  // ---- weight slab by LDS-DMA: flat float4 index q -> (row, col4); 64 lanes = 1 KiB contiguous in LDS.
-  // Rows past C_in*K and columns past C_out_pad are CLAMPED to valid weights (finite values): the
-  // former meet zero-filled input rows, the latter only feed output rows that are never stored.
-  auto issue_w = [&](int chunk, int buf) {
-    const int n4 = cic * K * CO4;
-    const int row_base = chunk * cic * K;
-    float* dst0 = Wbuf + buf * w_stage;
-    for (int i = wave; i * 64 < n4; i += 4) {
-      const int q = i * 64 + lane;
-      if (q < n4) {
-        const int row = q / CO4;
-        const int c4 = q - row * CO4;
-        int grow = row_base + row;
-        grow = grow < w_rows_total ? grow : w_rows_total - 1;
-        int co = co0 + 4 * c4;
-        co = co < a.C_out_pad ? co : a.C_out_pad - 4;
-        const float* src = wg + (long long)grow * a.C_out_pad + co;
-        __builtin_amdgcn_global_load_lds((glb_void_t*)src, (lds_void_t*)(dst0 + i * 256), 16, 0, 0);
-      }
-    }
-  };
-
-  // ---- input slab: iteration `it` (wave-uniform) covers row it/XB, columns (it%XB)*64 + lane
-  float xr[CONV_XMAX];
-  const int it_r0 = wave / XB, it_c0 = wave - it_r0 * XB;   // this wave's first (row, column block)
-  auto load_x = [&](int chunk) {
-    const int ci0 = chunk * cic;
-    int r = it_r0, cb = it_c0;
-#pragma unroll
-    for (int j = 0; j < CONV_XMAX; ++j) {
-      float v = 0.f;
-      const int c = cb * 64 + lane;
-      const int ci = ci0 + r;
-      if (r < cic && c < XW && ci < a.C_in) {
-        const int tin = tin0 + c;
-        int idx;
-        if (a.pad_mode == FAC_PAD_REFLECT) idx = reflect_index(tin, a.T_in, a.T_ext);
-        else idx = (tin >= 0 && tin < a.T_in) ? tin : -1;
-        if (idx >= 0) v = xg[(long long)ci * a.x_cs + idx];
-      }
-      xr[j] = v;
-      r += a.XQ;
-      cb += a.XR;
-      if (cb >= XB) { cb -= XB; ++r; }
-    }
-  };
-  auto store_x = [&](int chunk, int buf) {
-    const int ci0 = chunk * cic;
-    float* dst = Xbuf + buf * x_stage;
-    int r = it_r0, cb = it_c0;
-#pragma unroll
-    for (int j = 0; j < CONV_XMAX; ++j) {
-      const int c = cb * 64 + lane;
-      if (r < cic && c < XW) {
-        float v = xr[j];
-        if (a.alpha_in != nullptr) {
-          const int ci = ci0 + r;
-          const float al = a.alpha_in[ci < a.C_in ? ci : a.C_in - 1];
-          v = snake_apply(v, al, snake_inv(al));   // snake(0) == 0 keeps the zero fill
-        }
-        dst[r * XW + c] = v;
-      }
-      r += a.XQ;
-      cb += a.XR;
-      if (cb >= XB) { cb -= XB; ++r; }
-    }
-  };
-
-  issue_w(0, 0);
-  load_x(0);
-  store_x(0, 0);
-  __syncthreads();
-
   const int a_off = wm * (MB * 32) + l31;                 // column inside the weight row
-  const int b_off = (wn * (NB * 32) + l31) * a.stride;    // time offset inside the input row
+  const int b_off = (wn * (NB * 32) + l31) * a.stride + a.x_off;   // time offset inside the input row
   const int wrow_stride = K * CO_TILE;                    // floats per input channel in Wbuf
   const int dil = a.dil;
   const int nstride = 32 * a.stride;
 
+  __syncthreads();   // chunk 0 staged
   for (int chunk = 0; chunk < n_chunks; ++chunk) {
     const int buf = chunk & 1;
-    const bool has_next = chunk + 1 < n_chunks;
-    if (has_next) {
-      issue_w(chunk + 1, buf ^ 1);
-      load_x(chunk + 1);
-    }
     const float* Wb = Wbuf + buf * w_stage + a_off + kq * wrow_stride;
     const float* Xb = Xbuf + buf * x_stage + b_off + kq * XW;
     if constexpr (KT > 0) {
-      for (int c2 = 0; c2 < cic; c2 += 2 * UC) {
+      // Straight-line chunk: P = CIC/2*KT (channel pair, tap) positions of MB*NB MFMAs each.  The
+      // fragments of position p+2 are requested from LDS before the MFMAs of position p are issued
+      // (3-deep register ring, static indices), so ds_read latency never stalls the matrix pipe.
+      constexpr int CICc = ConvUnroll<KT>::CIC;
+      constexpr int P = CICc / 2 * KT;
+      float av[3][MB], bv[3][NB];
+      auto ldfrag = [&](int pos, float* avp, float* bvp) {
+        const int c2 = (pos / KT) * 2, kk = pos % KT;
+#ifdef FAC_ABL_NOLDS
 #pragma unroll
-        for (int u = 0; u < UC; ++u) {
-          const float* wp = Wb + (c2 + 2 * u) * wrow_stride;
-          const float* xp = Xb + (c2 + 2 * u) * XW;
+        for (int m = 0; m < MB; ++m) avp[m] = (float)(pos + m) * 1e-3f + (float)lane;
 #pragma unroll
-          for (int kk = 0; kk < KT; ++kk) {
-            float av[MB], bv[NB];
+        for (int n = 0; n < NB; ++n) bvp[n] = (float)(pos - n) * 1e-3f;
+#else
 #pragma unroll
-            for (int m = 0; m < MB; ++m) av[m] = wp[kk * CO_TILE + m * 32];
+        for (int m = 0; m < MB; ++m) avp[m] = Wb[c2 * wrow_stride + kk * CO_TILE + m * 32];
 #pragma unroll
-            for (int n = 0; n < NB; ++n) bv[n] = xp[kk * dil + n * nstride];
+        for (int n = 0; n < NB; ++n) bvp[n] = Xb[c2 * XW + kk * dil + n * nstride];
+#endif
+      };
+      ldfrag(0, av[0], bv[0]);
+      if constexpr (P > 1) ldfrag(1, av[1], bv[1]);
 #pragma unroll
-            for (int m = 0; m < MB; ++m)
+      for (int pos = 0; pos < P; ++pos) {
+        if (pos + 2 < P) ldfrag(pos + 2, av[(pos + 2) % 3], bv[(pos + 2) % 3]);
+        __builtin_amdgcn_sched_barrier(0);   // keep the reads two positions ahead of their MFMAs
 #pragma unroll
-              for (int n = 0; n < NB; ++n)
-                acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m], bv[n], acc[m][n], 0, 0, 0);
-          }
-        }
+        for (int m = 0; m < MB; ++m)
+#pragma unroll
+          for (int n = 0; n < NB; ++n)
+#ifdef FAC_ABL_NOMFMA
+            acc[m][n][pos & 15] += av[pos % 3][m] * bv[pos % 3][n];
+#else
+            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[pos % 3][m], bv[pos % 3][n], acc[m][n], 0, 0, 0);
+#endif
+        __builtin_amdgcn_sched_barrier(0);
       }
     } else {
       for (int c2 = 0; c2 < cic; c2 += 2) {
@@ -225,8 +303,9 @@ __global__ __launch_bounds__(256) void conv1d_mfma_kernel(ConvArgs a) {
         }
       }
     }
-    if (has_next) store_x(chunk + 1, buf ^ 1);
-    __syncthreads();   // also drains the LDS-DMA of the next weight slab (vmcnt(0))
+#ifndef FAC_ABL_NOBAR
+    __syncthreads();
+#endif
   }
 
   // ---- epilogue: C/D layout col = lane&31 (time), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (co)
@@ -235,32 +314,41 @@ __global__ __launch_bounds__(256) void conv1d_mfma_kernel(ConvArgs a) {
 #pragma unroll
   for (int m = 0; m < MB; ++m) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int co = co0 + wm * (MB * 32) + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * kq;
-      if (co >= a.C_out) continue;
-      const float bsv = a.bias ? a.bias[co] : 0.f;
-      float al = 0.f, inv = 0.f;
-      if (a.alpha_out) {
-        al = a.alpha_out[co];
-        inv = snake_inv(al);
+    for (int g = 0; g < 4; ++g) {
+      // rows 8g..8g+3 (+4 for the upper half-wave): issue every independent load of the group first
+      // (bias, Snake alpha, residuals -- y may alias res, so the compiler will not hoist residual
+      // loads above stores on its own), then do the math and the stores.
+      float bsv[4], alv[4], rv[4][NB];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int co = co0 + wm * (MB * 32) + m * 32 + i + 8 * g + 4 * kq;
+        const int cc = co < a.C_out ? co : a.C_out - 1;
+        bsv[i] = a.bias ? a.bias[cc] : 0.f;
+        alv[i] = a.alpha_out ? a.alpha_out[cc] : 0.f;
+#pragma unroll
+        for (int n = 0; n < NB; ++n) {
+          const int t = t0 + wn * (NB * 32) + n * 32 + l31;
+          rv[i][n] = (rg && co < a.C_out && t < a.T_out)
+                         ? rg[(long long)co * a.y_cs + (long long)t * a.y_tstride + phase] : 0.f;
+        }
       }
 #pragma unroll
-      for (int n = 0; n < NB; ++n) {
-        const int t = t0 + wn * (NB * 32) + n * 32 + l31;
-        if (t >= a.T_out) continue;
-        float v = acc[m][n][r] + bsv;
-        if (a.alpha_out) v = snake_apply(v, al, inv);
-        if (a.act == FAC_ACT_TANH) v = tanhf(v);
-        else if (a.act == FAC_ACT_MISH) {
-          // x * tanh(softplus(x)); softplus with torch's threshold 20
-          float sp = v > 20.f ? v : log1pf(expf(v));
-          v = v * tanhf(sp);
-        } else if (a.act == FAC_ACT_LOG_MEL) {
-          v = (logf(1e-5f + v) + 4.0f) / 4.0f;
+      for (int i = 0; i < 4; ++i) {
+        const int r = 4 * g + i;
+        const int co = co0 + wm * (MB * 32) + m * 32 + i + 8 * g + 4 * kq;
+        if (co >= a.C_out) continue;
+        const float al = alv[i];
+        const float inv = a.alpha_out ? snake_inv(al) : 0.f;
+#pragma unroll
+        for (int n = 0; n < NB; ++n) {
+          const int t = t0 + wn * (NB * 32) + n * 32 + l31;
+          if (t >= a.T_out) continue;
+          float v = acc[m][n][r] + bsv[i];
+          if (a.alpha_out) v = snake_apply(v, al, inv);
+          if (a.act != FAC_ACT_NONE) v = apply_act_slow(v, a.act);
+          v += rv[i][n];
+          yg[(long long)co * a.y_cs + (long long)t * a.y_tstride + phase] = v;
         }
-        const long long o = (long long)co * a.y_cs + (long long)t * a.y_tstride + phase;
-        if (rg) v += rg[o];
-        yg[o] = v;
       }
     }
   }
@@ -273,27 +361,39 @@ int launch_cfg(ConvArgs& a, hipStream_t s) {
   constexpr int T_TILE = 32 * NB * WN;
   constexpr int UC = ConvUnroll<KT>::UC;
   constexpr int STEP = 2 * UC;
-  a.XW = (T_TILE - 1) * a.stride + (a.K - 1) * a.dil + 1;
-  a.XB = (a.XW + 63) / 64;
+  // staged slab = receptive field of the tile, extended on the left to a 16-byte boundary and on the
+  // right to a multiple of 4 columns, so interior slabs move as float4
+  a.x_off = ((-a.pad_left) % 4 + 4) % 4;
+  a.XW = (((T_TILE - 1) * a.stride + (a.K - 1) * a.dil + 1 + a.x_off) + 3) & ~3;
+  a.XB = (a.XW / 4 + 63) / 64;   // 64-lane blocks of float4 columns per staged row
   a.XQ = 4 / a.XB;
   a.XR = 4 % a.XB;
   const int per_ci = a.K * CO_TILE + a.XW;       // floats per staged input channel
-  int lim = 9216 / per_ci;                       // ~36 KB per stage -> 2 stages x 2 workgroups per CU
-  const int lim_regs = (4 * CONV_XMAX) / a.XB;   // staged inputs must fit CONV_XMAX registers/thread
-  if (lim > lim_regs) lim = lim_regs;
-  if (lim > 32) lim = 32;
-  lim = (lim / STEP) * STEP;
-  if (lim < STEP) lim = STEP;
-  const int cin_r = ((a.C_in + STEP - 1) / STEP) * STEP;
-  int cic = lim < cin_r ? lim : cin_r;
-  // prefer a chunk size that divides the (rounded) channel count: no half-empty last chunk
-  for (int c = cic; c >= STEP && c * 2 > cic; c -= STEP)
-    if (cin_r % c == 0) { cic = c; break; }
-  a.cic = cic;
-  if (cic * a.XB > 4 * CONV_XMAX) {
-    set_error("conv1d: receptive field too wide to stage (K=%d stride=%d dil=%d)", a.K, a.stride, a.dil);
-    return FAC_ERR_ARG;
+  int cic;
+  if constexpr (KT > 0) {
+    cic = ConvUnroll<KT>::CIC;
+    // the compile-time stage must fit the register slots and ~half the LDS; otherwise use the
+    // run-time-sized generic path (unusual stride / dilation for this tap count)
+    if (cic * a.XB > 4 * CONV_XMAX || (size_t)2 * cic * per_ci * sizeof(float) > 80 * 1024)
+      return launch_cfg<MB, NB, WM, WN, 0>(a, s);
+  } else {
+    int lim = 9216 / per_ci;                       // ~36 KB per stage -> 2 stages x 2 workgroups per CU
+    const int lim_regs = (4 * CONV_XMAX) / a.XB;   // staged inputs must fit CONV_XMAX registers/thread
+    if (lim > lim_regs) lim = lim_regs;
+    if (lim > 32) lim = 32;
+    lim = (lim / STEP) * STEP;
+    if (lim < STEP) lim = STEP;
+    const int cin_r = ((a.C_in + STEP - 1) / STEP) * STEP;
+    cic = lim < cin_r ? lim : cin_r;
+    // prefer a chunk size that divides the (rounded) channel count: no half-empty last chunk
+    for (int c = cic; c >= STEP && c * 2 > cic; c -= STEP)
+      if (cin_r % c == 0) { cic = c; break; }
+    if (cic * a.XB > 4 * CONV_XMAX) {
+      set_error("conv1d: receptive field too wide to stage (K=%d stride=%d dil=%d)", a.K, a.stride, a.dil);
+      return FAC_ERR_ARG;
+    }
   }
+  a.cic = cic;
   const size_t lds = (size_t)2 * cic * per_ci * sizeof(float);
   if (lds > 160 * 1024) {
     set_error("conv1d: tile needs %zu B of LDS (K=%d stride=%d dil=%d)", lds, a.K, a.stride, a.dil);
@@ -306,8 +406,13 @@ int launch_cfg(ConvArgs& a, hipStream_t s) {
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  dim3 grid((a.T_out + T_TILE - 1) / T_TILE, (a.C_out + CO_TILE - 1) / CO_TILE, a.B * a.n_phase);
-  hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
+  a.n_t_tiles = (a.T_out + T_TILE - 1) / T_TILE;
+  const long long n_wg = (long long)a.n_t_tiles * ((a.C_out + CO_TILE - 1) / CO_TILE) * a.B * a.n_phase;
+  if (n_wg > 0x7fffffffll) {
+    set_error("conv1d: too many workgroups (%lld)", n_wg);
+    return FAC_ERR_ARG;
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)n_wg), dim3(512), lds, s, a);
   return check_launch("conv1d_mfma");
 }
 
