@@ -20,7 +20,7 @@ _f = C.c_float
 
 class ConvDesc(C.Structure):
     _fields_ = [
-        ("x", _p), ("w", _p), ("bias", _p), ("alpha_in", _p), ("alpha_out", _p), ("res", _p), ("y", _p),
+        ("x", _p), ("w", _p), ("bias", _p), ("alpha_in", _p), ("alpha_out", _p), ("res", _p), ("y", _p), ("y2", _p), ("alpha_y2", _p),
         ("x_bs", _i64), ("x_cs", _i64), ("y_bs", _i64), ("y_cs", _i64),
         ("B", C.c_int32), ("C_in", C.c_int32), ("T_in", C.c_int32), ("C_out", C.c_int32),
         ("C_out_pad", C.c_int32), ("T_out", C.c_int32),
@@ -50,7 +50,7 @@ SIGNATURES = {
     "fac_conv1d_variant": (_i, [C.POINTER(ConvDesc), C.c_char_p, _i]),
     "fac_snake_fwd": (_i, [_p, _p, _p, _i, _i, _i, _p]),
     "fac_lstm_to_time_major": (_i, [_p, _p, _i, _i, _i, _p]),
-    "fac_lstm_from_time_major": (_i, [_p, _p, _p, _i, _i, _i, _p]),
+    "fac_lstm_from_time_major": (_i, [_p, _p, _p, _p, _i, _i, _i, _p]),
     "fac_pack_lstm_whh": (_i, [_p, _p, _i, _p]),
     "fac_lstm_layer_fwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _p]),
     "fac_vq_fwd": (_i, [C.POINTER(VqDesc), _p]),

@@ -27,6 +27,10 @@ inline int check_launch(const char* what) {
     }                                   \
   } while (0)
 
+// Device-side twin of fac_cin_pad (include/facodec_hip.h): packed weights have zero rows up to a
+// multiple of 48 input channels.
+__host__ __device__ constexpr int cin_pad_dev(int c) { return ((c + 47) / 48) * 48; }
+
 // sin(y)^2 to ~1 ulp of sin: Cody-Waite reduction by pi/2 (3 constants, exact products via fma for
 // |k| < 2^13) + the Cephes single-precision minimax polynomials on [-pi/4, pi/4]; the quadrant only
 // decides WHICH polynomial is squared (sign drops out).  Arguments beyond +-4096 take libm's sinf.

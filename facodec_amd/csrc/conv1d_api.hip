@@ -13,11 +13,20 @@ static int select_variant(const fac_conv_desc* d) {
   return 4;
 }
 
+#ifdef FAC_PROF
+unsigned long long* g_conv_dbg = nullptr;
+#endif
+
 }  // namespace fac
+
+#ifdef FAC_PROF
+extern "C" void fac_debug_set_buffer(void* p) { fac::g_conv_dbg = (unsigned long long*)p; }
+#endif
 
 extern "C" int fac_conv1d_fwd(const fac_conv_desc* d, fac_stream_t stream) {
   using namespace fac;
-  FAC_REQUIRE(d && d->x && d->w && d->y, "conv1d: null pointer");
+  FAC_REQUIRE(d && d->x && d->w && (d->y || d->y2), "conv1d: null pointer");
+  FAC_REQUIRE(!d->y2 || d->alpha_y2, "conv1d: y2 needs alpha_y2");
   FAC_REQUIRE(d->B > 0 && d->C_in > 0 && d->C_out > 0 && d->T_in > 0 && d->T_out > 0,
               "conv1d: bad shape B=%d C_in=%d C_out=%d T_in=%d T_out=%d", d->B, d->C_in, d->C_out,
               d->T_in, d->T_out);
@@ -28,7 +37,7 @@ extern "C" int fac_conv1d_fwd(const fac_conv_desc* d, fac_stream_t stream) {
   FAC_REQUIRE((long long)d->B * d->n_phase <= 65535, "conv1d: B*n_phase too large for grid.z");
   ConvArgs a;
   a.x = d->x; a.w = d->w; a.bias = d->bias; a.alpha_in = d->alpha_in; a.alpha_out = d->alpha_out;
-  a.res = d->res; a.y = d->y;
+  a.res = d->res; a.y = d->y; a.y2 = d->y2; a.alpha2 = d->alpha_y2;
   a.x_bs = d->x_bs; a.x_cs = d->x_cs; a.y_bs = d->y_bs; a.y_cs = d->y_cs; a.w_bs = d->w_bs;
   a.B = d->B; a.C_in = d->C_in; a.T_in = d->T_in; a.C_out = d->C_out; a.C_out_pad = d->C_out_pad;
   a.T_out = d->T_out; a.K = d->K; a.stride = d->stride; a.dil = d->dilation;

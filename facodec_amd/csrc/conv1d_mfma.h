@@ -40,6 +40,8 @@ struct ConvArgs {
   const float* alpha_out;
   const float* res;
   float* y;
+  float* y2;            // optional pre-activated copy: snake(y, alpha2)
+  const float* alpha2;
   long long x_bs, x_cs, y_bs, y_cs, w_bs;
   int B, C_in, T_in, T_ext, C_out, C_out_pad, T_out;
   int K, stride, dil, pad_left, pad_mode;
@@ -49,6 +51,9 @@ struct ConvArgs {
   int XB;   // 64-wide column blocks per staged row = ceil(XW/64)
   int XQ, XR;  // 4 / XB, 4 % XB: (row, block) advance of one wave per staging iteration
   int n_t_tiles;
+#ifdef FAC_PROF
+  unsigned long long* dbg;   // per-workgroup cycle counters (tuning builds only)
+#endif
   int x_off;   // columns staged to the left of the receptive field so that the slab starts 16-B aligned
 };
 
@@ -106,19 +111,38 @@ __global__ __launch_bounds__(512, FAC_CONV_WPE) void conv1d_mfma_kernel(ConvArgs
   if (wave >= 4) {
     // ===================== staging waves: HBM/L2 -> LDS for chunk c+1 while chunk c is multiplied
     const int lw = wave - 4;
+    // Both roles share each SIMD's VALU issue port, and a pending MFMA of an older / higher-priority
+    // wave blocks it: at equal priority the staging waves got ~1 VALU slot per MFMA (measured: 12k
+    // cycles to ISSUE one chunk's loads; MFMA waves then idled 47 % of their life at the barrier).
+    // The staging stream is short (a few hundred instructions per chunk), so it runs at raised priority
+    // and the MFMA waves absorb the few lost slots.
+#ifndef FAC_ABL_NOPRIO
+    __builtin_amdgcn_s_setprio(3);
+#endif
     const float* xg = a.x + (long long)b * a.x_bs;
-    const float* wg = a.w + (long long)phase * a.C_in * K * a.C_out_pad +
+    const int w_rows_total = cin_pad_dev(a.C_in) * K;   // rows C_in*K.. are zero (fac_pack_conv_w)
+    const float* wg = a.w + (long long)phase * w_rows_total * a.C_out_pad +
                       (a.w_batched ? (long long)b * a.w_bs : 0ll);
     const int tin0 = t0 * a.stride - a.pad_left - a.x_off;   // multiple of 4 by construction
-    const int w_rows_total = a.C_in * K;
     // float4 global loads need 16-B aligned rows: base pointer, batch and channel strides
     const bool vec_ok = ((a.x_cs | a.x_bs) & 3) == 0 && ((reinterpret_cast<unsigned long long>(a.x) & 15) == 0);
     const int r_first = lw / XB, cb_first = lw - r_first * XB;
+    // pure-DMA input staging: no Snake prologue, 16-B aligned rows, and the whole slab inside the
+    // signal (no reflection / zero padding / ragged tail in this tile)
+    const bool x_dma = a.alpha_in == nullptr && vec_ok && tin0 >= 0 && tin0 + XW <= a.T_in;
 
+#ifdef FAC_PROF
+    unsigned long long lt_issue = 0, lt_wait = 0, lt_store = 0, lt_bar = 0;
+#endif
     auto stage = [&](int chunk, int buf) {
+#ifdef FAC_PROF
+      const unsigned long long q0 = __builtin_readcyclecounter();
+#endif
       // weight slab by LDS-DMA: flat float4 index q -> (row, col4); 64 lanes = 1 KiB contiguous in
-      // LDS.  Rows past C_in*K and columns past C_out_pad are CLAMPED to valid (finite) weights: the
-      // former meet zero-filled input rows, the latter only feed output rows that are never stored.
+      // LDS.  The packed buffer carries ZERO rows up to fac_cin_pad(C_in) channels, so a partially
+      // filled last stage multiplies zeros whatever the input slab holds there; columns past
+      // C_out_pad are clamped to valid weights and only feed output rows that are never stored.
+#ifndef FAC_ABL_NOW
       {
         const int n4 = cic * K * CO4;
         const int row_base = chunk * cic * K;
@@ -137,12 +161,36 @@ __global__ __launch_bounds__(512, FAC_CONV_WPE) void conv1d_mfma_kernel(ConvArgs
           }
         }
       }
+#endif
+#ifdef FAC_ABL_NOX
+      return;
+#endif
       // input slab: slot j of this wave covers row r, float4 column cb*64 + lane; all loads are
       // issued first, then Snake is applied on the way into LDS (once per staged element).
       // Interior + 16-B aligned rows move as float4; edges (reflection / zero padding / ragged ends)
       // fall back to per-element indexing.
       const int ci0 = chunk * cic;
       const int XW4 = XW >> 2;
+      if (x_dma) {
+        // Interior tile of an input that needs no Snake / padding: the slab rows go straight
+        // HBM/L2 -> LDS by LDS-DMA as well, one 16-B piece per lane -- no VGPRs and (almost) no
+        // VALU work next to the MFMAs.  Channels past C_in are clamped (their weights are zero).
+        float* dst = Xbuf + buf * x_stage;
+        for (int it = lw; it < cic * XB; it += 4) {
+          const int r = it / XB;
+          const int c4 = (it - r * XB) * 64 + lane;
+          if (c4 < XW4) {
+            int ci = ci0 + r;
+            ci = ci < a.C_in ? ci : a.C_in - 1;
+            const float* src = xg + (long long)ci * a.x_cs + tin0 + 4 * c4;
+            __builtin_amdgcn_global_load_lds((glb_void_t*)src, (lds_void_t*)(dst + r * XW + (it - r * XB) * 256), 16, 0, 0);
+          }
+        }
+#ifdef FAC_PROF
+        lt_issue += __builtin_readcyclecounter() - q0;
+#endif
+        return;
+      }
       float4 xr[CONV_XMAX];
       float xal[CONV_XMAX];
       {
@@ -178,6 +226,13 @@ __global__ __launch_bounds__(512, FAC_CONV_WPE) void conv1d_mfma_kernel(ConvArgs
           if (cb >= XB) { cb -= XB; ++r; }
         }
       }
+#ifdef FAC_PROF
+      const unsigned long long q1 = __builtin_readcyclecounter();
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      const unsigned long long q2 = __builtin_readcyclecounter();
+      lt_issue += q1 - q0;
+      lt_wait += q2 - q1;
+#endif
       {
         float* dst = Xbuf + buf * x_stage;
         int r = r_first, cb = cb_first;
@@ -200,6 +255,9 @@ __global__ __launch_bounds__(512, FAC_CONV_WPE) void conv1d_mfma_kernel(ConvArgs
           if (cb >= XB) { cb -= XB; ++r; }
         }
       }
+#ifdef FAC_PROF
+      lt_store += __builtin_readcyclecounter() - q2;
+#endif
     };
 
     stage(0, 0);
@@ -208,20 +266,26 @@ __global__ __launch_bounds__(512, FAC_CONV_WPE) void conv1d_mfma_kernel(ConvArgs
 #ifndef FAC_ABL_NOSTAGE
       if (chunk + 1 < n_chunks) stage(chunk + 1, (chunk & 1) ^ 1);
 #endif
+#ifdef FAC_PROF
+      const unsigned long long qb = __builtin_readcyclecounter();
+#endif
 #ifndef FAC_ABL_NOBAR
       __syncthreads();
 #endif
+#ifdef FAC_PROF
+      lt_bar += __builtin_readcyclecounter() - qb;
+#endif
     }
+#ifdef FAC_PROF
+    if (a.dbg && lane == 0) {
+      unsigned long long* d = a.dbg + (1ll << 21) + ((long long)blockIdx.x * 4 + lw) * 4;
+      d[0] = lt_issue; d[1] = lt_wait; d[2] = lt_store; d[3] = lt_bar;
+    }
+#endif
     return;
   }
 
   // ========================= MFMA waves
-  // Both roles share each SIMD's issue logic: without a priority the staging waves' VALU stream
-  // (index math, Snake) delays MFMA issue by ~25 % (ablation in profiles/).  MFMA waves therefore run
-  // at raised priority for their whole life; the staging waves fill the 64-cycle MFMA shadows.
-#ifndef FAC_ABL_NOPRIO
-  __builtin_amdgcn_s_setprio(3);
-#endif
   const int l31 = lane & 31;
   const int kq = lane >> 5;
   const int wm = wave / WN;
@@ -241,7 +305,13 @@ __global__ __launch_bounds__(512, FAC_CONV_WPE) void conv1d_mfma_kernel(ConvArgs
   const int dil = a.dil;
   const int nstride = 32 * a.stride;
 
+#ifdef FAC_PROF
+  unsigned long long t_start = __builtin_readcyclecounter(), t_bar = 0, t_first = 0;
+#endif
   __syncthreads();   // chunk 0 staged
+#ifdef FAC_PROF
+  t_first = __builtin_readcyclecounter() - t_start;
+#endif
   for (int chunk = 0; chunk < n_chunks; ++chunk) {
     const int buf = chunk & 1;
     const float* Wb = Wbuf + buf * w_stage + a_off + kq * wrow_stride;
@@ -303,13 +373,23 @@ __global__ __launch_bounds__(512, FAC_CONV_WPE) void conv1d_mfma_kernel(ConvArgs
         }
       }
     }
+#ifdef FAC_PROF
+    const unsigned long long tb0 = __builtin_readcyclecounter();
+#endif
 #ifndef FAC_ABL_NOBAR
     __syncthreads();
 #endif
+#ifdef FAC_PROF
+    t_bar += __builtin_readcyclecounter() - tb0;
+#endif
   }
+#ifdef FAC_PROF
+  const unsigned long long t_loop = __builtin_readcyclecounter() - t_start;
+#endif
 
   // ---- epilogue: C/D layout col = lane&31 (time), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (co)
-  float* yg = a.y + (long long)b * a.y_bs;
+  float* yg = a.y ? a.y + (long long)b * a.y_bs : nullptr;
+  float* y2g = a.y2 ? a.y2 + (long long)b * a.y_bs : nullptr;
   const float* rg = a.res ? a.res + (long long)b * a.y_bs : nullptr;
 #pragma unroll
   for (int m = 0; m < MB; ++m) {
@@ -318,13 +398,14 @@ __global__ __launch_bounds__(512, FAC_CONV_WPE) void conv1d_mfma_kernel(ConvArgs
       // rows 8g..8g+3 (+4 for the upper half-wave): issue every independent load of the group first
       // (bias, Snake alpha, residuals -- y may alias res, so the compiler will not hoist residual
       // loads above stores on its own), then do the math and the stores.
-      float bsv[4], alv[4], rv[4][NB];
+      float bsv[4], alv[4], al2[4], rv[4][NB];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int co = co0 + wm * (MB * 32) + m * 32 + i + 8 * g + 4 * kq;
         const int cc = co < a.C_out ? co : a.C_out - 1;
         bsv[i] = a.bias ? a.bias[cc] : 0.f;
         alv[i] = a.alpha_out ? a.alpha_out[cc] : 0.f;
+        al2[i] = y2g ? a.alpha2[cc] : 0.f;
 #pragma unroll
         for (int n = 0; n < NB; ++n) {
           const int t = t0 + wn * (NB * 32) + n * 32 + l31;
@@ -347,12 +428,24 @@ __global__ __launch_bounds__(512, FAC_CONV_WPE) void conv1d_mfma_kernel(ConvArgs
           if (a.alpha_out) v = snake_apply(v, al, inv);
           if (a.act != FAC_ACT_NONE) v = apply_act_slow(v, a.act);
           v += rv[i][n];
-          yg[(long long)co * a.y_cs + (long long)t * a.y_tstride + phase] = v;
+          const long long o = (long long)co * a.y_cs + (long long)t * a.y_tstride + phase;
+          if (yg) yg[o] = v;
+          if (y2g) y2g[o] = snake_apply(v, al2[i], snake_inv(al2[i]));
         }
       }
     }
   }
+#ifdef FAC_PROF
+  if (a.dbg && lane == 0) {
+    unsigned long long* d = a.dbg + ((long long)blockIdx.x * 4 + wave) * 4;
+    d[0] = t_first; d[1] = t_bar; d[2] = t_loop; d[3] = __builtin_readcyclecounter() - t_start;
+  }
+#endif
 }
+
+#ifdef FAC_PROF
+extern unsigned long long* g_conv_dbg;
+#endif
 
 // Picks channels-per-stage and launches one instantiation.
 template <int MB, int NB, int WM, int WN, int KT>
@@ -407,6 +500,9 @@ int launch_cfg(ConvArgs& a, hipStream_t s) {
     attr_set = true;
   }
   a.n_t_tiles = (a.T_out + T_TILE - 1) / T_TILE;
+#ifdef FAC_PROF
+  a.dbg = g_conv_dbg;
+#endif
   const long long n_wg = (long long)a.n_t_tiles * ((a.C_out + CO_TILE - 1) / CO_TILE) * a.B * a.n_phase;
   if (n_wg > 0x7fffffffll) {
     set_error("conv1d: too many workgroups (%lld)", n_wg);

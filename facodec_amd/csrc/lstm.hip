@@ -108,6 +108,7 @@ __global__ __launch_bounds__(256) void to_time_major_kernel(const float* __restr
 
 __global__ __launch_bounds__(256) void from_time_major_kernel(const float* __restrict__ yT,
                                                               const float* __restrict__ skip,
+                                                              const float* __restrict__ alpha,
                                                               float* __restrict__ out, int B, int H,
                                                               int T, int BP) {
   __shared__ float tile[32][33];
@@ -126,6 +127,7 @@ __global__ __launch_bounds__(256) void from_time_major_kernel(const float* __res
       const long long o = ((long long)b * H + h) * T + t;
       float v = tile[tx][ty + 8 * j];
       if (skip) v = __fadd_rn(v, skip[o]);
+      if (alpha) v = snake_apply(v, alpha[h], snake_inv(alpha[h]));
       out[o] = v;
     }
   }
@@ -143,13 +145,13 @@ extern "C" int fac_lstm_to_time_major(const float* x, float* xT, int B, int H, i
   return check_launch("lstm_to_time_major");
 }
 
-extern "C" int fac_lstm_from_time_major(const float* yT, const float* skip, float* out, int B,
-                                        int H, int T, fac_stream_t stream) {
+extern "C" int fac_lstm_from_time_major(const float* yT, const float* skip, const float* alpha,
+                                        float* out, int B, int H, int T, fac_stream_t stream) {
   using namespace fac;
   FAC_REQUIRE(yT && out && B > 0 && H > 0 && T > 0, "lstm_from_time_major: bad arguments");
   const int BP = fac_pad32(B);
   dim3 grid((T + 31) / 32, H, BP / 32);
-  hipLaunchKernelGGL(from_time_major_kernel, grid, dim3(256), 0, (hipStream_t)stream, yT, skip, out, B, H, T, BP);
+  hipLaunchKernelGGL(from_time_major_kernel, grid, dim3(256), 0, (hipStream_t)stream, yT, skip, alpha, out, B, H, T, BP);
   return check_launch("lstm_from_time_major");
 }
 

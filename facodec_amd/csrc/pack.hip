@@ -89,7 +89,7 @@ __global__ __launch_bounds__(256) void pack_convtr_kernel(const float* __restric
     const int p = pj >> 1, j = pj & 1;
     const int k = p + s * (1 - j);
     if (c0 + co < C_out_pad)
-      out[(((long long)p * C_in + ci) * 2 + j) * C_out_pad + c0 + co] = tl[co * (K + 1) + k];
+      out[(((long long)p * cin_pad_dev(C_in) + ci) * 2 + j) * C_out_pad + c0 + co] = tl[co * (K + 1) + k];
   }
 }
 

@@ -1,11 +1,20 @@
 """Encoder / Decoder of the codec (reference: dac/model/dac.py:25-165) as fused launch plans.
 
 Module tree = the reference's (same state-dict keys: `block.N...` / `model.N...`), but nothing is
-executed layer-by-layer: each ResidualUnit is two launches of the MFMA conv kernel --
-    conv k7 (dilated):  Snake(alpha1) prologue, bias + Snake(alpha2) epilogue
-    conv k1:            bias + residual-add epilogue
--- every other Snake is the prologue of the conv that consumes it, the final tanh is an epilogue,
-so no activation ever makes a separate trip through HBM.
+executed layer-by-layer.  Every Snake is folded into a neighbouring conv launch:
+
+  * a Snake whose input has no other consumer (inside a ResidualUnit, dac.py:31-34) is the EPILOGUE
+    of the conv producing that input;
+  * a Snake in front of a conv whose input IS also needed raw (the ResidualUnit's skip, :38-42) is
+    emitted by the producer as a SECOND output: each producer writes y and snake(y, alpha_next).
+    The consuming conv then stages a ready-made tensor by pure LDS-DMA -- the profile showed that any
+    VALU work (sin!) in the staging waves starves the MFMA waves sharing their SIMD;
+  * block-final Snakes (before the strided / transposed conv, before the last conv) have a single
+    consumer, so only the pre-activated copy is written.
+
+A ResidualUnit is therefore two launches of the MFMA conv kernel:
+    conv k7 (dilated):  input = pre-activated x, epilogue bias + Snake(alpha2)
+    conv k1:            epilogue bias + residual(x raw) [+ second output snake(., alpha_next)]
 """
 from torch import nn
 
@@ -25,13 +34,33 @@ class ResidualUnit(nn.Module):
             SConv1d(dim, dim, kernel_size=1, causal=causal, norm="weight_norm"),
         )
 
-    def forward(self, x):
+    @property
+    def alpha_in(self):
+        return self.block[0].flat()
+
+    def run(self, x, x_act, alpha_next=None, want_raw=True):
+        """x: raw input (skip path); x_act = snake(x, alpha_in) from the producer.
+        Returns (y, snake(y, alpha_next)); y is None when want_raw is False."""
         b = self.block
-        h = b[1].run(x, alpha_in=b[0].flat(), alpha_out=b[2].flat())
+        h = b[1].run(x_act, alpha_out=b[2].flat())
         if h.shape[-1] != x.shape[-1]:  # non-causal trimming of :38-41 never triggers with SConv1d padding
             pad = (x.shape[-1] - h.shape[-1]) // 2
             x = x[..., pad:-pad].contiguous()
-        return b[3].run(h, res=x)
+        if alpha_next is None:
+            return b[3].run(h, res=x), None
+        return b[3].run(h, res=x, alpha_y2=alpha_next, want_y=want_raw)
+
+    def forward(self, x):
+        return self.run(x, ops.snake(x, self.alpha_in))[0]
+
+
+def _run_units(units, x, x_act, alpha_after):
+    """Chains ResidualUnits; the last one only emits the copy pre-activated with `alpha_after`."""
+    for j, ru in enumerate(units):
+        last = j == len(units) - 1
+        nxt = alpha_after if last else units[j + 1].alpha_in
+        x, x_act = ru.run(x, x_act, alpha_next=nxt, want_raw=not last)
+    return x_act
 
 
 class EncoderBlock(nn.Module):
@@ -47,10 +76,18 @@ class EncoderBlock(nn.Module):
             SConv1d(dim // 2, dim, kernel_size=2 * stride, stride=stride, causal=causal, norm="weight_norm"),
         )
 
-    def forward(self, x):
+    @property
+    def alpha_in(self):
+        return self.block[0].alpha_in
+
+    def run(self, x, x_act, alpha_next=None):
+        """Returns the strided conv's (y, snake(y, alpha_next)) (just y when alpha_next is None)."""
         b = self.block
-        x = b[2](b[1](b[0](x)))
-        return b[4].run(x, alpha_in=b[3].flat())
+        z_act = _run_units([b[0], b[1], b[2]], x, x_act, b[3].flat())
+        return b[4].run(z_act, alpha_y2=alpha_next) if alpha_next is not None else (b[4].run(z_act), None)
+
+    def forward(self, x):
+        return self.run(x, ops.snake(x, self.alpha_in))[0]
 
 
 class Encoder(nn.Module):
@@ -71,10 +108,18 @@ class Encoder(nn.Module):
 
     def forward(self, x):
         mods = list(self.block)
-        x = mods[0].run(x)
-        for m in mods[1:-2]:
-            x = m(x)
-        return mods[-1].run(x, alpha_in=mods[-2].flat())
+        blocks = [m for m in mods if isinstance(m, EncoderBlock)]
+        final_alpha = mods[-2].flat()
+        x, x_act = mods[0].run(x, alpha_y2=blocks[0].alpha_in)
+        for i, blk in enumerate(blocks):
+            if i + 1 < len(blocks):
+                nxt = blocks[i + 1].alpha_in
+            else:
+                nxt = None if self.use_lstm else final_alpha   # the LSTM wants the raw tensor
+            x, x_act = blk.run(x, x_act, alpha_next=nxt)
+        if self.use_lstm:
+            x_act = mods[-3](x, alpha_out=final_alpha)           # SLSTM + skip, Snake on the way out
+        return mods[-1].run(x_act)
 
 
 class DecoderBlock(nn.Module):
@@ -91,10 +136,18 @@ class DecoderBlock(nn.Module):
             ResidualUnit(output_dim, dilation=9, causal=causal),
         )
 
-    def forward(self, x):
+    @property
+    def alpha_in(self):
+        return self.block[0].flat()
+
+    def run(self, x_act, alpha_after):
+        """x_act = snake(x, alpha_in); returns the block output pre-activated with `alpha_after`."""
         b = self.block
-        x = b[1].run(x, alpha_in=b[0].flat())
-        return b[4](b[3](b[2](x)))
+        y, y_act = b[1].run(x_act, alpha_y2=b[2].alpha_in)
+        return _run_units([b[2], b[3], b[4]], y, y_act, alpha_after)
+
+    def forward(self, x):
+        raise NotImplementedError("DecoderBlock is executed through Decoder.forward's fused plan")
 
 
 class Decoder(nn.Module):
@@ -103,6 +156,7 @@ class Decoder(nn.Module):
     def __init__(self, input_channel, channels, rates, d_out=1, causal=False, lstm=2):
         super().__init__()
         layers = [SConv1d(input_channel, channels, kernel_size=7, causal=causal, norm="weight_norm")]
+        self.use_lstm = lstm
         if lstm:
             layers.append(SLSTM(channels, num_layers=lstm))
         out_dim = channels
@@ -115,7 +169,14 @@ class Decoder(nn.Module):
 
     def forward(self, x):
         mods = list(self.model)
-        x = mods[0].run(x)
-        for m in mods[1:-3]:
-            x = m(x)
-        return mods[-2].run(x, alpha_in=mods[-3].flat(), act=ops.ACT_TANH)
+        blocks = [m for m in mods if isinstance(m, DecoderBlock)]
+        final_alpha = mods[-3].flat()
+        if self.use_lstm:
+            x = mods[0].run(x)
+            x_act = mods[1](x, alpha_out=blocks[0].alpha_in)
+        else:
+            _, x_act = mods[0].run(x, alpha_y2=blocks[0].alpha_in, want_y=False)
+        for i, blk in enumerate(blocks):
+            nxt = blocks[i + 1].alpha_in if i + 1 < len(blocks) else final_alpha
+            x_act = blk.run(x_act, nxt)
+        return mods[-2].run(x_act, act=ops.ACT_TANH)

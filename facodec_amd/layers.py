@@ -82,11 +82,12 @@ class SConv1d(nn.Module):
     def w(self):
         return self.conv.conv
 
-    def run(self, x, alpha_in=None, alpha_out=None, res=None, act=ops.ACT_NONE):
+    def run(self, x, alpha_in=None, alpha_out=None, res=None, act=ops.ACT_NONE, alpha_y2=None, want_y=True):
+        """alpha_y2: additionally emit snake(y, alpha_y2) for the next Snake->conv (returns (y, y2))."""
         w = self.w
         return ops.conv1d(x, w.packed(), w.c_out, self.kernel_size, bias=w.bias, stride=self.stride,
                           dilation=self.dilation, pad_mode=self.pad_mode, alpha_in=alpha_in, alpha_out=alpha_out,
-                          res=res, act=act, causal=self.causal)
+                          res=res, act=act, causal=self.causal, alpha_y2=alpha_y2, want_y=want_y)
 
     def forward(self, x):
         return self.run(x)
@@ -108,9 +109,10 @@ class SConvTranspose1d(nn.Module):
     def w(self):
         return self.convtr.convtr
 
-    def run(self, x, alpha_in=None):
+    def run(self, x, alpha_in=None, alpha_y2=None):
         w = self.w
-        return ops.conv_transpose1d(x, w.packed(), w.c_out, self.stride, bias=w.bias, alpha_in=alpha_in)
+        return ops.conv_transpose1d(x, w.packed(), w.c_out, self.stride, bias=w.bias, alpha_in=alpha_in,
+                                    alpha_y2=alpha_y2)
 
     def forward(self, x):
         return self.run(x)
@@ -152,7 +154,9 @@ class SLSTM(nn.Module):
         self.lstm = _LSTMParams(dimension, num_layers)
         self.dimension, self.num_layers, self.skip = dimension, num_layers, skip
 
-    def forward(self, x):
+    def forward(self, x, alpha_out=None):
+        """alpha_out: Snake alpha applied to the (skip-added) output by the transpose-back kernel, for
+        the Snake that follows the LSTM in the Encoder / precedes the first DecoderBlock's ConvTranspose."""
         B, H, T = x.shape
         inp = ops.lstm_to_time_major(x)
         for l in range(self.num_layers):
@@ -162,4 +166,4 @@ class SLSTM(nn.Module):
             whh = ops.pack_lstm_whh(getattr(p, f"weight_hh_l{l}").detach())
             pre = ops.conv1d(inp, w_ih, 4 * H, 1, bias=bias, pad_left=0, t_out=inp.shape[-1], pad_mode=ops.PAD_ZERO)
             inp = ops.lstm_layer(pre, whh, H)
-        return ops.lstm_from_time_major(inp, x if self.skip else None, B)
+        return ops.lstm_from_time_major(inp, x if self.skip else None, B, alpha_out)

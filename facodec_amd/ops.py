@@ -15,6 +15,11 @@ def pad32(n):
     return (n + 31) & ~31
 
 
+def cin_pad(c):
+    """Packed weights carry zero rows up to a multiple of 48 input channels (fac_cin_pad)."""
+    return ((c + 47) // 48) * 48
+
+
 def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
@@ -45,7 +50,8 @@ def wn_scale(v, g):
 
 
 def pack_conv_weight(v, g=None, out=None):
-    """(C_out, C_in, K) [+ weight-norm gain g (C_out,1,1)] -> packed (C_in, K, pad32(C_out))."""
+    """(C_out, C_in, K) [+ weight-norm gain g (C_out,1,1)] -> packed (cin_pad(C_in), K, pad32(C_out));
+    rows beyond C_in stay zero (the buffer is zero-initialised once and reused)."""
     v = _dev(v, "weight")
     if v.dim() == 2:
         v = v.unsqueeze(-1)
@@ -53,14 +59,14 @@ def pack_conv_weight(v, g=None, out=None):
     cp = pad32(c_out)
     scale = wn_scale(v, g) if g is not None else None
     if out is None:
-        out = torch.empty(c_in, k, cp, device=v.device, dtype=torch.float32)
+        out = torch.zeros(cin_pad(c_in), k, cp, device=v.device, dtype=torch.float32)
     _lib.check(_lib.load().fac_pack_conv_w(_ptr(v), _ptr(scale), _ptr(out), c_out, c_in, k, cp, _stream()),
                "fac_pack_conv_w")
     return out
 
 
 def pack_convtr_weight(v, g, stride, out=None):
-    """ConvTranspose1d (C_in, C_out, 2*stride) -> polyphase packed (stride, C_in, 2, pad32(C_out))."""
+    """ConvTranspose1d (C_in, C_out, 2*stride) -> polyphase packed (stride, cin_pad(C_in), 2, pad32(C_out))."""
     v = _dev(v, "weight")
     c_in, c_out, k = v.shape
     if k != 2 * stride:
@@ -68,7 +74,7 @@ def pack_convtr_weight(v, g, stride, out=None):
     cp = pad32(c_out)
     scale = wn_scale(v, g) if g is not None else None
     if out is None:
-        out = torch.empty(stride, c_in, 2, cp, device=v.device, dtype=torch.float32)
+        out = torch.zeros(stride, cin_pad(c_in), 2, cp, device=v.device, dtype=torch.float32)
     _lib.check(_lib.load().fac_pack_convtr_w(_ptr(v), _ptr(scale), _ptr(out), c_in, c_out, stride, cp, _stream()),
                "fac_pack_convtr_w")
     return out
@@ -128,10 +134,13 @@ def conv_out_len(t_in, k, stride, dilation):
 
 
 def conv1d(x, w_packed, c_out, k, bias=None, stride=1, dilation=1, pad_left=None, pad_mode=PAD_REFLECT,
-           t_out=None, alpha_in=None, alpha_out=None, res=None, act=ACT_NONE, out=None, causal=True):
+           t_out=None, alpha_in=None, alpha_out=None, res=None, act=ACT_NONE, out=None, causal=True,
+           alpha_y2=None, want_y=True):
     """Fused conv (see fac_conv1d_fwd).  x (B, C_in, T).  With pad_left=None the SConv1d padding
-    rule is applied (causal: everything on the left; non-causal: asymmetric split)."""
-    x = _dev(x, "x")
+    rule is applied (causal: everything on the left; non-causal: asymmetric split).
+    alpha_y2: also produce y2 = snake(y, alpha_y2) (returned as (y, y2); y is None if not want_y)."""
+    if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 3 and x.stride(2) == 1):
+        x = _dev(x, "x")     # channel-sliced views (time contiguous) are consumed in place
     B, c_in, t_in = x.shape
     if pad_left is None:
         t_o, padding_total, _ = conv_out_len(t_in, k, stride, dilation)
@@ -141,25 +150,28 @@ def conv1d(x, w_packed, c_out, k, bias=None, stride=1, dilation=1, pad_left=None
     if t_out is None:
         raise ValueError("t_out required with explicit pad_left")
     cp = w_packed.shape[-1]
-    if out is None:
+    if out is None and want_y:
         out = torch.empty(B, c_out, t_out, device=x.device, dtype=torch.float32)
+    y2 = torch.empty(B, c_out, t_out, device=x.device, dtype=torch.float32) if alpha_y2 is not None else None
     res = _dev(res, "res")
     d = ConvDesc()
     d.x, d.w, d.bias = x.data_ptr(), w_packed.data_ptr(), (bias.data_ptr() if bias is not None else None)
     d.alpha_in = alpha_in.data_ptr() if alpha_in is not None else None
     d.alpha_out = alpha_out.data_ptr() if alpha_out is not None else None
     d.res = res.data_ptr() if res is not None else None
-    d.y = out.data_ptr()
-    d.x_bs, d.x_cs = c_in * t_in, t_in
+    d.y = out.data_ptr() if out is not None else None
+    d.y2 = y2.data_ptr() if y2 is not None else None
+    d.alpha_y2 = alpha_y2.data_ptr() if alpha_y2 is not None else None
+    d.x_bs, d.x_cs = x.stride(0), x.stride(1)
     d.y_bs, d.y_cs = c_out * t_out, t_out
     d.B, d.C_in, d.T_in, d.C_out, d.C_out_pad, d.T_out = B, c_in, t_in, c_out, cp, t_out
     d.K, d.stride, d.dilation, d.pad_left, d.pad_mode = k, stride, dilation, pad_left, pad_mode
     d.n_phase, d.y_tstride, d.act, d.w_batched, d.w_bs = 1, 1, act, 0, 0
     _launch_conv(d, "fac_conv1d_fwd")
-    return out
+    return (out, y2) if alpha_y2 is not None else out
 
 
-def conv_transpose1d(x, w_packed, c_out, stride, bias=None, alpha_in=None, out=None):
+def conv_transpose1d(x, w_packed, c_out, stride, bias=None, alpha_in=None, out=None, alpha_y2=None):
     """Causal SConvTranspose1d (kernel 2*stride, right trim k-stride: dac/model/encodec.py:248-270)
     as `stride` polyphase 2-tap convs: y[., t*s+p] = W[p] x[t] + W[p+s] x[t-1]."""
     x = _dev(x, "x")
@@ -172,13 +184,16 @@ def conv_transpose1d(x, w_packed, c_out, stride, bias=None, alpha_in=None, out=N
     d.x, d.w, d.bias = x.data_ptr(), w_packed.data_ptr(), (bias.data_ptr() if bias is not None else None)
     d.alpha_in = alpha_in.data_ptr() if alpha_in is not None else None
     d.alpha_out, d.res, d.y = None, None, out.data_ptr()
+    y2 = torch.empty_like(out) if alpha_y2 is not None else None
+    d.y2 = y2.data_ptr() if y2 is not None else None
+    d.alpha_y2 = alpha_y2.data_ptr() if alpha_y2 is not None else None
     d.x_bs, d.x_cs = c_in * t_in, t_in
     d.y_bs, d.y_cs = c_out * t_total, t_total
     d.B, d.C_in, d.T_in, d.C_out, d.C_out_pad, d.T_out = B, c_in, t_in, c_out, cp, t_in
     d.K, d.stride, d.dilation, d.pad_left, d.pad_mode = 2, 1, 1, 1, PAD_ZERO
     d.n_phase, d.y_tstride, d.act, d.w_batched, d.w_bs = stride, stride, ACT_NONE, 0, 0
     _launch_conv(d, "fac_conv1d_fwd(convtr)")
-    return out
+    return (out, y2) if alpha_y2 is not None else out
 
 
 def snake(x, alpha, out=None):
@@ -199,10 +214,10 @@ def lstm_to_time_major(x):
     return xT
 
 
-def lstm_from_time_major(yT, skip, B):
+def lstm_from_time_major(yT, skip, B, alpha=None):
     T, H, BP = yT.shape
     out = torch.empty(B, H, T, device=yT.device, dtype=torch.float32)
-    _lib.check(_lib.load().fac_lstm_from_time_major(_ptr(yT), _ptr(skip), _ptr(out), B, H, T, _stream()),
+    _lib.check(_lib.load().fac_lstm_from_time_major(_ptr(yT), _ptr(skip), _ptr(alpha), _ptr(out), B, H, T, _stream()),
                "fac_lstm_from_time_major")
     return out
 

@@ -55,15 +55,17 @@ const char* fac_last_error(void);
 int fac_wn_scale(const float* v, const float* g, float* scale, int n_slices, int slice_len,
                  fac_stream_t stream);
 
-/* Conv1d / Linear weight v (C_out, C_in, K) -> packed (C_in, K, C_out_pad), co fastest,
- * packed[ci][k][co] = v[co][ci][k] * scale[co]; columns C_out..C_out_pad-1 are zero.
- * C_out_pad must be a multiple of 32 (fac_pad32). scale may be NULL (== 1). */
+/* Conv1d / Linear weight v (C_out, C_in, K) -> packed (C_in_pad, K, C_out_pad), co fastest,
+ * packed[ci][k][co] = v[co][ci][k] * scale[co]; columns C_out..C_out_pad-1 and rows
+ * C_in..C_in_pad-1 must be zero: the caller zero-initialises the buffer once, this call writes the
+ * valid rows.  C_out_pad = fac_pad32(C_out), C_in_pad = fac_cin_pad(C_in). scale may be NULL (== 1). */
 int fac_pack_conv_w(const float* v, const float* scale, float* packed, int C_out, int C_in,
                     int K, int C_out_pad, fac_stream_t stream);
 
 /* ConvTranspose1d weight v (C_in, C_out, K = 2*stride) with weight-norm over dim 0 (= C_in,
  * dac/model/encodec.py:163) -> `stride` polyphase 2-tap sub-filters:
- * packed[p][ci][j][co] = v[ci][co][p + stride*(1-j)] * scale[ci],  p < stride, j in {0,1}.
+ * packed[p][ci][j][co] = v[ci][co][p + stride*(1-j)] * scale[ci],  p < stride, j in {0,1},
+ * ci < C_in_pad (rows >= C_in zero, as above).
  * Output phase p of the transposed conv is then a causal 2-tap conv (see fac_conv1d_fwd). */
 int fac_pack_convtr_w(const float* v, const float* scale, float* packed, int C_in, int C_out,
                       int stride, int C_out_pad, fac_stream_t stream);
@@ -89,7 +91,11 @@ typedef struct fac_conv_desc {
   const float* alpha_in;  /* (C_in) Snake alpha applied to x on load, or NULL */
   const float* alpha_out; /* (C_out) Snake alpha applied after bias, or NULL */
   const float* res;       /* residual, same indexing as y, or NULL */
-  float* y;               /* element (b,c,u) at y[b*y_bs + c*y_cs + u] */
+  float* y;               /* element (b,c,u) at y[b*y_bs + c*y_cs + u]; may be NULL when y2 is given */
+  float* y2;              /* optional second output, same indexing: y2 = snake(y, alpha_y2) -- the
+                             pre-activated copy the next Snake->conv consumes, so that consumer can
+                             stage its input by pure LDS-DMA (no VALU work beside the MFMAs) */
+  const float* alpha_y2;  /* (C_out) Snake alpha of y2; required iff y2 != NULL */
   int64_t x_bs, x_cs;
   int64_t y_bs, y_cs;
   int32_t B, C_in, T_in, C_out, C_out_pad;
@@ -122,8 +128,9 @@ int fac_snake_fwd(const float* x, const float* alpha, float* y, int B, int C, in
 
 /* (B, H, T) -> (T, H, BP), zero-filling batch columns B..BP-1. */
 int fac_lstm_to_time_major(const float* x, float* xT, int B, int H, int T, fac_stream_t stream);
-/* out(B,H,T) = yT(T,H,BP) transposed back + skip(B,H,T) (skip may be NULL). */
-int fac_lstm_from_time_major(const float* yT, const float* skip, float* out, int B, int H, int T,
+/* out(B,H,T) = yT(T,H,BP) transposed back + skip(B,H,T) (skip may be NULL); if alpha (H) is given the
+ * Snake that follows the SLSTM in the model (dac/model/dac.py:95,112) is applied on the way out. */
+int fac_lstm_from_time_major(const float* yT, const float* skip, const float* alpha, float* out, int B, int H, int T,
                              fac_stream_t stream);
 /* W_hh (4H, H) -> layout streamed by the recurrent kernel (same element count). */
 int fac_pack_lstm_whh(const float* w_hh, float* packed, int H, fac_stream_t stream);
@@ -222,6 +229,9 @@ int fac_reduce_pair(const float* a, const float* b, float* out, float* scratch, 
                     int mode, float eps, float scale, int accumulate, fac_stream_t stream);
 
 static inline int fac_pad32(int n) { return (n + 31) & ~31; }
+/* packed weights carry zero rows up to a multiple of 48 input channels (lcm of the kernel's
+ * channels-per-stage choices), so a partially filled last stage multiplies zeros */
+static inline int fac_cin_pad(int c) { return ((c + 47) / 48) * 48; }
 
 #ifdef __cplusplus
 }

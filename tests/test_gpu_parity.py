@@ -104,6 +104,24 @@ def test_conv_transpose_against_oracle(B, ci, co, T, s, O, ops, cuda):
     assert yg.shape == y.shape and rel(yg, y) < OP_TOL
 
 
+def test_conv_second_output_is_snake_of_first(O, ops, cuda):
+    """y2 = snake(y, alpha_y2) (the pre-activated copy a following Snake->conv consumes by LDS-DMA);
+    also exercises the pure-DMA input path (no Snake prologue, interior tiles) against the oracle."""
+    g = _g(21)
+    x = torch.randn(2, 96, 5000, generator=g)
+    w = torch.randn(96, 96, 7, generator=g) / 26.0
+    b = torch.randn(96, generator=g) * 0.1
+    r = torch.randn(2, 96, 5000, generator=g)
+    a2 = 1 + 0.2 * torch.rand(96, generator=g)
+    y_ref = O.sconv1d(x, w, b, dilation=3) + r
+    wp = ops.pack_conv_weight(w.to(cuda))
+    y, y2 = ops.conv1d(x.to(cuda), wp, 96, 7, bias=b.to(cuda), dilation=3, res=r.to(cuda), alpha_y2=a2.to(cuda))
+    assert rel(y, y_ref) < OP_TOL and rel(y2, O.snake(y_ref, a2.view(1, -1, 1))) < OP_TOL
+    none_y, y2b = ops.conv1d(x.to(cuda), wp, 96, 7, bias=b.to(cuda), dilation=3, res=r.to(cuda), alpha_y2=a2.to(cuda),
+                             want_y=False)
+    assert none_y is None and torch.equal(y2b, y2)
+
+
 def test_conv_is_linear_in_its_input(ops, cuda):
     """Size-independent property at a full-size layer shape: conv(a x1 + b x2) == a conv(x1) + b conv(x2)."""
     g = _g(9)
@@ -121,11 +139,13 @@ def test_weight_norm_packing(O, ops, cuda):
     v = torch.randn(96, 48, 7, generator=g)
     gg = torch.rand(96, 1, 1, generator=g) + 0.5
     wp = ops.pack_conv_weight(v.to(cuda), gg.to(cuda))
-    assert wp.shape == (48, 7, 96)
+    assert wp.shape == (48, 7, 96)                               # C_in 48 is already a multiple of 48
     assert rel(wp.permute(2, 0, 1), O.weight_norm_weight(v, gg)) < 1e-6
-    v2 = torch.randn(40, 8, 1, generator=g)                      # C_out padded 40 -> 64 with zeros
+    v2 = torch.randn(40, 8, 1, generator=g)                      # C_out padded 40 -> 64, C_in 8 -> 48 with zeros
     wp2 = ops.pack_conv_weight(v2.to(cuda))
-    assert wp2.shape == (8, 1, 64) and float(wp2[:, :, 40:].abs().max()) == 0.0
+    assert wp2.shape == (48, 1, 64)
+    assert float(wp2[:, :, 40:].abs().max()) == 0.0 and float(wp2[8:].abs().max()) == 0.0
+    assert rel(wp2[:8, 0, :40].t(), v2[:, :, 0]) == 0.0
 
 
 def test_snake_standalone(O, ops, cuda):
