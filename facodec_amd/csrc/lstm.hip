@@ -2,12 +2,15 @@
 // zero initial state).  The input projection W_ih x_t + b runs as one big GEMM through
 // fac_conv1d_fwd; this file holds the strictly sequential part.
 //
-// Data layout is time-major with the batch innermost: h_t / y_t are (H, BP) slabs, BP = batch
-// padded to 32, so that the MFMA B operand (k = hidden index, n = batch) is a coalesced row read
-// and y[t] doubles as the h_{t} state for step t+1.
+// Work buffers are channel-major with the batch innermost: x / y are (H, T, BP), the gate
+// pre-activations (4H, T, BP), BP = batch padded to 32.  A time step's slab is then rows of 32
+// contiguous batch values (the MFMA B operand k = hidden index, n = batch is a coalesced row read),
+// y[:, t] doubles as the h_t state of step t+1, and -- the reason for this order -- each channel's
+// (t, b) plane is contiguous, so the input projection is ONE full-width GEMM for the conv kernel
+// (C = H, "time" = T*BP) instead of T narrow ones.
 //
 // One launch per time step.  Workgroup = 8 hidden units x 4 gates = one 32-row MFMA block for a
-// 32-wide batch block; its 8 waves split the K = H reduction, stream their slice of W_hh with
+// 32-wide batch block; its 16 (or 8) waves split the K = H reduction, stream their slice of W_hh with
 // fully coalesced float4 loads (weights are read exactly once per step; the per-XCD L2 / MALL
 // keeps them on chip between steps), reduce through LDS and apply the cell update in place.
 #include "common.h"
@@ -16,13 +19,17 @@ namespace fac {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-__global__ __launch_bounds__(512) void lstm_step_kernel(const float* __restrict__ pre_t,   // (4H, BP)
-                                                        const float* __restrict__ whh,     // packed
-                                                        const float* __restrict__ h_prev,  // (H, BP) or null
-                                                        float* __restrict__ c,             // (H, BP)
-                                                        float* __restrict__ y_t,           // (H, BP)
-                                                        int H, int BP) {
-  __shared__ float red[8][32][33];
+// NW waves split the K = H reduction; GPW = k-groups (of 8) per wave, 0 = run-time loop.  With GPW
+// known at compile time every weight / state load of the step is issued before the first MFMA, so
+// the step pays ONE memory round trip (the step is latency- and weight-bandwidth-bound: M = 32).
+template <int NW, int GPW>
+__global__ __launch_bounds__(NW * 64) void lstm_step_kernel(const float* __restrict__ pre_t,   // (4H, BP)
+                                                            const float* __restrict__ whh,     // packed
+                                                            const float* __restrict__ h_prev,  // (H, BP) or null
+                                                            float* __restrict__ c,             // (H, BP)
+                                                            float* __restrict__ y_t,           // (H, BP)
+                                                            int H, int BP, long long rs) {   // rs: row stride of pre/h/y
+  __shared__ float red[NW][32][33];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
@@ -31,27 +38,56 @@ __global__ __launch_bounds__(512) void lstm_step_kernel(const float* __restrict_
   const int ublk = blockIdx.x;
   const int col0 = blockIdx.y * 32;
 
+  // the gate pre-activations of this workgroup's 8 units do not depend on h: fetch them first
+  float pre_v[4] = {0.f, 0.f, 0.f, 0.f};
+  float c_old = 0.f;
+  if (tid < 256) {
+    const int u = tid >> 5, col = tid & 31;
+    const int unit = ublk * 8 + u;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) pre_v[q] = pre_t[(long long)(q * H + unit) * rs + col0 + col];
+    if (h_prev != nullptr) c_old = c[(long long)unit * BP + col0 + col];
+  }
+
   if (h_prev != nullptr) {
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     const int kgs = H / 8;
-    const int per_wave = kgs / 8;  // H % 64 == 0
+    const int per_wave = GPW > 0 ? GPW : kgs / NW;
     const int kg0 = wave * per_wave;
     const float4* ap = reinterpret_cast<const float4*>(whh) + ((long long)ublk * kgs + kg0) * 64 + lane;
-    const float* bp = h_prev + (long long)(kg0 * 8 + kq) * BP + col0 + l31;
+    const float* bp = h_prev + (long long)(kg0 * 8 + kq) * rs + col0 + l31;
+    if constexpr (GPW > 0) {
+      float4 a4[GPW];
+      float bv[GPW][4];
+#pragma unroll
+      for (int g = 0; g < GPW; ++g) {
+        a4[g] = ap[(long long)g * 64];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bv[g][j] = bp[(long long)(g * 8 + 2 * j) * rs];
+      }
+#pragma unroll
+      for (int g = 0; g < GPW; ++g) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[g].x, bv[g][0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[g].y, bv[g][1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[g].z, bv[g][2], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[g].w, bv[g][3], acc, 0, 0, 0);
+      }
+    } else {
 #pragma unroll 4
-    for (int g = 0; g < per_wave; ++g) {
-      const float4 a4 = ap[(long long)g * 64];
-      const float* bq = bp + (long long)g * 8 * BP;
-      const float b0 = bq[0];
-      const float b1 = bq[2 * BP];
-      const float b2 = bq[4 * BP];
-      const float b3 = bq[6 * BP];
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b0, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b1, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b2, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b3, acc, 0, 0, 0);
+      for (int g = 0; g < per_wave; ++g) {
+        const float4 a4 = ap[(long long)g * 64];
+        const float* bq = bp + (long long)g * 8 * rs;
+        const float b0 = bq[0];
+        const float b1 = bq[2 * rs];
+        const float b2 = bq[4 * rs];
+        const float b3 = bq[6 * rs];
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b0, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b1, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b2, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b3, acc, 0, 0, 0);
+      }
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -70,23 +106,22 @@ __global__ __launch_bounds__(512) void lstm_step_kernel(const float* __restrict_
       float s = 0.f;
       if (h_prev != nullptr) {
 #pragma unroll
-        for (int w = 0; w < 8; ++w) s += red[w][q * 8 + u][col];
+        for (int w = 0; w < NW; ++w) s += red[w][q * 8 + u][col];
       }
-      gate[q] = pre_t[(long long)(q * H + unit) * BP + col0 + col] + s;
+      gate[q] = pre_v[q] + s;
     }
     const float ig = sigmoid_f(gate[0]);
     const float fg = sigmoid_f(gate[1]);
     const float gg = tanhf(gate[2]);
     const float og = sigmoid_f(gate[3]);
     const long long o = (long long)unit * BP + col0 + col;
-    const float c_old = (h_prev != nullptr) ? c[o] : 0.f;
     const float c_new = __fadd_rn(__fmul_rn(fg, c_old), __fmul_rn(ig, gg));
     c[o] = c_new;
-    y_t[o] = __fmul_rn(og, tanhf(c_new));
+    y_t[(long long)unit * rs + col0 + col] = __fmul_rn(og, tanhf(c_new));
   }
 }
 
-// (B, H, T) -> (T, H, BP): per hidden unit, transpose the (b, t) plane through a 32x33 tile.
+// (B, H, T) -> (H, T, BP): per hidden unit, transpose the (b, t) plane through a 32x33 tile.
 __global__ __launch_bounds__(256) void to_time_major_kernel(const float* __restrict__ x,
                                                             float* __restrict__ xT, int B, int H,
                                                             int T, int BP) {
@@ -102,7 +137,7 @@ __global__ __launch_bounds__(256) void to_time_major_kernel(const float* __restr
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int t = t0 + ty + 8 * j, b = b0 + tx;
-    if (t < T) xT[((long long)t * H + h) * BP + b] = tile[tx][ty + 8 * j];
+    if (t < T) xT[((long long)h * T + t) * BP + b] = tile[tx][ty + 8 * j];
   }
 }
 
@@ -117,7 +152,7 @@ __global__ __launch_bounds__(256) void from_time_major_kernel(const float* __res
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int t = t0 + ty + 8 * j, b = b0 + tx;
-    tile[ty + 8 * j][tx] = (t < T) ? yT[((long long)t * H + h) * BP + b] : 0.f;
+    tile[ty + 8 * j][tx] = (t < T) ? yT[((long long)h * T + t) * BP + b] : 0.f;
   }
   __syncthreads();
 #pragma unroll
@@ -162,11 +197,30 @@ extern "C" int fac_lstm_layer_fwd(const float* pre, const float* whh_packed, flo
   FAC_REQUIRE(T > 0 && H > 0 && H % 64 == 0, "lstm_layer_fwd: H=%d must be a multiple of 64", H);
   FAC_REQUIRE(BP > 0 && BP % 32 == 0, "lstm_layer_fwd: BP=%d must be a multiple of 32", BP);
   dim3 grid(H / 8, BP / 32);
-  const long long slab = (long long)H * BP;
+  const long long rs = (long long)T * BP;   // channel-major work buffers: row (= hidden unit) stride
+  // 16 waves when the k-groups divide evenly, with the per-wave trip count fixed at compile time
+  // for the shipped sizes (H = 1024 -> 8, H = 1536 -> 12 groups per wave)
+  void (*kern)(const float*, const float*, const float*, float*, float*, int, int, long long);
+  int threads;
+  const int kgs = H / 8;
+  if (kgs % 16 == 0) {
+    threads = 1024;
+    switch (kgs / 16) {
+      case 12: kern = lstm_step_kernel<16, 12>; break;
+      case 8: kern = lstm_step_kernel<16, 8>; break;
+      case 4: kern = lstm_step_kernel<16, 4>; break;
+      case 2: kern = lstm_step_kernel<16, 2>; break;
+      case 1: kern = lstm_step_kernel<16, 1>; break;
+      default: kern = lstm_step_kernel<16, 0>; break;
+    }
+  } else {
+    threads = 512;
+    kern = lstm_step_kernel<8, 0>;
+  }
   for (int t = 0; t < T; ++t) {
-    const float* h_prev = t == 0 ? nullptr : yT + (long long)(t - 1) * slab;
-    hipLaunchKernelGGL(lstm_step_kernel, grid, dim3(512), 0, (hipStream_t)stream,
-                       pre + (long long)t * 4 * slab, whh_packed, h_prev, c, yT + (long long)t * slab, H, BP);
+    const float* h_prev = t == 0 ? nullptr : yT + (long long)(t - 1) * BP;
+    hipLaunchKernelGGL(kern, grid, dim3(threads), 0, (hipStream_t)stream, pre + (long long)t * BP,
+                       whh_packed, h_prev, c, yT + (long long)t * BP, H, BP, rs);
   }
   return check_launch("lstm_layer_fwd");
 }

@@ -146,8 +146,8 @@ class _LSTMParams(nn.Module):
 
 class SLSTM(nn.Module):
     """dac/model/encodec.py:272-288: multi-layer LSTM over time on (B, C, T) plus skip.
-    Input projections run as GEMMs on the MFMA conv kernel over the time-major (T, H, BP) view;
-    the recurrence is fac_lstm_layer_fwd (one launch per step)."""
+    Input projections run as ONE GEMM per layer on the MFMA conv kernel over the channel-major
+    (H, T*BP) work buffer; the recurrence is fac_lstm_layer_fwd (one launch per step)."""
 
     def __init__(self, dimension, num_layers=2, skip=True):
         super().__init__()
@@ -164,6 +164,9 @@ class SLSTM(nn.Module):
             w_ih = ops.pack_conv_weight(getattr(p, f"weight_ih_l{l}").detach())
             bias = ops.add(getattr(p, f"bias_ih_l{l}").detach(), getattr(p, f"bias_hh_l{l}").detach())
             whh = ops.pack_lstm_whh(getattr(p, f"weight_hh_l{l}").detach())
-            pre = ops.conv1d(inp, w_ih, 4 * H, 1, bias=bias, pad_left=0, t_out=inp.shape[-1], pad_mode=ops.PAD_ZERO)
-            inp = ops.lstm_layer(pre, whh, H)
+            T_, BP = inp.shape[1], inp.shape[2]
+            # one GEMM over every (t, b): the channel-major buffer is a (1, H, T*BP) "signal"
+            pre = ops.conv1d(inp.view(1, H, T_ * BP), w_ih, 4 * H, 1, bias=bias, pad_left=0, t_out=T_ * BP,
+                             pad_mode=ops.PAD_ZERO)
+            inp = ops.lstm_layer(pre.view(4 * H, T_, BP), whh, H)
         return ops.lstm_from_time_major(inp, x if self.skip else None, B, alpha_out)

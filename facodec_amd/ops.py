@@ -209,13 +209,13 @@ def snake(x, alpha, out=None):
 def lstm_to_time_major(x):
     x = _dev(x, "x")
     B, H, T = x.shape
-    xT = torch.empty(T, H, pad32(B), device=x.device, dtype=torch.float32)
+    xT = torch.empty(H, T, pad32(B), device=x.device, dtype=torch.float32)
     _lib.check(_lib.load().fac_lstm_to_time_major(_ptr(x), _ptr(xT), B, H, T, _stream()), "fac_lstm_to_time_major")
     return xT
 
 
 def lstm_from_time_major(yT, skip, B, alpha=None):
-    T, H, BP = yT.shape
+    H, T, BP = yT.shape
     out = torch.empty(B, H, T, device=yT.device, dtype=torch.float32)
     _lib.check(_lib.load().fac_lstm_from_time_major(_ptr(yT), _ptr(skip), _ptr(alpha), _ptr(out), B, H, T, _stream()),
                "fac_lstm_from_time_major")
@@ -232,9 +232,9 @@ def pack_lstm_whh(w_hh, out=None):
 
 
 def lstm_layer(pre, whh_packed, H):
-    """pre (T, 4H, BP) -> yT (T, H, BP)."""
-    T, _, BP = pre.shape
-    yT = torch.empty(T, H, BP, device=pre.device, dtype=torch.float32)
+    """pre (4H, T, BP) -> yT (H, T, BP)."""
+    _, T, BP = pre.shape
+    yT = torch.empty(H, T, BP, device=pre.device, dtype=torch.float32)
     c = torch.empty(H, BP, device=pre.device, dtype=torch.float32)
     _lib.check(_lib.load().fac_lstm_layer_fwd(_ptr(pre), _ptr(whh_packed), _ptr(yT), _ptr(c), T, H, BP, _stream()),
                "fac_lstm_layer_fwd")

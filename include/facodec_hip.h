@@ -122,21 +122,22 @@ int fac_snake_fwd(const float* x, const float* alpha, float* y, int B, int C, in
 /* ------------------------------------------------------------------------------------------
  * K5  SLSTM (dac/model/encodec.py:272-288): nn.LSTM(H, H, L) over time with zero initial
  * state, gates ordered i,f,g,o, then + x (skip).
- * Work buffers are time-major with the batch innermost and padded to a multiple of 32:
- *   BP = fac_pad32(B);  xT/yT: (T, H, BP);  pre: (T, 4H, BP);  c: (H, BP).
+ * Work buffers are channel-major with the batch innermost and padded to a multiple of 32:
+ *   BP = fac_pad32(B);  xT/yT: (H, T, BP);  pre: (4H, T, BP);  c: (H, BP).
+ * (each channel's (t, b) plane is contiguous, so W_ih x + b is one GEMM with C = H, "T" = T*BP)
  * ---------------------------------------------------------------------------------------- */
 
-/* (B, H, T) -> (T, H, BP), zero-filling batch columns B..BP-1. */
+/* (B, H, T) -> (H, T, BP), zero-filling batch columns B..BP-1. */
 int fac_lstm_to_time_major(const float* x, float* xT, int B, int H, int T, fac_stream_t stream);
-/* out(B,H,T) = yT(T,H,BP) transposed back + skip(B,H,T) (skip may be NULL); if alpha (H) is given the
+/* out(B,H,T) = yT(H,T,BP) transposed back + skip(B,H,T) (skip may be NULL); if alpha (H) is given the
  * Snake that follows the SLSTM in the model (dac/model/dac.py:95,112) is applied on the way out. */
 int fac_lstm_from_time_major(const float* yT, const float* skip, const float* alpha, float* out, int B, int H, int T,
                              fac_stream_t stream);
 /* W_hh (4H, H) -> layout streamed by the recurrent kernel (same element count). */
 int fac_pack_lstm_whh(const float* w_hh, float* packed, int H, fac_stream_t stream);
 /* One layer's recurrence: for t in 0..T-1:  gates = pre[t] + W_hh h_{t-1};  c,h update;
- * yT[t] = h_t.  pre already holds W_ih x_t + b_ih + b_hh.  c is scratch (H*BP floats).
- * H must be a multiple of 8. */
+ * yT[:, t] = h_t.  pre already holds W_ih x_t + b_ih + b_hh.  c is scratch (H*BP floats).
+ * H must be a multiple of 64. */
 int fac_lstm_layer_fwd(const float* pre, const float* whh_packed, float* yT, float* c, int T,
                        int H, int BP, fac_stream_t stream);
 
