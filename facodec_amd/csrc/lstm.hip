@@ -25,10 +25,11 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 template <int NW, int GPW>
 __global__ __launch_bounds__(NW * 64) void lstm_step_kernel(const float* __restrict__ pre_t,   // (4H, BP)
                                                             const float* __restrict__ whh,     // packed
-                                                            const float* __restrict__ h_prev,  // (H, BP) or null
+                                                            const float* __restrict__ h_prev,  // fragment-packed h_{t-1} or null
+                                                            float* __restrict__ h_next,        // fragment-packed h_t
                                                             float* __restrict__ c,             // (H, BP)
-                                                            float* __restrict__ y_t,           // (H, BP)
-                                                            int H, int BP, long long rs) {   // rs: row stride of pre/h/y
+                                                            float* __restrict__ y_t,           // (H, BP) rows of stride rs
+                                                            int H, int BP, long long rs) {   // rs: row stride of pre / y
   __shared__ float red[NW][32][33];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -57,36 +58,33 @@ __global__ __launch_bounds__(NW * 64) void lstm_step_kernel(const float* __restr
     const int per_wave = GPW > 0 ? GPW : kgs / NW;
     const int kg0 = wave * per_wave;
     const float4* ap = reinterpret_cast<const float4*>(whh) + ((long long)ublk * kgs + kg0) * 64 + lane;
-    const float* bp = h_prev + (long long)(kg0 * 8 + kq) * rs + col0 + l31;
+    // h_{t-1} in MFMA-B fragment order [col block][k group of 8][kq][32 batch][4 = k pair index]: one
+    // coalesced float4 per lane and group, exactly like the weights (4x fewer VMEM instructions than
+    // dword reads of a row-major state -- the step is VMEM-issue bound at M = 32)
+    const float4* bp = reinterpret_cast<const float4*>(h_prev) + ((long long)blockIdx.y * kgs + kg0) * 64 + lane;
     if constexpr (GPW > 0) {
-      float4 a4[GPW];
-      float bv[GPW][4];
+      float4 a4[GPW], b4[GPW];
 #pragma unroll
       for (int g = 0; g < GPW; ++g) {
         a4[g] = ap[(long long)g * 64];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) bv[g][j] = bp[(long long)(g * 8 + 2 * j) * rs];
+        b4[g] = bp[(long long)g * 64];
       }
 #pragma unroll
       for (int g = 0; g < GPW; ++g) {
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[g].x, bv[g][0], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[g].y, bv[g][1], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[g].z, bv[g][2], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[g].w, bv[g][3], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[g].x, b4[g].x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[g].y, b4[g].y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[g].z, b4[g].z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[g].w, b4[g].w, acc, 0, 0, 0);
       }
     } else {
 #pragma unroll 4
       for (int g = 0; g < per_wave; ++g) {
         const float4 a4 = ap[(long long)g * 64];
-        const float* bq = bp + (long long)g * 8 * rs;
-        const float b0 = bq[0];
-        const float b1 = bq[2 * rs];
-        const float b2 = bq[4 * rs];
-        const float b3 = bq[6 * rs];
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b0, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b1, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b2, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b3, acc, 0, 0, 0);
+        const float4 b4 = bp[(long long)g * 64];
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, acc, 0, 0, 0);
       }
     }
 #pragma unroll
@@ -117,7 +115,11 @@ __global__ __launch_bounds__(NW * 64) void lstm_step_kernel(const float* __restr
     const long long o = (long long)unit * BP + col0 + col;
     const float c_new = __fadd_rn(__fmul_rn(fg, c_old), __fmul_rn(ig, gg));
     c[o] = c_new;
-    y_t[(long long)unit * rs + col0 + col] = __fmul_rn(og, tanhf(c_new));
+    const float hv = __fmul_rn(og, tanhf(c_new));
+    y_t[(long long)unit * rs + col0 + col] = hv;
+    // same value in fragment order for the next step: unit = 8*kg + 2*jj + kq
+    const int kgn = unit >> 3, w8 = unit & 7;
+    h_next[((((long long)blockIdx.y * (H >> 3) + kgn) * 2 + (w8 & 1)) * 32 + col) * 4 + (w8 >> 1)] = hv;
   }
 }
 
@@ -200,7 +202,7 @@ extern "C" int fac_lstm_layer_fwd(const float* pre, const float* whh_packed, flo
   const long long rs = (long long)T * BP;   // channel-major work buffers: row (= hidden unit) stride
   // 16 waves when the k-groups divide evenly, with the per-wave trip count fixed at compile time
   // for the shipped sizes (H = 1024 -> 8, H = 1536 -> 12 groups per wave)
-  void (*kern)(const float*, const float*, const float*, float*, float*, int, int, long long);
+  void (*kern)(const float*, const float*, const float*, float*, float*, float*, int, int, long long);
   int threads;
   const int kgs = H / 8;
   if (kgs % 16 == 0) {
@@ -218,9 +220,11 @@ extern "C" int fac_lstm_layer_fwd(const float* pre, const float* whh_packed, flo
     kern = lstm_step_kernel<8, 0>;
   }
   for (int t = 0; t < T; ++t) {
-    const float* h_prev = t == 0 ? nullptr : yT + (long long)(t - 1) * BP;
+    // scratch = [c | h ping | h pong], H*BP floats each
+    float* hp[2] = {c + (long long)H * BP, c + 2ll * H * BP};
+    const float* h_prev = t == 0 ? nullptr : hp[(t - 1) & 1];
     hipLaunchKernelGGL(kern, grid, dim3(threads), 0, (hipStream_t)stream, pre + (long long)t * BP,
-                       whh_packed, h_prev, c, yT + (long long)t * BP, H, BP, rs);
+                       whh_packed, h_prev, hp[t & 1], c, yT + (long long)t * BP, H, BP, rs);
   }
   return check_launch("lstm_layer_fwd");
 }

@@ -235,7 +235,7 @@ def lstm_layer(pre, whh_packed, H):
     """pre (4H, T, BP) -> yT (H, T, BP)."""
     _, T, BP = pre.shape
     yT = torch.empty(H, T, BP, device=pre.device, dtype=torch.float32)
-    c = torch.empty(H, BP, device=pre.device, dtype=torch.float32)
+    c = torch.empty(3, H, BP, device=pre.device, dtype=torch.float32)   # cell state + 2 fragment-ordered h
     _lib.check(_lib.load().fac_lstm_layer_fwd(_ptr(pre), _ptr(whh_packed), _ptr(yT), _ptr(c), T, H, BP, _stream()),
                "fac_lstm_layer_fwd")
     return yT

@@ -136,7 +136,8 @@ int fac_lstm_from_time_major(const float* yT, const float* skip, const float* al
 /* W_hh (4H, H) -> layout streamed by the recurrent kernel (same element count). */
 int fac_pack_lstm_whh(const float* w_hh, float* packed, int H, fac_stream_t stream);
 /* One layer's recurrence: for t in 0..T-1:  gates = pre[t] + W_hh h_{t-1};  c,h update;
- * yT[:, t] = h_t.  pre already holds W_ih x_t + b_ih + b_hh.  c is scratch (H*BP floats).
+ * yT[:, t] = h_t.  pre already holds W_ih x_t + b_ih + b_hh.  c is scratch of 3*H*BP floats
+ * (cell state + two copies of h in MFMA fragment order).
  * H must be a multiple of 64. */
 int fac_lstm_layer_fwd(const float* pre, const float* whh_packed, float* yT, float* c, int T,
                        int H, int BP, fac_stream_t stream);
