@@ -307,6 +307,33 @@ __global__ __launch_bounds__(256) void reduce_pair_stage2(const float* __restric
   }
 }
 
+// losses.py:84  l2 = mean_{b,t} sqrt( mean_m ( log(a+eps) - log(b+eps) )^2 );  a, b (B, M, T).
+// One thread per (b, t) column (coalesced along t), partial sums per block into scratch.
+__global__ __launch_bounds__(256) void logdiff_rms_stage1(const float* __restrict__ a,
+                                                          const float* __restrict__ b,
+                                                          float* __restrict__ scratch, int M, int T,
+                                                          long long n_cols, float eps) {
+  __shared__ float part[4];
+  float s = 0.f;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n_cols; i += (long long)gridDim.x * 256) {
+    const long long bb = i / T;
+    const int t = (int)(i - bb * T);
+    const float* pa = a + bb * M * T + t;
+    const float* pb = b + bb * M * T + t;
+    float q = 0.f;
+    for (int m = 0; m < M; ++m) {
+      const float d = logf(fabsf(pa[(long long)m * T]) + eps) - logf(fabsf(pb[(long long)m * T]) + eps);
+      q = fmaf(d, d, q);
+    }
+    s += sqrtf(q / (float)M);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) scratch[blockIdx.x] = (part[0] + part[1]) + (part[2] + part[3]);
+}
+
 }  // namespace fac
 
 using namespace fac;
@@ -431,4 +458,17 @@ extern "C" int fac_reduce_pair(const float* a, const float* b, float* out, float
   hipLaunchKernelGGL(reduce_pair_stage2, dim3(1), dim3(256), 0, (hipStream_t)stream, scratch, out,
                      (int)g, scale, accumulate);
   return check_launch("reduce_pair");
+}
+
+extern "C" int fac_logdiff_rms(const float* a, const float* b, float* out, float* scratch, int B, int M,
+                               int T, float eps, float scale, int accumulate, fac_stream_t stream) {
+  FAC_REQUIRE(a && b && out && scratch && B > 0 && M > 0 && T > 0, "logdiff_rms: bad arguments");
+  const long long n_cols = (long long)B * T;
+  long long g = (n_cols + 255) / 256;
+  if (g > 1024) g = 1024;
+  hipLaunchKernelGGL(logdiff_rms_stage1, dim3((int)g), dim3(256), 0, (hipStream_t)stream, a, b, scratch, M, T,
+                     n_cols, eps);
+  hipLaunchKernelGGL(reduce_pair_stage2, dim3(1), dim3(256), 0, (hipStream_t)stream, scratch, out, (int)g, scale,
+                     accumulate);
+  return check_launch("logdiff_rms");
 }

@@ -1,0 +1,167 @@
+"""Spectral reconstruction losses of the training step, forward values on the HIP C ABI.
+
+Reference call sites: train.py:154-164,295-299 (`MelSpectrogramLoss`, `MultiScaleSTFTLoss`, `L1Loss`
+from dac/nn/loss.py, built on descript-audiotools' AudioSignal.stft / mel_spectrogram) and
+losses.py:65-89 (`reconstruction_loss`, torchaudio MelSpectrogram; named by the north star, not
+called by train.py).  The STFT / mel semantics of those third-party packages are restated in dsp.py
+(PARITY UNPINNED: the reference vendors neither package nor holds tests for them).
+
+Launch plan per scale: estimate and reference are stacked into one batch of 2B signals ->
+`fac_stft_frames` (centre / reflect framing) -> windowed real-DFT as ONE GEMM on the MFMA conv kernel
+(`fac_conv1d_fwd`, K = window) -> `fac_spec_power` (|.| or |.|^2) -> mel filterbank GEMM ->
+`fac_reduce_pair` / `fac_logdiff_rms` (deterministic two-stage reductions accumulating into one scalar).
+Backward (d loss / d estimate) arrives with the training path.
+"""
+import math
+
+import torch
+from torch import nn
+
+from . import dsp, ops
+
+
+def _audio(x):
+    """Accepts a (B, 1, T) / (B, T) tensor or an object exposing `.audio_data` (audiotools.AudioSignal)."""
+    x = getattr(x, "audio_data", x)
+    return x.reshape(x.shape[0], x.shape[-1])
+
+
+class _SpectralScale:
+    """Constants of one STFT scale, packed once per device: windowed DFT basis and (optional) mel bank."""
+
+    def __init__(self, device, n_fft, win, hop, fbank=None):
+        basis, off = dsp.dft_basis(n_fft, win)
+        self.n_fft, self.win, self.hop, self.off = n_fft, win, hop, off
+        self.F = n_fft // 2 + 1
+        self.basis = ops.pack_conv_weight(torch.from_numpy(basis).to(device).unsqueeze(-1))
+        self.n_mels = None
+        if fbank is not None:            # (n_mels, F)
+            fb = torch.as_tensor(fbank, dtype=torch.float32, device=device).contiguous()
+            self.n_mels = fb.shape[0]
+            self.fb = ops.pack_conv_weight(fb.unsqueeze(-1))
+
+    def spectrum(self, waves, power):
+        """waves (N, T) -> (N, F, frames) magnitude (power 1) or power (2) spectrogram."""
+        N, T = waves.shape
+        frames_n = 1 + T // self.hop
+        fr = ops.stft_frames(waves, self.win, frames_n, self.hop, self.n_fft // 2, self.off)
+        spec = ops.conv1d(fr, self.basis, 2 * self.F, 1, pad_left=0, pad_mode=ops.PAD_ZERO, t_out=frames_n)
+        return ops.spec_power(spec, power)
+
+    def mel(self, spec):
+        return ops.conv1d(spec, self.fb, self.n_mels, 1, pad_left=0, pad_mode=ops.PAD_ZERO, t_out=spec.shape[-1])
+
+
+class _LossBase(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self._scales = {}
+        self._scratch = None
+
+    def _bufs(self, device):
+        if self._scratch is None or self._scratch.device != device:
+            self._scratch = torch.empty(1024, device=device, dtype=torch.float32)
+        return torch.zeros(1, device=device, dtype=torch.float32), self._scratch
+
+
+class MelSpectrogramLoss(_LossBase):
+    """dac/nn/loss.py:231-327.  Per scale: L1 of log10(clamp(mel, eps)^pow) (x log_weight) and L1 of mel
+    (x mag_weight); mel = |STFT| @ librosa-style Slaney filterbank (window = periodic Hann of the scale)."""
+
+    def __init__(self, n_mels=(150, 80), window_lengths=(2048, 512), loss_fn=None, clamp_eps=1e-5, mag_weight=1.0,
+                 log_weight=1.0, pow=2.0, weight=1.0, match_stride=False, mel_fmin=(0.0, 0.0), mel_fmax=(None, None),
+                 window_type=None, sample_rate=24000):
+        super().__init__()
+        if match_stride:
+            raise NotImplementedError("match_stride STFT (discriminator front-end) is not built yet")
+        self.n_mels, self.window_lengths = list(n_mels), list(window_lengths)
+        self.clamp_eps, self.mag_weight, self.log_weight, self.pow, self.weight = clamp_eps, mag_weight, log_weight, pow, weight
+        self.mel_fmin, self.mel_fmax, self.sample_rate = list(mel_fmin), list(mel_fmax), sample_rate
+
+    def forward(self, x, y):
+        xs, ys = _audio(x), _audio(y)
+        B = xs.shape[0]
+        sr = getattr(x, "sample_rate", self.sample_rate)
+        both = torch.cat([xs, ys], 0).contiguous()
+        out, scratch = self._bufs(both.device)
+        for nm, fmin, fmax, w in zip(self.n_mels, self.mel_fmin, self.mel_fmax, self.window_lengths):
+            key = (both.device, w, nm, fmin, fmax, sr)
+            if key not in self._scales:
+                self._scales[key] = _SpectralScale(both.device, w, w, w // 4, dsp.mel_fbank_slaney(sr, w, nm, fmin, fmax))
+            sc = self._scales[key]
+            mel = sc.mel(sc.spectrum(both, 1))                       # (2B, n_mels, frames)
+            n = mel[:B].numel()
+            # log10(clamp(m, eps)^pow) = pow * log10(max(m, eps))
+            ops.reduce_pair(mel[:B], mel[B:], out, scratch, 1, self.clamp_eps, self.log_weight * self.pow / n, True)
+            if self.mag_weight != 0.0:
+                ops.reduce_pair(mel[:B], mel[B:], out, scratch, 0, 0.0, self.mag_weight / n, True)
+        return out[0]
+
+
+class MultiScaleSTFTLoss(_LossBase):
+    """dac/nn/loss.py:142-228: per window L1 of log10(clamp(|S|, eps)^pow) + L1 of |S|."""
+
+    def __init__(self, window_lengths=(2048, 512), loss_fn=None, clamp_eps=1e-5, mag_weight=1.0, log_weight=1.0,
+                 pow=2.0, weight=1.0, match_stride=False, window_type=None):
+        super().__init__()
+        if match_stride:
+            raise NotImplementedError("match_stride STFT (discriminator front-end) is not built yet")
+        self.window_lengths = list(window_lengths)
+        self.clamp_eps, self.mag_weight, self.log_weight, self.pow, self.weight = clamp_eps, mag_weight, log_weight, pow, weight
+
+    def forward(self, x, y):
+        xs, ys = _audio(x), _audio(y)
+        B = xs.shape[0]
+        both = torch.cat([xs, ys], 0).contiguous()
+        out, scratch = self._bufs(both.device)
+        for w in self.window_lengths:
+            key = (both.device, w)
+            if key not in self._scales:
+                self._scales[key] = _SpectralScale(both.device, w, w, w // 4)
+            mag = self._scales[key].spectrum(both, 1)
+            n = mag[:B].numel()
+            ops.reduce_pair(mag[:B], mag[B:], out, scratch, 1, self.clamp_eps, self.log_weight * self.pow / n, True)
+            ops.reduce_pair(mag[:B], mag[B:], out, scratch, 0, 0.0, self.mag_weight / n, True)
+        return out[0]
+
+
+class L1Loss(_LossBase):
+    """dac/nn/loss.py:11-48 on the waveforms."""
+
+    def __init__(self, attribute="audio_data", weight=1.0, **kwargs):
+        super().__init__()
+        self.weight = weight
+
+    def forward(self, x, y):
+        xs, ys = _audio(x).contiguous(), _audio(y).contiguous()
+        out, scratch = self._bufs(xs.device)
+        ops.reduce_pair(xs, ys, out, scratch, 0, 0.0, 1.0 / xs.numel(), False)
+        return out[0]
+
+
+_RECON_CACHE = {}
+
+
+def reconstruction_loss(x, G_x, eps=1e-7):
+    """losses.py:65-89: 100*MSE + sum_{s=64..2048} [ L1(mel) + sqrt(s/2) * mean_t RMS_mel(log diff) ] with
+    torchaudio MelSpectrogram(sample_rate=16000, n_fft=max(s,512), win_length=s, hop=s//4, n_mels=64)."""
+    xs, gs = _audio(x).contiguous(), _audio(G_x).contiguous()
+    B = xs.shape[0]
+    dev = xs.device
+    out = torch.zeros(1, device=dev, dtype=torch.float32)
+    scratch = torch.empty(1024, device=dev, dtype=torch.float32)
+    ops.reduce_pair(xs, gs, out, scratch, 2, 0.0, 100.0 / xs.numel(), False)
+    both = torch.cat([xs, gs], 0).contiguous()
+    for i in range(6, 12):
+        s = 2 ** i
+        n_fft = max(s, 512)
+        key = (dev, s)
+        if key not in _RECON_CACHE:
+            fb = dsp.mel_fbank_htk(n_fft // 2 + 1, 64, 16000).T.copy()          # (64, F)
+            _RECON_CACHE[key] = _SpectralScale(dev, n_fft, s, s // 4, fb)
+        sc = _RECON_CACHE[key]
+        mel = sc.mel(sc.spectrum(both, 2))                                       # (2B, 64, frames)
+        n = mel[:B].numel()
+        ops.reduce_pair(mel[:B], mel[B:], out, scratch, 0, 0.0, 1.0 / n, True)
+        ops.logdiff_rms(mel[:B], mel[B:], out, scratch, eps, math.sqrt(s / 2) / (B * mel.shape[-1]), True)
+    return out[0]

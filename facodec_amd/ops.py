@@ -371,3 +371,12 @@ def reduce_pair(a, b, out, scratch, mode, eps=0.0, scale=1.0, accumulate=False):
     _lib.check(_lib.load().fac_reduce_pair(_ptr(a), _ptr(b), _ptr(out), _ptr(scratch), a.numel(), mode, eps, scale,
                                            1 if accumulate else 0, _stream()), "fac_reduce_pair")
     return out
+
+
+def logdiff_rms(a, b, out, scratch, eps, scale=1.0, accumulate=False):
+    """losses.py:84 term on (B, M, T) tensors, accumulated into out[0]."""
+    a, b = _dev(a), _dev(b)
+    B, M, T = a.shape
+    _lib.check(_lib.load().fac_logdiff_rms(_ptr(a), _ptr(b), _ptr(out), _ptr(scratch), B, M, T, eps, scale,
+                                           1 if accumulate else 0, _stream()), "fac_logdiff_rms")
+    return out

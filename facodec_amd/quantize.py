@@ -220,11 +220,12 @@ class LogMelFrontend(nn.Module):
         self._basis = None
         return super()._apply(fn, *a, **kw)
 
-    def forward(self, wave):
-        """wave (B, 1, T) or (B, T) -> normalised log-mel (B, n_mels, T // hop)."""
+    def forward(self, wave, all_frames=False):
+        """wave (B, 1, T) or (B, T) -> normalised log-mel (B, n_mels, T // hop) (the quantizer's crop,
+        modules/quantize.py:242) or, with all_frames, all 1 + T // hop centred frames (meldataset.py:45)."""
         w = wave.reshape(wave.shape[0], wave.shape[-1])
         B, T = w.shape
-        n_frames = T // self.hop
+        n_frames = T // self.hop + (1 if all_frames else 0)
         basis, fbp, off = self._consts(w.device)
         F_ = self.n_fft // 2 + 1
         frames = ops.stft_frames(w, self.win, n_frames, self.hop, self.n_fft // 2, off)

@@ -230,6 +230,11 @@ int fac_spec_power(const float* spec, float* out, int B, int F, int n_frames, in
 int fac_reduce_pair(const float* a, const float* b, float* out, float* scratch, int64_t n,
                     int mode, float eps, float scale, int accumulate, fac_stream_t stream);
 
+/* losses.py:84:  out[0] (+)= scale * sum_{b,t} sqrt( mean_m (log(|a|+eps) - log(|b|+eps))^2 ),
+ * a, b (B, M, T); scratch >= 1024 floats; deterministic two-stage reduction. */
+int fac_logdiff_rms(const float* a, const float* b, float* out, float* scratch, int B, int M, int T,
+                    float eps, float scale, int accumulate, fac_stream_t stream);
+
 static inline int fac_pad32(int n) { return (n + 31) & ~31; }
 /* packed weights carry zero rows up to a multiple of 48 input channels (lcm of the kernel's
  * channels-per-stage choices), so a partially filled last stage multiplies zeros */
