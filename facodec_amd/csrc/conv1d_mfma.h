@@ -68,7 +68,8 @@ struct ConvUnroll {
 #define FAC_CONV_WPE 4
 #endif
 template <int MB, int NB, int WM, int WN, int KT>
-__global__ __launch_bounds__(512, FAC_CONV_WPE) void conv1d_mfma_kernel(ConvArgs a) {
+__global__ __launch_bounds__((WM * WN + 4) * 64, (WM * WN == 4 ? FAC_CONV_WPE : 3)) void conv1d_mfma_kernel(ConvArgs a) {
+  constexpr int NMW = WM * WN;   // MFMA waves (4 or 8); 4 staging waves follow them
   constexpr int CO_TILE = 32 * MB * WM;
   constexpr int T_TILE = 32 * NB * WN;
   constexpr int CO4 = CO_TILE / 4;
@@ -76,7 +77,7 @@ __global__ __launch_bounds__(512, FAC_CONV_WPE) void conv1d_mfma_kernel(ConvArgs
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // 0-3: MFMA waves, 4-7: staging waves
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // [0, NMW): MFMA waves, then 4 staging waves
 
   // Work decode.  Workgroups are dispatched round-robin over the 8 XCDs (observed: block i -> XCD
   // i % 8, speed only, never correctness): remap so that each XCD walks a CONTIGUOUS range of the tile
@@ -108,9 +109,9 @@ __global__ __launch_bounds__(512, FAC_CONV_WPE) void conv1d_mfma_kernel(ConvArgs
   float* Xbuf = smem + 2 * w_stage;   // [2][cic][XW]
   const int n_chunks = (a.C_in + cic - 1) / cic;
 
-  if (wave >= 4) {
+  if (wave >= NMW) {
     // ===================== staging waves: HBM/L2 -> LDS for chunk c+1 while chunk c is multiplied
-    const int lw = wave - 4;
+    const int lw = wave - NMW;
     // Both roles share each SIMD's VALU issue port, and a pending MFMA of an older / higher-priority
     // wave blocks it: at equal priority the staging waves got ~1 VALU slot per MFMA (measured: 12k
     // cycles to ISSUE one chunk's loads; MFMA waves then idled 47 % of their life at the barrier).
@@ -443,7 +444,7 @@ __global__ __launch_bounds__(512, FAC_CONV_WPE) void conv1d_mfma_kernel(ConvArgs
   }
 #ifdef FAC_PROF
   if (a.dbg && lane == 0) {
-    unsigned long long* d = a.dbg + ((long long)blockIdx.x * 4 + wave) * 4;
+    unsigned long long* d = a.dbg + ((long long)blockIdx.x * 4 + (wave & 3)) * 4;
     d[0] = t_first; d[1] = t_bar; d[2] = t_loop; d[3] = __builtin_readcyclecounter() - t_start;
   }
 #endif
@@ -473,7 +474,7 @@ int launch_cfg(ConvArgs& a, hipStream_t s) {
     cic = ConvUnroll<KT>::CIC;
     // the compile-time stage must fit the register slots and ~half the LDS; otherwise use the
     // run-time-sized generic path (unusual stride / dilation for this tap count)
-    if (cic * a.XB > 4 * CONV_XMAX || (size_t)2 * cic * per_ci * sizeof(float) > 80 * 1024)
+    if (cic * a.XB > 4 * CONV_XMAX || (size_t)2 * cic * per_ci * sizeof(float) > (WM * WN == 4 ? 80 : 160) * 1024)
       return launch_cfg<MB, NB, WM, WN, 0>(a, s);
   } else {
     int lim = 9216 / per_ci;                       // ~36 KB per stage -> 2 stages x 2 workgroups per CU
@@ -514,7 +515,7 @@ int launch_cfg(ConvArgs& a, hipStream_t s) {
     set_error("conv1d: too many workgroups (%lld)", n_wg);
     return FAC_ERR_ARG;
   }
-  hipLaunchKernelGGL(kern, dim3((unsigned)n_wg), dim3(512), lds, s, a);
+  hipLaunchKernelGGL(kern, dim3((unsigned)n_wg), dim3((WM * WN + 4) * 64), lds, s, a);
   return check_launch("conv1d_mfma");
 }
 
@@ -524,5 +525,7 @@ int conv_dispatch_96x128(ConvArgs& a, hipStream_t s);
 int conv_dispatch_64x128(ConvArgs& a, hipStream_t s);
 int conv_dispatch_32x256(ConvArgs& a, hipStream_t s);
 int conv_dispatch_128x32(ConvArgs& a, hipStream_t s);
+int conv_dispatch_128x256(ConvArgs& a, hipStream_t s);
+int conv_dispatch_96x256(ConvArgs& a, hipStream_t s);
 
 }  // namespace fac
