@@ -20,7 +20,7 @@ _f = C.c_float
 
 class ConvDesc(C.Structure):
     _fields_ = [
-        ("x", _p), ("w", _p), ("bias", _p), ("alpha_in", _p), ("alpha_out", _p), ("res", _p), ("y", _p), ("y2", _p), ("alpha_y2", _p),
+        ("x", _p), ("w", _p), ("bias", _p), ("alpha_in", _p), ("alpha_out", _p), ("res", _p), ("y", _p), ("y2", _p), ("alpha_y2", _p), ("w_k1", _p), ("bias_k1", _p),
         ("x_bs", _i64), ("x_cs", _i64), ("y_bs", _i64), ("y_cs", _i64),
         ("B", C.c_int32), ("C_in", C.c_int32), ("T_in", C.c_int32), ("C_out", C.c_int32),
         ("C_out_pad", C.c_int32), ("T_out", C.c_int32),

@@ -43,6 +43,12 @@ extern "C" int fac_conv1d_fwd(const fac_conv_desc* d, fac_stream_t stream) {
   ConvArgs a;
   a.x = d->x; a.w = d->w; a.bias = d->bias; a.alpha_in = d->alpha_in; a.alpha_out = d->alpha_out;
   a.res = d->res; a.y = d->y; a.y2 = d->y2; a.alpha2 = d->alpha_y2;
+  a.w1 = d->w_k1; a.bias1 = d->bias_k1;
+  if (d->w_k1) {
+    FAC_REQUIRE(d->C_in == d->C_out && d->C_out_pad == d->C_out && d->n_phase == 1 && d->stride == 1 &&
+                    d->alpha_out && d->act == FAC_ACT_NONE && !d->w_batched,
+                "conv1d: fused ResidualUnit needs C_in == C_out (multiple of 32), stride 1, a Snake alpha_out");
+  }
   a.x_bs = d->x_bs; a.x_cs = d->x_cs; a.y_bs = d->y_bs; a.y_cs = d->y_cs; a.w_bs = d->w_bs;
   a.B = d->B; a.C_in = d->C_in; a.T_in = d->T_in; a.C_out = d->C_out; a.C_out_pad = d->C_out_pad;
   a.T_out = d->T_out; a.K = d->K; a.stride = d->stride; a.dil = d->dilation;
@@ -56,6 +62,7 @@ extern "C" int fac_conv1d_fwd(const fac_conv_desc* d, fac_stream_t stream) {
     a.T_ext = d->T_in > max_pad ? d->T_in : max_pad + 1;
   }
   hipStream_t s = (hipStream_t)stream;
+  if (d->w_k1) return conv_dispatch_fused_ru(a, s);
   switch (select_variant(d)) {
     case 0: return conv_dispatch_128x32(a, s);
     case 1: return conv_dispatch_32x256(a, s);
@@ -74,6 +81,10 @@ extern "C" int fac_conv1d_variant(const fac_conv_desc* d, char* name, int name_l
                                 "conv1d_mfma_kernel<2,1,1,4,K> 64x128", "conv1d_mfma_kernel<3,1,1,4,K> 96x128",
                                 "conv1d_mfma_kernel<2,2,2,2,K> 128x128", "conv1d_mfma_kernel<2,2,2,4,K> 128x256",
                                 "conv1d_mfma_kernel<3,1,1,8,K> 96x256"};
+  if (d->w_k1) {
+    if (name && name_len > 0) snprintf(name, name_len, "conv1d_mfma_kernel<C/32,1,1,4,7,fused RU> Cx128");
+    return 7;
+  }
   const int v = select_variant(d);
   if (name && name_len > 0) snprintf(name, name_len, "%s", names[v]);
   return v;

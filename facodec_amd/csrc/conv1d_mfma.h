@@ -42,6 +42,8 @@ struct ConvArgs {
   float* y;
   float* y2;            // optional pre-activated copy: snake(y, alpha2)
   const float* alpha2;
+  const float* w1;      // fused ResidualUnit: packed 1x1 weights (C, 1, C) applied to snake(conv + bias)
+  const float* bias1;
   long long x_bs, x_cs, y_bs, y_cs, w_bs;
   int B, C_in, T_in, T_ext, C_out, C_out_pad, T_out;
   int K, stride, dil, pad_left, pad_mode;
@@ -67,7 +69,7 @@ struct ConvUnroll {
 #ifndef FAC_CONV_WPE
 #define FAC_CONV_WPE 4
 #endif
-template <int MB, int NB, int WM, int WN, int KT>
+template <int MB, int NB, int WM, int WN, int KT, bool FUSE = false>
 __global__ __launch_bounds__((WM * WN + 4) * 64, (WM * WN == 4 ? FAC_CONV_WPE : 3)) void conv1d_mfma_kernel(ConvArgs a) {
   constexpr int NMW = WM * WN;   // MFMA waves (4 or 8); 4 staging waves follow them
   constexpr int CO_TILE = 32 * MB * WM;
@@ -277,6 +279,21 @@ __global__ __launch_bounds__((WM * WN + 4) * 64, (WM * WN == 4 ? FAC_CONV_WPE : 
       lt_bar += __builtin_readcyclecounter() - qb;
 #endif
     }
+    if constexpr (FUSE) {
+      // fused ResidualUnit: every stage buffer is free now -- DMA the whole 1x1 weight matrix
+      // [C][CO_TILE] over them while the MFMA waves apply bias + Snake to their accumulators
+      const int n4 = CO_TILE * CO4;
+      for (int i = lw; i * 64 < n4; i += 4) {
+        const int q = i * 64 + lane;
+        if (q < n4) {
+          const int row = q / CO4;
+          const int c4 = q - row * CO4;
+          const float* src = a.w1 + (long long)row * a.C_out_pad + 4 * c4;
+          __builtin_amdgcn_global_load_lds((glb_void_t*)src, (lds_void_t*)(smem + i * 256), 16, 0, 0);
+        }
+      }
+      __syncthreads();
+    }
 #ifdef FAC_PROF
     if (a.dbg && lane == 0) {
       unsigned long long* d = a.dbg + (1ll << 21) + ((long long)blockIdx.x * 4 + lw) * 4;
@@ -392,54 +409,108 @@ __global__ __launch_bounds__((WM * WN + 4) * 64, (WM * WN == 4 ? FAC_CONV_WPE : 
   float* yg = a.y ? a.y + (long long)b * a.y_bs : nullptr;
   float* y2g = a.y2 ? a.y2 + (long long)b * a.y_bs : nullptr;
   const float* rg = a.res ? a.res + (long long)b * a.y_bs : nullptr;
-  // Row groups (m, g) = rows 8g..8g+3 (+4 for the upper half-wave) of 32-row block m.  Every load a
-  // group needs (bias, Snake alphas, residuals -- y may alias res, so the compiler will not hoist
-  // residual loads above stores by itself) is issued one group AHEAD of its math and stores
-  // (2-deep register ring, static indices): one exposed memory round trip per workgroup instead of
-  // one per group (12-16 of them: measured 30k cycles of epilogue on the k=1 residual layers).
-  constexpr int NG = MB * 4;
-  float bsv[2][4], alv[2][4], al2[2][4], rv[2][4][NB];
-  auto ld_group = [&](int gi, int slot) {
-    const int m = gi >> 2, g = gi & 3;
+  // One 32-row block `blk` (block index m of this wave) -> bias, activation, residual, stores.
+  // Row groups g = rows 8g..8g+3 (+4 for the upper half-wave).  Every load a group needs (bias, Snake
+  // alphas, residuals -- y may alias res, so the compiler will not hoist residual loads above stores
+  // by itself) is issued one group AHEAD of its math and stores (2-deep register ring, static
+  // indices): one exposed memory round trip per block instead of one per group (measured 30k cycles
+  // of epilogue on the k=1 residual layers before).
+  auto emit_block = [&](const f32x16 (&blk)[NB], int m, const float* bias, const float* alpha_out, int act) {
+    float bsv[2][4], alv[2][4], al2[2][4], rv[2][4][NB];
+    auto ld_group = [&](int g, int slot) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int co = co0 + wm * (MB * 32) + m * 32 + i + 8 * g + 4 * kq;
-      const int cc = co < a.C_out ? co : a.C_out - 1;
-      bsv[slot][i] = a.bias ? a.bias[cc] : 0.f;
-      alv[slot][i] = a.alpha_out ? a.alpha_out[cc] : 0.f;
-      al2[slot][i] = y2g ? a.alpha2[cc] : 0.f;
+      for (int i = 0; i < 4; ++i) {
+        const int co = co0 + wm * (MB * 32) + m * 32 + i + 8 * g + 4 * kq;
+        const int cc = co < a.C_out ? co : a.C_out - 1;
+        bsv[slot][i] = bias ? bias[cc] : 0.f;
+        alv[slot][i] = alpha_out ? alpha_out[cc] : 0.f;
+        al2[slot][i] = y2g ? a.alpha2[cc] : 0.f;
 #pragma unroll
-      for (int n = 0; n < NB; ++n) {
-        const int t = t0 + wn * (NB * 32) + n * 32 + l31;
-        rv[slot][i][n] = (rg && co < a.C_out && t < a.T_out)
-                             ? rg[(long long)co * a.y_cs + (long long)t * a.y_tstride + phase] : 0.f;
+        for (int n = 0; n < NB; ++n) {
+          const int t = t0 + wn * (NB * 32) + n * 32 + l31;
+          rv[slot][i][n] = (rg && co < a.C_out && t < a.T_out)
+                               ? rg[(long long)co * a.y_cs + (long long)t * a.y_tstride + phase] : 0.f;
+        }
+      }
+    };
+    ld_group(0, 0);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int slot = g & 1;
+      if (g + 1 < 4) ld_group(g + 1, slot ^ 1);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int r = 4 * g + i;
+        const int co = co0 + wm * (MB * 32) + m * 32 + i + 8 * g + 4 * kq;
+        if (co >= a.C_out) continue;
+        const float al = alv[slot][i];
+        const float inv = alpha_out ? snake_inv(al) : 0.f;
+#pragma unroll
+        for (int n = 0; n < NB; ++n) {
+          const int t = t0 + wn * (NB * 32) + n * 32 + l31;
+          if (t >= a.T_out) continue;
+          float v = blk[n][r] + bsv[slot][i];
+          if (alpha_out) v = snake_apply(v, al, inv);
+          if (act != FAC_ACT_NONE) v = apply_act_slow(v, act);
+          v += rv[slot][i][n];
+          const long long o = (long long)co * a.y_cs + (long long)t * a.y_tstride + phase;
+          if (yg) yg[o] = v;
+          if (y2g) y2g[o] = snake_apply(v, al2[slot][i], snake_inv(al2[slot][i]));
+        }
       }
     }
   };
-  ld_group(0, 0);
+
+  if constexpr (!FUSE) {
 #pragma unroll
-  for (int gi = 0; gi < NG; ++gi) {
-    const int m = gi >> 2, g = gi & 3, slot = gi & 1;
-    if (gi + 1 < NG) ld_group(gi + 1, slot ^ 1);
+    for (int m = 0; m < MB; ++m) emit_block(acc[m], m, a.bias, a.alpha_out, a.act);
+  } else {
+    // ---- fused ResidualUnit tail (dac/model/dac.py:33-34,38-42): h = snake(conv7 + b7, alpha2) stays in
+    // the accumulators; in the C/D layout register r of a 32x32 tile holds rows R0(r) (lanes 0-31) and
+    // R0(r)+4 (lanes 32-63) of column lane&31 -- exactly an MFMA B fragment for the k-pair
+    // (R0(r), R0(r)+4).  So the 1x1 conv y = W1 h runs straight out of the registers (A = W1 from LDS),
+    // and h never travels to LDS or HBM.  Needs every channel in one wave: tiles with WM == 1.
+    static_assert(WM == 1, "fused ResidualUnit needs all channels of a column in one wave");
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int r = 4 * g + i;
-      const int co = co0 + wm * (MB * 32) + m * 32 + i + 8 * g + 4 * kq;
-      if (co >= a.C_out) continue;
-      const float al = alv[slot][i];
-      const float inv = a.alpha_out ? snake_inv(al) : 0.f;
+    for (int m = 0; m < MB; ++m) {
 #pragma unroll
-      for (int n = 0; n < NB; ++n) {
-        const int t = t0 + wn * (NB * 32) + n * 32 + l31;
-        if (t >= a.T_out) continue;
-        float v = acc[m][n][r] + bsv[slot][i];
-        if (a.alpha_out) v = snake_apply(v, al, inv);
-        if (a.act != FAC_ACT_NONE) v = apply_act_slow(v, a.act);
-        v += rv[slot][i][n];
-        const long long o = (long long)co * a.y_cs + (long long)t * a.y_tstride + phase;
-        if (yg) yg[o] = v;
-        if (y2g) y2g[o] = snake_apply(v, al2[slot][i], snake_inv(al2[slot][i]));
+      for (int g = 0; g < 4; ++g) {
+        float bs[4], al[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int c = m * 32 + i + 8 * g + 4 * kq;
+          bs[i] = a.bias ? a.bias[c] : 0.f;
+          al[i] = a.alpha_out[c];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float inv = snake_inv(al[i]);
+#pragma unroll
+          for (int n = 0; n < NB; ++n) acc[m][n][4 * g + i] = snake_apply(acc[m][n][4 * g + i] + bs[i], al[i], inv);
+        }
       }
+    }
+    __syncthreads();   // W1 landed in LDS (staged by the staging waves meanwhile)
+    const float* W1s = smem + 4 * kq * CO_TILE + l31;   // [c][CO_TILE]; this lane's k row offset and column
+#pragma unroll
+    for (int cb = 0; cb < MB; ++cb) {
+      f32x16 acc2[NB];
+#pragma unroll
+      for (int n = 0; n < NB; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc2[n][r] = 0.f;
+#pragma unroll
+      for (int m = 0; m < MB; ++m) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int c0r = m * 32 + (r & 3) + 8 * (r >> 2);
+          const float av1 = W1s[c0r * CO_TILE + cb * 32];
+#pragma unroll
+          for (int n = 0; n < NB; ++n)
+            acc2[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1, acc[m][n][r], acc2[n], 0, 0, 0);
+        }
+      }
+      emit_block(acc2, cb, a.bias1, nullptr, FAC_ACT_NONE);
     }
   }
 #ifdef FAC_PROF
@@ -455,7 +526,7 @@ extern unsigned long long* g_conv_dbg;
 #endif
 
 // Picks channels-per-stage and launches one instantiation.
-template <int MB, int NB, int WM, int WN, int KT>
+template <int MB, int NB, int WM, int WN, int KT, bool FUSE = false>
 int launch_cfg(ConvArgs& a, hipStream_t s) {
   constexpr int CO_TILE = 32 * MB * WM;
   constexpr int T_TILE = 32 * NB * WN;
@@ -475,7 +546,7 @@ int launch_cfg(ConvArgs& a, hipStream_t s) {
     // the compile-time stage must fit the register slots and ~half the LDS; otherwise use the
     // run-time-sized generic path (unusual stride / dilation for this tap count)
     if (cic * a.XB > 4 * CONV_XMAX || (size_t)2 * cic * per_ci * sizeof(float) > (WM * WN == 4 ? 80 : 160) * 1024)
-      return launch_cfg<MB, NB, WM, WN, 0>(a, s);
+      return launch_cfg<MB, NB, WM, WN, 0, FUSE>(a, s);
   } else {
     int lim = 9216 / per_ci;                       // ~36 KB per stage -> 2 stages x 2 workgroups per CU
     const int lim_regs = (4 * CONV_XMAX) / a.XB;   // staged inputs must fit CONV_XMAX registers/thread
@@ -499,7 +570,7 @@ int launch_cfg(ConvArgs& a, hipStream_t s) {
     set_error("conv1d: tile needs %zu B of LDS (K=%d stride=%d dil=%d)", lds, a.K, a.stride, a.dil);
     return FAC_ERR_ARG;
   }
-  auto kern = conv1d_mfma_kernel<MB, NB, WM, WN, KT>;
+  auto kern = conv1d_mfma_kernel<MB, NB, WM, WN, KT, FUSE>;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -527,5 +598,6 @@ int conv_dispatch_32x256(ConvArgs& a, hipStream_t s);
 int conv_dispatch_128x32(ConvArgs& a, hipStream_t s);
 int conv_dispatch_128x256(ConvArgs& a, hipStream_t s);
 int conv_dispatch_96x256(ConvArgs& a, hipStream_t s);
+int conv_dispatch_fused_ru(ConvArgs& a, hipStream_t s);
 
 }  // namespace fac

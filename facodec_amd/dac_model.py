@@ -22,6 +22,9 @@ from . import ops
 from .layers import SConv1d, SConvTranspose1d, SLSTM, Snake1d
 
 
+FUSED_RU_CHANNELS = (64, 96, 128)   # channel counts the single-launch ResidualUnit kernel is built for
+
+
 class ResidualUnit(nn.Module):
     """dac/model/dac.py:25-42.  block = [Snake, SConv k7 dil d, Snake, SConv k1]."""
 
@@ -42,6 +45,13 @@ class ResidualUnit(nn.Module):
         """x: raw input (skip path); x_act = snake(x, alpha_in) from the producer.
         Returns (y, snake(y, alpha_next)); y is None when want_raw is False."""
         b = self.block
+        k7, k1 = b[1], b[3]
+        if k7.w.c_out in FUSED_RU_CHANNELS and k7.causal and x_act.shape[-1] == x.shape[-1]:
+            # whole unit in one launch: the 1x1 conv runs out of the k7 accumulators (conv1d_fused_ru.hip)
+            return_pair = ops.conv1d(x_act, k7.w.packed(), k7.w.c_out, 7, bias=k7.w.bias, dilation=k7.dilation,
+                                     alpha_out=b[2].flat(), res=x, w_k1=k1.w.packed(), bias_k1=k1.w.bias,
+                                     alpha_y2=alpha_next, want_y=want_raw or alpha_next is None)
+            return return_pair if alpha_next is not None else (return_pair, None)
         h = b[1].run(x_act, alpha_out=b[2].flat())
         if h.shape[-1] != x.shape[-1]:  # non-causal trimming of :38-41 never triggers with SConv1d padding
             pad = (x.shape[-1] - h.shape[-1]) // 2

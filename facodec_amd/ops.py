@@ -119,6 +119,8 @@ def _launch_conv(d, what):
     _lib.check(lib.fac_conv1d_fwd(C.byref(d), _stream()), what)
     e1.record()
     flops = 2.0 * d.B * d.n_phase * d.C_out * d.T_out * d.C_in * d.K
+    if d.w_k1:
+        flops += 2.0 * d.B * d.C_out * d.T_out * d.C_out   # fused 1x1 conv
     _PROFILE.records.append((buf.value.decode(), flops, e0, e1))
 
 
@@ -135,10 +137,11 @@ def conv_out_len(t_in, k, stride, dilation):
 
 def conv1d(x, w_packed, c_out, k, bias=None, stride=1, dilation=1, pad_left=None, pad_mode=PAD_REFLECT,
            t_out=None, alpha_in=None, alpha_out=None, res=None, act=ACT_NONE, out=None, causal=True,
-           alpha_y2=None, want_y=True):
+           alpha_y2=None, want_y=True, w_k1=None, bias_k1=None):
     """Fused conv (see fac_conv1d_fwd).  x (B, C_in, T).  With pad_left=None the SConv1d padding
     rule is applied (causal: everything on the left; non-causal: asymmetric split).
-    alpha_y2: also produce y2 = snake(y, alpha_y2) (returned as (y, y2); y is None if not want_y)."""
+    alpha_y2: also produce y2 = snake(y, alpha_y2) (returned as (y, y2); y is None if not want_y).
+    w_k1 / bias_k1: fused ResidualUnit tail -- y = w_k1 * snake(conv + bias, alpha_out) + bias_k1 + res."""
     if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 3 and x.stride(2) == 1):
         x = _dev(x, "x")     # channel-sliced views (time contiguous) are consumed in place
     B, c_in, t_in = x.shape
@@ -162,6 +165,8 @@ def conv1d(x, w_packed, c_out, k, bias=None, stride=1, dilation=1, pad_left=None
     d.y = out.data_ptr() if out is not None else None
     d.y2 = y2.data_ptr() if y2 is not None else None
     d.alpha_y2 = alpha_y2.data_ptr() if alpha_y2 is not None else None
+    d.w_k1 = w_k1.data_ptr() if w_k1 is not None else None
+    d.bias_k1 = bias_k1.data_ptr() if bias_k1 is not None else None
     d.x_bs, d.x_cs = x.stride(0), x.stride(1)
     d.y_bs, d.y_cs = c_out * t_out, t_out
     d.B, d.C_in, d.T_in, d.C_out, d.C_out_pad, d.T_out = B, c_in, t_in, c_out, cp, t_out

@@ -96,6 +96,10 @@ typedef struct fac_conv_desc {
                              pre-activated copy the next Snake->conv consumes, so that consumer can
                              stage its input by pure LDS-DMA (no VALU work beside the MFMAs) */
   const float* alpha_y2;  /* (C_out) Snake alpha of y2; required iff y2 != NULL */
+  const float* w_k1;      /* optional fused ResidualUnit tail (dac/model/dac.py:33-34): packed 1x1 weights
+                             (fac_pack_conv_w of (C, C, 1)); then y = w_k1 * snake(conv + bias, alpha_out)
+                             + bias_k1 + res.  Needs C_in == C_out in {64, 96, 128}, K = 7, stride 1. */
+  const float* bias_k1;   /* (C_out) bias of the 1x1 conv, or NULL */
   int64_t x_bs, x_cs;
   int64_t y_bs, y_cs;
   int32_t B, C_in, T_in, C_out, C_out_pad;

@@ -418,3 +418,26 @@ def test_meldataset_preprocess_against_oracle(O, cuda):
     ref = (torch.log(1e-5 + torch.matmul(spec.transpose(-1, -2), fb).transpose(-1, -2)) + 4) / 4
     got = preprocess(w.to(cuda))
     assert got.shape == ref.shape == (1, 80, 101) and rel(got, ref) < E2E_TOL
+
+
+@pytest.mark.parametrize("C,T,d", [(64, 700, 1), (96, 1000, 3), (128, 517, 9)])
+def test_fused_residual_unit_against_oracle(C, T, d, O, cuda):
+    """Single-launch ResidualUnit (k7 -> Snake -> k1 -> +x out of the accumulators) vs the oracle's unit."""
+    from facodec_amd.dac_model import ResidualUnit
+    ru = ResidualUnit(C, dilation=d, causal=True)
+    sd = synth.load_synthetic(ru, seed=C)
+    x = torch.randn(2, C, T, generator=_g(C + d))
+    ref = O.residual_unit(x, sd, "", d, True)
+    a_next = 1 + 0.2 * torch.rand(C, generator=_g(1))
+    ru = ru.to(cuda)
+    xg = x.to(cuda)
+    with torch.no_grad():
+        y, y2 = ru.run(xg, ops_snake(xg, ru.alpha_in), alpha_next=a_next.to(cuda))
+        y_only = ru(xg)
+    assert rel(y, ref) < OP_TOL and rel(y_only, ref) < OP_TOL
+    assert rel(y2, O.snake(ref, a_next.view(1, -1, 1))) < OP_TOL
+
+
+def ops_snake(x, alpha):
+    from facodec_amd import ops as _ops
+    return _ops.snake(x, alpha)
