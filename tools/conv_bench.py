@@ -28,6 +28,8 @@ L.append(("dec out 96->1 k7 tanh", 96, 1, 48000, 7, 1, 1, 1, 0, 0, 0))
 L.append(("lstm proj H=1024 (T=32 tile)", 1024, 4096, 32, 1, 1, 1, 0, 0, 0, 0))
 L.append(("lstm proj H=1536 (T=32 tile)", 1536, 6144, 32, 1, 1, 1, 0, 0, 0, 0))
 
+for C, T in ((64, 48000), (128, 24000), (96, 48000)):
+    L.append((f"FUSED RU C={C} T={T} d=3", C, C, T, 7, 1, 3, 0, 1, 1, 2))
 sel = os.environ.get("SEL")
 rows = []
 for (name, ci, co, T, K, s, d, sin, sout, res, tr) in L:
@@ -38,7 +40,15 @@ for (name, ci, co, T, K, s, d, sin, sout, res, tr) in L:
     ai = torch.ones(ci, device=dev) if sin else None
     ao = torch.ones(co, device=dev) if sout else None
     bias = torch.zeros(co, device=dev)
-    if tr:
+    if tr == 2:
+        w = torch.randn(co, ci, K, device=dev) * 0.01
+        wp = ops.pack_conv_weight(w)
+        w1p = ops.pack_conv_weight(torch.randn(co, ci, 1, device=dev) * 0.05)
+        r = torch.randn(Bx, co, T, device=dev)
+        a2 = torch.ones(co, device=dev)
+        fn = lambda: ops.conv1d(x, wp, co, K, bias=bias, dilation=d, alpha_out=ao, res=r, alpha_y2=a2, w_k1=w1p, bias_k1=bias)
+        flops = 2.0 * Bx * co * T * ci * (K + 1)
+    elif tr:
         w = torch.randn(ci, co, K, device=dev) * 0.01
         wp = ops.pack_convtr_weight(w, None, s)
         fn = lambda: ops.conv_transpose1d(x, wp, co, s, bias=bias, alpha_in=ai)
