@@ -15,10 +15,12 @@ def per_kernel(path, counter):
     for r in csv.DictReader(open(path)):
         if r["Counter_Name"] != counter:
             continue
-        m = re.match(r"void fac::conv1d_mfma_kernel<(\d+), (\d+), (\d+), (\d+), (\d+)>", r["Kernel_Name"])
+        m = re.match(r"void fac::conv1d_mfma_kernel<(\d+), (\d+), (\d+), (\d+), (\d+)(?:, (true|false))?(?:, \d+)?>", r["Kernel_Name"])
         if not m:
             continue
         key = "conv1d_mfma_kernel<%s,%s,%s,%s,K>" % m.groups()[:4]
+        if m.group(6) == "true":
+            key = "conv1d_mfma_kernel<C/32,1,1,4,7,fused"
         tot[key] += float(r["Counter_Value"])
         n[key] += 1
     return tot, n
