@@ -35,7 +35,7 @@ FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 de
 
 def build(device, seed=0):
     model = build_model(default_model_params())
-    for k in model:
+    for k in ("encoder", "quantizer", "decoder"):        # the forward path; predictors are train-step only
         synth.load_synthetic(model[k], seed=seed, prefix=k + ".")
         model[k].eval().to(device)
     return model
@@ -56,7 +56,7 @@ def cpu_baseline(batch=4, passes=5):
     host's cores over a bounded sample of the same workload."""
     from oracle import facodec_oracle as O
     model = build_model(default_model_params())
-    sds = {k: synth.synth_state_dict(synth.param_shapes(model[k]), 0, k + ".") for k in model}
+    sds = {k: synth.synth_state_dict(synth.param_shapes(model[k]), 0, k + ".") for k in ("encoder", "quantizer", "decoder")}
     del model
     wave = synth.synth_clips(batch, int(CLIP_SECONDS * SAMPLE_RATE), seed=0)
     # thread sweep on the GPU box's host (tools/cpu_thread_sweep.py: 8/16/32/64/128 threads ->
@@ -91,7 +91,7 @@ def main():
         print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
-    device = torch.device(f"cuda:{local_rank}")
+    device = torch.device(f"cuda:{local_rank % torch.cuda.device_count()}")
     torch.cuda.set_device(device)
 
     model = build(device)

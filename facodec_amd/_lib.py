@@ -67,6 +67,7 @@ SIGNATURES = {
     "fac_stft_frames": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     "fac_spec_power": (_i, [_p, _p, _i, _i, _i, _i, _p]),
     "fac_reduce_pair": (_i, [_p, _p, _p, _p, _i64, _i, _f, _f, _i, _p]),
+    "fac_aa_snakebeta_fwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _p]),
     "fac_logdiff_rms": (_i, [_p, _p, _p, _p, _i, _i, _i, _f, _f, _i, _p]),
 }
 

@@ -17,7 +17,8 @@ def init_distributed(backend=None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"  # "nccl" is RCCL on ROCm
+            # "nccl" is RCCL on ROCm; FAC_DIST_BACKEND=gloo lets two ranks share one GPU in a smoke test
+            backend = os.environ.get("FAC_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, local_rank, world
 

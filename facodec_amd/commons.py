@@ -33,9 +33,9 @@ def recursive_munch(d):
 
 
 def build_model(args, stage="codec"):
-    """modules/commons.py:283-348.  Returns Munch(encoder, quantizer, decoder).  The reference also
-    builds `discriminator` and `fa_predictors` (train-step only); those are the next rows of the
-    scope table and are reported as missing rather than silently faked."""
+    """modules/commons.py:283-348.  Returns Munch(encoder, quantizer, decoder, fa_predictors).  The
+    reference also builds `discriminator` (train-step only): next row of the scope table (SURVEY.md
+    section 8f), reported as missing rather than silently faked."""
     if stage != "codec":
         raise ValueError(f"Unknown stage: {stage}")
     from .dac_model import Encoder, Decoder
@@ -49,7 +49,14 @@ def build_model(args, stage="codec"):
                             timbre_norm=args.timbre_norm)
     decoder = Decoder(input_channel=1024, channels=args.DAC.decoder_dim, rates=args.DAC.decoder_rates,
                       causal=args.causal, lstm=args.lstm)
-    return Munch(encoder=encoder, quantizer=quantizer, decoder=decoder)
+    from .predictors import FApredictors
+    fa_predictors = FApredictors(in_dim=1024, use_gr_content_f0=args.use_gr_content_f0,
+                                 use_gr_prosody_phone=args.use_gr_prosody_phone, use_gr_residual_f0=True,
+                                 use_gr_residual_phone=True, use_gr_timbre_content=True,
+                                 use_gr_timbre_prosody=args.use_gr_timbre_prosody, use_gr_x_timbre=True,
+                                 norm_f0=args.norm_f0, timbre_norm=args.timbre_norm,
+                                 use_gr_content_global_f0=args.use_gr_content_global_f0)
+    return Munch(encoder=encoder, quantizer=quantizer, decoder=decoder, fa_predictors=fa_predictors)
 
 
 def default_model_params():

@@ -307,6 +307,65 @@ __global__ __launch_bounds__(256) void reduce_pair_stage2(const float* __restric
   }
 }
 
+// K13: anti-aliased SnakeBeta (alias_free_torch/act.py:24-29 around modules/quantize.py:77-90), fused:
+//   u[m]  = 2 * sum_i xp[i] f[m + 15 - 2 i]          (replicate-pad 5, conv_transpose stride 2, crop 15/15;
+//                                                     alias_free_torch/resample.py:28-37)
+//   a[m]  = u[m] + sin(u[m] e^alpha)^2 / (e^beta + 1e-9)
+//   y[t]  = sum_j ap[2 t + j] f[j]                    (replicate-pad 5/6, stride-2 depthwise conv; filter.py:89-96)
+// One workgroup per (b, c, 256-step tile): x tile + halo in LDS, the 2x-rate activations in LDS, then the
+// decimating filter.  HBM-bound: reads x once, writes y once.
+__global__ __launch_bounds__(256) void aa_snakebeta_kernel(const float* __restrict__ x,
+                                                           const float* __restrict__ alpha_log,
+                                                           const float* __restrict__ beta_log,
+                                                           const float* __restrict__ filt,
+                                                           float* __restrict__ y, int C, int T) {
+  constexpr int TT = 256;
+  __shared__ float xs[TT + 16];        // x[t0-8 .. t0+TT+7], index clamped (replicate padding)
+  __shared__ float as[2 * TT + 16];    // a[2 t0 - 5 .. 2 t0 + 2 TT + 6]
+  __shared__ float f[12];
+  const int bc = blockIdx.y;
+  const int c = bc % C;
+  const int t0 = blockIdx.x * TT;
+  const float* xr = x + (long long)bc * T;
+  if (threadIdx.x < 12) f[threadIdx.x] = filt[threadIdx.x];
+  for (int i = threadIdx.x; i < TT + 16; i += 256) {
+    int t = t0 - 8 + i;
+    t = t < 0 ? 0 : (t > T - 1 ? T - 1 : t);
+    xs[i] = xr[t];
+  }
+  __syncthreads();
+  const float ea = expf(alpha_log[c]);
+  const float inv = __fdiv_rn(1.0f, __fadd_rn(expf(beta_log[c]), 1e-9f));
+  for (int i = threadIdx.x; i < 2 * TT + 12; i += 256) {
+    int m = 2 * t0 - 5 + i;                       // position in the 2x-rate signal, clamped like F.pad(replicate)
+    m = m < 0 ? 0 : (m > 2 * T - 1 ? 2 * T - 1 : m);
+    // u[m] = 2 * sum over padded index ip with 0 <= m + 15 - 2 ip <= 11; xp[ip] = x[clamp(ip - 5)]
+    float u = 0.f;
+    const int ip_lo = (m + 4 + 1) >> 1;           // ceil((m + 4) / 2)
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+      const int ip = ip_lo + q;
+      const int k = m + 15 - 2 * ip;
+      if (k >= 0 && k <= 11) {
+        int t = ip - 5;
+        t = t < 0 ? 0 : (t > T - 1 ? T - 1 : t);
+        u = fmaf(xs[t - (t0 - 8)], f[k], u);
+      }
+    }
+    u = __fmul_rn(2.0f, u);
+    const float sn = sin_sq(__fmul_rn(u, ea));
+    as[i] = __fadd_rn(u, __fmul_rn(inv, sn));
+  }
+  __syncthreads();
+  const int t = t0 + threadIdx.x;
+  if (t < T) {
+    float o = 0.f;
+#pragma unroll
+    for (int j = 0; j < 12; ++j) o = fmaf(as[2 * threadIdx.x + j], f[j], o);
+    y[(long long)bc * T + t] = o;
+  }
+}
+
 // losses.py:84  l2 = mean_{b,t} sqrt( mean_m ( log(a+eps) - log(b+eps) )^2 );  a, b (B, M, T).
 // One thread per (b, t) column (coalesced along t), partial sums per block into scratch.
 __global__ __launch_bounds__(256) void logdiff_rms_stage1(const float* __restrict__ a,
@@ -471,4 +530,15 @@ extern "C" int fac_logdiff_rms(const float* a, const float* b, float* out, float
   hipLaunchKernelGGL(reduce_pair_stage2, dim3(1), dim3(256), 0, (hipStream_t)stream, scratch, out, (int)g, scale,
                      accumulate);
   return check_launch("logdiff_rms");
+}
+
+extern "C" int fac_aa_snakebeta_fwd(const float* x, const float* alpha_log, const float* beta_log,
+                                    const float* filter12, float* y, int B, int C, int T,
+                                    fac_stream_t stream) {
+  FAC_REQUIRE(x && alpha_log && beta_log && filter12 && y && B > 0 && C > 0 && T > 0,
+              "aa_snakebeta_fwd: bad arguments");
+  FAC_REQUIRE((long long)B * C <= 65535, "aa_snakebeta_fwd: B*C too large");
+  hipLaunchKernelGGL(aa_snakebeta_kernel, dim3((T + 255) / 256, B * C), dim3(256), 0, (hipStream_t)stream, x,
+                     alpha_log, beta_log, filter12, y, C, T);
+  return check_launch("aa_snakebeta_fwd");
 }

@@ -89,3 +89,26 @@ def dft_basis(n_fft, win_length=None, window=None):
     ang = 2.0 * math.pi * ((f * n) % n_fft).astype(np.float64) / n_fft
     w = window.astype(np.float64)[None, :]
     return np.concatenate([np.cos(ang) * w, -np.sin(ang) * w], 0).astype(np.float32), off
+
+
+def kaiser_sinc_filter1d(cutoff, half_width, kernel_size):
+    """alias_free_torch/filter.py:27-58 restated with torch float32 ops in the same order (so the buffer
+    equals the one a reference checkpoint carries).  Returns (1, 1, kernel_size)."""
+    import torch
+    even = kernel_size % 2 == 0
+    half_size = kernel_size // 2
+    delta_f = 4 * half_width
+    A = 2.285 * (half_size - 1) * math.pi * delta_f + 7.95
+    if A > 50.0:
+        beta = 0.1102 * (A - 8.7)
+    elif A >= 21.0:
+        beta = 0.5842 * (A - 21) ** 0.4 + 0.07886 * (A - 21.0)
+    else:
+        beta = 0.0
+    window = torch.kaiser_window(kernel_size, beta=beta, periodic=False)
+    time = (torch.arange(-half_size, half_size) + 0.5) if even else (torch.arange(kernel_size) - half_size)
+    if cutoff == 0:
+        return torch.zeros(1, 1, kernel_size)
+    filt = 2 * cutoff * window * torch.sinc(2 * cutoff * time)
+    filt = filt / filt.sum()
+    return filt.view(1, 1, kernel_size)

@@ -385,3 +385,13 @@ def logdiff_rms(a, b, out, scratch, eps, scale=1.0, accumulate=False):
     _lib.check(_lib.load().fac_logdiff_rms(_ptr(a), _ptr(b), _ptr(out), _ptr(scratch), B, M, T, eps, scale,
                                            1 if accumulate else 0, _stream()), "fac_logdiff_rms")
     return out
+
+
+def aa_snakebeta(x, alpha_log, beta_log, filter12):
+    """Anti-aliased SnakeBeta (Activation1d(SnakeBeta(alpha_logscale=True)))."""
+    x = _dev(x)
+    B, c, T = x.shape
+    y = torch.empty_like(x)
+    _lib.check(_lib.load().fac_aa_snakebeta_fwd(_ptr(x), _ptr(alpha_log), _ptr(beta_log), _ptr(filter12), _ptr(y), B, c, T,
+                                                _stream()), "fac_aa_snakebeta_fwd")
+    return y

@@ -234,6 +234,13 @@ int fac_spec_power(const float* spec, float* out, int B, int F, int n_frames, in
 int fac_reduce_pair(const float* a, const float* b, float* out, float* scratch, int64_t n,
                     int mode, float eps, float scale, int accumulate, fac_stream_t stream);
 
+/* K13  anti-aliased SnakeBeta activation of the predictor heads (alias_free_torch/act.py:24-29:
+ * 2x Kaiser-sinc upsample -> SnakeBeta with log-scale alpha/beta, modules/quantize.py:77-90 -> 2x
+ * low-pass downsample), fused into one pass.  x, y (B, C, T); alpha_log, beta_log (C); filter12 = the
+ * 12-tap filter both resamplers share (alias_free_torch/filter.py:27-58). */
+int fac_aa_snakebeta_fwd(const float* x, const float* alpha_log, const float* beta_log,
+                         const float* filter12, float* y, int B, int C, int T, fac_stream_t stream);
+
 /* losses.py:84:  out[0] (+)= scale * sum_{b,t} sqrt( mean_m (log(|a|+eps) - log(|b|+eps))^2 ),
  * a, b (B, M, T); scratch >= 1024 floats; deterministic two-stage reduction. */
 int fac_logdiff_rms(const float* a, const float* b, float* out, float* scratch, int B, int M, int T,

@@ -450,6 +450,59 @@ def codec_forward(sds, wave, n_c=2):
 
 
 # ---------------------------------------------------------------------------------------------
+# predictor heads (train-step only; fully inside the reference tree, pinned)
+# ---------------------------------------------------------------------------------------------
+
+
+def aa_snakebeta(x, alpha_log, beta_log, filt):
+    """Activation1d(SnakeBeta(alpha_logscale=True)): alias_free_torch/act.py:24-29,
+    resample.py:28-37 (replicate-pad 5, depthwise conv_transpose stride 2, x2, crop 15/15),
+    modules/quantize.py:77-90, alias_free_torch/filter.py:89-96 (replicate-pad 5/6, stride-2 depthwise)."""
+    C = x.shape[1]
+    u = F.pad(x, (5, 5), mode="replicate")
+    u = 2 * F.conv_transpose1d(u, filt.expand(C, -1, -1), stride=2, groups=C)
+    u = u[..., 15:-15]
+    a = torch.exp(alpha_log).view(1, -1, 1)
+    b = torch.exp(beta_log).view(1, -1, 1)
+    u = u + (1.0 / (b + 1e-9)) * torch.sin(u * a).pow(2)
+    u = F.pad(u, (5, 6), mode="replicate")
+    return F.conv1d(u, filt.expand(C, -1, -1), stride=2, groups=C)
+
+
+def cnnlstm_forward(x, sd, p, n_heads, global_pred=False):
+    """CNNLSTM.forward modules/quantize.py:106-125 (3 ResidualUnits :92-104 with dilation 1,2,3 and
+    zero 'same' padding, anti-aliased activation, Linear heads; optional time mean)."""
+    for j, d in enumerate((1, 2, 3)):
+        q = f"{p}model.{j}.block."
+        y = aa_snakebeta(x, sd[q + "0.act.alpha"], sd[q + "0.act.beta"], sd[q + "0.upsample.filter"])
+        y = F.conv1d(y, conv_weight(sd, q + "1."), sd[q + "1.bias"], dilation=d, padding=3 * d)
+        y = aa_snakebeta(y, sd[q + "2.act.alpha"], sd[q + "2.act.beta"], sd[q + "2.upsample.filter"])
+        y = F.conv1d(y, conv_weight(sd, q + "3."), sd[q + "3.bias"])
+        x = x + y
+    q = f"{p}model.3."
+    x = aa_snakebeta(x, sd[q + "act.alpha"], sd[q + "act.beta"], sd[q + "upsample.filter"]).transpose(1, 2)
+    if global_pred:
+        x = x.mean(dim=1)
+    return [F.linear(x, sd[f"{p}heads.{i}.weight"], sd[f"{p}heads.{i}.bias"]) for i in range(n_heads)]
+
+
+def predictors_forward(sd, quantized, timbre):
+    """FApredictors.forward_v2 modules/quantize.py:564-606 with build_model's flags
+    (modules/commons.py:311-322: use_gr_content_f0=False, use_gr_prosody_phone=False,
+    use_gr_residual_f0=True, use_gr_residual_phone=True, use_gr_x_timbre=True); GradientReversal
+    (gradient_reversal.py:11-23) is the identity in the forward pass."""
+    z_p, z_c, z_r = quantized
+    content = cnnlstm_forward(z_c, sd, "phone_predictor.", 1)[0]
+    spk = F.linear(timbre, sd["timbre_predictor.weight"], sd["timbre_predictor.bias"])
+    f0, uv = cnnlstm_forward(z_p, sd, "f0_predictor.", 2)
+    rev_f0, rev_uv = cnnlstm_forward(z_r, sd, "rev_f0_predictor.1.", 2)
+    rev_content = cnnlstm_forward(z_r, sd, "rev_content_predictor.1.", 1)[0]
+    x_spk = cnnlstm_forward(z_p + z_c + z_r, sd, "rev_timbre_predictor.1.", 1, global_pred=True)[0]
+    return (dict(f0=f0, uv=uv, content=content, timbre=spk),
+            dict(rev_f0=rev_f0, rev_uv=rev_uv, rev_content=rev_content, x_timbre=x_spk))
+
+
+# ---------------------------------------------------------------------------------------------
 # losses  (third-party STFT/mel semantics: PARITY UNPINNED)
 # ---------------------------------------------------------------------------------------------
 

@@ -172,7 +172,8 @@ def main():
     # --------------------------------------------------------------- 1. state-dict contract
     with torch.no_grad():
         model = build_model(recursive_munch(model_params()))
-    shapes = {k: {n: list(v.shape) for n, v in model[k].state_dict().items()} for k in ("encoder", "quantizer", "decoder")}
+    shapes = {k: {n: list(v.shape) for n, v in model[k].state_dict().items()}
+              for k in ("encoder", "quantizer", "decoder", "fa_predictors")}
     json.dump(shapes, open(os.path.join(HERE, "state_shapes.json"), "w"), indent=0, sort_keys=True)
 
     # --------------------------------------------------------------- 2. reduced config, layer probes
@@ -244,6 +245,21 @@ def main():
         # quantizer run on the ORACLE's latent (what a from-scratch pipeline sees)
         _, _, _, _, _, o_codes2 = O.quantizer_forward(sds["quantizer"], oz, wave, n_c=2)
         report["e2e_codes_oracle_pipeline_mismatch"] = int(sum((a != b).sum() for a, b in zip(o_codes2, codes)))
+
+        # predictor heads (train.py:270), eval mode, on the quantizer's outputs
+        model.fa_predictors.eval()
+        sd_p = synth.load_synthetic(model.fa_predictors, seed=0, prefix="fa_predictors.")
+        preds, rev_preds = model.fa_predictors(quantized, timbre)
+        sd_p_full = {k: v for k, v in model.fa_predictors.state_dict().items()}
+        o_preds, o_rev = O.predictors_forward(sd_p_full, quantized, timbre)
+        report["predictors_oracle_rel"] = max(rel_err(o_preds[k], preds[k]) for k in preds)
+        report["rev_predictors_oracle_rel"] = max(rel_err(o_rev[k], rev_preds[k]) for k in rev_preds)
+        np.savez_compressed(
+            os.path.join(HERE, "predictors.npz"), f0=preds["f0"].numpy(), uv=preds["uv"].numpy(),
+            content_probe=preds["content"][:, ::4, ::16].numpy(), timbre_probe=preds["timbre"][:, ::50].numpy(),
+            rev_f0=rev_preds["rev_f0"].numpy(), rev_uv=rev_preds["rev_uv"].numpy(),
+            rev_content_probe=rev_preds["rev_content"][:, ::4, ::16].numpy(),
+            x_timbre_probe=rev_preds["x_timbre"][:, ::50].numpy())
 
         # losses through the reference's own dac/nn/loss.py (over the audiotools shim)
         from dac.nn.loss import MelSpectrogramLoss, MultiScaleSTFTLoss, L1Loss

@@ -254,7 +254,7 @@ def test_small_encoder_decoder_vs_reference_golden(cuda, golden_dir):
 def full_model(cuda):
     from facodec_amd.commons import build_model, default_model_params
     model = build_model(default_model_params())
-    for k in model:
+    for k in ("encoder", "quantizer", "decoder"):
         synth.load_synthetic(model[k], seed=0, prefix=k + ".")
         model[k].eval().to(cuda)
     return model
@@ -441,3 +441,58 @@ def test_fused_residual_unit_against_oracle(C, T, d, O, cuda):
 def ops_snake(x, alpha):
     from facodec_amd import ops as _ops
     return _ops.snake(x, alpha)
+
+
+def test_anti_aliased_snakebeta_against_oracle(O, ops, cuda):
+    """K13: Activation1d(SnakeBeta) fused kernel, incl. the replicate-padded edges and a ragged tile."""
+    from facodec_amd import dsp
+    g = _g(31)
+    filt = dsp.kaiser_sinc_filter1d(0.25, 0.3, 12)
+    for (B, C, T) in ((2, 7, 160), (1, 3, 5), (1, 2, 777)):
+        x = torch.randn(B, C, T, generator=g) * 2
+        al = 0.3 * torch.randn(C, generator=g)
+        be = 0.3 * torch.randn(C, generator=g)
+        ref = O.aa_snakebeta(x, al, be, filt)
+        got = ops.aa_snakebeta(x.to(cuda), al.to(cuda), be.to(cuda), filt.reshape(-1).to(cuda))
+        assert got.shape == ref.shape and rel(got, ref) < OP_TOL
+
+
+def test_predictors_vs_reference_golden(full_model, cuda, golden_dir):
+    """train.py:270 `model.fa_predictors(quantized, timbre)` on the quantizer's outputs; values recorded
+    from the real reference (tests/golden/predictors.npz)."""
+    d = np.load(os.path.join(golden_dir, "predictors.npz"))
+    from facodec_amd.commons import build_model, default_model_params
+    pred = build_model(default_model_params()).fa_predictors
+    synth.load_synthetic(pred, seed=0, prefix="fa_predictors.")
+    pred.eval().to(cuda)
+    m = full_model
+    wave = synth.synth_clips(2, 48000, seed=0).to(cuda)
+    with torch.no_grad():
+        z = m.encoder(wave)
+        outs, quantized, _, _, timbre = m.quantizer(z, wave, n_c=2)
+        preds, rev = pred(quantized, timbre)
+    assert preds["f0"].shape == (2, 160, 1) and preds["content"].shape == (2, 160, 1024) and preds["timbre"].shape == (2, 20000)
+    assert rel(preds["f0"], d["f0"]) < E2E_TOL and rel(preds["uv"], d["uv"]) < E2E_TOL
+    assert rel(preds["content"][:, ::4, ::16], d["content_probe"]) < E2E_TOL
+    assert rel(preds["timbre"][:, ::50], d["timbre_probe"]) < E2E_TOL
+    assert rel(rev["rev_f0"], d["rev_f0"]) < E2E_TOL and rel(rev["rev_uv"], d["rev_uv"]) < E2E_TOL
+    assert rel(rev["rev_content"][:, ::4, ::16], d["rev_content_probe"]) < E2E_TOL
+    assert rel(rev["x_timbre"][:, ::50], d["x_timbre_probe"]) < E2E_TOL
+
+
+def test_long_clip_single_item_batch(full_model, O, cuda):
+    """configs[0]-style call: ONE clip (B = 1), 10 s instead of 2 s -- many time tiles, ragged last tiles,
+    T not a multiple of the 300-sample hop (encoder emits ceil(T/300) frames, quantizer crops to floor)."""
+    m = full_model
+    T = 240000 + 130
+    wave = synth.synth_clips(1, T, seed=13).to(cuda)
+    sds = {k: {n: v.detach().cpu() for n, v in m[k].state_dict().items()} for k in ("encoder", "quantizer", "decoder")}
+    with torch.no_grad():
+        z = m.encoder(wave)
+        outs, _, _, _, timbre, codes = m.quantizer(z, wave, n_c=2, return_codes=True)
+        y = m.decoder(outs)
+        r = O.codec_forward(sds, wave.cpu(), n_c=2)
+    assert z.shape == r["z"].shape == (1, 1024, 801) and y.shape == r["wave"].shape == (1, 1, 800 * 300)
+    assert rel(z, r["z"]) < E2E_TOL and rel(y, r["wave"]) < E2E_TOL and rel(timbre, r["timbre"]) < E2E_TOL
+    mism = sum(int((a.cpu() != b).sum()) for a, b in zip(codes, r["codes"]))
+    assert mism == 0, f"{mism} code mismatches of {sum(c.numel() for c in codes)}"

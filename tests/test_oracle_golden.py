@@ -84,6 +84,14 @@ def test_end_to_end_real_config(golden_dir):
     assert abs(float(O.waveform_l1_loss(y, wave)) - float(d["loss_l1"])) / float(d["loss_l1"]) < 1e-4
 
 
+def test_predictor_filter_buffer_equals_reference_formula():
+    """alias_free_torch/filter.py:27-58 restated in dsp.kaiser_sinc_filter1d: beta ~ 4.663, taps sum to 1."""
+    from facodec_amd import dsp
+    f = dsp.kaiser_sinc_filter1d(0.25, 0.3, 12)
+    assert f.shape == (1, 1, 12) and abs(float(f.sum()) - 1.0) < 1e-6
+    assert torch.allclose(f.flatten(), f.flatten().flip(0), atol=1e-7)      # symmetric even-length filter
+
+
 def test_filterbanks_against_transformers():
     """Cross-check of the restated third-party filterbanks."""
     from transformers.audio_utils import mel_filter_bank
