@@ -13,7 +13,9 @@ static int select_variant(const fac_conv_desc* d) {
   // k = 1 convs re-use nothing across taps: per staged byte they do 7x less MFMA work than k = 7 and are
   // LDS-DMA-bound on 128-wide time tiles; long sequences take 256-wide tiles with 8 MFMA waves
   // (measured +15..30 % on the k = 1 layers, neutral on k = 7).
-  const bool wide = d->K == 1 && d->T_out >= 512 && d->n_phase == 1;
+  const bool wide = d->K == 1 && d->n_phase == 1 && d->T_out >= 512;   // (wide tiles measured slower for K = 2)
+  // 2 s clips are 160 latent frames: a 160-wide tile wastes nothing where 128 + 32 would waste 37 %
+  if (d->T_out > 128 && d->T_out <= 160 && co > 64) return 8;
   if (co % 128 != 0 && co % 96 == 0) return wide ? 6 : 3;
   return wide ? 5 : 4;
 }
@@ -70,6 +72,7 @@ extern "C" int fac_conv1d_fwd(const fac_conv_desc* d, fac_stream_t stream) {
     case 3: return conv_dispatch_96x128(a, s);
     case 5: return conv_dispatch_128x256(a, s);
     case 6: return conv_dispatch_96x256(a, s);
+    case 8: return conv_dispatch_128x160(a, s);
     default: return conv_dispatch_128x128(a, s);
   }
 }
@@ -80,7 +83,7 @@ extern "C" int fac_conv1d_variant(const fac_conv_desc* d, char* name, int name_l
   static const char* names[] = {"conv1d_mfma_kernel<1,1,4,1,K> 128x32", "conv1d_mfma_kernel<1,2,1,4,K> 32x256",
                                 "conv1d_mfma_kernel<2,1,1,4,K> 64x128", "conv1d_mfma_kernel<3,1,1,4,K> 96x128",
                                 "conv1d_mfma_kernel<2,2,2,2,K> 128x128", "conv1d_mfma_kernel<2,2,2,4,K> 128x256",
-                                "conv1d_mfma_kernel<3,1,1,8,K> 96x256"};
+                                "conv1d_mfma_kernel<3,1,1,8,K> 96x256", "fused", "conv1d_mfma_kernel<1,5,4,1,K> 128x160"};
   if (d->w_k1) {
     if (name && name_len > 0) snprintf(name, name_len, "conv1d_mfma_kernel<C/32,1,1,4,7,fused RU> Cx128");
     return 7;

@@ -18,4 +18,15 @@ int conv_dispatch_96x256(ConvArgs& a, hipStream_t s) {
     default: return launch_cfg<3,1,1,8, 0>(a, s);
   }
 }
+// 128 x 160: four MFMA waves stacked along C_out, each 32 rows x 160 columns -- the latent-rate layers
+// of a 2 s clip (160 frames) fit one tile exactly.
+int conv_dispatch_128x160(ConvArgs& a, hipStream_t s) {
+  switch (a.K) {
+    case 1: return launch_cfg<1,5,4,1, 1>(a, s);
+    case 2: return launch_cfg<1,5,4,1, 2>(a, s);
+    case 3: return launch_cfg<1,5,4,1, 3>(a, s);
+    case 7: return launch_cfg<1,5,4,1, 7>(a, s);
+    default: return launch_cfg<1,5,4,1, 0>(a, s);
+  }
+}
 }  // namespace fac
