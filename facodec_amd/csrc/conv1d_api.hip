@@ -24,6 +24,12 @@ static int select_variant(const fac_conv_desc* d) {
 unsigned long long* g_conv_dbg = nullptr;
 #endif
 
+// One or two output channels, plain stride-1 conv with nothing but bias / activation in the epilogue.
+static bool narrow_ok(const fac_conv_desc* d) {
+  return d->C_out <= 2 && d->stride == 1 && d->n_phase == 1 && d->y_tstride == 1 && !d->res && !d->y2 &&
+         !d->w_batched && d->y && (long long)d->B <= 65535;
+}
+
 }  // namespace fac
 
 #ifdef FAC_PROF
@@ -65,6 +71,7 @@ extern "C" int fac_conv1d_fwd(const fac_conv_desc* d, fac_stream_t stream) {
   }
   hipStream_t s = (hipStream_t)stream;
   if (d->w_k1) return conv_dispatch_fused_ru(a, s);
+  if (narrow_ok(d)) return conv_dispatch_narrow(a, s);
   switch (select_variant(d)) {
     case 0: return conv_dispatch_128x32(a, s);
     case 1: return conv_dispatch_32x256(a, s);
@@ -87,6 +94,10 @@ extern "C" int fac_conv1d_variant(const fac_conv_desc* d, char* name, int name_l
   if (d->w_k1) {
     if (name && name_len > 0) snprintf(name, name_len, "conv1d_mfma_kernel<C/32,1,1,4,7,fused RU> Cx128");
     return 7;
+  }
+  if (narrow_ok(d)) {
+    if (name && name_len > 0) snprintf(name, name_len, "conv1d_narrow_kernel (VALU, C_out<=2)");
+    return 9;
   }
   const int v = select_variant(d);
   if (name && name_len > 0) snprintf(name, name_len, "%s", names[v]);

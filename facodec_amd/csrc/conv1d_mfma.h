@@ -600,5 +600,6 @@ int conv_dispatch_128x256(ConvArgs& a, hipStream_t s);
 int conv_dispatch_96x256(ConvArgs& a, hipStream_t s);
 int conv_dispatch_fused_ru(ConvArgs& a, hipStream_t s);
 int conv_dispatch_128x160(ConvArgs& a, hipStream_t s);
+int conv_dispatch_narrow(ConvArgs& a, hipStream_t s);
 
 }  // namespace fac

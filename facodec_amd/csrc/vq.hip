@@ -121,6 +121,7 @@ __global__ __launch_bounds__(256) void vq_fwd_kernel(VqArgs a) {
     const int c_begin = wave * cper;
     const int c_end = min(a.D, c_begin + cper);
     const float* zp = a.z_in + bofs + t;
+#pragma unroll 8
     for (int c = c_begin; c < c_end; ++c) {
       const float xv = tv ? zp[(long long)c * a.T] : 0.f;
       const float* wr = a.w_in + (long long)c * 32;
@@ -198,20 +199,40 @@ __global__ __launch_bounds__(256) void vq_fwd_kernel(VqArgs a) {
     if (lane == 0 && a.loss_part) a.loss_part[(long long)b * gridDim.x + tile] = l;
   }
 
-  // ---- out_proj + residual bookkeeping: wave w handles channels w, w+4, ...
+  // ---- out_proj + residual bookkeeping: wave w handles channels w, w+4, ...  The loads of 8 channels
+  // are issued together before their math (the accumulator / residual may alias the input, so the
+  // compiler would otherwise serialise one memory round trip per channel: 256 of them per wave).
   if (tv) {
     const float mk = a.mask ? a.mask[b] : 1.0f;
-    for (int c = wave; c < a.D; c += 4) {
-      const float* wr = a.w_out + (long long)c * VQ_CD;
-      const float sc = a.w_out_scale ? a.w_out_scale[c] : 1.0f;
-      float o = __fmul_rn(__fmul_rn(wr[0], sc), zst[0]);
+    constexpr int UB = 8;
+    for (int c0 = wave; c0 < a.D; c0 += 4 * UB) {
+      float zin[UB], zacc[UB], bo[UB], sc[UB], wv[UB][VQ_CD];
 #pragma unroll
-      for (int d = 1; d < VQ_CD; ++d) o = fmaf(__fmul_rn(wr[d], sc), zst[d], o);
-      o = __fadd_rn(o, a.b_out[c]);
-      const long long off = bofs + (long long)c * a.T + t;
-      if (a.zq_out) a.zq_out[off] = o;
-      if (a.zq_acc) a.zq_acc[off] = __fadd_rn(a.zq_acc[off], __fmul_rn(o, mk));
-      if (a.residual) a.residual[off] = __fsub_rn(a.z_in[off], o);
+      for (int u = 0; u < UB; ++u) {
+        const int c = c0 + 4 * u;
+        const bool cv = c < a.D;
+        const int cc = cv ? c : a.D - 1;
+        const long long off = bofs + (long long)cc * a.T + t;
+        zin[u] = a.residual ? a.z_in[off] : 0.f;
+        zacc[u] = a.zq_acc ? a.zq_acc[off] : 0.f;
+        bo[u] = a.b_out[cc];
+        sc[u] = a.w_out_scale ? a.w_out_scale[cc] : 1.0f;
+#pragma unroll
+        for (int d = 0; d < VQ_CD; ++d) wv[u][d] = a.w_out[(long long)cc * VQ_CD + d];
+      }
+#pragma unroll
+      for (int u = 0; u < UB; ++u) {
+        const int c = c0 + 4 * u;
+        if (c >= a.D) continue;
+        float o = __fmul_rn(__fmul_rn(wv[u][0], sc[u]), zst[0]);
+#pragma unroll
+        for (int d = 1; d < VQ_CD; ++d) o = fmaf(__fmul_rn(wv[u][d], sc[u]), zst[d], o);
+        o = __fadd_rn(o, bo[u]);
+        const long long off = bofs + (long long)c * a.T + t;
+        if (a.zq_out) a.zq_out[off] = o;
+        if (a.zq_acc) a.zq_acc[off] = __fadd_rn(zacc[u], __fmul_rn(o, mk));
+        if (a.residual) a.residual[off] = __fsub_rn(zin[u], o);
+      }
     }
   }
 }
