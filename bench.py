@@ -59,7 +59,7 @@ def cpu_baseline(batch=4, passes=5):
     sds = {k: synth.synth_state_dict(synth.param_shapes(model[k]), 0, k + ".") for k in ("encoder", "quantizer", "decoder")}
     del model
     wave = synth.synth_clips(batch, int(CLIP_SECONDS * SAMPLE_RATE), seed=0)
-    # thread sweep on the GPU box's host (tools/cpu_thread_sweep.py: 8/16/32/64/128 threads ->
+    # thread sweep on the GPU box's host (tests/tools/cpu_thread_sweep.py: 8/16/32/64/128 threads ->
     # 1.91/2.14/1.79/1.21/0.48 audio-s/s): 16 threads is the oracle's best case, so that is the baseline
     prev_threads = torch.get_num_threads()
     threads = min(16, os.cpu_count() or 1)
