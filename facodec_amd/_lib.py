@@ -25,7 +25,8 @@ class ConvDesc(C.Structure):
         ("B", C.c_int32), ("C_in", C.c_int32), ("T_in", C.c_int32), ("C_out", C.c_int32),
         ("C_out_pad", C.c_int32), ("T_out", C.c_int32),
         ("K", C.c_int32), ("stride", C.c_int32), ("dilation", C.c_int32), ("pad_left", C.c_int32),
-        ("pad_mode", C.c_int32), ("n_phase", C.c_int32), ("y_tstride", C.c_int32), ("act", C.c_int32),
+        ("pad_mode", C.c_int32), ("n_phase", C.c_int32), ("y_tstride", C.c_int32), ("phase_shift", C.c_int32),
+        ("act", C.c_int32),
         ("w_batched", C.c_int32), ("w_bs", _i64),
     ]
 
@@ -55,7 +56,8 @@ SIGNATURES = {
     "fac_lstm_layer_fwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _p]),
     "fac_vq_fwd": (_i, [C.POINTER(VqDesc), _p]),
     "fac_vq_search": (_i, [_p, _p, _p, _i64, _i, _p]),
-    "fac_gate_tanh_sigmoid": (_i, [_p, _p, _i, _i, _i, _p]),
+    "fac_gate_tanh_sigmoid": (_i, [_p, _p, _i64, _p, _i, _i, _i, _p]),
+    "fac_embed_sum": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
     "fac_glu_residual": (_i, [_p, _p, _p, _i, _i, _i, _p]),
     "fac_add": (_i, [_p, _p, _p, _i64, _p]),
     "fac_sub2": (_i, [_p, _p, _p, _p, _i64, _p]),

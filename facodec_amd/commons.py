@@ -36,10 +36,24 @@ def build_model(args, stage="codec"):
     """modules/commons.py:283-348.  Returns Munch(encoder, quantizer, decoder, fa_predictors).  The
     reference also builds `discriminator` (train-step only): next row of the scope table (SURVEY.md
     section 8f), reported as missing rather than silently faked."""
-    if stage != "codec":
-        raise ValueError(f"Unknown stage: {stage}")
     from .dac_model import Encoder, Decoder
     from .quantize import FAquantizer
+
+    if stage == "redecoder":      # modules/commons.py:385-413 (discriminator: train-only, not built)
+        from .redecoder import Redecoder
+        return Munch(encoder=Redecoder(args),
+                     decoder=Decoder(input_channel=1024, channels=args.DAC.decoder_dim, rates=args.DAC.decoder_rates,
+                                     causal=args.decoder_causal, lstm=args.decoder_lstm))
+    if stage == "encoder":        # modules/commons.py:414-439
+        return Munch(encoder=Encoder(d_model=args.DAC.encoder_dim, strides=args.DAC.encoder_rates, d_latent=1024,
+                                     causal=args.encoder_causal, lstm=args.encoder_lstm),
+                     quantizer=FAquantizer(in_dim=1024, n_p_codebooks=1, n_c_codebooks=args.n_c_codebooks,
+                                           n_t_codebooks=2, n_r_codebooks=3, codebook_size=1024, codebook_dim=8,
+                                           quantizer_dropout=0.5, causal=args.encoder_causal,
+                                           separate_prosody_encoder=args.separate_prosody_encoder,
+                                           timbre_norm=args.timbre_norm))
+    if stage != "codec":
+        raise ValueError(f"Unknown stage: {stage}")
 
     encoder = Encoder(d_model=args.DAC.encoder_dim, strides=args.DAC.encoder_rates, d_latent=1024,
                       causal=args.causal, lstm=args.lstm)
@@ -65,6 +79,15 @@ def default_model_params():
         fixed=True, causal=True, lstm=2, norm_f0=True, use_gr_content_f0=False, use_gr_prosody_phone=False,
         use_gr_timbre_prosody=False, separate_prosody_encoder=True, n_c_codebooks=2, timbre_norm=True,
         use_gr_content_global_f0=True, w2v="w2v-ctc",
+        DAC=dict(encoder_dim=64, encoder_rates=[2, 5, 5, 6], decoder_dim=1536, decoder_rates=[6, 5, 5, 2], sr=24000)))
+
+
+def default_redecoder_params():
+    """configs/config_redecoder.yml:28-48 `model_params`."""
+    return recursive_munch(dict(
+        encoder_causal=True, decoder_causal=False, encoder_lstm=2, decoder_lstm=0, n_c_codebooks=2, n_p_codebooks=1,
+        timbre_norm=True, separate_prosody_encoder=True, encoder_type="wavenet", wavenet_embed_dim=512,
+        mamba_embed_dim=768, prob_random_mask_prosody=1.0, prob_random_mask_content=[0.0, 1.0],
         DAC=dict(encoder_dim=64, encoder_rates=[2, 5, 5, 6], decoder_dim=1536, decoder_rates=[6, 5, 5, 2], sr=24000)))
 
 

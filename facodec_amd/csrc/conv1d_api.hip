@@ -26,7 +26,7 @@ unsigned long long* g_conv_dbg = nullptr;
 
 // One or two output channels, plain stride-1 conv with nothing but bias / activation in the epilogue.
 static bool narrow_ok(const fac_conv_desc* d) {
-  return d->C_out <= 2 && d->stride == 1 && d->n_phase == 1 && d->y_tstride == 1 && !d->res && !d->y2 &&
+  return d->C_out <= 2 && d->stride == 1 && d->n_phase == 1 && d->phase_shift == 0 && d->y_tstride == 1 && !d->res && !d->y2 &&
          !d->w_batched && d->y && (long long)d->B <= 65535;
 }
 
@@ -62,6 +62,8 @@ extern "C" int fac_conv1d_fwd(const fac_conv_desc* d, fac_stream_t stream) {
   a.T_out = d->T_out; a.K = d->K; a.stride = d->stride; a.dil = d->dilation;
   a.pad_left = d->pad_left; a.pad_mode = d->pad_mode; a.n_phase = d->n_phase;
   a.y_tstride = d->y_tstride; a.act = d->act; a.w_batched = d->w_batched;
+  a.phase_shift = d->phase_shift;
+  FAC_REQUIRE(d->phase_shift >= 0 && d->phase_shift < d->n_phase + (d->n_phase == 1), "conv1d: bad phase_shift");
   // length of pad1d's temporary zero extension (only differs from T_in for inputs shorter than the pad)
   {
     long long last = (long long)(d->T_out - 1) * d->stride + (long long)(d->K - 1) * d->dilation - d->pad_left;

@@ -48,6 +48,7 @@ struct ConvArgs {
   int B, C_in, T_in, T_ext, C_out, C_out_pad, T_out;
   int K, stride, dil, pad_left, pad_mode;
   int n_phase, y_tstride, act, w_batched;
+  int phase_shift;   // left trim of a non-causal transposed conv (0 = causal)
   int cic;  // input channels per LDS stage (multiple of 2*UC)
   int XW;   // staged input width = (T_TILE-1)*stride + (K-1)*dil + 1
   int XB;   // 64-wide column blocks per staged row = ceil(XW/64)
@@ -100,6 +101,15 @@ __global__ __launch_bounds__((WM * WN + 4) * 64, (WM * WN == 4 ? FAC_CONV_WPE : 
     co0 = ct * CO_TILE;
     b = bp / a.n_phase;
     phase = bp - b * a.n_phase;
+  }
+  // Output offset of this polyphase component and its input shift: phases below the left trim of a
+  // non-causal transposed conv land one output period later and read x[t], x[t+1] (one tap later).
+  // (the staged slab is the same for every phase -- one column wider -- and only the fragment read
+  // offset moves, so the slab stays 16-byte aligned for the LDS-DMA)
+  int y_off = phase - a.phase_shift, tap_shift = 0;
+  if (y_off < 0) {
+    y_off += a.n_phase;
+    tap_shift = 1;
   }
 
   const int K = KT > 0 ? KT : a.K;
@@ -318,7 +328,7 @@ __global__ __launch_bounds__((WM * WN + 4) * 64, (WM * WN == 4 ? FAC_CONV_WPE : 
       for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
 
   const int a_off = wm * (MB * 32) + l31;                 // column inside the weight row
-  const int b_off = (wn * (NB * 32) + l31) * a.stride + a.x_off;   // time offset inside the input row
+  const int b_off = (wn * (NB * 32) + l31) * a.stride + a.x_off + tap_shift;   // time offset inside the input row
   const int wrow_stride = K * CO_TILE;                    // floats per input channel in Wbuf
   const int dil = a.dil;
   const int nstride = 32 * a.stride;
@@ -429,7 +439,7 @@ __global__ __launch_bounds__((WM * WN + 4) * 64, (WM * WN == 4 ? FAC_CONV_WPE : 
         for (int n = 0; n < NB; ++n) {
           const int t = t0 + wn * (NB * 32) + n * 32 + l31;
           rv[slot][i][n] = (rg && co < a.C_out && t < a.T_out)
-                               ? rg[(long long)co * a.y_cs + (long long)t * a.y_tstride + phase] : 0.f;
+                               ? rg[(long long)co * a.y_cs + (long long)t * a.y_tstride + y_off] : 0.f;
         }
       }
     };
@@ -453,7 +463,7 @@ __global__ __launch_bounds__((WM * WN + 4) * 64, (WM * WN == 4 ? FAC_CONV_WPE : 
           if (alpha_out) v = snake_apply(v, al, inv);
           if (act != FAC_ACT_NONE) v = apply_act_slow(v, act);
           v += rv[slot][i][n];
-          const long long o = (long long)co * a.y_cs + (long long)t * a.y_tstride + phase;
+          const long long o = (long long)co * a.y_cs + (long long)t * a.y_tstride + y_off;
           if (yg) yg[o] = v;
           if (y2g) y2g[o] = snake_apply(v, al2[slot][i], snake_inv(al2[slot][i]));
         }
@@ -535,7 +545,7 @@ int launch_cfg(ConvArgs& a, hipStream_t s) {
   // staged slab = receptive field of the tile, extended on the left to a 16-byte boundary and on the
   // right to a multiple of 4 columns, so interior slabs move as float4
   a.x_off = ((-a.pad_left) % 4 + 4) % 4;
-  a.XW = (((T_TILE - 1) * a.stride + (a.K - 1) * a.dil + 1 + a.x_off) + 3) & ~3;
+  a.XW = (((T_TILE - 1) * a.stride + (a.K - 1) * a.dil + 1 + a.x_off + (a.phase_shift > 0 ? 1 : 0)) + 3) & ~3;
   a.XB = (a.XW / 4 + 63) / 64;   // 64-lane blocks of float4 columns per staged row
   a.XQ = 4 / a.XB;
   a.XR = 4 % a.XB;

@@ -33,16 +33,42 @@ __global__ void snake_kernel(const float* __restrict__ x, const float* __restric
   }
 }
 
-// modules/commons.py:113-120
-__global__ void gate_kernel(const float* __restrict__ a, float* __restrict__ out, int C, int T,
-                            long long n) {
+// modules/commons.py:113-120; g (B, 2C) is the per-clip conditioning row added before the gate
+// (WN with gin_channels: g_l broadcast over time, modules/wavenet.py:146-155), or NULL.
+__global__ void gate_kernel(const float* __restrict__ a, const float* __restrict__ g,
+                            float* __restrict__ out, int C, int T, long long g_bs, long long n) {
   const long long ct = (long long)C * T;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
        i += (long long)gridDim.x * blockDim.x) {
     const long long b = i / ct, r = i - b * ct;
-    const float ta = a[b * 2 * ct + r];
-    const float sa = a[b * 2 * ct + ct + r];
+    float ta = a[b * 2 * ct + r];
+    float sa = a[b * 2 * ct + ct + r];
+    if (g) {
+      const int c = (int)(r / T);
+      ta = __fadd_rn(ta, g[b * g_bs + c]);
+      sa = __fadd_rn(sa, g[b * g_bs + C + c]);
+    }
     out[i] = __fmul_rn(tanhf(ta), sigmoid_f(sa));
+  }
+}
+
+// Redecoder input (modules/redecoder.py:35-45): x[b, :, t] = sum_i table_i[codes[b, i, t], :], written
+// channel-major (B, E, T) for the conv stack.  tables (n_tab, V, E) row-major; codes (B, n_codes, T) int64,
+// table i reads code row code_row0 + i.
+__global__ void embed_sum_kernel(const long long* __restrict__ codes, const float* __restrict__ tables,
+                                 float* __restrict__ out, int n_tab, int n_codes, int code_row0, int V,
+                                 int E, int T, long long n, int accumulate) {
+  const long long et = (long long)E * T;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (long long)gridDim.x * blockDim.x) {
+    const long long b = i / et, r = i - b * et;
+    const int e = (int)(r / T), t = (int)(r - (long long)e * T);
+    float s = accumulate ? out[i] : 0.f;
+    for (int k = 0; k < n_tab; ++k) {
+      const long long id = codes[(b * n_codes + code_row0 + k) * T + t];
+      s = __fadd_rn(s, tables[((long long)k * V + id) * E + e]);
+    }
+    out[i] = s;
   }
 }
 
@@ -411,12 +437,23 @@ extern "C" int fac_snake_fwd(const float* x, const float* alpha, float* y, int B
   return check_launch("snake_fwd");
 }
 
-extern "C" int fac_gate_tanh_sigmoid(const float* a, float* out, int B, int C, int T,
-                                     fac_stream_t stream) {
+extern "C" int fac_gate_tanh_sigmoid(const float* a, const float* g, int64_t g_bs, float* out, int B,
+                                     int C, int T, fac_stream_t stream) {
   FAC_REQUIRE(a && out && B > 0 && C > 0 && T > 0, "gate_tanh_sigmoid: bad arguments");
   const long long n = (long long)B * C * T;
-  EW_LAUNCH(gate_kernel, n, a, out, C, T, n);
+  EW_LAUNCH(gate_kernel, n, a, g, out, C, T, (long long)g_bs, n);
   return check_launch("gate_tanh_sigmoid");
+}
+
+extern "C" int fac_embed_sum(const int64_t* codes, const float* tables, float* out, int B, int n_tab,
+                             int n_codes, int code_row0, int V, int E, int T, int accumulate,
+                             fac_stream_t stream) {
+  FAC_REQUIRE(codes && tables && out && B > 0 && n_tab >= 0 && V > 0 && E > 0 && T > 0 &&
+                  code_row0 >= 0 && code_row0 + n_tab <= n_codes, "embed_sum: bad arguments");
+  const long long n = (long long)B * E * T;
+  EW_LAUNCH(embed_sum_kernel, n, (const long long*)codes, tables, out, n_tab, n_codes, code_row0, V, E, T, n,
+            accumulate);
+  return check_launch("embed_sum");
 }
 
 extern "C" int fac_glu_residual(const float* a, const float* res, float* out, int B, int C, int T,

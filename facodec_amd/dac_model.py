@@ -47,11 +47,11 @@ class ResidualUnit(nn.Module):
         Returns (y, snake(y, alpha_next)); y is None when want_raw is False."""
         b = self.block
         k7, k1 = b[1], b[3]
-        if k7.w.c_out in FUSED_RU_CHANNELS and k7.causal and x_act.shape[-1] == x.shape[-1]:
+        if k7.w.c_out in FUSED_RU_CHANNELS and x_act.shape[-1] == x.shape[-1]:
             # whole unit in one launch: the 1x1 conv runs out of the k7 accumulators (conv1d_fused_ru.hip)
             return_pair = ops.conv1d(x_act, k7.w.packed(), k7.w.c_out, 7, bias=k7.w.bias, dilation=k7.dilation,
                                      alpha_out=b[2].flat(), res=x, w_k1=k1.w.packed(), bias_k1=k1.w.bias,
-                                     alpha_y2=alpha_next, want_y=want_raw or alpha_next is None)
+                                     alpha_y2=alpha_next, want_y=want_raw or alpha_next is None, causal=k7.causal)
             return return_pair if alpha_next is not None else (return_pair, None)
         h = b[1].run(x_act, alpha_out=b[2].flat())
         if h.shape[-1] != x.shape[-1]:  # non-causal trimming of :38-41 never triggers with SConv1d padding

@@ -99,11 +99,10 @@ class SConvTranspose1d(nn.Module):
 
     def __init__(self, in_channels, out_channels, kernel_size, stride=1, causal=False, norm="none"):
         super().__init__()
-        if not causal:
-            raise NotImplementedError("non-causal SConvTranspose1d (redecoder path) is not built yet")
         self.convtr = _Norm("convtr", ConvWeights(in_channels, out_channels, kernel_size, norm == "weight_norm",
                                                   transposed=True, stride=stride))
         self.stride = stride
+        self.causal = causal
 
     @property
     def w(self):
@@ -112,7 +111,7 @@ class SConvTranspose1d(nn.Module):
     def run(self, x, alpha_in=None, alpha_y2=None):
         w = self.w
         return ops.conv_transpose1d(x, w.packed(), w.c_out, self.stride, bias=w.bias, alpha_in=alpha_in,
-                                    alpha_y2=alpha_y2)
+                                    alpha_y2=alpha_y2, causal=self.causal)
 
     def forward(self, x):
         return self.run(x)

@@ -176,7 +176,7 @@ def conv1d(x, w_packed, c_out, k, bias=None, stride=1, dilation=1, pad_left=None
     return (out, y2) if alpha_y2 is not None else out
 
 
-def conv_transpose1d(x, w_packed, c_out, stride, bias=None, alpha_in=None, out=None, alpha_y2=None):
+def conv_transpose1d(x, w_packed, c_out, stride, bias=None, alpha_in=None, out=None, alpha_y2=None, causal=True):
     """Causal SConvTranspose1d (kernel 2*stride, right trim k-stride: dac/model/encodec.py:248-270)
     as `stride` polyphase 2-tap convs: y[., t*s+p] = W[p] x[t] + W[p+s] x[t-1]."""
     x = _dev(x, "x")
@@ -197,6 +197,8 @@ def conv_transpose1d(x, w_packed, c_out, stride, bias=None, alpha_in=None, out=N
     d.B, d.C_in, d.T_in, d.C_out, d.C_out_pad, d.T_out = B, c_in, t_in, c_out, cp, t_in
     d.K, d.stride, d.dilation, d.pad_left, d.pad_mode = 2, 1, 1, 1, PAD_ZERO
     d.n_phase, d.y_tstride, d.act, d.w_batched, d.w_bs = stride, stride, ACT_NONE, 0, 0
+    # non-causal: trim ceil(s/2) on the left, floor(s/2) on the right (dac/model/encodec.py:265-269)
+    d.phase_shift = 0 if causal else stride - stride // 2
     _launch_conv(d, "fac_conv1d_fwd(convtr)")
     return (out, y2) if alpha_y2 is not None else out
 
@@ -283,11 +285,26 @@ def vq_search(latents, codebook):
 
 
 # --------------------------------------------------------------------------------- small fused ops
-def gate_tanh_sigmoid(a):
+def gate_tanh_sigmoid(a, g=None):
+    """g: optional (B, 2C) conditioning rows (may be a strided slice of a wider (B, n) tensor)."""
     a = _dev(a)
     B, c2, T = a.shape
     out = torch.empty(B, c2 // 2, T, device=a.device, dtype=torch.float32)
-    _lib.check(_lib.load().fac_gate_tanh_sigmoid(_ptr(a), _ptr(out), B, c2 // 2, T, _stream()), "fac_gate_tanh_sigmoid")
+    g_bs = g.stride(0) if g is not None else 0
+    _lib.check(_lib.load().fac_gate_tanh_sigmoid(_ptr(a), _ptr(g), g_bs, _ptr(out), B, c2 // 2, T, _stream()),
+               "fac_gate_tanh_sigmoid")
+    return out
+
+
+def embed_sum(codes, tables, code_row0=0, out=None):
+    """out (B, E, T) (+)= sum_i tables[i][codes[:, code_row0 + i]]; tables (n, V, E), codes (B, N, T) int64."""
+    B, n_codes, T = codes.shape
+    n_tab, V, E = tables.shape
+    acc = out is not None
+    if out is None:
+        out = torch.empty(B, E, T, device=codes.device, dtype=torch.float32)
+    _lib.check(_lib.load().fac_embed_sum(_ptr(codes.contiguous()), _ptr(_dev(tables)), _ptr(out), B, n_tab, n_codes,
+                                         code_row0, V, E, T, 1 if acc else 0, _stream()), "fac_embed_sum")
     return out
 
 

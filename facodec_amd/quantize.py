@@ -99,15 +99,18 @@ class ResidualVectorQuantize(nn.Module):
 
 # ------------------------------------------------------------------------------------ WaveNet
 class WN(nn.Module):
-    """modules/wavenet.py:103-166 (g=None path).  Keys: in_layers.i.conv.conv.*, res_skip_layers.i.conv.conv.*"""
+    """modules/wavenet.py:103-166.  Keys: [cond_layer.conv.conv.*,] in_layers.i.conv.conv.*,
+    res_skip_layers.i.conv.conv.*.  With gin_channels the conditioning g (B, gin, 1) goes through one
+    1x1 conv (2*hidden*n_layers rows) and layer i adds its slice before the tanh/sigmoid gate -- here
+    inside the gate kernel (the reference broadcasts it over time first)."""
 
     def __init__(self, hidden_channels, kernel_size, dilation_rate, n_layers, gin_channels=0, p_dropout=0, causal=False):
         super().__init__()
-        if gin_channels != 0:
-            raise NotImplementedError("conditioned WN (redecoder) is not built yet")
-        self.hidden_channels, self.n_layers = hidden_channels, n_layers
+        self.hidden_channels, self.n_layers, self.gin_channels = hidden_channels, n_layers, gin_channels
         self.in_layers = nn.ModuleList()
         self.res_skip_layers = nn.ModuleList()
+        if gin_channels != 0:
+            self.cond_layer = SConv1d(gin_channels, 2 * hidden_channels * n_layers, 1, norm="weight_norm")
         for i in range(n_layers):
             self.in_layers.append(SConv1d(hidden_channels, 2 * hidden_channels, kernel_size,
                                           dilation=dilation_rate ** i, norm="weight_norm", causal=causal))
@@ -117,9 +120,13 @@ class WN(nn.Module):
     def forward(self, x, x_mask=None, g=None):
         x = x.clone()
         out = torch.zeros_like(x)
+        cond = None
+        if g is not None:
+            cond = self.cond_layer.run(g.reshape(g.shape[0], -1, 1)).reshape(g.shape[0], -1)   # (B, 2*H*L)
+        H2 = 2 * self.hidden_channels
         for i in range(self.n_layers):
             a = self.in_layers[i].run(x)
-            acts = ops.gate_tanh_sigmoid(a)
+            acts = ops.gate_tanh_sigmoid(a, None if cond is None else cond[:, i * H2:(i + 1) * H2])
             rs = self.res_skip_layers[i].run(acts)
             ops.wn_res_skip_(rs, x, out, last=(i == self.n_layers - 1))
         return out

@@ -107,6 +107,9 @@ typedef struct fac_conv_desc {
   int32_t K, stride, dilation, pad_left, pad_mode;
   int32_t n_phase;        /* 1 for Conv1d; = upsampling stride for polyphase ConvTranspose1d */
   int32_t y_tstride;      /* 1 for Conv1d; = n_phase for ConvTranspose1d (y_toff = phase) */
+  int32_t phase_shift;    /* non-causal ConvTranspose1d trims `phase_shift` samples on the LEFT
+                             (dac/model/encodec.py:265-269): phase p then lands at offset p - shift, and
+                             phases with p < shift read x[t], x[t+1] instead of x[t-1], x[t]; 0 = causal */
   int32_t act;            /* FAC_ACT_* applied last (before residual) */
   int32_t w_batched;      /* 0: shared weights; 1: per-b weights at w + b*w_bs (attention-style) */
   int64_t w_bs;
@@ -186,8 +189,15 @@ int fac_vq_search(const float* latents, const float* codebook, int64_t* idx, int
  * Small fused elementwise / reduction ops of the quantizer (modules/quantize.py:375-454).
  * ---------------------------------------------------------------------------------------- */
 
-/* acts = tanh(a[:, :C]) * sigmoid(a[:, C:])  (modules/commons.py:113-120), a (B,2C,T) -> (B,C,T) */
-int fac_gate_tanh_sigmoid(const float* a, float* out, int B, int C, int T, fac_stream_t stream);
+/* acts = tanh((a+g)[:, :C]) * sigmoid((a+g)[:, C:])  (modules/commons.py:113-120), a (B,2C,T) -> (B,C,T);
+ * g: optional per-clip conditioning (row b at g + b*g_bs, 2C values broadcast over time:
+ * modules/wavenet.py:146-155 with gin_channels), or NULL. */
+int fac_gate_tanh_sigmoid(const float* a, const float* g, int64_t g_bs, float* out, int B, int C, int T,
+                          fac_stream_t stream);
+/* Code-embedding sum of the Redecoder (modules/redecoder.py:35-45): out (B, E, T) (+)= sum over n_tab
+ * tables (n_tab, V, E) of table_i[codes[b, code_row0 + i, t]]; codes (B, n_codes, T) int64. */
+int fac_embed_sum(const int64_t* codes, const float* tables, float* out, int B, int n_tab, int n_codes,
+                  int code_row0, int V, int E, int T, int accumulate, fac_stream_t stream);
 /* GLU residual: out = res + a[:, :C] * sigmoid(a[:, C:])  (modules/style_encoder.py:26-31) */
 int fac_glu_residual(const float* a, const float* res, float* out, int B, int C, int T,
                      fac_stream_t stream);

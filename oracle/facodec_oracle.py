@@ -339,13 +339,19 @@ def logmel_frontend(wave, n_bins, sample_rate=24000, n_fft=2048, win_length=1200
 # ---------------------------------------------------------------------------------------------
 
 
-def wavenet_forward(x, sd, p, hidden, n_layers, kernel_size=5, dilation_rate=1, causal=True):
-    """WN.forward modules/wavenet.py:138-166 with g=None, mask of ones, dropout off (eval);
-    gate = tanh(a[:hidden]) * sigmoid(a[hidden:]) (modules/commons.py:113-120)."""
+def wavenet_forward(x, sd, p, hidden, n_layers, kernel_size=5, dilation_rate=1, causal=True, g=None):
+    """WN.forward modules/wavenet.py:138-166, mask of ones, dropout off (eval);
+    gate = tanh((a+g_l)[:hidden]) * sigmoid((a+g_l)[hidden:]) (modules/commons.py:113-120); g (B, gin, 1)
+    goes through cond_layer (a non-causal weight-normed 1x1 SConv1d, :120-121,142-143)."""
     out = torch.zeros_like(x)
+    if g is not None:
+        q = f"{p}cond_layer.conv.conv."
+        g = sconv1d(g, conv_weight(sd, q), sd[q + "bias"], causal=False)
     for i in range(n_layers):
         q = f"{p}in_layers.{i}.conv.conv."
         a = sconv1d(x, conv_weight(sd, q), sd[q + "bias"], dilation=dilation_rate ** i, causal=causal)
+        if g is not None:
+            a = a + g[:, i * 2 * hidden:(i + 1) * 2 * hidden, :]
         acts = torch.tanh(a[:, :hidden]) * torch.sigmoid(a[:, hidden:])
         q = f"{p}res_skip_layers.{i}.conv.conv."
         rs = sconv1d(acts, conv_weight(sd, q), sd[q + "bias"], causal=causal)
@@ -447,6 +453,24 @@ def codec_forward(sds, wave, n_c=2):
     y = decoder_forward(sds["decoder"], outs)
     return dict(z=z, outs=outs, quantized=quantized, commitment=commit, codebook=cbl, timbre=timbre,
                 codes=codes, wave=y)
+
+
+def redecoder_forward(sd, p_code, c_code, timbre, use_p_code=True, use_c_code=True, n_c=2, embed_dim=512,
+                      causal=False):
+    """Redecoder.forward modules/redecoder.py:35-48 (wavenet type): summed code embeddings -> WN(16 layers,
+    g = timbre) -> 1x1 conv."""
+    B, _, T = p_code.shape
+    x = torch.zeros(B, T, embed_dim)
+    if use_p_code:
+        i = 0
+        while f"prosody_embed.{i}.weight" in sd:
+            x = x + F.embedding(p_code[:, i, :], sd[f"prosody_embed.{i}.weight"])
+            i += 1
+    if use_c_code:
+        for i in range(n_c):
+            x = x + F.embedding(c_code[:, i, :], sd[f"content_embed.{i}.weight"])
+    x = wavenet_forward(x.transpose(1, 2), sd, "encoder.", embed_dim, 16, causal=causal, g=timbre.unsqueeze(2))
+    return F.conv1d(x, sd["conv_out.weight"], sd["conv_out.bias"])
 
 
 # ---------------------------------------------------------------------------------------------

@@ -246,6 +246,7 @@ def main():
         _, _, _, _, _, o_codes2 = O.quantizer_forward(sds["quantizer"], oz, wave, n_c=2)
         report["e2e_codes_oracle_pipeline_mismatch"] = int(sum((a != b).sum() for a, b in zip(o_codes2, codes)))
 
+        probe_t_early = np.arange(0, 48000, 47)
         # predictor heads (train.py:270), eval mode, on the quantizer's outputs
         model.fa_predictors.eval()
         sd_p = synth.load_synthetic(model.fa_predictors, seed=0, prefix="fa_predictors.")
@@ -260,6 +261,31 @@ def main():
             rev_f0=rev_preds["rev_f0"].numpy(), rev_uv=rev_preds["rev_uv"].numpy(),
             rev_content_probe=rev_preds["rev_content"][:, ::4, ::16].numpy(),
             x_timbre_probe=rev_preds["x_timbre"][:, ::50].numpy())
+
+        # voice-conversion path (reconstruct_redecoder.py:110-122): stage 'redecoder', non-causal decoder
+        rparams = dict(encoder_causal=True, decoder_causal=False, encoder_lstm=2, decoder_lstm=0, n_c_codebooks=2,
+                       n_p_codebooks=1, timbre_norm=True, separate_prosody_encoder=True, encoder_type="wavenet",
+                       wavenet_embed_dim=512, mamba_embed_dim=768, prob_random_mask_prosody=1.0,
+                       prob_random_mask_content=[0.0, 1.0],
+                       DAC=dict(encoder_dim=64, encoder_rates=[2, 5, 5, 6], decoder_dim=1536, decoder_rates=[6, 5, 5, 2], sr=24000))
+        rmodel = build_model(recursive_munch(rparams), stage="redecoder")
+        for k in ("encoder", "decoder"):
+            rmodel[k].eval()
+        sd_re = synth.load_synthetic(rmodel.encoder, seed=0, prefix="redecoder.encoder.")
+        sd_rd = synth.load_synthetic(rmodel.decoder, seed=0, prefix="redecoder.decoder.")
+        timbre_tgt = timbre.flip(0)                      # "target speaker" = the other clip's timbre
+        zr = rmodel.encoder(codes[0], codes[1], timbre_tgt, use_p_code=False, n_c=1)
+        yr = rmodel.decoder(zr)
+        o_zr = O.redecoder_forward(sd_re, codes[0], codes[1], timbre_tgt, use_p_code=False, n_c=1)
+        o_yr = O.decoder_forward(sd_rd, zr, causal=False, lstm=0)
+        report["redecoder_oracle_rel"] = rel_err(o_zr, zr)
+        report["redecoder_decoder_oracle_rel"] = rel_err(o_yr, yr)
+        shapes["redecoder.encoder"] = {n: list(v.shape) for n, v in rmodel.encoder.state_dict().items()}
+        shapes["redecoder.decoder"] = {n: list(v.shape) for n, v in rmodel.decoder.state_dict().items()}
+        json.dump(shapes, open(os.path.join(HERE, "state_shapes.json"), "w"), indent=0, sort_keys=True)
+        np.savez_compressed(os.path.join(HERE, "redecoder.npz"), z_probe=zr[:, ::8, :].numpy(),
+                            wave_probe=yr[:, 0, probe_t_early].numpy(), probe_t=probe_t_early,
+                            wave_absmax=np.float32(yr.abs().max()))
 
         # losses through the reference's own dac/nn/loss.py (over the audiotools shim)
         from dac.nn.loss import MelSpectrogramLoss, MultiScaleSTFTLoss, L1Loss

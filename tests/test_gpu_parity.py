@@ -496,3 +496,79 @@ def test_long_clip_single_item_batch(full_model, O, cuda):
     assert rel(z, r["z"]) < E2E_TOL and rel(y, r["wave"]) < E2E_TOL and rel(timbre, r["timbre"]) < E2E_TOL
     mism = sum(int((a.cpu() != b).sum()) for a, b in zip(codes, r["codes"]))
     assert mism == 0, f"{mism} code mismatches of {sum(c.numel() for c in codes)}"
+
+
+# ------------------------------------------------------------------------------ voice-conversion path
+@pytest.mark.parametrize("B,ci,co,T,s", [(2, 256, 128, 160, 6), (2, 128, 64, 333, 5), (1, 192, 96, 1000, 2), (1, 24, 12, 7, 5)])
+def test_noncausal_conv_transpose_against_oracle(B, ci, co, T, s, O, ops, cuda):
+    """SConvTranspose1d with causal=False (dac/nn/layers.py: the k - stride trim is split right = total // 2,
+    left = total - right): the phase-shifted polyphase launch."""
+    g = _g(s + 40)
+    x = torch.randn(B, ci, T, generator=g)
+    v = torch.randn(ci, co, 2 * s, generator=g) / (ci * 2) ** 0.5
+    gg = torch.rand(ci, 1, 1, generator=g) + 0.5
+    b = torch.randn(co, generator=g) * 0.1
+    a2 = 1 + 0.2 * torch.rand(co, generator=g)
+    y = O.sconvtr1d(x, O.weight_norm_weight(v, gg), b, s, causal=False)
+    wp = ops.pack_convtr_weight(v.to(cuda), gg.to(cuda), s)
+    yg, yg2 = ops.conv_transpose1d(x.to(cuda), wp, co, s, bias=b.to(cuda), alpha_y2=a2.to(cuda), causal=False)
+    assert yg.shape == y.shape and rel(yg, y) < OP_TOL
+    assert rel(yg2, O.snake(y, a2.view(1, -1, 1))) < OP_TOL
+
+
+@pytest.mark.parametrize("C,T,d", [(64, 700, 1), (96, 1000, 9), (192, 400, 3)])
+def test_noncausal_residual_unit_against_oracle(C, T, d, O, cuda):
+    from facodec_amd.dac_model import ResidualUnit
+    ru = ResidualUnit(C, dilation=d, causal=False)
+    sd = synth.load_synthetic(ru, seed=31)
+    x = torch.randn(2, C, T, generator=_g(C))
+    ref = O.residual_unit(x, sd, "", d, causal=False)
+    with torch.no_grad():
+        out = ru.to(cuda)(x.to(cuda))
+    assert rel(out, ref) < OP_TOL
+
+
+def test_conditioned_noncausal_wavenet_against_oracle(O, cuda):
+    from facodec_amd.quantize import WN
+    wn = WN(128, 5, 1, 4, gin_channels=96, causal=False)
+    sd = synth.load_synthetic(wn, seed=9)
+    x = torch.randn(3, 128, 77, generator=_g(3))
+    gvec = torch.randn(3, 96, generator=_g(4))
+    ref = O.wavenet_forward(x, sd, "", 128, 4, causal=False, g=gvec.unsqueeze(2))
+    with torch.no_grad():
+        out = wn.to(cuda)(x.to(cuda), None, g=gvec.to(cuda))
+    assert rel(out, ref) < OP_TOL
+
+
+def test_embed_sum_is_exact(ops, cuda):
+    g = _g(12)
+    tabs = torch.randn(3, 1024, 64, generator=g)
+    codes = torch.randint(0, 1024, (2, 3, 50), generator=g)
+    ref = sum(torch.nn.functional.embedding(codes[:, i], tabs[i]) for i in range(3)).transpose(1, 2)
+    out = ops.embed_sum(codes.to(cuda), tabs.to(cuda))
+    assert rel(out, ref) < 1e-6
+    out2 = ops.embed_sum(codes.to(cuda), tabs[:2].to(cuda), 1)          # tables applied to rows 1..2
+    ref2 = sum(torch.nn.functional.embedding(codes[:, 1 + i], tabs[i]) for i in range(2)).transpose(1, 2)
+    assert rel(out2, ref2) < 1e-6
+
+
+def test_redecoder_vs_reference_golden(full_model, cuda, golden_dir):
+    """reconstruct_redecoder.py:95-122: codes of the source clip + timbre of the target -> Redecoder ->
+    non-causal decoder.  Golden from the real reference (stage='redecoder', config_redecoder.yml)."""
+    from facodec_amd.commons import build_model, default_redecoder_params
+    d = np.load(os.path.join(golden_dir, "redecoder.npz"))
+    rm = build_model(default_redecoder_params(), stage="redecoder")
+    for k in ("encoder", "decoder"):
+        synth.load_synthetic(rm[k], seed=0, prefix="redecoder." + k + ".")
+        rm[k].eval().to(cuda)
+    wave = synth.synth_clips(2, 48000, seed=0).to(cuda)
+    m = full_model
+    with torch.no_grad():
+        z = m.encoder(wave)
+        _, _, _, _, timbre, codes = m.quantizer(z, wave, n_c=2, return_codes=True)
+        zr = rm.encoder(codes[0], codes[1], timbre.flip(0), use_p_code=False, n_c=1)
+        yr = rm.decoder(zr)
+    assert zr.shape == (2, 1024, 160) and yr.shape == (2, 1, 48000)
+    assert rel(zr[:, ::8], d["z_probe"]) < E2E_TOL
+    assert rel(yr[:, 0, torch.from_numpy(d["probe_t"])], d["wave_probe"]) < E2E_TOL
+    assert abs(float(yr.abs().max()) - float(d["wave_absmax"])) < 1e-4
