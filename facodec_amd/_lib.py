@@ -27,7 +27,7 @@ class ConvDesc(C.Structure):
         ("K", C.c_int32), ("stride", C.c_int32), ("dilation", C.c_int32), ("pad_left", C.c_int32),
         ("pad_mode", C.c_int32), ("n_phase", C.c_int32), ("y_tstride", C.c_int32), ("phase_shift", C.c_int32),
         ("act", C.c_int32),
-        ("w_batched", C.c_int32), ("w_bs", _i64),
+        ("w_batched", C.c_int32), ("w_bs", _i64), ("ws", _p), ("ws_bytes", _i64),
     ]
 
 
@@ -54,6 +54,8 @@ SIGNATURES = {
     "fac_lstm_from_time_major": (_i, [_p, _p, _p, _p, _i, _i, _i, _p]),
     "fac_pack_lstm_whh": (_i, [_p, _p, _i, _p]),
     "fac_lstm_layer_fwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _p]),
+    "fac_lstm_layer_fwd_from": (_i, [_p, _p, _p, _p, _i, _i, _i, _i64, _p]),
+    "fac_stream_push": (_i, [_p, _p, _i64, _i64, _i, _i, _i, _p]),
     "fac_vq_fwd": (_i, [C.POINTER(VqDesc), _p]),
     "fac_vq_search": (_i, [_p, _p, _p, _i64, _i, _p]),
     "fac_gate_tanh_sigmoid": (_i, [_p, _p, _i64, _p, _i, _i, _i, _p]),

@@ -194,7 +194,13 @@ extern "C" int fac_lstm_from_time_major(const float* yT, const float* skip, cons
 
 extern "C" int fac_lstm_layer_fwd(const float* pre, const float* whh_packed, float* yT, float* c,
                                   int T, int H, int BP, fac_stream_t stream) {
+  return fac_lstm_layer_fwd_from(pre, whh_packed, yT, c, T, H, BP, 0, stream);
+}
+
+extern "C" int fac_lstm_layer_fwd_from(const float* pre, const float* whh_packed, float* yT, float* c,
+                                       int T, int H, int BP, int64_t step0, fac_stream_t stream) {
   using namespace fac;
+  FAC_REQUIRE(step0 >= 0, "lstm_layer_fwd: negative step0");
   FAC_REQUIRE(pre && whh_packed && yT && c, "lstm_layer_fwd: null pointer");
   FAC_REQUIRE(T > 0 && H > 0 && H % 64 == 0, "lstm_layer_fwd: H=%d must be a multiple of 64", H);
   FAC_REQUIRE(BP > 0 && BP % 32 == 0, "lstm_layer_fwd: BP=%d must be a multiple of 32", BP);
@@ -222,9 +228,10 @@ extern "C" int fac_lstm_layer_fwd(const float* pre, const float* whh_packed, flo
   for (int t = 0; t < T; ++t) {
     // scratch = [c | h ping | h pong], H*BP floats each
     float* hp[2] = {c + (long long)H * BP, c + 2ll * H * BP};
-    const float* h_prev = t == 0 ? nullptr : hp[(t - 1) & 1];
+    const long long g = step0 + t;   // global step index: the two h buffers alternate on it
+    const float* h_prev = g == 0 ? nullptr : hp[(g - 1) & 1];
     hipLaunchKernelGGL(kern, grid, dim3(threads), 0, (hipStream_t)stream, pre + (long long)t * BP,
-                       whh_packed, h_prev, hp[t & 1], c, yT + (long long)t * BP, H, BP, rs);
+                       whh_packed, h_prev, hp[g & 1], c, yT + (long long)t * BP, H, BP, rs);
   }
   return check_launch("lstm_layer_fwd");
 }

@@ -111,6 +111,29 @@ __global__ void mul_mask_kernel(float* __restrict__ x, const float* __restrict__
   }
 }
 
+// streaming left-context buffer: one workgroup per row; the tail is read into
+// registers before any lane overwrites the front, so overlapping source / destination are safe
+__global__ __launch_bounds__(256) void stream_push_kernel(float* __restrict__ buf, const float* __restrict__ src,
+                                                          long long cap, int hist, int n_prev, int n_new) {
+  float* row = buf + (long long)blockIdx.x * cap;
+  if (n_prev > 0 && hist > 0) {
+    float r[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int idx = threadIdx.x + 256 * i;
+      r[i] = idx < hist ? row[n_prev + idx] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int idx = threadIdx.x + 256 * i;
+      if (idx < hist) row[idx] = r[i];
+    }
+  }
+  const float* s = src + (long long)blockIdx.x * n_new;
+  for (int j = threadIdx.x; j < n_new; j += 256) row[hist + j] = s[j];
+}
+
 // modules/wavenet.py:159-165
 __global__ void wn_res_skip_kernel(const float* __restrict__ rs, float* __restrict__ x,
                                    float* __restrict__ out, int C, int T, int last, long long n) {
@@ -482,6 +505,17 @@ extern "C" int fac_mul_mask(float* x, const float* mask, int B, int C, int T, fa
   const long long n = (long long)B * C * T;
   EW_LAUNCH(mul_mask_kernel, n, x, mask, C, T, n);
   return check_launch("mul_mask");
+}
+
+extern "C" int fac_stream_push(float* buf, const float* src, int64_t rows, int64_t cap, int hist, int n_prev,
+                               int n_new, fac_stream_t stream) {
+  FAC_REQUIRE(buf && src && rows > 0 && hist >= 0 && hist <= 2048 && n_prev >= 0 && n_new > 0 &&
+                  cap >= (int64_t)hist + n_new && cap >= (int64_t)hist + n_prev,
+              "stream_push: bad arguments (rows=%lld cap=%lld hist=%d n_prev=%d n_new=%d)", (long long)rows,
+              (long long)cap, hist, n_prev, n_new);
+  hipLaunchKernelGGL(stream_push_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, buf, src,
+                     (long long)cap, hist, n_prev, n_new);
+  return check_launch("stream_push");
 }
 
 extern "C" int fac_wn_res_skip(const float* rs, float* x, float* out, int B, int C, int T, int last,

@@ -107,8 +107,23 @@ def set_conv_profile(p):
     _PROFILE = p
 
 
+_CONV_WS = {}
+CONV_WS_BYTES = 32 << 20
+
+
+def _conv_workspace(device):
+    """Zero-filled scratch handed to every conv launch (fac_conv_desc.ws): one per device, used by the
+    split-reduction kernel for launches with few output columns.  All launches go to torch's current stream."""
+    ws = _CONV_WS.get(device)
+    if ws is None:
+        ws = _CONV_WS[device] = torch.zeros(CONV_WS_BYTES // 4, device=device, dtype=torch.float32)
+    return ws
+
+
 def _launch_conv(d, what):
     lib = _lib.load()
+    ws = _conv_workspace(torch.device("cuda", torch.cuda.current_device()))
+    d.ws, d.ws_bytes = ws.data_ptr(), CONV_WS_BYTES
     if _PROFILE is None:
         _lib.check(lib.fac_conv1d_fwd(C.byref(d), _stream()), what)
         return
@@ -176,11 +191,19 @@ def conv1d(x, w_packed, c_out, k, bias=None, stride=1, dilation=1, pad_left=None
     return (out, y2) if alpha_y2 is not None else out
 
 
-def conv_transpose1d(x, w_packed, c_out, stride, bias=None, alpha_in=None, out=None, alpha_y2=None, causal=True):
+def conv_transpose1d(x, w_packed, c_out, stride, bias=None, alpha_in=None, out=None, alpha_y2=None, causal=True,
+                     has_history=False):
     """Causal SConvTranspose1d (kernel 2*stride, right trim k-stride: dac/model/encodec.py:248-270)
-    as `stride` polyphase 2-tap convs: y[., t*s+p] = W[p] x[t] + W[p+s] x[t-1]."""
-    x = _dev(x, "x")
+    as `stride` polyphase 2-tap convs: y[., t*s+p] = W[p] x[t] + W[p+s] x[t-1].
+    has_history (streaming): x's first column is x[t0-1] of an earlier chunk (instead of the zero of
+    the start of the signal); x may then be a time-contiguous view of a wider buffer."""
+    if not (has_history and x.is_cuda and x.dtype == torch.float32 and x.stride(2) == 1):
+        x = _dev(x, "x")
     B, c_in, t_in = x.shape
+    x_bs, x_cs = x.stride(0), x.stride(1)
+    if has_history:
+        assert causal
+        t_in -= 1
     t_total = t_in * stride
     cp = w_packed.shape[-1]
     if out is None:
@@ -192,10 +215,10 @@ def conv_transpose1d(x, w_packed, c_out, stride, bias=None, alpha_in=None, out=N
     y2 = torch.empty_like(out) if alpha_y2 is not None else None
     d.y2 = y2.data_ptr() if y2 is not None else None
     d.alpha_y2 = alpha_y2.data_ptr() if alpha_y2 is not None else None
-    d.x_bs, d.x_cs = c_in * t_in, t_in
+    d.x_bs, d.x_cs = x_bs, x_cs
     d.y_bs, d.y_cs = c_out * t_total, t_total
-    d.B, d.C_in, d.T_in, d.C_out, d.C_out_pad, d.T_out = B, c_in, t_in, c_out, cp, t_in
-    d.K, d.stride, d.dilation, d.pad_left, d.pad_mode = 2, 1, 1, 1, PAD_ZERO
+    d.B, d.C_in, d.T_in, d.C_out, d.C_out_pad, d.T_out = B, c_in, x.shape[-1], c_out, cp, t_in
+    d.K, d.stride, d.dilation, d.pad_left, d.pad_mode = 2, 1, 1, (0 if has_history else 1), PAD_ZERO
     d.n_phase, d.y_tstride, d.act, d.w_batched, d.w_bs = stride, stride, ACT_NONE, 0, 0
     # non-causal: trim ceil(s/2) on the left, floor(s/2) on the right (dac/model/encodec.py:265-269)
     d.phase_shift = 0 if causal else stride - stride // 2
@@ -238,14 +261,26 @@ def pack_lstm_whh(w_hh, out=None):
     return out
 
 
-def lstm_layer(pre, whh_packed, H):
-    """pre (4H, T, BP) -> yT (H, T, BP)."""
+def lstm_layer(pre, whh_packed, H, state=None, step0=0):
+    """pre (4H, T, BP) -> yT (H, T, BP).  state (3, H, BP): carried cell / hidden buffers of a streaming
+    session with `step0` steps already taken (None: fresh zero state)."""
     _, T, BP = pre.shape
     yT = torch.empty(H, T, BP, device=pre.device, dtype=torch.float32)
-    c = torch.empty(3, H, BP, device=pre.device, dtype=torch.float32)   # cell state + 2 fragment-ordered h
-    _lib.check(_lib.load().fac_lstm_layer_fwd(_ptr(pre), _ptr(whh_packed), _ptr(yT), _ptr(c), T, H, BP, _stream()),
-               "fac_lstm_layer_fwd")
+    if state is None:
+        state = torch.empty(3, H, BP, device=pre.device, dtype=torch.float32)   # cell state + 2 fragment-ordered h
+        step0 = 0
+    _lib.check(_lib.load().fac_lstm_layer_fwd_from(_ptr(pre), _ptr(whh_packed), _ptr(yT), _ptr(state), T, H, BP,
+                                                   step0, _stream()), "fac_lstm_layer_fwd_from")
     return yT
+
+
+def stream_push(buf, src, hist, n_prev):
+    """buf (B, C, cap) left-context buffer; appends src (B, C, n) behind the last `hist` columns."""
+    src = _dev(src, "src")
+    B, c, cap = buf.shape
+    assert buf.is_contiguous() and src.shape[:2] == buf.shape[:2]
+    _lib.check(_lib.load().fac_stream_push(_ptr(buf), _ptr(src), B * c, cap, hist, n_prev, src.shape[-1], _stream()),
+               "fac_stream_push")
 
 
 # --------------------------------------------------------------------------------- VQ (K7)

@@ -84,6 +84,8 @@ int fac_pack_convtr_w(const float* v, const float* scale, float* packed, int C_i
  * xpad is x extended by reflection (FAC_PAD_REFLECT: index -j -> j on the left, T-1+j -> T-1-j
  * on the right, zero where the mirror falls outside x as pad1d :104-111 does) or zeros.
  * ---------------------------------------------------------------------------------------- */
+#define FAC_CONV_WS_BYTES (32ll << 20)
+
 typedef struct fac_conv_desc {
   const float* x;         /* (B, C_in, T_in); element (b,c,t) at x[b*x_bs + c*x_cs + t] */
   const float* w;         /* packed weights, see fac_pack_conv_w / fac_pack_convtr_w */
@@ -113,6 +115,12 @@ typedef struct fac_conv_desc {
   int32_t act;            /* FAC_ACT_* applied last (before residual) */
   int32_t w_batched;      /* 0: shared weights; 1: per-b weights at w + b*w_bs (attention-style) */
   int64_t w_bs;
+  /* Optional scratch for launches with few output columns (B*T_out <= 128: streaming hops, per-clip
+   * Linears): lets the library split the C_in*K reduction across workgroups (conv1d_skinny.hip).  Zero-filled
+   * once by the caller, >= FAC_CONV_WS_BYTES, owned by ONE stream at a time (the library leaves its ticket
+   * counters zeroed after every launch).  NULL: the tiled kernel is used for every shape. */
+  void* ws;
+  int64_t ws_bytes;
 } fac_conv_desc;
 
 int fac_conv1d_fwd(const fac_conv_desc* d, fac_stream_t stream);
@@ -148,6 +156,16 @@ int fac_pack_lstm_whh(const float* w_hh, float* packed, int H, fac_stream_t stre
  * H must be a multiple of 64. */
 int fac_lstm_layer_fwd(const float* pre, const float* whh_packed, float* yT, float* c, int T,
                        int H, int BP, fac_stream_t stream);
+/* Same recurrence continued from a carried state (streaming inference): `c` is the scratch
+ * of an earlier call on the same stream of frames, `step0` the number of steps already taken
+ * (0 = zero initial state, identical to fac_lstm_layer_fwd). */
+int fac_lstm_layer_fwd_from(const float* pre, const float* whh_packed, float* yT, float* c, int T,
+                            int H, int BP, int64_t step0, fac_stream_t stream);
+/* Left-context buffer of a streaming causal conv: every row of buf (rows x cap) holds
+ * [hist columns of history | n_prev columns appended last time]; moves the last `hist` columns to the
+ * front (skipped when n_prev == 0) and appends src (rows x n_new, dense) behind them.  hist <= 2048. */
+int fac_stream_push(float* buf, const float* src, int64_t rows, int64_t cap, int hist, int n_prev, int n_new,
+                    fac_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * K7  factorized VQ step (dac/nn/quantize.py:34-94 VectorQuantize.forward + the residual

@@ -60,6 +60,12 @@ CONV_CASES = [
     (1, 1024, 1536, 160, 7, 1, 1, False, False, False, 0, "reflect"),
     (5, 256, 512, 32, 1, 1, 1, False, False, False, 0, "reflect"),     # narrow-N tile (LSTM projections)
     (1, 37, 45, 129, 5, 1, 2, True, True, True, 0, "reflect"),        # odd everything
+    # few output columns, zero padding: the split-reduction ("skinny") kernel
+    (1, 768, 768, 12, 7, 1, 3, False, True, True, 0, "zero"),
+    (2, 1024, 1536, 2, 7, 1, 1, False, False, False, 0, "zero"),
+    (3, 512, 1024, 30, 12, 6, 1, False, False, False, 1, "zero"),
+    (1, 384, 200, 61, 7, 1, 9, False, True, True, 0, "zero"),         # C_out not a multiple of 128 / 32
+    (8, 1024, 2048, 1, 1, 1, 1, False, False, False, 0, "zero"),      # per-clip Linear
 ]
 
 
@@ -572,3 +578,90 @@ def test_redecoder_vs_reference_golden(full_model, cuda, golden_dir):
     assert rel(zr[:, ::8], d["z_probe"]) < E2E_TOL
     assert rel(yr[:, 0, torch.from_numpy(d["probe_t"])], d["wave_probe"]) < E2E_TOL
     assert abs(float(yr.abs().max()) - float(d["wave_absmax"])) < 1e-4
+
+
+# ------------------------------------------------------------------------------ streaming (configs[4])
+@pytest.mark.parametrize("use_graphs", [False, True])
+def test_streaming_matches_offline(full_model, cuda, use_graphs):
+    """480-sample hops with carried state == the offline causal model on the whole signal: codes bit-exact,
+    waveform within 1e-4 (the reference has no streaming code, parity target = offline)."""
+    from facodec_amd.streaming import HOP, StreamingCodec
+    m = full_model
+    n_hops = 27
+    T = 4800 + n_hops * HOP                                   # 17 760 samples... must be a multiple of 300
+    n_hops = 25
+    T = 4800 + n_hops * HOP                                   # 16 800 = 56 frames
+    wave = synth.synth_clips(2, T, seed=11).to(cuda)
+    with torch.no_grad():
+        z = m.encoder(wave)
+        outs, _, _, _, timbre, codes = m.quantizer(z, wave, n_c=2, return_codes=True)
+        y = m.decoder(outs)
+        sess = StreamingCodec(m, timbre, n_c=2, use_graphs=use_graphs)
+        got_codes, got_wave, frame = [[], [], []], [], 0
+        pieces = [sess.prime(wave[:, :, :4800])]
+        for h in range(n_hops):
+            o = sess.push(wave[:, :, 4800 + h * HOP: 4800 + (h + 1) * HOP])
+            pieces.append({k: ([c.clone() for c in v] if isinstance(v, list) else (v.clone() if torch.is_tensor(v) else v))
+                           for k, v in o.items()})
+        pieces.append(sess.finish())
+    for o in pieces:
+        if o["codes"] is None:
+            continue
+        assert o["frame0"] == frame
+        frame += o["codes"][0].shape[-1]
+        for i in range(3):
+            got_codes[i].append(o["codes"][i])
+        got_wave.append(o["wave"])
+    assert frame == T // 300
+    for i in range(3):
+        assert torch.equal(torch.cat(got_codes[i], -1), codes[i]), f"codes[{i}]"
+    assert rel(torch.cat(got_wave, -1), y) < E2E_TOL
+
+
+def test_stream_push_kernel(ops, cuda):
+    g = _g(3)
+    buf = torch.zeros(2, 3, 10 + 7, device=cuda)
+    ref = torch.zeros(2, 3, 0)
+    n_prev = 0
+    for n in (7, 3, 5, 1, 7):
+        x = torch.randn(2, 3, n, generator=g)
+        ops.stream_push(buf, x.to(cuda), 10, n_prev)
+        ref = torch.cat([ref, x], -1)
+        tail = ref[:, :, -(10 + n):]
+        assert torch.equal(buf[:, :, 10 + n - tail.shape[-1]:10 + n].cpu(), tail)
+        n_prev = n
+
+
+def test_skinny_conv_variant_and_second_output(O, ops, cuda):
+    """The few-column launches must actually take the split-reduction kernel, and its epilogue must emit
+    the pre-activated copy; also the transposed conv with carried history (streaming)."""
+    import ctypes
+    from facodec_amd import _lib
+    g = _g(77)
+    x = torch.randn(1, 384, 40, generator=g)
+    w = torch.randn(384, 384, 7, generator=g) / 52.0
+    b = torch.randn(384, generator=g) * 0.1
+    a2 = 1 + 0.2 * torch.rand(384, generator=g)
+    r = torch.randn(1, 384, 34, generator=g)
+    y_ref = torch.nn.functional.conv1d(x, w, b) + r
+    wp = ops.pack_conv_weight(w.to(cuda))
+    prof = ops.ConvLaunchProfile()
+    ops.set_conv_profile(prof)
+    try:
+        y, y2 = ops.conv1d(x.to(cuda), wp, 384, 7, bias=b.to(cuda), pad_left=0, pad_mode=ops.PAD_ZERO, t_out=34,
+                           res=r.to(cuda), alpha_y2=a2.to(cuda))
+        torch.cuda.synchronize()
+    finally:
+        ops.set_conv_profile(None)
+    assert any("skinny" in k for k in prof.summary()), prof.summary().keys()
+    assert rel(y, y_ref) < OP_TOL and rel(y2, O.snake(y_ref, a2.view(1, -1, 1))) < OP_TOL
+    # transposed conv, second chunk of a stream == the tail of the whole-signal result
+    s = 5
+    xx = torch.randn(2, 256, 9, generator=g)
+    v = torch.randn(256, 128, 2 * s, generator=g) / 22.0
+    gg = torch.rand(256, 1, 1, generator=g) + 0.5
+    bb = torch.randn(128, generator=g) * 0.1
+    full = O.sconvtr1d(xx, O.weight_norm_weight(v, gg), bb, s, causal=True)
+    wpt = ops.pack_convtr_weight(v.to(cuda), gg.to(cuda), s)
+    tail = ops.conv_transpose1d(xx[:, :, 5:].to(cuda), wpt, 128, s, bias=bb.to(cuda), has_history=True)
+    assert rel(tail, full[:, :, 6 * s:]) < OP_TOL
