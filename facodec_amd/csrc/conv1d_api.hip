@@ -73,8 +73,8 @@ extern "C" int fac_conv1d_fwd(const fac_conv_desc* d, fac_stream_t stream) {
   }
   hipStream_t s = (hipStream_t)stream;
   if (d->w_k1) return conv_dispatch_fused_ru(a, s);
-  if (narrow_ok(d)) return conv_dispatch_narrow(a, s);
   if (conv_skinny_ok(a, d->ws, d->ws_bytes)) return conv_dispatch_skinny(a, d->ws, d->ws_bytes, s);
+  if (narrow_ok(d)) return conv_dispatch_narrow(a, s);
   switch (select_variant(d)) {
     case 0: return conv_dispatch_128x32(a, s);
     case 1: return conv_dispatch_32x256(a, s);
@@ -98,19 +98,19 @@ extern "C" int fac_conv1d_variant(const fac_conv_desc* d, char* name, int name_l
     if (name && name_len > 0) snprintf(name, name_len, "conv1d_mfma_kernel<C/32,1,1,4,7,fused RU> Cx128");
     return 7;
   }
-  if (narrow_ok(d)) {
-    if (name && name_len > 0) snprintf(name, name_len, "conv1d_narrow_kernel (VALU, C_out<=2)");
-    return 9;
-  }
   {
     ConvArgs a{};
     a.alpha_in = d->alpha_in; a.w1 = d->w_k1; a.w_batched = d->w_batched; a.phase_shift = d->phase_shift;
-    a.pad_mode = d->pad_mode; a.B = d->B; a.T_out = d->T_out; a.C_in = d->C_in; a.C_out = d->C_out; a.K = d->K;
+    a.pad_mode = d->pad_mode; a.pad_left = d->pad_left; a.B = d->B; a.T_out = d->T_out; a.C_in = d->C_in; a.C_out = d->C_out; a.K = d->K;
     a.n_phase = d->n_phase; a.x_cs = d->x_cs; a.x_bs = d->x_bs;
     if (conv_skinny_ok(a, d->ws, d->ws_bytes)) {
-      if (name && name_len > 0) snprintf(name, name_len, "conv1d_skinny_kernel (split reduction, <=128 columns)");
+      if (name && name_len > 0) snprintf(name, name_len, "conv1d_skinny_kernel (split reduction, <=640 columns)");
       return 10;
     }
+  }
+  if (narrow_ok(d)) {
+    if (name && name_len > 0) snprintf(name, name_len, "conv1d_narrow_kernel (VALU, C_out<=2)");
+    return 9;
   }
   const int v = select_variant(d);
   if (name && name_len > 0) snprintf(name, name_len, "%s", names[v]);

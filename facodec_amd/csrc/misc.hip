@@ -286,6 +286,49 @@ __global__ __launch_bounds__(256) void layernorm_c_kernel(const float* __restric
   }
 }
 
+// T <= 8 (streaming hops): the (C, T) block of one clip is contiguous -- stage it in LDS with coalesced
+// loads and run the SAME per-(wave, lane) arithmetic as layernorm_c_kernel on it (bit-identical results,
+// without C/4 dependent global round trips per lane).
+__global__ __launch_bounds__(256) void layernorm_c_small_t_kernel(const float* __restrict__ x,
+                                                                  const float* __restrict__ style,
+                                                                  float* __restrict__ out, int C, int T) {
+  extern __shared__ float xs[];   // [C][T]
+  __shared__ float red[2][4][8];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.x;
+  const float* xb = x + (long long)b * C * T;
+  for (int i = tid; i < C * T; i += 256) xs[i] = xb[i];
+  __syncthreads();
+  const bool tv = lane < T;
+  float s = 0.f;
+  if (tv) for (int c = wave; c < C; c += 4) s += xs[c * T + lane];
+  if (tv) red[0][wave][lane] = s;
+  __syncthreads();
+  float mean = 0.f, rstd = 0.f;
+  if (tv) {
+    mean = ((red[0][0][lane] + red[0][1][lane]) + (red[0][2][lane] + red[0][3][lane])) / (float)C;
+    float vs = 0.f;
+    for (int c = wave; c < C; c += 4) {
+      const float d = xs[c * T + lane] - mean;
+      vs = fmaf(d, d, vs);
+    }
+    red[1][wave][lane] = vs;
+  }
+  __syncthreads();
+  if (tv) {
+    const float var = ((red[1][0][lane] + red[1][1][lane]) + (red[1][2][lane] + red[1][3][lane])) / (float)C;
+    rstd = __fdiv_rn(1.0f, sqrtf(var + 1e-5f));
+    const float* gm = style + (long long)b * 2 * C;
+    for (int c = wave; c < C; c += 4) {
+      const float nv = __fmul_rn(xs[c * T + lane] - mean, rstd);
+      xs[c * T + lane] = __fadd_rn(__fmul_rn(nv, gm[c]), gm[C + c]);   // (c, lane) is touched by this thread only
+    }
+  }
+  __syncthreads();
+  float* ob = out + (long long)b * C * T;
+  for (int i = tid; i < C * T; i += 256) ob[i] = xs[i];
+}
+
 // centre=True STFT framing (torch.stft pad_mode='reflect'): frames[b][n][f].
 __global__ void stft_frames_kernel(const float* __restrict__ wave, float* __restrict__ frames, int T,
                                    int n_win, int n_frames, int hop, int pad, int n_off,
@@ -553,6 +596,11 @@ extern "C" int fac_masked_mean(const float* x, const float* mask, float* out, in
 extern "C" int fac_layernorm_c_affine(const float* x, const float* style, float* out, int B, int C,
                                       int T, fac_stream_t stream) {
   FAC_REQUIRE(x && style && out && B > 0 && C > 0 && T > 0, "layernorm_c_affine: bad arguments");
+  if (T <= 8 && (size_t)C * T * 4 <= 64 * 1024) {
+    hipLaunchKernelGGL(layernorm_c_small_t_kernel, dim3(B), dim3(256), (size_t)C * T * 4, (hipStream_t)stream, x,
+                       style, out, C, T);
+    return check_launch("layernorm_c_affine(small T)");
+  }
   hipLaunchKernelGGL(layernorm_c_kernel, dim3((T + 63) / 64, B), dim3(256), 0, (hipStream_t)stream, x,
                      style, out, C, T);
   return check_launch("layernorm_c_affine");

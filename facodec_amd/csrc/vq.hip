@@ -237,6 +237,106 @@ __global__ __launch_bounds__(256) void vq_fwd_kernel(VqArgs a) {
   }
 }
 
+// Few time steps (streaming hops: T = 1-2 frames): the lane-per-time-step kernel above would leave one
+// lane per wave busy and pay ~100 dependent memory round trips.  Here one workgroup owns one (b, t) and its
+// 256 lanes spread over channels / codes, with the SAME arithmetic per value: the in-proj FMA chains run
+// over the same channel quarters in the same order (from LDS), the code scan keeps "first maximum wins",
+// the out-proj is per channel -- results are bit-identical to vq_fwd_kernel.
+__global__ __launch_bounds__(256) void vq_fwd_small_t_kernel(VqArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* cbn = sm;                              // [Kc][8]
+  float* cc = cbn + a.Kc * VQ_CD;               // [Kc]
+  float* xs = cc + a.Kc;                        // [D]
+  float* wsm = xs + a.D;                        // [D][8]
+  float* part = wsm + a.D * VQ_CD;              // [4][8]
+  float* zes = part + 4 * VQ_CD;                // [8]
+  float* bestv = zes + VQ_CD;                   // [256]
+  int* bestk = reinterpret_cast<int*>(bestv + 256);
+  const int tid = threadIdx.x;
+  const int t = blockIdx.x, b = blockIdx.y;
+  const long long bofs = (long long)b * a.D * a.T;
+
+  load_codebook(a.codebook, cbn, cc, a.Kc, tid, 256);
+  for (int c = tid; c < a.D; c += 256) {
+    xs[c] = a.z_in[bofs + (long long)c * a.T + t];
+    const float4 lo = *reinterpret_cast<const float4*>(a.w_in + (long long)c * 32);
+    const float4 hi = *reinterpret_cast<const float4*>(a.w_in + (long long)c * 32 + 4);
+    *reinterpret_cast<float4*>(wsm + c * VQ_CD) = lo;
+    *reinterpret_cast<float4*>(wsm + c * VQ_CD + 4) = hi;
+  }
+  __syncthreads();
+  if (tid < 32) {   // (quarter q, dim d): the chain of vq_fwd_kernel's wave q
+    const int q = tid >> 3, d = tid & 7;
+    const int cper = (a.D + 3) / 4;
+    const int c_begin = q * cper, c_end = min(a.D, c_begin + cper);
+    float sacc = 0.f;
+    for (int c = c_begin; c < c_end; ++c) sacc = fmaf(wsm[c * VQ_CD + d], xs[c], sacc);
+    part[q * VQ_CD + d] = sacc;
+  }
+  __syncthreads();
+  if (tid < VQ_CD) {
+    float v = (part[0 * VQ_CD + tid] + part[1 * VQ_CD + tid]) + (part[2 * VQ_CD + tid] + part[3 * VQ_CD + tid]);
+    v = __fadd_rn(v, a.b_in[tid]);
+    zes[tid] = v;
+    if (a.z_e) a.z_e[((long long)b * VQ_CD + tid) * a.T + t] = v;
+  }
+  __syncthreads();
+  float ze[VQ_CD], e[VQ_CD];
+#pragma unroll
+  for (int d = 0; d < VQ_CD; ++d) ze[d] = zes[d];
+  {
+    const float nrm = fmaxf(sqrtf(row_norm_sq(ze)), 1e-12f);
+#pragma unroll
+    for (int d = 0; d < VQ_CD; ++d) e[d] = __fdiv_rn(ze[d], nrm);
+  }
+  const float ee = row_norm_sq(e);
+  {
+    const int kper = (a.Kc + 255) / 256;
+    const int k_begin = min(a.Kc, tid * kper), k_end = min(a.Kc, k_begin + kper);
+    float bv;
+    int bk;
+    scan_codes(e, ee, cbn, cc, k_begin, k_end, bv, bk);
+    bestv[tid] = k_begin < k_end ? bv : -INFINITY;
+    bestk[tid] = bk;
+  }
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {   // ties keep the lower index (first maximum wins)
+    if (tid < off) {
+      if (bestv[tid + off] > bestv[tid] || (bestv[tid + off] == bestv[tid] && bestk[tid + off] < bestk[tid])) {
+        bestv[tid] = bestv[tid + off];
+        bestk[tid] = bestk[tid + off];
+      }
+    }
+    __syncthreads();
+  }
+  const int idx = bestk[0];
+  float zst[VQ_CD];
+  {
+    const float* cr = a.codebook + (long long)idx * VQ_CD;
+#pragma unroll
+    for (int d = 0; d < VQ_CD; ++d) {
+      const float zq = cr[d];
+      zst[d] = __fadd_rn(ze[d], __fsub_rn(zq, ze[d]));
+    }
+  }
+  if (tid == 0) a.codes[(long long)b * a.codes_bs + t] = idx;
+  const float mk = a.mask ? a.mask[b] : 1.0f;
+  for (int c = tid; c < a.D; c += 256) {
+    const long long off = bofs + (long long)c * a.T + t;
+    const float zin = a.residual ? a.z_in[off] : 0.f;
+    const float zacc = a.zq_acc ? a.zq_acc[off] : 0.f;
+    const float sc = a.w_out_scale ? a.w_out_scale[c] : 1.0f;
+    const float* wr = a.w_out + (long long)c * VQ_CD;
+    float o = __fmul_rn(__fmul_rn(wr[0], sc), zst[0]);
+#pragma unroll
+    for (int d = 1; d < VQ_CD; ++d) o = fmaf(__fmul_rn(wr[d], sc), zst[d], o);
+    o = __fadd_rn(o, a.b_out[c]);
+    if (a.zq_out) a.zq_out[off] = o;
+    if (a.zq_acc) a.zq_acc[off] = __fadd_rn(zacc, __fmul_rn(o, mk));
+    if (a.residual) a.residual[off] = __fsub_rn(zin, o);
+  }
+}
+
 // Search only: latents (N, 8) row-major -> idx.
 __global__ __launch_bounds__(256) void vq_search_kernel(const float* __restrict__ lat,
                                                         const float* __restrict__ cb,
@@ -314,6 +414,19 @@ extern "C" int fac_vq_fwd(const fac_vq_desc* d, fac_stream_t stream) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(vq_fwd_kernel),
                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
+  }
+  if (d->T <= 8 && !d->loss_part && d->D <= 4096) {   // streaming hops: one workgroup per (b, t)
+    const size_t lds_s = ((size_t)d->Kc * (VQ_CD + 1) + (size_t)d->D * (VQ_CD + 1) + 4 * VQ_CD + VQ_CD + 512) * 4;
+    if (lds_s <= 160 * 1024) {
+      static bool attr_s = false;
+      if (!attr_s) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(vq_fwd_small_t_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_s = true;
+      }
+      hipLaunchKernelGGL(vq_fwd_small_t_kernel, dim3(d->T, d->B), dim3(256), lds_s, (hipStream_t)stream, a);
+      return check_launch("vq_fwd(small T)");
+    }
   }
   dim3 grid((d->T + VQ_TT - 1) / VQ_TT, d->B);
   hipLaunchKernelGGL(vq_fwd_kernel, grid, dim3(256), lds, (hipStream_t)stream, a);

@@ -129,7 +129,8 @@ class _RUStream:
     def run(self, x, x_act, alpha_next, want_raw):
         b = self.ru.block
         k7, k1 = b[1], b[3]
-        if k7.w.c_out in FUSED_RU_CHANNELS:
+        # small chunks: two split-reduction launches beat the fused single-tile kernel (latency, not throughput)
+        if k7.w.c_out in FUSED_RU_CHANNELS and x.shape[0] * x.shape[-1] > 640:
             pair = _conv(k7, self.tap, x_act, alpha_out=b[2].flat(), res=x, w_k1=k1.w.packed(), bias_k1=k1.w.bias,
                          alpha_y2=alpha_next, want_y=want_raw or alpha_next is None)
             return pair if alpha_next is not None else (pair, None)
