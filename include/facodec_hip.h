@@ -116,9 +116,9 @@ typedef struct fac_conv_desc {
   int32_t w_batched;      /* 0: shared weights; 1: per-b weights at w + b*w_bs (attention-style) */
   int64_t w_bs;
   /* Optional scratch for launches with few output columns (B*T_out <= 128: streaming hops, per-clip
-   * Linears): lets the library split the C_in*K reduction across workgroups (conv1d_skinny.hip).  Zero-filled
-   * once by the caller, >= FAC_CONV_WS_BYTES, owned by ONE stream at a time (the library leaves its ticket
-   * counters zeroed after every launch).  NULL: the tiled kernel is used for every shape. */
+   * Linears): lets the library split the C_in*K reduction across workgroups (conv1d_skinny.hip).  At least
+   * FAC_CONV_WS_BYTES, owned by ONE stream at a time (partial sums live there between the two kernels of a
+   * launch).  NULL: the tiled kernel is used for every shape. */
   void* ws;
   int64_t ws_bytes;
 } fac_conv_desc;
