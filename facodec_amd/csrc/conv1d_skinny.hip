@@ -169,6 +169,7 @@ static SkinnyGeom skinny_geom(const ConvArgs& a, int* n_tiles) {
   g.co_tiles = (a.C_out + SK_CO - 1) / SK_CO;
   const int tiles = g.co_tiles * g.n_cb * a.n_phase;
   int S = (512 + tiles - 1) / tiles;                      // ~2 workgroups per CU
+  if (tiles >= 128) S = 1;                                // enough tiles already: skip the reduce kernel
   const int max_s = g.rows / 32 > 0 ? g.rows / 32 : 1;    // >= 8 rows per wave
   if (S > max_s) S = max_s;
   if (S > SK_MAX_S) S = SK_MAX_S;
@@ -184,7 +185,7 @@ bool conv_skinny_ok(const ConvArgs& a, const void* ws, long long ws_bytes) {
   const long long ncol = (long long)a.B * a.T_out;
   if (ncol > SK_MAX_COLS) return false;
   const long long rows = (long long)(cin_pad_dev(a.C_in) / 2) * a.K;
-  if (rows < 96) return false;                          // too little to split: the tiled kernel is fine
+  if (rows < 24) return false;                          // too little to split: the tiled kernel is fine
   int tiles;
   const SkinnyGeom g = skinny_geom(a, &tiles);
   return ws_bytes >= (long long)tiles * g.S * 16384;

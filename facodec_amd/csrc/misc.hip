@@ -294,6 +294,7 @@ __global__ __launch_bounds__(256) void layernorm_c_small_t_kernel(const float* _
                                                                   float* __restrict__ out, int C, int T) {
   extern __shared__ float xs[];   // [C][T]
   __shared__ float red[2][4][8];
+  __shared__ float stat[2][8];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int b = blockIdx.x;
   const float* xb = x + (long long)b * C * T;
@@ -301,13 +302,17 @@ __global__ __launch_bounds__(256) void layernorm_c_small_t_kernel(const float* _
   __syncthreads();
   const bool tv = lane < T;
   float s = 0.f;
-  if (tv) for (int c = wave; c < C; c += 4) s += xs[c * T + lane];
-  if (tv) red[0][wave][lane] = s;
+  if (tv) {
+#pragma unroll 16
+    for (int c = wave; c < C; c += 4) s += xs[c * T + lane];
+    red[0][wave][lane] = s;
+  }
   __syncthreads();
   float mean = 0.f, rstd = 0.f;
   if (tv) {
     mean = ((red[0][0][lane] + red[0][1][lane]) + (red[0][2][lane] + red[0][3][lane])) / (float)C;
     float vs = 0.f;
+#pragma unroll 16
     for (int c = wave; c < C; c += 4) {
       const float d = xs[c * T + lane] - mean;
       vs = fmaf(d, d, vs);
@@ -318,15 +323,20 @@ __global__ __launch_bounds__(256) void layernorm_c_small_t_kernel(const float* _
   if (tv) {
     const float var = ((red[1][0][lane] + red[1][1][lane]) + (red[1][2][lane] + red[1][3][lane])) / (float)C;
     rstd = __fdiv_rn(1.0f, sqrtf(var + 1e-5f));
-    const float* gm = style + (long long)b * 2 * C;
-    for (int c = wave; c < C; c += 4) {
-      const float nv = __fmul_rn(xs[c * T + lane] - mean, rstd);
-      xs[c * T + lane] = __fadd_rn(__fmul_rn(nv, gm[c]), gm[C + c]);   // (c, lane) is touched by this thread only
+    if (wave == 0) {
+      stat[0][lane] = mean;
+      stat[1][lane] = rstd;
     }
   }
   __syncthreads();
+  // normalise + affine with every lane busy (per element the same two roundings as layernorm_c_kernel)
+  const float* gm = style + (long long)b * 2 * C;
   float* ob = out + (long long)b * C * T;
-  for (int i = tid; i < C * T; i += 256) ob[i] = xs[i];
+  for (int i = tid; i < C * T; i += 256) {
+    const int c = i / T, tt = i - c * T;
+    const float nv = __fmul_rn(xs[i] - stat[0][tt], stat[1][tt]);
+    ob[i] = __fadd_rn(__fmul_rn(nv, gm[c]), gm[C + c]);
+  }
 }
 
 // centre=True STFT framing (torch.stft pad_mode='reflect'): frames[b][n][f].

@@ -270,6 +270,7 @@ __global__ __launch_bounds__(256) void vq_fwd_small_t_kernel(VqArgs a) {
     const int cper = (a.D + 3) / 4;
     const int c_begin = q * cper, c_end = min(a.D, c_begin + cper);
     float sacc = 0.f;
+#pragma unroll 16
     for (int c = c_begin; c < c_end; ++c) sacc = fmaf(wsm[c * VQ_CD + d], xs[c], sacc);
     part[q * VQ_CD + d] = sacc;
   }
