@@ -27,7 +27,7 @@ class ConvDesc(C.Structure):
         ("K", C.c_int32), ("stride", C.c_int32), ("dilation", C.c_int32), ("pad_left", C.c_int32),
         ("pad_mode", C.c_int32), ("n_phase", C.c_int32), ("y_tstride", C.c_int32), ("phase_shift", C.c_int32),
         ("act", C.c_int32),
-        ("w_batched", C.c_int32), ("w_bs", _i64), ("ws", _p), ("ws_bytes", _i64),
+        ("w_batched", C.c_int32), ("w_bs", _i64), ("ws", _p), ("ws_bytes", _i64), ("w_split", _p),
     ]
 
 
@@ -46,6 +46,8 @@ SIGNATURES = {
     "fac_last_error": (C.c_char_p, []),
     "fac_wn_scale": (_i, [_p, _p, _p, _i, _i, _p]),
     "fac_pack_conv_w": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
+    "fac_conv_w_split_bytes": (_i64, [_i, _i, _i]),
+    "fac_pack_conv_w_split": (_i, [_p, _p, _p, _i, _i, _i, _p]),
     "fac_pack_convtr_w": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
     "fac_conv1d_fwd": (_i, [C.POINTER(ConvDesc), _p]),
     "fac_conv1d_variant": (_i, [C.POINTER(ConvDesc), C.c_char_p, _i]),

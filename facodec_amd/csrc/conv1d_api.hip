@@ -75,6 +75,13 @@ extern "C" int fac_conv1d_fwd(const fac_conv_desc* d, fac_stream_t stream) {
   if (d->w_k1) return conv_dispatch_fused_ru(a, s);
   if (conv_skinny_ok(a, d->ws, d->ws_bytes)) return conv_dispatch_skinny(a, d->ws, d->ws_bytes, s);
   if (narrow_ok(d)) return conv_dispatch_narrow(a, s);
+  if (d->w_split) {
+    if (conv_bsplit_ok(a)) {
+      a.w = reinterpret_cast<const float*>(d->w_split);
+      return conv_dispatch_bsplit(a, s);
+    }
+    FAC_REQUIRE(d->w != d->w_split, "conv1d: shape does not qualify for the split-bf16 kernel and no fp32 weights were given");
+  }
   switch (select_variant(d)) {
     case 0: return conv_dispatch_128x32(a, s);
     case 1: return conv_dispatch_32x256(a, s);
@@ -111,6 +118,16 @@ extern "C" int fac_conv1d_variant(const fac_conv_desc* d, char* name, int name_l
   if (narrow_ok(d)) {
     if (name && name_len > 0) snprintf(name, name_len, "conv1d_narrow_kernel (VALU, C_out<=2)");
     return 9;
+  }
+  if (d->w_split) {
+    ConvArgs a{};
+    a.K = d->K; a.stride = d->stride; a.n_phase = d->n_phase; a.phase_shift = d->phase_shift; a.y_tstride = d->y_tstride;
+    a.alpha_in = d->alpha_in; a.w1 = d->w_k1; a.w_batched = d->w_batched; a.C_in = d->C_in; a.dil = d->dilation;
+    a.B = d->B; a.T_out = d->T_out;
+    if (conv_bsplit_ok(a)) {
+      if (name && name_len > 0) snprintf(name, name_len, "conv1d_bsplit_kernel<7> 64x256 (bf16x3 split, fp32-exact)");
+      return 11;
+    }
   }
   const int v = select_variant(d);
   if (name && name_len > 0) snprintf(name, name_len, "%s", names[v]);

@@ -1,0 +1,403 @@
+// fp32 convolution on the bf16 matrix pipe, without giving up fp32 accuracy.
+//
+// Every fp32 value is EXACTLY the sum of three round-to-nearest bf16 terms (8 + 8 + 8 significand bits:
+// x = hi + mid + lo), and a product of two bf16 values is exact in fp32.  So w*x = sum of 9 exact cross
+// products accumulated in fp32; the three smallest (mid*lo, lo*mid, lo*lo, <= 2^-24 relative) are below the
+// rounding of the fp32 accumulation itself and are dropped: SIX v_mfma_f32_32x32x16_bf16 per K = 16 step.
+// Measured on MI355X (tools/microbench/bf16_split_probe.hip): the bf16 pipe sustains 2 184 TFLOP/s, the fp32
+// pipe 138 TFLOP/s, so six bf16 MFMAs cost 1/2.6 of the fp32 MFMAs they replace; error against fp64 of a
+// K = 4 096 dot product: 2.16e-6 (this scheme) vs 2.57e-6 (v_mfma_f32_32x32x2_f32) relative to max|ref|.
+// Inputs, outputs, bias, Snake, residuals and the accumulators stay fp32; nothing is stored in bf16 in HBM
+// except the (pre-split, lossless) weights.
+//
+// Tile: 64 output channels x 256 time steps per workgroup, 4 MFMA waves (each 64 x 64 = 2 x 2 MFMA blocks)
+// + NSW staging waves.  Stage = G groups of 8 input channels x all K taps = H = G*K "half slots" (8 channels
+// of one tap, ordered tap-major); one MFMA contracts K = 16 = two half slots (half-wave 0: slot 2s, half-wave
+// 1: slot 2s+1), an odd H is padded with a zero slot.  G = 2, K = 7: 7 MFMA steps per 16 channels, no padding.
+//   weights : pre-split in HBM as [co tile][stage][plane][half slot][64 co][8 ci] bf16 -- one contiguous slab
+//             per stage, moved by LDS-DMA; an A fragment (8 ci of one co) is one ds_read_b128;
+//   inputs  : fp32 (B, C, T) rows -> the staging waves split each value (5 VALU ops) and write
+//             [plane][ci group][column][8 ci] -- a B fragment of any tap is one aligned ds_read_b128 at column
+//             t + k*dilation (no alignment constraints on dilation, unlike the fp32 slab).  The fp32 loads of
+//             stage c+2 are issued one stage before they are split (register double buffer).
+// Two stages of LDS (146 KB): one workgroup per CU.  Measured alternatives that fit two workgroups per CU
+// (8-channel stages with tap pairs: 80 KB; a single stage of 73 KB with the co-resident workgroup as the
+// second pipeline stage) ran at 100-120 TFLOP/s-equivalent against 125-180 for this layout.
+#include "conv1d_mfma.h"
+
+namespace fac {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int BS_CO = 64;
+constexpr int BS_TT = 256;
+constexpr int BS_G = 2;     // ci groups of 8 per stage
+constexpr int BS_NSW = 4;   // staging waves
+constexpr int BS_XU = 3;    // (ci group, 64-column block) staging units per staging wave: XW <= 384
+
+__device__ __forceinline__ void split3(float x, __bf16& h, __bf16& m, __bf16& l) {
+  h = (__bf16)x;
+  const float r1 = x - (float)h;
+  m = (__bf16)r1;
+  l = (__bf16)(r1 - (float)m);
+}
+
+__host__ __device__ constexpr int bs_slots(int K, int G) { return (G * K + 1) & ~1; }
+
+// v (C_out, C_in, K) [* scale per C_out] -> split layout described above.  One thread per (tile, stage, half
+// slot, co): 8 input channels -> three 16-byte pieces.
+__global__ void pack_conv_split_kernel(const float* __restrict__ v, const float* __restrict__ scale,
+                                       bf16x8* __restrict__ out, int C_out, int C_in, int K, int G, int H, int n_st,
+                                       long long n) {
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (long long)gridDim.x * blockDim.x) {
+    const int co = (int)(idx % BS_CO);
+    long long r = idx / BS_CO;
+    const int hs = (int)(r % H);          // half slot -> (ci group, tap)
+    r /= H;
+    const int s = (int)(r % n_st);
+    const int ct = (int)(r / n_st);
+    const int g = hs % G, k = hs / G;     // slot = tap-major, group-minor: both half slots of a step share the tap (G = 2)
+    const int cog = ct * BS_CO + co;
+    const float sc = (scale != nullptr && cog < C_out) ? scale[cog] : 1.0f;
+    bf16x8 h, m, l;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int ci = (s * G + g) * 8 + i;
+      float w = 0.f;
+      if (cog < C_out && ci < C_in && k < K) {
+        w = v[((long long)cog * C_in + ci) * K + k];
+        if (scale != nullptr) w = __fmul_rn(w, sc);
+      }
+      __bf16 a, b2, c;
+      split3(w, a, b2, c);
+      h[i] = a; m[i] = b2; l[i] = c;
+    }
+    const long long base = ((long long)ct * n_st + s) * 3;
+    out[((base + 0) * H + hs) * BS_CO + co] = h;
+    out[((base + 1) * H + hs) * BS_CO + co] = m;
+    out[((base + 2) * H + hs) * BS_CO + co] = l;
+  }
+}
+
+template <int KT, int G, int NSW>
+__global__ __launch_bounds__((4 + NSW) * 64, 2) void conv1d_bsplit_kernel(ConvArgs a) {
+  constexpr int MB = 2, NB = 2;
+  constexpr int H = bs_slots(KT, G);                  // half slots per stage (even)
+  constexpr int W_STAGE = 3 * H * BS_CO * 16;         // bytes
+  extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // 0-3: MFMA waves, then the staging waves
+  const int XW = a.XW;
+  const int X_STAGE = 48 * G * XW;                              // 3 planes x G groups x XW x 16 B
+  unsigned char* Wbuf = sm;              // [2][W_STAGE]
+  unsigned char* Xbuf = sm + 2 * W_STAGE;   // [2][X_STAGE]
+
+  // XCD-aware work decode (see conv1d_mfma.h): each XCD walks a contiguous range of (co tile, b, t tile)
+  int t0, co0, b;
+  {
+    const int n = gridDim.x;
+    const int q8 = n >> 3, r8 = n & 7;
+    const int xcd = blockIdx.x & 7, within = blockIdx.x >> 3;
+    const int id = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + within;
+    const int nt = a.n_t_tiles;
+    const int tt = id % nt;
+    const int rest = id / nt;
+    b = rest % a.B;
+    co0 = (rest / a.B) * BS_CO;
+    t0 = tt * BS_TT;
+  }
+  const int n_chunks = (a.C_in + 8 * G - 1) / (8 * G);
+  const int dil = a.dil;
+
+  if (wave >= 4) {
+    // ===================== staging waves
+    const int lw = wave - 4;
+    __builtin_amdgcn_s_setprio(3);
+    const float* xg = a.x + (long long)b * a.x_bs;
+    const unsigned char* wsrc = reinterpret_cast<const unsigned char*>(a.w) + (long long)(co0 / BS_CO) * n_chunks * W_STAGE;
+    const int n_blk = (XW + 63) >> 6;
+    // (ci group, 64-column block) units of this wave; the column -> input index map is chunk-invariant
+    int u_g[BS_XU], u_c[BS_XU], u_idx[BS_XU];
+#pragma unroll
+    for (int j = 0; j < BS_XU; ++j) {
+      const int u = lw + NSW * j;
+      u_g[j] = u % G;
+      const int c = (u / G) * 64 + lane;
+      u_c[j] = (u < G * n_blk && c < XW) ? c : -1;
+      const int tin = t0 - a.pad_left + c;
+      int idx;
+      if (a.pad_mode == FAC_PAD_REFLECT) idx = reflect_index(tin, a.T_in, a.T_ext);
+      else idx = (tin >= 0 && tin < a.T_in) ? tin : -1;
+      u_idx[j] = u_c[j] >= 0 ? idx : -1;
+    }
+    auto stage_w = [&](int chunk, int buf) {   // weights: one contiguous slab, 16 B per lane
+#ifndef FAC_ABL_NOSTAGE
+      constexpr int N16 = W_STAGE / 16;
+      const unsigned char* src = wsrc + (long long)chunk * W_STAGE;
+      unsigned char* dst = Wbuf + buf * W_STAGE;
+      for (int i = lw; i * 64 < N16; i += NSW) {
+        const int q = i * 64 + lane;
+        if (q < N16)
+          __builtin_amdgcn_global_load_lds((glb_void_t*)(src + (long long)q * 16), (lds_void_t*)(dst + i * 1024), 16, 0, 0);
+      }
+#endif
+    };
+    auto load_x = [&](int chunk, float (&xr)[BS_XU][8]) {
+#ifndef FAC_ABL_NOSTAGE
+#pragma unroll
+      for (int j = 0; j < BS_XU; ++j) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int ci = (chunk * G + u_g[j]) * 8 + i;
+          xr[j][i] = (u_idx[j] >= 0 && ci < a.C_in) ? xg[(long long)ci * a.x_cs + u_idx[j]] : 0.f;
+        }
+      }
+#endif
+    };
+    auto write_x = [&](int buf, const float (&xr)[BS_XU][8]) {
+#ifndef FAC_ABL_NOSTAGE
+      unsigned char* xd = Xbuf + buf * X_STAGE;
+#pragma unroll
+      for (int j = 0; j < BS_XU; ++j) {
+        if (u_c[j] < 0) continue;
+        bf16x8 h, m, l;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          __bf16 p0, p1, p2;
+          split3(xr[j][i], p0, p1, p2);
+          h[i] = p0; m[i] = p1; l[i] = p2;
+        }
+        *reinterpret_cast<bf16x8*>(xd + ((0 * G + u_g[j]) * XW + u_c[j]) * 16) = h;
+        *reinterpret_cast<bf16x8*>(xd + ((1 * G + u_g[j]) * XW + u_c[j]) * 16) = m;
+        *reinterpret_cast<bf16x8*>(xd + ((2 * G + u_g[j]) * XW + u_c[j]) * 16) = l;
+      }
+#endif
+    };
+    // The fp32 inputs of chunk c+2 are requested one whole stage before they are split and written
+    // (register double buffer, static indices): their HBM/L2 latency hides behind the MFMAs of chunk c.
+    float xa[BS_XU][8], xb[BS_XU][8];
+    load_x(0, xa);
+    stage_w(0, 0);
+    if (n_chunks > 1) load_x(1, xb);
+    write_x(0, xa);
+    __syncthreads();
+    for (int chunk = 0; chunk < n_chunks; chunk += 2) {
+      if (chunk + 1 < n_chunks) {
+        stage_w(chunk + 1, 1);
+        if (chunk + 2 < n_chunks) load_x(chunk + 2, xa);
+        write_x(1, xb);
+      }
+      __syncthreads();
+      if (chunk + 1 >= n_chunks) break;
+      if (chunk + 2 < n_chunks) {
+        stage_w(chunk + 2, 0);
+        if (chunk + 3 < n_chunks) load_x(chunk + 3, xb);
+        write_x(0, xa);
+      }
+      __syncthreads();
+    }
+    return;
+  }
+
+  // ========================= MFMA waves
+  const int l31 = lane & 31;
+  const int kq = lane >> 5;
+  const int n0 = wave * 64;
+  f32x16 acc[MB][NB];
+#pragma unroll
+  for (int m = 0; m < MB; ++m)
+#pragma unroll
+    for (int n = 0; n < NB; ++n)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+
+  // Half slot hs = (tap hs / G, group hs % G).  For step st the two half-waves read slots 2st and 2st+1:
+  // G = 2: same tap st, groups 0 / 1;  G = 1: taps 2st / 2st+1 -- either way a per-lane base plus a uniform
+  // per-step offset.
+  const int x_lane = (G == 2 ? kq * XW : kq * dil) * 16;
+  const int x_step = (G == 2 ? dil : 2 * dil) * 16;
+
+  __syncthreads();   // chunk 0 staged
+  for (int chunk = 0; chunk < n_chunks; ++chunk) {
+    const int buf = chunk & 1;
+    const unsigned char* Wb = Wbuf + buf * W_STAGE + (kq * BS_CO + l31) * 16;          // half slot 2s + kq
+    const unsigned char* Xb = Xbuf + buf * X_STAGE + (n0 + l31) * 16 + x_lane;
+    // A fragments are requested one step ahead (register double buffer); B fragments at the start of their
+    // step, in the order the six terms consume them (the compiler waits per fragment, and the second workgroup
+    // on the CU covers what latency remains) -- keeps the kernel under the 170 VGPRs of 3 waves per SIMD.
+    bf16x8 A[2][MB][3], Bf[NB][3];
+    auto ldA = [&](int st, bf16x8 (&Ad)[MB][3]) {
+#ifdef FAC_ABL_NOLDS
+      if (st > 1) return;
+#endif
+#pragma unroll
+      for (int p = 0; p < 3; ++p)
+#pragma unroll
+        for (int m = 0; m < MB; ++m)
+          Ad[m][p] = *reinterpret_cast<const bf16x8*>(Wb + ((p * H + 2 * st) * BS_CO + m * 32) * 16);
+    };
+    auto ldB = [&](int st) {
+#ifdef FAC_ABL_NOLDS
+      if (st > 0) return;
+#endif
+      const int xo = st * x_step;
+      constexpr int PO[3] = {1, 0, 2};   // planes in order of first use: mid, hi, lo
+#pragma unroll
+      for (int pi = 0; pi < 3; ++pi)
+#pragma unroll
+        for (int n = 0; n < NB; ++n)
+          Bf[n][PO[pi]] = *reinterpret_cast<const bf16x8*>(Xb + xo + (PO[pi] * G * XW + n * 32) * 16);
+    };
+    ldA(0, A[0]);
+#pragma unroll
+    for (int st = 0; st < H / 2; ++st) {
+      ldB(st);
+      if (st + 1 < H / 2) ldA(st + 1, A[(st + 1) & 1]);
+      __builtin_amdgcn_sched_barrier(0);
+      const int s = st & 1;
+      // smallest terms first: mid*mid, lo*hi, hi*lo, mid*hi, hi*mid, hi*hi.  The term loop is OUTSIDE the
+      // block loops so that consecutive MFMAs write different accumulators (no back-to-back dependency).
+      constexpr int TA[6] = {1, 2, 0, 1, 0, 0}, TB[6] = {1, 0, 2, 0, 1, 0};
+#ifndef FAC_ABL_NOMFMA
+#pragma unroll
+      for (int q = 0; q < 6; ++q)
+#pragma unroll
+        for (int m = 0; m < MB; ++m)
+#pragma unroll
+          for (int n = 0; n < NB; ++n)
+            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[s][m][TA[q]], Bf[n][TB[q]], acc[m][n], 0, 0, 0);
+#else
+#pragma unroll
+      for (int m = 0; m < MB; ++m)
+#pragma unroll
+        for (int n = 0; n < NB; ++n) acc[m][n][st & 15] += (float)A[s][m][0][0] * (float)Bf[n][1][1] + (float)A[s][m][2][3] + (float)Bf[n][2][5] + (float)A[s][m][1][7] * (float)Bf[n][0][2];
+#endif
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();
+  }
+
+#ifdef FAC_ABL_NOEPI
+  {
+    float sacc = 0.f;
+#pragma unroll
+    for (int m = 0; m < MB; ++m)
+#pragma unroll
+      for (int n = 0; n < NB; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sacc += acc[m][n][r];
+    if (sacc == 123.456f) a.y[0] = sacc;
+    return;
+  }
+#endif
+  // ---- epilogue (C/D layout of the 32x32 tile is the fp32 MFMA's): bias, Snake, activation, residual, y / y2
+  float* yg = a.y ? a.y + (long long)b * a.y_bs : nullptr;
+  float* y2g = a.y2 ? a.y2 + (long long)b * a.y_bs : nullptr;
+  const float* rg = a.res ? a.res + (long long)b * a.y_bs : nullptr;
+#pragma unroll
+  for (int m = 0; m < MB; ++m) {
+    float bsv[2][4], alv[2][4], al2[2][4], rv[2][4][NB];
+    auto ld_group = [&](int g, int slot) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int co = co0 + m * 32 + i + 8 * g + 4 * kq;
+        const int cc = co < a.C_out ? co : a.C_out - 1;
+        bsv[slot][i] = a.bias ? a.bias[cc] : 0.f;
+        alv[slot][i] = a.alpha_out ? a.alpha_out[cc] : 0.f;
+        al2[slot][i] = y2g ? a.alpha2[cc] : 0.f;
+#pragma unroll
+        for (int n = 0; n < NB; ++n) {
+          const int t = t0 + n0 + n * 32 + l31;
+          rv[slot][i][n] = (rg && co < a.C_out && t < a.T_out) ? rg[(long long)co * a.y_cs + t] : 0.f;
+        }
+      }
+    };
+    ld_group(0, 0);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int slot = g & 1;
+      if (g + 1 < 4) ld_group(g + 1, slot ^ 1);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int r = 4 * g + i;
+        const int co = co0 + m * 32 + i + 8 * g + 4 * kq;
+        if (co >= a.C_out) continue;
+        const float al = alv[slot][i];
+        const float inv = a.alpha_out ? snake_inv(al) : 0.f;
+#pragma unroll
+        for (int n = 0; n < NB; ++n) {
+          const int t = t0 + n0 + n * 32 + l31;
+          if (t >= a.T_out) continue;
+          float v = acc[m][n][r] + bsv[slot][i];
+          if (a.alpha_out) v = snake_apply(v, al, inv);
+          if (a.act != FAC_ACT_NONE) v = apply_act_slow(v, a.act);
+          v += rv[slot][i][n];
+          const long long o = (long long)co * a.y_cs + t;
+          if (yg) yg[o] = v;
+          if (y2g) y2g[o] = snake_apply(v, al2[slot][i], snake_inv(al2[slot][i]));
+        }
+      }
+    }
+  }
+}
+
+bool conv_bsplit_ok(const ConvArgs& a) {
+  return a.K == 7 && a.stride == 1 && a.n_phase == 1 && a.phase_shift == 0 && a.y_tstride == 1 && !a.alpha_in &&
+         !a.w1 && !a.w_batched && a.C_in % (8 * BS_G) == 0 && BS_G * ((BS_TT + 6 * a.dil + 63) / 64) <= BS_NSW * BS_XU &&
+         (long long)a.B * a.T_out > 640;
+}
+
+int conv_dispatch_bsplit(ConvArgs& a, hipStream_t s) {
+  constexpr int KT = 7;
+  constexpr int H = bs_slots(KT, BS_G);
+  a.XW = BS_TT + (KT - 1) * a.dil;
+  const size_t lds = 2 * ((size_t)3 * H * BS_CO * 16 + (size_t)48 * BS_G * a.XW);
+  if (lds > 160 * 1024) {
+    set_error("conv1d(bf16 split): tile needs %zu B of LDS (dil=%d)", lds, a.dil);
+    return FAC_ERR_ARG;
+  }
+  auto kern = conv1d_bsplit_kernel<KT, BS_G, BS_NSW>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  a.n_t_tiles = (a.T_out + BS_TT - 1) / BS_TT;
+  const long long n_wg = (long long)a.n_t_tiles * ((a.C_out + BS_CO - 1) / BS_CO) * a.B;
+  if (n_wg > 0x7fffffffll) {
+    set_error("conv1d: too many workgroups (%lld)", n_wg);
+    return FAC_ERR_ARG;
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)n_wg), dim3((4 + BS_NSW) * 64), lds, s, a);
+  return check_launch("conv1d_bsplit");
+}
+
+}  // namespace fac
+
+// tuning aid: resident workgroups per CU the runtime computes for the split kernel at a given LDS size
+extern "C" int fac_debug_bsplit_occupancy(int lds_bytes) {
+  int n = -1;
+  auto kern = fac::conv1d_bsplit_kernel<7, fac::BS_G, fac::BS_NSW>;
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kern, (4 + fac::BS_NSW) * 64, (size_t)lds_bytes) != hipSuccess) return -1;
+  return n;
+}
+
+extern "C" int64_t fac_conv_w_split_bytes(int C_out, int C_in, int K) {
+  using namespace fac;
+  const int64_t n_ct = (C_out + BS_CO - 1) / BS_CO, n_st = (C_in + 8 * BS_G - 1) / (8 * BS_G);
+  return n_ct * n_st * 3 * bs_slots(K, BS_G) * BS_CO * 16;
+}
+
+extern "C" int fac_pack_conv_w_split(const float* v, const float* scale, void* out, int C_out, int C_in, int K,
+                                     fac_stream_t stream) {
+  using namespace fac;
+  FAC_REQUIRE(v && out && C_out > 0 && C_in > 0 && K > 0, "pack_conv_w_split: bad arguments");
+  const int n_ct = (C_out + BS_CO - 1) / BS_CO, n_st = (C_in + 8 * BS_G - 1) / (8 * BS_G), H = bs_slots(K, BS_G);
+  const long long n = (long long)n_ct * n_st * H * BS_CO;
+  const int blocks = (int)((n + 255) / 256 < 65535 ? (n + 255) / 256 : 65535);
+  hipLaunchKernelGGL(pack_conv_split_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, v, scale,
+                     reinterpret_cast<bf16x8*>(out), C_out, C_in, K, BS_G, H, n_st, n);
+  return check_launch("pack_conv_w_split");
+}

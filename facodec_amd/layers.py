@@ -39,6 +39,7 @@ class ConvWeights(nn.Module):
             self.weight = nn.Parameter(w)
         self.bias = nn.Parameter(_uniform_(torch.empty(c_out), 1.0 / math.sqrt(fan_in))) if bias else None
         self._packed = None
+        self._split = None
         self.freeze_packed = False
 
     def packed(self):
@@ -53,8 +54,18 @@ class ConvWeights(nn.Module):
             self._packed = ops.pack_conv_weight(v.detach(), g.detach() if g is not None else None, out=self._packed)
         return self._packed
 
+    def packed_split(self):
+        """The same weights as three exact bf16 planes (ops.pack_conv_weight_split) for the k = 7 convs."""
+        if self._split is not None and self.freeze_packed:
+            return self._split
+        v = self.weight_v if self.weight_norm else self.weight
+        g = self.weight_g if self.weight_norm else None
+        self._split = ops.pack_conv_weight_split(v.detach(), g.detach() if g is not None else None, out=self._split)
+        return self._split
+
     def _apply(self, fn, *a, **kw):
-        self._packed = None  # device / dtype moves invalidate the packed copy
+        self._packed = None  # device / dtype moves invalidate the packed copies
+        self._split = None
         return super()._apply(fn, *a, **kw)
 
 
@@ -85,9 +96,14 @@ class SConv1d(nn.Module):
     def run(self, x, alpha_in=None, alpha_out=None, res=None, act=ops.ACT_NONE, alpha_y2=None, want_y=True):
         """alpha_y2: additionally emit snake(y, alpha_y2) for the next Snake->conv (returns (y, y2))."""
         w = self.w
-        return ops.conv1d(x, w.packed(), w.c_out, self.kernel_size, bias=w.bias, stride=self.stride,
-                          dilation=self.dilation, pad_mode=self.pad_mode, alpha_in=alpha_in, alpha_out=alpha_out,
-                          res=res, act=act, causal=self.causal, alpha_y2=alpha_y2, want_y=want_y)
+        split = None
+        if (ops.BF16_SPLIT and self.kernel_size == 7 and self.stride == 1 and alpha_in is None and w.c_in % 16 == 0
+                and w.c_out > 2 and x.shape[0] * x.shape[-1] > 640):
+            split = w.packed_split()
+        return ops.conv1d(x, w.packed() if split is None else None, w.c_out, self.kernel_size, bias=w.bias,
+                          stride=self.stride, dilation=self.dilation, pad_mode=self.pad_mode, alpha_in=alpha_in,
+                          alpha_out=alpha_out, res=res, act=act, causal=self.causal, alpha_y2=alpha_y2, want_y=want_y,
+                          w_split=split)
 
     def forward(self, x):
         return self.run(x)

@@ -4,6 +4,7 @@ happens in Python / ATen here -- every op below is one or more kernels of libfac
 """
 import ctypes as C
 import math
+import os
 
 import torch
 
@@ -101,6 +102,10 @@ class ConvLaunchProfile:
 
 _PROFILE = None
 
+# k = 7 convs on the bf16 matrix pipe with fp32-exact operand splitting (conv1d_bsplit.hip).  Results have
+# fp32-MFMA-grade error; FAC_BF16_SPLIT=0 keeps every conv on the fp32 MFMA kernel.
+BF16_SPLIT = os.environ.get("FAC_BF16_SPLIT", "1") != "0"
+
 
 def set_conv_profile(p):
     global _PROFILE
@@ -139,6 +144,20 @@ def _launch_conv(d, what):
     _PROFILE.records.append((buf.value.decode(), flops, e0, e1))
 
 
+def pack_conv_weight_split(v, g=None, out=None):
+    """(C_out, C_in, K) [weight-normed with g] -> split-bf16 layout of fac_pack_conv_w_split (uint8 buffer)."""
+    v = _dev(v, "weight")
+    c_out, c_in, k = v.shape
+    lib = _lib.load()
+    scale = wn_scale(v, g) if g is not None else None
+    nbytes = lib.fac_conv_w_split_bytes(c_out, c_in, k)
+    if out is None:
+        out = torch.empty(nbytes, device=v.device, dtype=torch.uint8)
+    _lib.check(lib.fac_pack_conv_w_split(_ptr(v), _ptr(scale), out.data_ptr(), c_out, c_in, k, _stream()),
+               "fac_pack_conv_w_split")
+    return out
+
+
 def conv_out_len(t_in, k, stride, dilation):
     """Output length and (pad_left, extra_right) of a causal SConv1d (dac/model/encodec.py:71-78,212-222)."""
     k_eff = (k - 1) * dilation + 1
@@ -152,7 +171,7 @@ def conv_out_len(t_in, k, stride, dilation):
 
 def conv1d(x, w_packed, c_out, k, bias=None, stride=1, dilation=1, pad_left=None, pad_mode=PAD_REFLECT,
            t_out=None, alpha_in=None, alpha_out=None, res=None, act=ACT_NONE, out=None, causal=True,
-           alpha_y2=None, want_y=True, w_k1=None, bias_k1=None):
+           alpha_y2=None, want_y=True, w_k1=None, bias_k1=None, w_split=None):
     """Fused conv (see fac_conv1d_fwd).  x (B, C_in, T).  With pad_left=None the SConv1d padding
     rule is applied (causal: everything on the left; non-causal: asymmetric split).
     alpha_y2: also produce y2 = snake(y, alpha_y2) (returned as (y, y2); y is None if not want_y).
@@ -167,13 +186,14 @@ def conv1d(x, w_packed, c_out, k, bias=None, stride=1, dilation=1, pad_left=None
             t_out = t_o
     if t_out is None:
         raise ValueError("t_out required with explicit pad_left")
-    cp = w_packed.shape[-1]
+    cp = w_packed.shape[-1] if w_packed is not None else pad32(c_out)
     if out is None and want_y:
         out = torch.empty(B, c_out, t_out, device=x.device, dtype=torch.float32)
     y2 = torch.empty(B, c_out, t_out, device=x.device, dtype=torch.float32) if alpha_y2 is not None else None
     res = _dev(res, "res")
     d = ConvDesc()
-    d.x, d.w, d.bias = x.data_ptr(), w_packed.data_ptr(), (bias.data_ptr() if bias is not None else None)
+    d.x, d.bias = x.data_ptr(), (bias.data_ptr() if bias is not None else None)
+    d.w = w_packed.data_ptr() if w_packed is not None else w_split.data_ptr()   # split-only launch: see fac_conv_desc.w_split
     d.alpha_in = alpha_in.data_ptr() if alpha_in is not None else None
     d.alpha_out = alpha_out.data_ptr() if alpha_out is not None else None
     d.res = res.data_ptr() if res is not None else None
@@ -182,6 +202,7 @@ def conv1d(x, w_packed, c_out, k, bias=None, stride=1, dilation=1, pad_left=None
     d.alpha_y2 = alpha_y2.data_ptr() if alpha_y2 is not None else None
     d.w_k1 = w_k1.data_ptr() if w_k1 is not None else None
     d.bias_k1 = bias_k1.data_ptr() if bias_k1 is not None else None
+    d.w_split = w_split.data_ptr() if w_split is not None else None
     d.x_bs, d.x_cs = x.stride(0), x.stride(1)
     d.y_bs, d.y_cs = c_out * t_out, t_out
     d.B, d.C_in, d.T_in, d.C_out, d.C_out_pad, d.T_out = B, c_in, t_in, c_out, cp, t_out

@@ -121,9 +121,19 @@ typedef struct fac_conv_desc {
    * launch).  NULL: the tiled kernel is used for every shape. */
   void* ws;
   int64_t ws_bytes;
+  /* Optional: the same weights in the split-bf16 layout of fac_pack_conv_w_split.  When given and the shape
+   * qualifies (K = 7, stride 1, C_in % 16 == 0, no Snake prologue), the conv runs on the bf16 matrix pipe
+   * with fp32-exact operand splitting (conv1d_bsplit.hip); `w` is still required for every other shape. */
+  const void* w_split;
 } fac_conv_desc;
 
 int fac_conv1d_fwd(const fac_conv_desc* d, fac_stream_t stream);
+/* Weights (C_out, C_in, K) [* scale per output channel, as fac_pack_conv_w] -> three bf16 planes hi/mid/lo with
+ * hi + mid + lo == w exactly, laid out per (64-channel tile, 16-input-channel stage) for LDS-DMA.
+ * `out` must hold fac_conv_w_split_bytes(C_out, C_in, K) bytes. */
+int64_t fac_conv_w_split_bytes(int C_out, int C_in, int K);
+int fac_pack_conv_w_split(const float* v, const float* scale, void* out, int C_out, int C_in, int K,
+                          fac_stream_t stream);
 /* Which kernel instantiation fac_conv1d_fwd picks for this descriptor: returns its id (>= 0) and
  * writes a printable name; lets a profiler attribute per-launch timings without re-deriving
  * the tile-selection rule. */

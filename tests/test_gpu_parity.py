@@ -665,3 +665,42 @@ def test_skinny_conv_variant_and_second_output(O, ops, cuda):
     wpt = ops.pack_convtr_weight(v.to(cuda), gg.to(cuda), s)
     tail = ops.conv_transpose1d(xx[:, :, 5:].to(cuda), wpt, 128, s, bias=bb.to(cuda), has_history=True)
     assert rel(tail, full[:, :, 6 * s:]) < OP_TOL
+
+
+# ------------------------------------------------------------------------------ fp32-exact bf16 split convs
+@pytest.mark.parametrize("B,C,T,d,mode", [(2, 128, 1000, 1, "reflect"), (1, 192, 777, 3, "reflect"), (2, 768, 960, 9, "reflect"),
+                                           (1, 96, 2000, 9, "zero"), (3, 256, 300, 1, "reflect")])
+def test_split_bf16_conv_matches_fp32_grade(B, C, T, d, mode, O, ops, cuda):
+    """conv1d_bsplit.hip: w and x as three exact bf16 terms, six bf16 MFMAs per K step, fp32 accumulation.
+    Bar: the SAME tolerance as the fp32-MFMA kernel against the oracle, and an error against an fp64 conv no
+    larger than 1.5x the fp32-MFMA kernel's."""
+    g = _g(C + d)
+    x = torch.randn(B, C, T, generator=g)
+    w = torch.randn(C, C, 7, generator=g) / (C * 7) ** 0.5
+    gg = torch.rand(C, 1, 1, generator=g) + 0.5
+    b = torch.randn(C, generator=g) * 0.1
+    ao = 1 + 0.2 * torch.rand(C, generator=g)
+    a2 = 1 + 0.2 * torch.rand(C, generator=g)
+    r = torch.randn(B, C, T, generator=g)
+    wn = O.weight_norm_weight(w, gg)
+    y_ref = O.snake(O.sconv1d(x, wn, b, dilation=d, causal=True, pad_mode=mode), ao.view(1, -1, 1)) + r
+    pm = ops.PAD_REFLECT if mode == "reflect" else ops.PAD_ZERO
+    kw = dict(bias=b.to(cuda), dilation=d, pad_mode=pm, alpha_out=ao.to(cuda), res=r.to(cuda), alpha_y2=a2.to(cuda))
+    ws = ops.pack_conv_weight_split(w.to(cuda), gg.to(cuda))
+    prof = ops.ConvLaunchProfile()
+    ops.set_conv_profile(prof)
+    try:
+        y, y2 = ops.conv1d(x.to(cuda), None, C, 7, w_split=ws, **kw)
+        torch.cuda.synchronize()
+    finally:
+        ops.set_conv_profile(None)
+    assert any("bsplit" in k for k in prof.summary()), prof.summary().keys()
+    yf, _ = ops.conv1d(x.to(cuda), ops.pack_conv_weight(w.to(cuda), gg.to(cuda)), C, 7, **kw)
+    assert rel(y, y_ref) < OP_TOL and rel(y2, O.snake(y_ref, a2.view(1, -1, 1))) < OP_TOL
+    # plain conv against fp64
+    y64 = torch.nn.functional.conv1d(torch.nn.functional.pad(x.double(), (6 * d, 0)), wn.double(), b.double(), dilation=d)
+    kw0 = dict(bias=b.to(cuda), dilation=d, pad_left=6 * d, pad_mode=ops.PAD_ZERO, t_out=T)
+    e_split = rel(ops.conv1d(x.to(cuda), None, C, 7, w_split=ws, **kw0), y64)
+    e_fp32 = rel(ops.conv1d(x.to(cuda), ops.pack_conv_weight(w.to(cuda), gg.to(cuda)), C, 7, **kw0), y64)
+    assert e_split < 1.5 * e_fp32 + 1e-7, (e_split, e_fp32)
+    assert rel(y, yf) < OP_TOL

@@ -56,14 +56,20 @@ for (name, ci, co, T, K, s, d, sin, sout, res, tr) in L:
     else:
         w = torch.randn(co, ci, K, device=dev) * 0.01
         wp = ops.pack_conv_weight(w)
-        y0 = ops.conv1d(x, wp, co, K, bias=bias, stride=s, dilation=d, alpha_in=ai, alpha_out=ao)
+        wsp = None
+        if os.environ.get("SPLIT") == "1" and K == 7 and s == 1 and not sin and ci % 16 == 0 and co > 2:
+            wsp, wp = ops.pack_conv_weight_split(w), None      # SPLIT=1: k7 rows on the bf16x3 kernel
+            name += " [split]"
+        y0 = ops.conv1d(x, wp, co, K, bias=bias, stride=s, dilation=d, alpha_in=ai, alpha_out=ao, w_split=wsp)
         r = torch.randn_like(y0) if res else None
         a2 = torch.ones(co, device=dev) if res else None   # k1 convs also emit the pre-activated copy
-        fn = lambda: ops.conv1d(x, wp, co, K, bias=bias, stride=s, dilation=d, alpha_in=ai, alpha_out=ao, res=r, alpha_y2=a2)
+        fn = lambda: ops.conv1d(x, wp, co, K, bias=bias, stride=s, dilation=d, alpha_in=ai, alpha_out=ao, res=r, alpha_y2=a2, w_split=wsp)
         flops = 2.0 * Bx * co * y0.shape[-1] * ci * K
-    fn(); torch.cuda.synchronize()
+    for _ in range(int(os.environ.get('WARM', '1'))):
+        fn()
+    torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    n = 3
+    n = int(os.environ.get('REP', '3'))
     e0.record()
     for _ in range(n):
         fn()

@@ -28,6 +28,25 @@ __global__ __launch_bounds__(256) void rate_bf16(float* out, int iters) {
   out[blockIdx.x * 256 + threadIdx.x] = c0[0] + c1[1] + c2[2] + c3[3];
 }
 
+__global__ __launch_bounds__(1024) void rate_bf16_lds(float* out, int iters) {
+  extern __shared__ float pin[];
+  bf16x8 a[6], b[6];
+  for (int q = 0; q < 6; ++q)
+    for (int i = 0; i < 8; ++i) { a[q][i] = (__bf16)(float)(threadIdx.x + i + q); b[q][i] = (__bf16)(float)(i + 1 - q); }
+  f32x16 c0 = {0}, c1 = {0}, c2 = {0}, c3 = {0};
+  for (int it = 0; it < iters / 6; ++it) {
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {   // distinct operands per MFMA, 4 accumulators: the conv kernel's issue pattern
+      c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[q], b[q], c0, 0, 0, 0);
+      c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[q], b[5 - q], c1, 0, 0, 0);
+      c2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[5 - q], b[q], c2, 0, 0, 0);
+      c3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[5 - q], b[5 - q], c3, 0, 0, 0);
+    }
+  }
+  if (threadIdx.x == 0) pin[0] = c0[0];
+  out[(blockIdx.x * 256 + threadIdx.x) % (2048 * 256)] = c0[0] + c1[1] + c2[2] + c3[3] + pin[0];
+}
+
 __global__ __launch_bounds__(256) void rate_f32(float* out, int iters) {
   float a = threadIdx.x, b = 1.5f;
   f32x16 c0 = {0}, c1 = {0}, c2 = {0}, c3 = {0};
@@ -99,6 +118,19 @@ int main() {
       float ms; CK(hipEventElapsedTime(&ms, e0, e1));
       const double flop = (double)blocks * 4 * iters * 4 * 2.0 * 32 * 32 * (which == 0 ? 2 : 16);
       printf("%s: %.3f ms  %.1f TFLOP/s\n", which == 0 ? "mfma_f32_32x32x2_f32 " : "mfma_f32_32x32x16_bf16", ms, flop / ms / 1e9);
+    }
+  }
+  // one MFMA wave per SIMD vs two: does a single wave keep the bf16 pipe busy?  (100 KB of LDS pins one
+  // workgroup per CU; 256 threads = 1 wave per SIMD, 512 = 2)
+  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(rate_bf16_lds), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
+  for (int threads : {256, 512, 1024}) {
+    for (int rep = 0; rep < 2; ++rep) {
+      CK(hipEventRecord(e0));
+      hipLaunchKernelGGL(rate_bf16_lds, dim3(256 * 4), dim3(threads), 100 * 1024, 0, d, iters);
+      CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+      float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+      const double flop = (double)256 * 4 * (threads / 64) * iters * 4 * 2.0 * 32 * 32 * 16;
+      printf("bf16 MFMA, 1 WG/CU, %d waves/SIMD: %.3f ms  %.1f TFLOP/s\n", threads / 256, ms, flop / ms / 1e9);
     }
   }
   // numerics
