@@ -17,10 +17,16 @@ def per_kernel(path, counter):
             continue
         m = re.match(r"void fac::conv1d_mfma_kernel<(\d+), (\d+), (\d+), (\d+), (\d+)(?:, (true|false))?(?:, \d+)?>", r["Kernel_Name"])
         if not m:
-            continue
-        key = "conv1d_mfma_kernel<%s,%s,%s,%s,K>" % m.groups()[:4]
-        if m.group(6) == "true":
-            key = "conv1d_mfma_kernel<C/32,1,1,4,7,fused"
+            if "conv1d_bsplit_kernel" in r["Kernel_Name"]:
+                key = "conv1d_bsplit_kernel<7>"
+            elif "conv1d_skinny_kernel" in r["Kernel_Name"]:
+                key = "conv1d_skinny_kernel"
+            else:
+                continue
+        else:
+            key = "conv1d_mfma_kernel<%s,%s,%s,%s,K>" % m.groups()[:4]
+            if m.group(6) == "true":
+                key = "conv1d_mfma_kernel<C/32,1,1,4,7,fused"
         tot[key] += float(r["Counter_Value"])
         n[key] += 1
     return tot, n
