@@ -93,6 +93,10 @@ def load():
         raise FacodecHipError(
             f"{LIB_PATH} not found: the HIP extension is required (no CPU fallback). "
             "Build it with `python -m facodec_amd.build` (needs hipcc, cross-compiles gfx950).")
+    # One HIP runtime per process: torch bundles its own libamdhip64, and a second copy (the system one, pulled
+    # in if this library were loaded first) initialises with "no ROCm-capable device".  Import torch first so
+    # that our DT_NEEDED entry resolves to the copy already in the process.
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)
