@@ -30,10 +30,19 @@ namespace fac {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int BS_CO = 64;
-constexpr int BS_TT = 256;
-constexpr int BS_G = 2;     // ci groups of 8 per stage
 constexpr int BS_NSW = 4;   // staging waves
-constexpr int BS_XU = 3;    // (ci group, 64-column block) staging units per staging wave: XW <= 384
+#ifndef FAC_BS_NSW_WIDE
+#define FAC_BS_NSW_WIDE 4
+#endif
+constexpr int BS_NSW_WIDE = FAC_BS_NSW_WIDE;
+constexpr int BS_XU = 3;    // (ci group, 64-column block) staging units per staging wave
+// Two shapes of the same kernel (the weight layout depends on G, so the choice is a pure function of C_in):
+//   wide    (C_in >= BS_WIDE_MIN): G = 2 groups of 8 channels per stage, 4 MFMA waves, tile 64 x 256
+//   narrow  (C_in <  BS_WIDE_MIN): G = 1, tap PAIRS per MFMA (7 taps + one zero tap), 8 MFMA waves, tile 64 x 512:
+//           few-channel layers have few stages per tile, so a tile twice as long (and two MFMA waves per SIMD)
+//           amortises the per-tile prologue / epilogue that one resident workgroup per CU cannot hide.
+constexpr int BS_WIDE_MIN = 160;
+__host__ __device__ constexpr int bs_group(int C_in) { return C_in >= BS_WIDE_MIN ? 2 : 1; }
 
 __device__ __forceinline__ void split3(float x, __bf16& h, __bf16& m, __bf16& l) {
   h = (__bf16)x;
@@ -79,15 +88,16 @@ __global__ void pack_conv_split_kernel(const float* __restrict__ v, const float*
   }
 }
 
-template <int KT, int G, int NSW>
-__global__ __launch_bounds__((4 + NSW) * 64, 2) void conv1d_bsplit_kernel(ConvArgs a) {
+template <int KT, int G, int NMW, int NSW>
+__global__ __launch_bounds__((NMW + NSW) * 64, (NMW + NSW) / 4) void conv1d_bsplit_kernel(ConvArgs a) {
   constexpr int MB = 2, NB = 2;
+  constexpr int BS_TT = 64 * NMW;                     // time steps per tile
   constexpr int H = bs_slots(KT, G);                  // half slots per stage (even)
   constexpr int W_STAGE = 3 * H * BS_CO * 16;         // bytes
   extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // 0-3: MFMA waves, then the staging waves
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // [0, NMW): MFMA waves, then the staging waves
   const int XW = a.XW;
   const int X_STAGE = 48 * G * XW;                              // 3 planes x G groups x XW x 16 B
   unsigned char* Wbuf = sm;              // [2][W_STAGE]
@@ -110,11 +120,12 @@ __global__ __launch_bounds__((4 + NSW) * 64, 2) void conv1d_bsplit_kernel(ConvAr
   const int n_chunks = (a.C_in + 8 * G - 1) / (8 * G);
   const int dil = a.dil;
 
-  if (wave >= 4) {
+  if (wave >= NMW) {
     // ===================== staging waves
-    const int lw = wave - 4;
+    const int lw = wave - NMW;
     __builtin_amdgcn_s_setprio(3);
     const float* xg = a.x + (long long)b * a.x_bs;
+    const int xcs = (int)a.x_cs;     // one clip's rows stay far below 2^31 elements (checked by the dispatcher)
     const unsigned char* wsrc = reinterpret_cast<const unsigned char*>(a.w) + (long long)(co0 / BS_CO) * n_chunks * W_STAGE;
     const int n_blk = (XW + 63) >> 6;
     // (ci group, 64-column block) units of this wave; the column -> input index map is chunk-invariant
@@ -150,7 +161,7 @@ __global__ __launch_bounds__((4 + NSW) * 64, 2) void conv1d_bsplit_kernel(ConvAr
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
           const int ci = (chunk * G + u_g[j]) * 8 + i;
-          xr[j][i] = (u_idx[j] >= 0 && ci < a.C_in) ? xg[(long long)ci * a.x_cs + u_idx[j]] : 0.f;
+          xr[j][i] = (u_idx[j] >= 0 && ci < a.C_in) ? xg[ci * xcs + u_idx[j]] : 0.f;   // 32-bit offset off a uniform base
         }
       }
 #endif
@@ -201,6 +212,9 @@ __global__ __launch_bounds__((4 + NSW) * 64, 2) void conv1d_bsplit_kernel(ConvAr
   }
 
   // ========================= MFMA waves
+#ifdef FAC_PROF
+  const unsigned long long tp0 = wall_clock64();
+#endif
   const int l31 = lane & 31;
   const int kq = lane >> 5;
   const int n0 = wave * 64;
@@ -219,6 +233,9 @@ __global__ __launch_bounds__((4 + NSW) * 64, 2) void conv1d_bsplit_kernel(ConvAr
   const int x_step = (G == 2 ? dil : 2 * dil) * 16;
 
   __syncthreads();   // chunk 0 staged
+#ifdef FAC_PROF
+  const unsigned long long tp1 = wall_clock64();
+#endif
   for (int chunk = 0; chunk < n_chunks; ++chunk) {
     const int buf = chunk & 1;
     const unsigned char* Wb = Wbuf + buf * W_STAGE + (kq * BS_CO + l31) * 16;          // half slot 2s + kq
@@ -249,13 +266,20 @@ __global__ __launch_bounds__((4 + NSW) * 64, 2) void conv1d_bsplit_kernel(ConvAr
         for (int n = 0; n < NB; ++n)
           Bf[n][PO[pi]] = *reinterpret_cast<const bf16x8*>(Xb + xo + (PO[pi] * G * XW + n * 32) * 16);
     };
-    ldA(0, A[0]);
+    // 8 MFMA waves (2 per SIMD, 3 waves per SIMD in all -> 170 VGPRs): the sibling wave hides the LDS latency,
+    // so A is fetched at the start of its step too and only one A buffer is kept
+    constexpr bool ADBL = NMW == 4;
+    if (ADBL) ldA(0, A[0]);
 #pragma unroll
     for (int st = 0; st < H / 2; ++st) {
       ldB(st);
-      if (st + 1 < H / 2) ldA(st + 1, A[(st + 1) & 1]);
+      if (ADBL) {
+        if (st + 1 < H / 2) ldA(st + 1, A[(st + 1) & 1]);
+      } else {
+        ldA(st, A[0]);
+      }
       __builtin_amdgcn_sched_barrier(0);
-      const int s = st & 1;
+      const int s = ADBL ? (st & 1) : 0;
       // smallest terms first: mid*mid, lo*hi, hi*lo, mid*hi, hi*mid, hi*hi.  The term loop is OUTSIDE the
       // block loops so that consecutive MFMAs write different accumulators (no back-to-back dependency).
       constexpr int TA[6] = {1, 2, 0, 1, 0, 0}, TB[6] = {1, 0, 2, 0, 1, 0};
@@ -278,6 +302,9 @@ __global__ __launch_bounds__((4 + NSW) * 64, 2) void conv1d_bsplit_kernel(ConvAr
     __syncthreads();
   }
 
+#ifdef FAC_PROF
+  const unsigned long long tp2 = wall_clock64();
+#endif
 #ifdef FAC_ABL_NOEPI
   {
     float sacc = 0.f;
@@ -340,37 +367,57 @@ __global__ __launch_bounds__((4 + NSW) * 64, 2) void conv1d_bsplit_kernel(ConvAr
       }
     }
   }
+#ifdef FAC_PROF
+  if (a.dbg && wave == 0 && lane == 0) {
+    unsigned hw;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    unsigned long long* d = a.dbg + (long long)blockIdx.x * 8;
+    d[0] = tp0; d[1] = tp1; d[2] = tp2; d[3] = wall_clock64(); d[4] = hw; d[5] = xcc;
+  }
+#endif
 }
 
 bool conv_bsplit_ok(const ConvArgs& a) {
-  return a.K == 7 && a.stride == 1 && a.n_phase == 1 && a.phase_shift == 0 && a.y_tstride == 1 && !a.alpha_in &&
-         !a.w1 && !a.w_batched && a.C_in % (8 * BS_G) == 0 && BS_G * ((BS_TT + 6 * a.dil + 63) / 64) <= BS_NSW * BS_XU &&
-         (long long)a.B * a.T_out > 640;
+  if (!(a.K == 7 && a.stride == 1 && a.n_phase == 1 && a.phase_shift == 0 && a.y_tstride == 1 && !a.alpha_in &&
+        !a.w1 && !a.w_batched && (long long)a.B * a.T_out > 640))
+    return false;
+  const int G = bs_group(a.C_in), tt = G == 2 ? 256 : 512, kp = G == 2 ? 6 : 7;   // G = 1 also reads the zero tap
+  return a.C_in % (8 * G) == 0 && G * ((tt + kp * a.dil + 63) / 64) <= BS_NSW * BS_XU &&
+         a.x_cs * (long long)a.C_in < (1ll << 31);
 }
 
-int conv_dispatch_bsplit(ConvArgs& a, hipStream_t s) {
-  constexpr int KT = 7;
-  constexpr int H = bs_slots(KT, BS_G);
-  a.XW = BS_TT + (KT - 1) * a.dil;
-  const size_t lds = 2 * ((size_t)3 * H * BS_CO * 16 + (size_t)48 * BS_G * a.XW);
+template <int KT, int G, int NMW, int NSW>
+static int bsplit_launch(ConvArgs& a, hipStream_t s) {
+  constexpr int H = bs_slots(KT, G), TT = 64 * NMW;
+  a.XW = TT + (H / G - 1) * a.dil;       // G = 1: the padded zero tap still reads (finite) staged columns
+  const size_t lds = 2 * ((size_t)3 * H * BS_CO * 16 + (size_t)48 * G * a.XW);
   if (lds > 160 * 1024) {
     set_error("conv1d(bf16 split): tile needs %zu B of LDS (dil=%d)", lds, a.dil);
     return FAC_ERR_ARG;
   }
-  auto kern = conv1d_bsplit_kernel<KT, BS_G, BS_NSW>;
+  auto kern = conv1d_bsplit_kernel<KT, G, NMW, NSW>;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  a.n_t_tiles = (a.T_out + BS_TT - 1) / BS_TT;
+  a.n_t_tiles = (a.T_out + TT - 1) / TT;
   const long long n_wg = (long long)a.n_t_tiles * ((a.C_out + BS_CO - 1) / BS_CO) * a.B;
   if (n_wg > 0x7fffffffll) {
     set_error("conv1d: too many workgroups (%lld)", n_wg);
     return FAC_ERR_ARG;
   }
-  hipLaunchKernelGGL(kern, dim3((unsigned)n_wg), dim3((4 + BS_NSW) * 64), lds, s, a);
+#ifdef FAC_PROF
+  a.dbg = g_conv_dbg;
+#endif
+  hipLaunchKernelGGL(kern, dim3((unsigned)n_wg), dim3((NMW + NSW) * 64), lds, s, a);
   return check_launch("conv1d_bsplit");
+}
+
+int conv_dispatch_bsplit(ConvArgs& a, hipStream_t s) {
+  return bs_group(a.C_in) == 2 ? bsplit_launch<7, 2, 4, BS_NSW_WIDE>(a, s) : bsplit_launch<7, 1, 8, BS_NSW>(a, s);
 }
 
 }  // namespace fac
@@ -378,7 +425,7 @@ int conv_dispatch_bsplit(ConvArgs& a, hipStream_t s) {
 // tuning aid: resident workgroups per CU the runtime computes for the split kernel at a given LDS size
 extern "C" int fac_debug_bsplit_occupancy(int lds_bytes) {
   int n = -1;
-  auto kern = fac::conv1d_bsplit_kernel<7, fac::BS_G, fac::BS_NSW>;
+  auto kern = fac::conv1d_bsplit_kernel<7, 2, 4, fac::BS_NSW_WIDE>;
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kern, (4 + fac::BS_NSW) * 64, (size_t)lds_bytes) != hipSuccess) return -1;
   return n;
@@ -386,18 +433,20 @@ extern "C" int fac_debug_bsplit_occupancy(int lds_bytes) {
 
 extern "C" int64_t fac_conv_w_split_bytes(int C_out, int C_in, int K) {
   using namespace fac;
-  const int64_t n_ct = (C_out + BS_CO - 1) / BS_CO, n_st = (C_in + 8 * BS_G - 1) / (8 * BS_G);
-  return n_ct * n_st * 3 * bs_slots(K, BS_G) * BS_CO * 16;
+  const int G = bs_group(C_in);
+  const int64_t n_ct = (C_out + BS_CO - 1) / BS_CO, n_st = (C_in + 8 * G - 1) / (8 * G);
+  return n_ct * n_st * 3 * bs_slots(K, G) * BS_CO * 16;
 }
 
 extern "C" int fac_pack_conv_w_split(const float* v, const float* scale, void* out, int C_out, int C_in, int K,
                                      fac_stream_t stream) {
   using namespace fac;
   FAC_REQUIRE(v && out && C_out > 0 && C_in > 0 && K > 0, "pack_conv_w_split: bad arguments");
-  const int n_ct = (C_out + BS_CO - 1) / BS_CO, n_st = (C_in + 8 * BS_G - 1) / (8 * BS_G), H = bs_slots(K, BS_G);
+  const int G = bs_group(C_in);
+  const int n_ct = (C_out + BS_CO - 1) / BS_CO, n_st = (C_in + 8 * G - 1) / (8 * G), H = bs_slots(K, G);
   const long long n = (long long)n_ct * n_st * H * BS_CO;
   const int blocks = (int)((n + 255) / 256 < 65535 ? (n + 255) / 256 : 65535);
   hipLaunchKernelGGL(pack_conv_split_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, v, scale,
-                     reinterpret_cast<bf16x8*>(out), C_out, C_in, K, BS_G, H, n_st, n);
+                     reinterpret_cast<bf16x8*>(out), C_out, C_in, K, G, H, n_st, n);
   return check_launch("pack_conv_w_split");
 }

@@ -28,11 +28,20 @@ __global__ __launch_bounds__(256) void rate_bf16(float* out, int iters) {
   out[blockIdx.x * 256 + threadIdx.x] = c0[0] + c1[1] + c2[2] + c3[3];
 }
 
+template <bool RANDOM>
 __global__ __launch_bounds__(1024) void rate_bf16_lds(float* out, int iters) {
   extern __shared__ float pin[];
   bf16x8 a[6], b[6];
+  unsigned h = threadIdx.x * 2654435761u + blockIdx.x * 40503u + 12345u;
   for (int q = 0; q < 6; ++q)
-    for (int i = 0; i < 8; ++i) { a[q][i] = (__bf16)(float)(threadIdx.x + i + q); b[q][i] = (__bf16)(float)(i + 1 - q); }
+    for (int i = 0; i < 8; ++i) {
+      if (RANDOM) {   // operands with random mantissas / signs: the data-dependent power of real activations
+        h = h * 1664525u + 1013904223u; a[q][i] = (__bf16)(((int)(h >> 8) & 0xffff) / 32768.0f - 1.0f);
+        h = h * 1664525u + 1013904223u; b[q][i] = (__bf16)(((int)(h >> 8) & 0xffff) / 32768.0f - 1.0f);
+      } else {
+        a[q][i] = (__bf16)(float)(threadIdx.x + i + q); b[q][i] = (__bf16)(float)(i + 1 - q);
+      }
+    }
   f32x16 c0 = {0}, c1 = {0}, c2 = {0}, c3 = {0};
   for (int it = 0; it < iters / 6; ++it) {
 #pragma unroll
@@ -122,17 +131,21 @@ int main() {
   }
   // one MFMA wave per SIMD vs two: does a single wave keep the bf16 pipe busy?  (100 KB of LDS pins one
   // workgroup per CU; 256 threads = 1 wave per SIMD, 512 = 2)
-  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(rate_bf16_lds), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
-  for (int threads : {256, 512, 1024}) {
-    for (int rep = 0; rep < 2; ++rep) {
-      CK(hipEventRecord(e0));
-      hipLaunchKernelGGL(rate_bf16_lds, dim3(256 * 4), dim3(threads), 100 * 1024, 0, d, iters);
-      CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
-      float ms; CK(hipEventElapsedTime(&ms, e0, e1));
-      const double flop = (double)256 * 4 * (threads / 64) * iters * 4 * 2.0 * 32 * 32 * 16;
-      printf("bf16 MFMA, 1 WG/CU, %d waves/SIMD: %.3f ms  %.1f TFLOP/s\n", threads / 256, ms, flop / ms / 1e9);
+  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(rate_bf16_lds<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
+  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(rate_bf16_lds<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
+  for (int random = 0; random < 2; ++random)
+    for (int threads : {256, 512}) {
+      for (int rep = 0; rep < 3; ++rep) {
+        CK(hipEventRecord(e0));
+        if (random) hipLaunchKernelGGL(rate_bf16_lds<true>, dim3(256 * 4), dim3(threads), 100 * 1024, 0, d, iters * 4);
+        else hipLaunchKernelGGL(rate_bf16_lds<false>, dim3(256 * 4), dim3(threads), 100 * 1024, 0, d, iters * 4);
+        CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        const double flop = (double)256 * 4 * (threads / 64) * (iters * 4 / 6 * 6) * 4 * 2.0 * 32 * 32 * 16;
+        printf("bf16 MFMA, 1 WG/CU, %d waves/SIMD, %s operands: %.3f ms  %.1f TFLOP/s\n", threads / 256,
+               random ? "random" : "constant", ms, flop / ms / 1e9);
+      }
     }
-  }
   // numerics
   for (int K : {256, 4096}) {
     std::vector<float> A(32 * K), B(K * 32);
