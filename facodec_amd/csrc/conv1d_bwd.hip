@@ -1,0 +1,329 @@
+// Backward pieces of the conv stack (first kernels of the training step, BASELINE.json configs[2]).
+//
+//   bwd_data  of a stride-1 conv   = the forward kernel on the tap-flipped, channel-transposed weights
+//                                    (fac_pack_conv_w_bwd) over dy, giving the gradient of the PADDED input,
+//                                    followed by fac_pad_fold_bwd (reflection sends a padded position's gradient
+//                                    back to the sample it mirrors: dac/model/encodec.py:96-113 pad1d);
+//             of a strided conv    = the polyphase transposed-conv launch on the forward weights (same (C_out,
+//                                    C_in, K) tensor = conv_transpose's (in, out, K)), then the same fold;
+//             of a transposed conv = the strided forward conv on its own weights;
+//   bwd_weight                     = conv1d_wgrad_kernel below: dW[co][ci][k] = sum_{b,t} dy[b][co][t] *
+//                                    xpad[b][ci][t*s + k*d]  as an fp32-MFMA GEMM whose contraction runs over
+//                                    time; (b, t) ranges are split across workgroups and the partial dW are added
+//                                    in split order by a second kernel (deterministic);
+//   weight-norm, Snake and bias backward are small reductions.
+// Reference semantics: torch autograd through dac/model/encodec.py SConv1d / dac/nn/layers.py snake (checked
+// against autograd of the CPU oracle in tests/test_gpu_parity.py).
+#include "conv1d_mfma.h"
+
+namespace fac {
+
+// packed[(co*K + k')*CP + ci] = v[co][ci][K-1-k'] * scale[co]   (rows co < C_out; the buffer is zero-filled by
+// the caller up to fac_cin_pad(C_out) rows and CP = pad32(C_in) columns)
+__global__ void pack_conv_bwd_kernel(const float* __restrict__ v, const float* __restrict__ scale,
+                                     float* __restrict__ packed, int C_out, int C_in, int K, int CP, long long n) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const int ci = (int)(i % C_in);
+    const long long r = i / C_in;
+    const int kp = (int)(r % K);
+    const int co = (int)(r / K);
+    float w = v[((long long)co * C_in + ci) * K + (K - 1 - kp)];
+    if (scale) w = __fmul_rn(w, scale[co]);
+    packed[((long long)co * K + kp) * CP + ci] = w;
+  }
+}
+
+// dx[b][c][j] = dxpad[pad_left + j] (+ the gradients of the padded positions that mirror sample j)
+__global__ void pad_fold_bwd_kernel(const float* __restrict__ dxpad, float* __restrict__ dx, int T, int Tp,
+                                    int pad_left, int mode, long long n) {
+  const int pad_right = Tp - pad_left - T;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const int j = (int)(i % T);
+    const long long row = i / T;
+    const float* p = dxpad + row * Tp;
+    float g = p[pad_left + j];
+    if (mode == FAC_PAD_REFLECT) {
+      if (j >= 1 && j <= pad_left) g += p[pad_left - j];                       // xpad[pad_left - j] = x[j]
+      const int m = T - 1 - j;                                                 // xpad[pad_left + T-1 + m] = x[T-1-m]
+      if (m >= 1 && m <= pad_right) g += p[pad_left + T - 1 + m];
+    }
+    dx[i] = g;
+  }
+}
+
+struct WgArgs {
+  const float* x;      // (B, C_in, T_in)
+  const float* dy;     // (B, C_out, T_out)
+  float* part;         // [S][C_out][C_in][K]
+  long long x_bs, x_cs, dy_bs, dy_cs;
+  int B, C_in, T_in, T_ext, C_out, T_out, K, stride, dil, pad_left, pad_mode;
+  int CIT;             // input channels per column tile (CIT*K <= 128)
+  int XWl;             // staged input columns per time tile
+  int n_tt;            // 64-step time tiles per clip
+  int tiles_per_split;
+};
+
+constexpr int WG_TT = 64;
+
+__global__ __launch_bounds__(256) void conv1d_wgrad_kernel(WgArgs a) {
+  extern __shared__ float sm[];
+  float* dyl = sm;                          // [64][WG_TT + 1]
+  float* xl = sm + 64 * (WG_TT + 1);        // [CIT][XWl]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, kk = lane >> 5;
+  const int co0 = blockIdx.x * 64;
+  const int ci0 = blockIdx.y * a.CIT;
+  const int z = blockIdx.z;
+  const int cb = wave & 1, jb0 = (wave >> 1) * 2;
+  const int ncol = min(a.CIT, a.C_in - ci0) * a.K;
+
+  // this lane's B-operand columns: J = jb*32 + l31 -> (local channel, tap)
+  int xoff[2];
+  bool jok[2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int J = (jb0 + q) * 32 + l31;
+    jok[q] = J < ncol;
+    const int cl = jok[q] ? J / a.K : 0, k = jok[q] ? J - cl * a.K : 0;
+    xoff[q] = cl * a.XWl + k * a.dil;
+  }
+  f32x16 acc[2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+
+  const int tile_lo = z * a.tiles_per_split;
+  const int tile_hi = min(a.B * a.n_tt, tile_lo + a.tiles_per_split);
+  for (int tile = tile_lo; tile < tile_hi; ++tile) {
+    const int b = tile / a.n_tt, t0 = (tile - b * a.n_tt) * WG_TT;
+    const float* dyb = a.dy + (long long)b * a.dy_bs;
+    const float* xb = a.x + (long long)b * a.x_bs;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = r * 4 + wave, t = t0 + lane;
+      const int co = co0 + row;
+      dyl[row * (WG_TT + 1) + lane] = (co < a.C_out && t < a.T_out) ? dyb[(long long)co * a.dy_cs + t] : 0.f;
+    }
+    const int tin0 = t0 * a.stride - a.pad_left;
+    for (int idx = tid; idx < a.CIT * a.XWl; idx += 256) {
+      const int cl = idx / a.XWl, c = idx - cl * a.XWl;
+      const int ci = ci0 + cl;
+      int tin = tin0 + c;
+      if (a.pad_mode == FAC_PAD_REFLECT) tin = reflect_index(tin, a.T_in, a.T_ext);
+      xl[idx] = (ci < a.C_in && tin >= 0 && tin < a.T_in) ? xb[(long long)ci * a.x_cs + tin] : 0.f;
+    }
+    __syncthreads();
+    const float* ap = dyl + (cb * 32 + l31) * (WG_TT + 1) + kk;
+#pragma unroll 8
+    for (int tt = 0; tt < WG_TT; tt += 2) {
+      const float av = ap[tt];
+      const int xt = (tt + kk) * a.stride;
+      const float b0 = jok[0] ? xl[xoff[0] + xt] : 0.f;
+      const float b1 = jok[1] ? xl[xoff[1] + xt] : 0.f;
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b0, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b1, acc[1], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  // partial dW of this split: row = output channel, columns (ci, k) contiguous
+  float* pz = a.part + (long long)z * a.C_out * a.C_in * a.K;
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int J = (jb0 + q) * 32 + l31;
+    if (J >= ncol) continue;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int co = co0 + cb * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk;
+      if (co < a.C_out) pz[((long long)co * a.C_in + ci0) * a.K + J] = acc[q][r];
+    }
+  }
+}
+
+__global__ void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int S, long long n) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    float s = part[i];
+    for (int z = 1; z < S; ++z) s += part[(long long)z * n + i];
+    dw[i] = s;
+  }
+}
+
+// w = g v/||v|| per row: dg = <dW, v>/||v||;  dv = g/||v|| (dW - v <dW, v>/||v||^2)   (one workgroup per row)
+__global__ __launch_bounds__(256) void weight_norm_bwd_kernel(const float* __restrict__ v, const float* __restrict__ g,
+                                                              const float* __restrict__ dw, float* __restrict__ dv,
+                                                              float* __restrict__ dg, int m) {
+  __shared__ float red[2][256];
+  const int row = blockIdx.x, tid = threadIdx.x;
+  const float* vr = v + (long long)row * m;
+  const float* dr = dw + (long long)row * m;
+  float s_vv = 0.f, s_dv = 0.f;
+  for (int i = tid; i < m; i += 256) {
+    s_vv = fmaf(vr[i], vr[i], s_vv);
+    s_dv = fmaf(dr[i], vr[i], s_dv);
+  }
+  red[0][tid] = s_vv;
+  red[1][tid] = s_dv;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (tid < o) { red[0][tid] += red[0][tid + o]; red[1][tid] += red[1][tid + o]; }
+    __syncthreads();
+  }
+  const float nrm = sqrtf(red[0][0]), dot = red[1][0];
+  const float gn = g[row] / nrm;
+  if (tid == 0) dg[row] = dot / nrm;
+  const float c = dot / red[0][0];
+  for (int i = tid; i < m; i += 256) dv[(long long)row * m + i] = gn * (dr[i] - vr[i] * c);
+}
+
+// y = x + sin^2(a x)/(a + 1e-9):  dy/dx = 1 + a sin(2 a x)/(a + 1e-9);  dy/da = (x sin(2 a x)(a+eps) - sin^2(a x))/(a+eps)^2
+// One workgroup per channel (deterministic tree for d alpha).
+__global__ __launch_bounds__(256) void snake_bwd_kernel(const float* __restrict__ x, const float* __restrict__ alpha,
+                                                        const float* __restrict__ dy, float* __restrict__ dx,
+                                                        float* __restrict__ dalpha, int B, int C, int T) {
+  __shared__ float red[256];
+  const int c = blockIdx.x, tid = threadIdx.x;
+  const float al = alpha[c], ae = al + 1e-9f;
+  float s = 0.f;
+  for (int b = 0; b < B; ++b) {
+    const long long base = ((long long)b * C + c) * T;
+    for (int t = tid; t < T; t += 256) {
+      const float xv = x[base + t], g = dy[base + t];
+      const float ax = al * xv;
+      const float sn = sinf(ax), cs = cosf(ax);
+      const float s2 = 2.f * sn * cs;
+      dx[base + t] = g * (1.f + al * s2 / ae);
+      s += g * (xv * s2 * ae - sn * sn) / (ae * ae);
+    }
+  }
+  red[tid] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (tid < o) red[tid] += red[tid + o];
+    __syncthreads();
+  }
+  if (tid == 0 && dalpha) dalpha[c] = red[0];
+}
+
+__global__ __launch_bounds__(256) void bias_grad_kernel(const float* __restrict__ dy, float* __restrict__ db, int B, int C, int T) {
+  __shared__ float red[256];
+  const int c = blockIdx.x, tid = threadIdx.x;
+  float s = 0.f;
+  for (int b = 0; b < B; ++b) {
+    const float* p = dy + ((long long)b * C + c) * T;
+    for (int t = tid; t < T; t += 256) s += p[t];
+  }
+  red[tid] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (tid < o) red[tid] += red[tid + o];
+    __syncthreads();
+  }
+  if (tid == 0) db[c] = red[0];
+}
+
+static int wgrad_geometry(int B, int C_in, int C_out, int T_out, int K, int* cit, int* splits, int* n_tt, int* per) {
+  if (K > 128) return -1;
+  *cit = 128 / K;
+  *n_tt = (T_out + WG_TT - 1) / WG_TT;
+  const long long tiles = (long long)B * *n_tt;
+  const long long wgs = (long long)((C_out + 63) / 64) * ((C_in + *cit - 1) / *cit);
+  long long S = (2048 + wgs - 1) / wgs;
+  if (S > tiles) S = tiles;
+  if (S > 64) S = 64;
+  if (S < 1) S = 1;
+  *per = (int)((tiles + S - 1) / S);
+  *splits = (int)((tiles + *per - 1) / *per);
+  return 0;
+}
+
+}  // namespace fac
+
+extern "C" int fac_pack_conv_w_bwd(const float* v, const float* scale, float* packed, int C_out, int C_in, int K,
+                                   int C_in_pad, fac_stream_t stream) {
+  using namespace fac;
+  FAC_REQUIRE(v && packed && C_out > 0 && C_in > 0 && K > 0 && C_in_pad >= C_in && C_in_pad % 32 == 0,
+              "pack_conv_w_bwd: bad arguments");
+  const long long n = (long long)C_out * C_in * K;
+  const int blocks = (int)((n + 255) / 256 < 65535 ? (n + 255) / 256 : 65535);
+  hipLaunchKernelGGL(pack_conv_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, v, scale, packed, C_out, C_in,
+                     K, C_in_pad, n);
+  return check_launch("pack_conv_w_bwd");
+}
+
+extern "C" int fac_pad_fold_bwd(const float* dxpad, float* dx, int B, int C, int T, int Tp, int pad_left, int pad_mode,
+                                fac_stream_t stream) {
+  using namespace fac;
+  FAC_REQUIRE(dxpad && dx && B > 0 && C > 0 && T > 0 && pad_left >= 0 && Tp >= pad_left + T, "pad_fold_bwd: bad arguments");
+  FAC_REQUIRE(pad_mode != FAC_PAD_REFLECT || (T > pad_left && T > Tp - pad_left - T),
+              "pad_fold_bwd: reflect padding needs a signal longer than the pad");
+  const long long n = (long long)B * C * T;
+  const int blocks = (int)((n + 255) / 256 < 65535 ? (n + 255) / 256 : 65535);
+  hipLaunchKernelGGL(pad_fold_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dxpad, dx, T, Tp, pad_left,
+                     pad_mode, n);
+  return check_launch("pad_fold_bwd");
+}
+
+extern "C" int64_t fac_conv1d_bwd_weight_ws_bytes(int B, int C_in, int C_out, int T_out, int K) {
+  int cit, S, n_tt, per;
+  if (fac::wgrad_geometry(B, C_in, C_out, T_out, K, &cit, &S, &n_tt, &per)) return -1;
+  return (int64_t)S * C_out * C_in * K * 4;
+}
+
+extern "C" int fac_conv1d_bwd_weight(const float* x, const float* dy, float* dw, void* ws, int64_t ws_bytes, int B,
+                                     int C_in, int T_in, int C_out, int T_out, int K, int stride, int dilation,
+                                     int pad_left, int pad_mode, fac_stream_t stream) {
+  using namespace fac;
+  FAC_REQUIRE(x && dy && dw && ws && B > 0 && C_in > 0 && C_out > 0 && T_in > 0 && T_out > 0 && K > 0 && stride > 0 &&
+                  dilation > 0 && pad_left >= 0,
+              "conv1d_bwd_weight: bad arguments");
+  WgArgs a;
+  int S;
+  FAC_REQUIRE(wgrad_geometry(B, C_in, C_out, T_out, K, &a.CIT, &S, &a.n_tt, &a.tiles_per_split) == 0,
+              "conv1d_bwd_weight: K=%d too large", K);
+  FAC_REQUIRE(ws_bytes >= (int64_t)S * C_out * C_in * K * 4, "conv1d_bwd_weight: workspace too small");
+  a.x = x; a.dy = dy; a.part = reinterpret_cast<float*>(ws);
+  a.x_bs = (long long)C_in * T_in; a.x_cs = T_in; a.dy_bs = (long long)C_out * T_out; a.dy_cs = T_out;
+  a.B = B; a.C_in = C_in; a.T_in = T_in; a.C_out = C_out; a.T_out = T_out; a.K = K; a.stride = stride; a.dil = dilation;
+  a.pad_left = pad_left; a.pad_mode = pad_mode;
+  {
+    long long last = (long long)(T_out - 1) * stride + (long long)(K - 1) * dilation - pad_left;
+    int pad_right = last >= T_in ? (int)(last - T_in + 1) : 0;
+    int max_pad = pad_left > pad_right ? pad_left : pad_right;
+    a.T_ext = T_in > max_pad ? T_in : max_pad + 1;
+  }
+  a.XWl = (WG_TT - 1) * stride + (K - 1) * dilation + 1;
+  const size_t lds = ((size_t)64 * (WG_TT + 1) + (size_t)a.CIT * a.XWl) * sizeof(float);
+  FAC_REQUIRE(lds <= 160 * 1024, "conv1d_bwd_weight: tile needs %zu B of LDS", lds);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv1d_wgrad_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  dim3 grid((C_out + 63) / 64, (C_in + a.CIT - 1) / a.CIT, S);
+  hipLaunchKernelGGL(conv1d_wgrad_kernel, grid, dim3(256), lds, (hipStream_t)stream, a);
+  const long long n = (long long)C_out * C_in * K;
+  const int blocks = (int)((n + 255) / 256 < 65535 ? (n + 255) / 256 : 65535);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a.part, dw, S, n);
+  return check_launch("conv1d_bwd_weight");
+}
+
+extern "C" int fac_weight_norm_bwd(const float* v, const float* g, const float* dw, float* dv, float* dg, int n_rows,
+                                   int row_len, fac_stream_t stream) {
+  FAC_REQUIRE(v && g && dw && dv && dg && n_rows > 0 && row_len > 0, "weight_norm_bwd: bad arguments");
+  hipLaunchKernelGGL(fac::weight_norm_bwd_kernel, dim3(n_rows), dim3(256), 0, (hipStream_t)stream, v, g, dw, dv, dg, row_len);
+  return fac::check_launch("weight_norm_bwd");
+}
+
+extern "C" int fac_snake_bwd(const float* x, const float* alpha, const float* dy, float* dx, float* dalpha, int B, int C,
+                             int T, fac_stream_t stream) {
+  FAC_REQUIRE(x && alpha && dy && dx && B > 0 && C > 0 && T > 0, "snake_bwd: bad arguments");
+  hipLaunchKernelGGL(fac::snake_bwd_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, x, alpha, dy, dx, dalpha, B, C, T);
+  return fac::check_launch("snake_bwd");
+}
+
+extern "C" int fac_bias_grad(const float* dy, float* db, int B, int C, int T, fac_stream_t stream) {
+  FAC_REQUIRE(dy && db && B > 0 && C > 0 && T > 0, "bias_grad: bad arguments");
+  hipLaunchKernelGGL(fac::bias_grad_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, dy, db, B, C, T);
+  return fac::check_launch("bias_grad");
+}

@@ -468,3 +468,82 @@ def aa_snakebeta(x, alpha_log, beta_log, filter12):
     _lib.check(_lib.load().fac_aa_snakebeta_fwd(_ptr(x), _ptr(alpha_log), _ptr(beta_log), _ptr(filter12), _ptr(y), B, c, T,
                                                 _stream()), "fac_aa_snakebeta_fwd")
     return y
+
+
+# --------------------------------------------------------------------------------- backward of the conv stack
+def pack_conv_weight_bwd(v, g=None):
+    """(C_out, C_in, K) [weight-normed] -> packed weights of the bwd-data conv (taps flipped, channels swapped)."""
+    v = _dev(v, "weight")
+    c_out, c_in, k = v.shape
+    packed = torch.zeros(cin_pad(c_out), k, pad32(c_in), device=v.device, dtype=torch.float32)
+    scale = wn_scale(v, g) if g is not None else None
+    _lib.check(_lib.load().fac_pack_conv_w_bwd(_ptr(v), _ptr(scale), _ptr(packed), c_out, c_in, k, pad32(c_in), _stream()),
+               "fac_pack_conv_w_bwd")
+    return packed
+
+
+def conv1d_bwd_data(dy, v, g, t_in, stride=1, dilation=1, pad_mode=PAD_REFLECT, causal=True):
+    """Gradient w.r.t. the input of SConv1d (dac/model/encodec.py:212-228) given dy (B, C_out, T_out)."""
+    dy = _dev(dy, "dy")
+    c_out, c_in, k = v.shape
+    B, _, t_out = dy.shape
+    t_o, padding_total, extra = conv_out_len(t_in, k, stride, dilation)
+    assert t_o == t_out, (t_o, t_out)
+    pad_left = padding_total if causal else padding_total - padding_total // 2
+    pad_right = (padding_total - pad_left) + extra
+    tp = pad_left + t_in + pad_right
+    if stride == 1:
+        dxpad = conv1d(dy, pack_conv_weight_bwd(v, g), c_in, k, dilation=dilation, pad_left=(k - 1) * dilation,
+                       pad_mode=PAD_ZERO, t_out=tp)
+    else:
+        if k != 2 * stride or dilation != 1:
+            raise NotImplementedError("strided bwd_data is built for the model's k = 2*stride convs")
+        dy_ext = torch.cat([dy, torch.zeros(B, c_out, 1, device=dy.device)], dim=2)
+        dxpad = conv_transpose1d(dy_ext, pack_convtr_weight(v, g, stride), c_in, stride)
+        assert dxpad.shape[-1] == tp, (dxpad.shape, tp)
+    dx = torch.empty(B, c_in, t_in, device=dy.device, dtype=torch.float32)
+    _lib.check(_lib.load().fac_pad_fold_bwd(_ptr(dxpad), _ptr(dx), B, c_in, t_in, tp, pad_left, pad_mode, _stream()),
+               "fac_pad_fold_bwd")
+    return dx
+
+
+def conv1d_bwd_weight(x, dy, k, stride=1, dilation=1, pad_mode=PAD_REFLECT, causal=True):
+    """dW (C_out, C_in, K) of SConv1d."""
+    x, dy = _dev(x, "x"), _dev(dy, "dy")
+    B, c_in, t_in = x.shape
+    _, c_out, t_out = dy.shape
+    _, padding_total, _ = conv_out_len(t_in, k, stride, dilation)
+    pad_left = padding_total if causal else padding_total - padding_total // 2
+    lib = _lib.load()
+    nbytes = lib.fac_conv1d_bwd_weight_ws_bytes(B, c_in, c_out, t_out, k)
+    ws = torch.empty(nbytes // 4, device=x.device, dtype=torch.float32)
+    dw = torch.empty(c_out, c_in, k, device=x.device, dtype=torch.float32)
+    _lib.check(lib.fac_conv1d_bwd_weight(_ptr(x), _ptr(dy), _ptr(dw), _ptr(ws), nbytes, B, c_in, t_in, c_out, t_out, k,
+                                         stride, dilation, pad_left, pad_mode, _stream()), "fac_conv1d_bwd_weight")
+    return dw
+
+
+def weight_norm_bwd(v, g, dw):
+    v, g, dw = _dev(v), _dev(g), _dev(dw)
+    n = v.shape[0]
+    dv, dg = torch.empty_like(v), torch.empty_like(g)
+    _lib.check(_lib.load().fac_weight_norm_bwd(_ptr(v), _ptr(g), _ptr(dw), _ptr(dv), _ptr(dg), n, v.numel() // n, _stream()),
+               "fac_weight_norm_bwd")
+    return dv, dg
+
+
+def snake_bwd(x, alpha, dy):
+    x, dy = _dev(x, "x"), _dev(dy, "dy")
+    B, c, t = x.shape
+    dx, dalpha = torch.empty_like(x), torch.empty(c, device=x.device, dtype=torch.float32)
+    _lib.check(_lib.load().fac_snake_bwd(_ptr(x), _ptr(alpha), _ptr(dy), _ptr(dx), _ptr(dalpha), B, c, t, _stream()),
+               "fac_snake_bwd")
+    return dx, dalpha
+
+
+def bias_grad(dy):
+    dy = _dev(dy, "dy")
+    B, c, t = dy.shape
+    db = torch.empty(c, device=dy.device, dtype=torch.float32)
+    _lib.check(_lib.load().fac_bias_grad(_ptr(dy), _ptr(db), B, c, t, _stream()), "fac_bias_grad")
+    return db

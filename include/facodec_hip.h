@@ -178,6 +178,36 @@ int fac_stream_push(float* buf, const float* src, int64_t rows, int64_t cap, int
                     fac_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Backward of the conv stack (first kernels of the training step; autograd semantics of
+ * dac/model/encodec.py SConv1d / SConvTranspose1d, dac/nn/layers.py snake, weight_norm).
+ *
+ * bwd_data of a stride-1 conv: run fac_conv1d_fwd over dy with the weights packed by fac_pack_conv_w_bwd
+ * (taps flipped, channels transposed; C_out becomes the input-channel axis: rows up to fac_cin_pad(C_out),
+ * columns C_in_pad = pad32(C_in), zero-filled by the caller), pad_left = (K-1)*dilation, zero padding,
+ * T_out = padded input length; then fac_pad_fold_bwd maps the gradient of the padded signal back to x
+ * (reflection: a padded position's gradient is added to the sample it mirrors).  Strided convs (K = 2*stride):
+ * the transposed-conv launch on the forward weights (fac_pack_convtr_w), then the same fold.
+ * ---------------------------------------------------------------------------------------- */
+int fac_pack_conv_w_bwd(const float* v, const float* scale, float* packed, int C_out, int C_in, int K, int C_in_pad,
+                        fac_stream_t stream);
+int fac_pad_fold_bwd(const float* dxpad, float* dx, int B, int C, int T, int Tp, int pad_left, int pad_mode,
+                     fac_stream_t stream);
+/* dW (C_out, C_in, K) = sum over (b, t) of dy[b][co][t] * xpad[b][ci][t*stride + k*dilation]; ws: scratch of
+ * fac_conv1d_bwd_weight_ws_bytes(...) bytes (partial sums per (b, t) range, added in a fixed order). */
+int64_t fac_conv1d_bwd_weight_ws_bytes(int B, int C_in, int C_out, int T_out, int K);
+int fac_conv1d_bwd_weight(const float* x, const float* dy, float* dw, void* ws, int64_t ws_bytes, int B, int C_in,
+                          int T_in, int C_out, int T_out, int K, int stride, int dilation, int pad_left, int pad_mode,
+                          fac_stream_t stream);
+/* w = g*v/||v|| per row (n_rows x row_len): dv, dg from dW. */
+int fac_weight_norm_bwd(const float* v, const float* g, const float* dw, float* dv, float* dg, int n_rows, int row_len,
+                        fac_stream_t stream);
+/* y = x + sin^2(alpha x)/(alpha + 1e-9): dx (B,C,T) and dalpha (C) (dalpha may be NULL). */
+int fac_snake_bwd(const float* x, const float* alpha, const float* dy, float* dx, float* dalpha, int B, int C, int T,
+                  fac_stream_t stream);
+/* db[c] = sum over (b, t) of dy. */
+int fac_bias_grad(const float* dy, float* db, int B, int C, int T, fac_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * K7  factorized VQ step (dac/nn/quantize.py:34-94 VectorQuantize.forward + the residual
  * bookkeeping of ResidualVectorQuantize.forward :173-193; search identical to
  * quantize/fvq.py:101-116):

@@ -704,3 +704,44 @@ def test_split_bf16_conv_matches_fp32_grade(B, C, T, d, mode, O, ops, cuda):
     e_fp32 = rel(ops.conv1d(x.to(cuda), ops.pack_conv_weight(w.to(cuda), gg.to(cuda)), C, 7, **kw0), y64)
     assert e_split < 1.5 * e_fp32 + 1e-7, (e_split, e_fp32)
     assert rel(y, yf) < OP_TOL
+
+
+# ------------------------------------------------------------------------------ backward of the conv stack
+BWD_TOL = 1e-4
+
+
+@pytest.mark.parametrize("B,ci,co,T,k,s,d,mode", [(2, 64, 96, 500, 7, 1, 3, "reflect"), (2, 128, 128, 333, 7, 1, 9, "reflect"),
+                                                    (3, 96, 96, 257, 1, 1, 1, "reflect"), (2, 64, 128, 480, 4, 2, 1, "reflect"),
+                                                    (1, 256, 512, 300, 10, 5, 1, "reflect"), (2, 40, 24, 200, 5, 1, 2, "zero")])
+def test_conv_backward_against_autograd(B, ci, co, T, k, s, d, mode, O, ops, cuda):
+    """bwd_data / bwd_weight / weight-norm / bias gradients of SConv1d against torch autograd through the
+    CPU oracle (dac/model/encodec.py:212-228 + weight_norm)."""
+    g = _g(ci + co + k)
+    x = torch.randn(B, ci, T, generator=g, requires_grad=True)
+    v = (torch.randn(co, ci, k, generator=g) / (ci * k) ** 0.5).requires_grad_()
+    gg = (torch.rand(co, 1, 1, generator=g) + 0.5).requires_grad_()
+    b = (torch.randn(co, generator=g) * 0.1).requires_grad_()
+    y = O.sconv1d(x, O.weight_norm_weight(v, gg), b, stride=s, dilation=d, causal=True, pad_mode=mode)
+    r = torch.randn(*y.shape, generator=g)
+    (y * r).sum().backward()
+    pm = ops.PAD_REFLECT if mode == "reflect" else ops.PAD_ZERO
+    dy = r.to(cuda)
+    vd, gd = v.detach().to(cuda), gg.detach().to(cuda)
+    dx = ops.conv1d_bwd_data(dy, vd, gd, T, stride=s, dilation=d, pad_mode=pm)
+    dw = ops.conv1d_bwd_weight(x.detach().to(cuda), dy, k, stride=s, dilation=d, pad_mode=pm)
+    dv, dg = ops.weight_norm_bwd(vd, gd, dw)
+    db = ops.bias_grad(dy)
+    assert rel(dx, x.grad) < BWD_TOL
+    assert rel(dv, v.grad) < BWD_TOL and rel(dg, gg.grad) < BWD_TOL
+    assert rel(db, b.grad) < BWD_TOL
+
+
+def test_snake_backward_against_autograd(O, ops, cuda):
+    g = _g(5)
+    x = torch.randn(3, 48, 700, generator=g, requires_grad=True)
+    al = (1 + 0.3 * torch.rand(48, generator=g)).requires_grad_()
+    y = O.snake(x, al.view(1, -1, 1))
+    r = torch.randn(*y.shape, generator=g)
+    (y * r).sum().backward()
+    dx, da = ops.snake_bwd(x.detach().to(cuda), al.detach().to(cuda), r.to(cuda))
+    assert rel(dx, x.grad) < BWD_TOL and rel(da, al.grad) < BWD_TOL
