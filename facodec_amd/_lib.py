@@ -64,6 +64,9 @@ SIGNATURES = {
     "fac_pack_lstm_whh": (_i, [_p, _p, _i, _p]),
     "fac_lstm_layer_fwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _p]),
     "fac_lstm_layer_fwd_from": (_i, [_p, _p, _p, _p, _i, _i, _i, _i64, _p]),
+    "fac_lstm_layer_fwd_train": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i64, _p]),
+    "fac_lstm_gate_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i64, _i, _p]),
+    "fac_tanh_bwd": (_i, [_p, _p, _p, _i64, _p]),
     "fac_stream_push": (_i, [_p, _p, _i64, _i64, _i, _i, _i, _p]),
     "fac_vq_fwd": (_i, [C.POINTER(VqDesc), _p]),
     "fac_vq_search": (_i, [_p, _p, _p, _i64, _i, _p]),

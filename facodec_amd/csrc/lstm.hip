@@ -29,6 +29,8 @@ __global__ __launch_bounds__(NW * 64) void lstm_step_kernel(const float* __restr
                                                             float* __restrict__ h_next,        // fragment-packed h_t
                                                             float* __restrict__ c,             // (H, BP)
                                                             float* __restrict__ y_t,           // (H, BP) rows of stride rs
+                                                            float* __restrict__ save_g,        // training: activated gates of this step (4H rows, stride rs) or null
+                                                            float* __restrict__ save_c,        // training: c_t (H rows, stride rs) or null
                                                             int H, int BP, long long rs) {   // rs: row stride of pre / y
   __shared__ float red[NW][32][33];
   const int tid = threadIdx.x;
@@ -117,10 +119,47 @@ __global__ __launch_bounds__(NW * 64) void lstm_step_kernel(const float* __restr
     c[o] = c_new;
     const float hv = __fmul_rn(og, tanhf(c_new));
     y_t[(long long)unit * rs + col0 + col] = hv;
+    if (save_g != nullptr) {   // what BPTT needs (nn.LSTM keeps the same in its reserve space)
+      save_g[(long long)(0 * H + unit) * rs + col0 + col] = ig;
+      save_g[(long long)(1 * H + unit) * rs + col0 + col] = fg;
+      save_g[(long long)(2 * H + unit) * rs + col0 + col] = gg;
+      save_g[(long long)(3 * H + unit) * rs + col0 + col] = og;
+      save_c[(long long)unit * rs + col0 + col] = c_new;
+    }
     // same value in fragment order for the next step: unit = 8*kg + 2*jj + kq
     const int kgn = unit >> 3, w8 = unit & 7;
     h_next[((((long long)blockIdx.y * (H >> 3) + kgn) * 2 + (w8 & 1)) * 32 + col) * 4 + (w8 >> 1)] = hv;
   }
+}
+
+// One BPTT step of an LSTM layer (elementwise part): dh = dy_t + W_hh^T dgates_{t+1} (the product `rec`, computed by
+// the conv kernel, or null at the last step); gate derivatives from the saved activations; carries dc.
+__global__ void lstm_gate_bwd_kernel(const float* __restrict__ dy_t, const float* __restrict__ rec,
+                                     const float* __restrict__ gates_t, const float* __restrict__ c_t,
+                                     const float* __restrict__ c_prev, float* __restrict__ dc,
+                                     float* __restrict__ dgates_t, int H, int BP, long long rs, int first) {
+  const long long n = (long long)H * BP;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const int unit = (int)(i / BP), col = (int)(i - (long long)unit * BP);
+    const long long o = (long long)unit * rs + col;
+    const float ig = gates_t[o], fg = gates_t[(long long)H * rs + o], gg = gates_t[2ll * H * rs + o], og = gates_t[3ll * H * rs + o];
+    const float ct = c_t[o], cp = c_prev ? c_prev[o] : 0.f;
+    const float tc = tanhf(ct);
+    float dh = dy_t[o];
+    if (rec) dh += rec[i];
+    const float d_o = dh * tc;
+    const float dcv = dh * og * (1.f - tc * tc) + (first ? 0.f : dc[i]);
+    dc[i] = dcv * fg;
+    dgates_t[o] = dcv * gg * ig * (1.f - ig);
+    dgates_t[(long long)H * rs + o] = dcv * cp * fg * (1.f - fg);
+    dgates_t[2ll * H * rs + o] = dcv * ig * (1.f - gg * gg);
+    dgates_t[3ll * H * rs + o] = d_o * og * (1.f - og);
+  }
+}
+
+__global__ void tanh_bwd_kernel(const float* __restrict__ y, const float* __restrict__ dy, float* __restrict__ dx, long long n) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+    dx[i] = dy[i] * (1.f - y[i] * y[i]);
 }
 
 // (B, H, T) -> (H, T, BP): per hidden unit, transpose the (b, t) plane through a 32x33 tile.
@@ -199,7 +238,13 @@ extern "C" int fac_lstm_layer_fwd(const float* pre, const float* whh_packed, flo
 
 extern "C" int fac_lstm_layer_fwd_from(const float* pre, const float* whh_packed, float* yT, float* c,
                                        int T, int H, int BP, int64_t step0, fac_stream_t stream) {
+  return fac_lstm_layer_fwd_train(pre, whh_packed, yT, c, nullptr, nullptr, T, H, BP, step0, stream);
+}
+
+extern "C" int fac_lstm_layer_fwd_train(const float* pre, const float* whh_packed, float* yT, float* c, float* gates_save,
+                                        float* c_save, int T, int H, int BP, int64_t step0, fac_stream_t stream) {
   using namespace fac;
+  FAC_REQUIRE((gates_save == nullptr) == (c_save == nullptr), "lstm_layer_fwd: gates_save and c_save go together");
   FAC_REQUIRE(step0 >= 0, "lstm_layer_fwd: negative step0");
   FAC_REQUIRE(pre && whh_packed && yT && c, "lstm_layer_fwd: null pointer");
   FAC_REQUIRE(T > 0 && H > 0 && H % 64 == 0, "lstm_layer_fwd: H=%d must be a multiple of 64", H);
@@ -208,7 +253,7 @@ extern "C" int fac_lstm_layer_fwd_from(const float* pre, const float* whh_packed
   const long long rs = (long long)T * BP;   // channel-major work buffers: row (= hidden unit) stride
   // 16 waves when the k-groups divide evenly, with the per-wave trip count fixed at compile time
   // for the shipped sizes (H = 1024 -> 8, H = 1536 -> 12 groups per wave)
-  void (*kern)(const float*, const float*, const float*, float*, float*, float*, int, int, long long);
+  void (*kern)(const float*, const float*, const float*, float*, float*, float*, float*, float*, int, int, long long);
   int threads;
   const int kgs = H / 8;
   if (kgs % 16 == 0) {
@@ -231,7 +276,29 @@ extern "C" int fac_lstm_layer_fwd_from(const float* pre, const float* whh_packed
     const long long g = step0 + t;   // global step index: the two h buffers alternate on it
     const float* h_prev = g == 0 ? nullptr : hp[(g - 1) & 1];
     hipLaunchKernelGGL(kern, grid, dim3(threads), 0, (hipStream_t)stream, pre + (long long)t * BP,
-                       whh_packed, h_prev, hp[g & 1], c, yT + (long long)t * BP, H, BP, rs);
+                       whh_packed, h_prev, hp[g & 1], c, yT + (long long)t * BP,
+                       gates_save ? gates_save + (long long)t * BP : nullptr, c_save ? c_save + (long long)t * BP : nullptr, H,
+                       BP, rs);
   }
   return check_launch("lstm_layer_fwd");
+}
+
+extern "C" int fac_lstm_gate_bwd(const float* dy_t, const float* rec, const float* gates_t, const float* c_t,
+                                 const float* c_prev, float* dc, float* dgates_t, int H, int BP, int64_t rs, int first,
+                                 fac_stream_t stream) {
+  using namespace fac;
+  FAC_REQUIRE(dy_t && gates_t && c_t && dc && dgates_t && H > 0 && BP > 0, "lstm_gate_bwd: bad arguments");
+  const long long n = (long long)H * BP;
+  const int blocks = (int)((n + 255) / 256);
+  hipLaunchKernelGGL(lstm_gate_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dy_t, rec, gates_t, c_t, c_prev,
+                     dc, dgates_t, H, BP, (long long)rs, first);
+  return check_launch("lstm_gate_bwd");
+}
+
+extern "C" int fac_tanh_bwd(const float* y, const float* dy, float* dx, int64_t n, fac_stream_t stream) {
+  using namespace fac;
+  FAC_REQUIRE(y && dy && dx && n > 0, "tanh_bwd: bad arguments");
+  const int blocks = (int)((n + 255) / 256 < 65535 ? (n + 255) / 256 : 65535);
+  hipLaunchKernelGGL(tanh_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, y, dy, dx, (long long)n);
+  return check_launch("tanh_bwd");
 }

@@ -18,6 +18,7 @@ A ResidualUnit is therefore two launches of the MFMA conv kernel:
 """
 from torch import nn
 
+from . import autograd as A
 from . import ops
 from .layers import SConv1d, SConvTranspose1d, SLSTM, Snake1d
 
@@ -62,6 +63,10 @@ class ResidualUnit(nn.Module):
         return b[3].run(h, res=x, alpha_y2=alpha_next, want_y=want_raw)
 
     def forward(self, x):
+        if self.training:        # layer-by-layer with autograd (facodec_amd/autograd.py)
+            b = self.block
+            y = A.conv(b[3], A.snake(b[2], A.conv(b[1], A.snake(b[0], x))))
+            return A.add(x, y)
         return self.run(x, ops.snake(x, self.alpha_in))[0]
 
 
@@ -117,7 +122,22 @@ class Encoder(nn.Module):
         self.block = nn.Sequential(*layers)
         self.enc_dim = d_model
 
+    def _forward_train(self, x):
+        mods = list(self.block)
+        x = A.conv(mods[0], x)
+        for m in mods[1:-2]:
+            if isinstance(m, EncoderBlock):
+                b = m.block
+                for ru in (b[0], b[1], b[2]):
+                    x = ru(x)
+                x = A.conv(b[4], A.snake(b[3], x))
+            else:
+                x = A.slstm(m, x)
+        return A.conv(mods[-1], A.snake(mods[-2], x))
+
     def forward(self, x):
+        if self.training:
+            return self._forward_train(x)
         mods = list(self.block)
         blocks = [m for m in mods if isinstance(m, EncoderBlock)]
         final_alpha = mods[-2].flat()
@@ -178,7 +198,22 @@ class Decoder(nn.Module):
                    nn.Tanh()]
         self.model = nn.Sequential(*layers)
 
+    def _forward_train(self, x):
+        mods = list(self.model)
+        x = A.conv(mods[0], x)
+        for m in mods[1:-3]:
+            if isinstance(m, DecoderBlock):
+                b = m.block
+                x = A.conv_tr(b[1], A.snake(b[0], x))
+                for ru in (b[2], b[3], b[4]):
+                    x = ru(x)
+            else:
+                x = A.slstm(m, x)
+        return A.conv(mods[-2], A.snake(mods[-3], x), act=ops.ACT_TANH)
+
     def forward(self, x):
+        if self.training:
+            return self._forward_train(x)
         mods = list(self.model)
         blocks = [m for m in mods if isinstance(m, DecoderBlock)]
         final_alpha = mods[-3].flat()

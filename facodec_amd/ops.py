@@ -282,16 +282,18 @@ def pack_lstm_whh(w_hh, out=None):
     return out
 
 
-def lstm_layer(pre, whh_packed, H, state=None, step0=0):
+def lstm_layer(pre, whh_packed, H, state=None, step0=0, save=None):
     """pre (4H, T, BP) -> yT (H, T, BP).  state (3, H, BP): carried cell / hidden buffers of a streaming
-    session with `step0` steps already taken (None: fresh zero state)."""
+    session with `step0` steps already taken (None: fresh zero state).  save = (gates (4H,T,BP), c (H,T,BP)):
+    training mode, the activations back-propagation through time needs are stored there."""
     _, T, BP = pre.shape
     yT = torch.empty(H, T, BP, device=pre.device, dtype=torch.float32)
     if state is None:
         state = torch.empty(3, H, BP, device=pre.device, dtype=torch.float32)   # cell state + 2 fragment-ordered h
         step0 = 0
-    _lib.check(_lib.load().fac_lstm_layer_fwd_from(_ptr(pre), _ptr(whh_packed), _ptr(yT), _ptr(state), T, H, BP,
-                                                   step0, _stream()), "fac_lstm_layer_fwd_from")
+    sg, sc = save if save is not None else (None, None)
+    _lib.check(_lib.load().fac_lstm_layer_fwd_train(_ptr(pre), _ptr(whh_packed), _ptr(yT), _ptr(state), _ptr(sg), _ptr(sc),
+                                                    T, H, BP, step0, _stream()), "fac_lstm_layer_fwd")
     return yT
 
 
@@ -547,3 +549,33 @@ def bias_grad(dy):
     db = torch.empty(c, device=dy.device, dtype=torch.float32)
     _lib.check(_lib.load().fac_bias_grad(_ptr(dy), _ptr(db), B, c, t, _stream()), "fac_bias_grad")
     return db
+
+
+def conv_transpose1d_bwd(x, dy, v, g, stride):
+    """Causal SConvTranspose1d (kernel 2*stride): -> (dx, dW (C_in, C_out, K)).  dx is the strided forward conv of dy
+    on the same weights; dW the weight-gradient kernel with the roles of input and output swapped."""
+    x, dy = _dev(x, "x"), _dev(dy, "dy")
+    B, c_in, t_in = x.shape
+    c_out, k = v.shape[1], v.shape[2]
+    assert k == 2 * stride and dy.shape == (B, c_out, t_in * stride)
+    dx = conv1d(dy, pack_conv_weight(v, g), c_in, k, stride=stride, pad_left=0, pad_mode=PAD_ZERO, t_out=t_in)
+    lib = _lib.load()
+    nbytes = lib.fac_conv1d_bwd_weight_ws_bytes(B, c_out, c_in, t_in, k)
+    ws = torch.empty(nbytes // 4, device=x.device, dtype=torch.float32)
+    dw = torch.empty(c_in, c_out, k, device=x.device, dtype=torch.float32)
+    _lib.check(lib.fac_conv1d_bwd_weight(_ptr(dy), _ptr(x), _ptr(dw), _ptr(ws), nbytes, B, c_out, t_in * stride, c_in, t_in,
+                                         k, stride, 1, 0, PAD_ZERO, _stream()), "fac_conv1d_bwd_weight(convtr)")
+    return dx, dw
+
+
+def lstm_gate_bwd(dy_t, rec, gates_t, c_t, c_prev, dc, dgates_t, H, BP, rs, first):
+    """Views into (rows, T, BP) buffers at one time step (row stride rs); rec / dc dense (H, BP)."""
+    _lib.check(_lib.load().fac_lstm_gate_bwd(_ptr(dy_t), _ptr(rec), _ptr(gates_t), _ptr(c_t), _ptr(c_prev), _ptr(dc),
+                                             _ptr(dgates_t), H, BP, rs, 1 if first else 0, _stream()), "fac_lstm_gate_bwd")
+
+
+def tanh_bwd(y, dy):
+    y, dy = _dev(y), _dev(dy)
+    dx = torch.empty_like(dy)
+    _lib.check(_lib.load().fac_tanh_bwd(_ptr(y), _ptr(dy), _ptr(dx), dy.numel(), _stream()), "fac_tanh_bwd")
+    return dx

@@ -171,6 +171,16 @@ int fac_lstm_layer_fwd(const float* pre, const float* whh_packed, float* yT, flo
  * (0 = zero initial state, identical to fac_lstm_layer_fwd). */
 int fac_lstm_layer_fwd_from(const float* pre, const float* whh_packed, float* yT, float* c, int T,
                             int H, int BP, int64_t step0, fac_stream_t stream);
+/* Training-mode recurrence: additionally stores the activated gates (4H, T, BP) and the cell states (H, T, BP)
+ * that back-propagation through time needs (both NULL: identical to fac_lstm_layer_fwd_from). */
+int fac_lstm_layer_fwd_train(const float* pre, const float* whh_packed, float* yT, float* c, float* gates_save,
+                             float* c_save, int T, int H, int BP, int64_t step0, fac_stream_t stream);
+/* Elementwise part of one BPTT step: dh = dy_t + rec (rec = W_hh^T dgates_{t+1}, NULL at the last step), gate
+ * derivatives from the saved activations -> dgates_t (rows of stride rs), carried dc (H, BP) (first = last time step). */
+int fac_lstm_gate_bwd(const float* dy_t, const float* rec, const float* gates_t, const float* c_t, const float* c_prev,
+                      float* dc, float* dgates_t, int H, int BP, int64_t rs, int first, fac_stream_t stream);
+/* dx = dy * (1 - y^2) */
+int fac_tanh_bwd(const float* y, const float* dy, float* dx, int64_t n, fac_stream_t stream);
 /* Left-context buffer of a streaming causal conv: every row of buf (rows x cap) holds
  * [hist columns of history | n_prev columns appended last time]; moves the last `hist` columns to the
  * front (skipped when n_prev == 0) and appends src (rows x n_new, dense) behind them.  hist <= 2048. */
