@@ -371,6 +371,76 @@ __global__ void spec_power_kernel(const float* __restrict__ spec, float* __restr
   }
 }
 
+// ---- backward of the spectral losses (d loss / d estimate) ------------------------------------------------
+// d/da of scale * |a - b| (mode 0) or scale * |log10 max(a, eps) - log10 max(b, eps)| (mode 1)
+__global__ void pair_bwd_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ da,
+                                long long n, int mode, float eps, float scale, int accumulate) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const float av = a[i], bv = b[i];
+    float g;
+    if (mode == 0) {
+      g = av > bv ? 1.f : (av < bv ? -1.f : 0.f);
+    } else {
+      const float d = log10f(fmaxf(av, eps)) - log10f(fmaxf(bv, eps));
+      const float sgn = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+      g = av > eps ? sgn / (av * 2.302585092994046f) : 0.f;
+    }
+    g *= scale;
+    da[i] = accumulate ? da[i] + g : g;
+  }
+}
+
+// spec (B, 2F, frames) = [re | im]; out = |z| (power 1) or |z|^2 (power 2): dspec from dout
+__global__ void spec_power_bwd_kernel(const float* __restrict__ spec, const float* __restrict__ dout,
+                                      float* __restrict__ dspec, int F, int n_frames, int power, long long n) {
+  const long long per_b = (long long)F * n_frames;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const long long b = i / per_b, r = i - b * per_b;
+    const float re = spec[b * 2 * per_b + r], im = spec[b * 2 * per_b + per_b + r];
+    float cr, cim;
+    if (power == 2) {
+      cr = 2.f * re; cim = 2.f * im;
+    } else {
+      const float m = sqrtf(re * re + im * im);
+      cr = m > 0.f ? re / m : 0.f; cim = m > 0.f ? im / m : 0.f;
+    }
+    dspec[b * 2 * per_b + r] = dout[i] * cr;
+    dspec[b * 2 * per_b + per_b + r] = dout[i] * cim;
+  }
+}
+
+// adjoint of stft_frames_kernel: every sample gathers the frame entries that read it, directly or through
+// the reflection at either end (deterministic: no atomics)
+__global__ void stft_frames_bwd_kernel(const float* __restrict__ dframes, float* __restrict__ dwave, int T, int n_win,
+                                       int n_frames, int hop, int pad, int n_off, long long n) {
+  const long long per_b = (long long)n_win * n_frames;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const long long b = i / T;
+    const int t = (int)(i - b * T);
+    const float* df = dframes + b * per_b;
+    float g = 0.f;
+    // padded-signal positions u = f*hop + nn + n_off - pad that resolve to sample t
+    int us[3];
+    int nu = 0;
+    us[nu++] = t;
+    if (t >= 1) us[nu++] = -t;                      // left reflection:  u < 0  -> -u
+    if (t <= T - 2) us[nu++] = 2 * (T - 1) - t;     // right reflection: u >= T -> 2(T-1) - u
+    for (int q = 0; q < nu; ++q) {
+      const int w = us[q] + pad - n_off;            // = f*hop + nn
+      int f_hi = w / hop;
+      if (w < 0) continue;
+      if (f_hi > n_frames - 1) f_hi = n_frames - 1;
+      int f_lo = (w - n_win + 1 + hop - 1) / hop;
+      if (w - n_win + 1 < 0) f_lo = 0;
+      for (int f = f_lo; f <= f_hi; ++f) {
+        const int nn = w - f * hop;
+        if (nn >= 0 && nn < n_win) g += df[(long long)nn * n_frames + f];
+      }
+    }
+    dwave[i] = g;
+  }
+}
+
 __device__ __forceinline__ float pair_term(float a, float b, int mode, float eps) {
   if (mode == 0) return fabsf(a - b);
   if (mode == 1) return fabsf(log10f(fmaxf(a, eps)) - log10f(fmaxf(b, eps)));
@@ -670,4 +740,27 @@ extern "C" int fac_aa_snakebeta_fwd(const float* x, const float* alpha_log, cons
   hipLaunchKernelGGL(aa_snakebeta_kernel, dim3((T + 255) / 256, B * C), dim3(256), 0, (hipStream_t)stream, x,
                      alpha_log, beta_log, filter12, y, C, T);
   return check_launch("aa_snakebeta_fwd");
+}
+
+extern "C" int fac_pair_bwd(const float* a, const float* b, float* da, int64_t n, int mode, float eps, float scale,
+                            int accumulate, fac_stream_t stream) {
+  FAC_REQUIRE(a && b && da && n > 0 && (mode == 0 || mode == 1), "pair_bwd: bad arguments");
+  EW_LAUNCH(pair_bwd_kernel, n, a, b, da, (long long)n, mode, eps, scale, accumulate);
+  return check_launch("pair_bwd");
+}
+
+extern "C" int fac_spec_power_bwd(const float* spec, const float* dout, float* dspec, int B, int F, int n_frames, int power,
+                                  fac_stream_t stream) {
+  FAC_REQUIRE(spec && dout && dspec && B > 0 && F > 0 && n_frames > 0 && (power == 1 || power == 2), "spec_power_bwd: bad arguments");
+  const long long n = (long long)B * F * n_frames;
+  EW_LAUNCH(spec_power_bwd_kernel, n, spec, dout, dspec, F, n_frames, power, n);
+  return check_launch("spec_power_bwd");
+}
+
+extern "C" int fac_stft_frames_bwd(const float* dframes, float* dwave, int B, int T, int n_win, int n_frames, int hop, int pad,
+                                   int n_off, fac_stream_t stream) {
+  FAC_REQUIRE(dframes && dwave && B > 0 && T > 1 && n_win > 0 && n_frames > 0 && hop > 0 && pad < T, "stft_frames_bwd: bad arguments");
+  const long long n = (long long)B * T;
+  EW_LAUNCH(stft_frames_bwd_kernel, n, dframes, dwave, T, n_win, n_frames, hop, pad, n_off, n);
+  return check_launch("stft_frames_bwd");
 }

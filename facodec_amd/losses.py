@@ -33,12 +33,15 @@ class _SpectralScale:
         basis, off = dsp.dft_basis(n_fft, win)
         self.n_fft, self.win, self.hop, self.off = n_fft, win, hop, off
         self.F = n_fft // 2 + 1
-        self.basis = ops.pack_conv_weight(torch.from_numpy(basis).to(device).unsqueeze(-1))
+        basis_t = torch.from_numpy(basis).to(device).unsqueeze(-1)
+        self.basis = ops.pack_conv_weight(basis_t)
+        self.basis_bwd = ops.pack_conv_weight_bwd(basis_t)       # transposed GEMM of the backward pass
         self.n_mels = None
         if fbank is not None:            # (n_mels, F)
             fb = torch.as_tensor(fbank, dtype=torch.float32, device=device).contiguous()
             self.n_mels = fb.shape[0]
             self.fb = ops.pack_conv_weight(fb.unsqueeze(-1))
+            self.fb_bwd = ops.pack_conv_weight_bwd(fb.unsqueeze(-1))
 
     def spectrum(self, waves, power):
         """waves (N, T) -> (N, F, frames) magnitude (power 1) or power (2) spectrogram."""
@@ -50,6 +53,44 @@ class _SpectralScale:
 
     def mel(self, spec):
         return ops.conv1d(spec, self.fb, self.n_mels, 1, pad_left=0, pad_mode=ops.PAD_ZERO, t_out=spec.shape[-1])
+
+    def backward_to_wave(self, waves, terms, use_mel):
+        """d/d waves of sum_i scale_i * pair_term(mode_i)(S(waves), target) for S = mel or magnitude spectrogram.
+        terms: [(mode, eps, scale)], target already computed.  Recomputes the forward of `waves` (cheap, saves
+        keeping every scale's spectra alive between forward and backward)."""
+        N, T = waves.shape
+        frames_n = 1 + T // self.hop
+        fr = ops.stft_frames(waves, self.win, frames_n, self.hop, self.n_fft // 2, self.off)
+        spec = ops.conv1d(fr, self.basis, 2 * self.F, 1, pad_left=0, pad_mode=ops.PAD_ZERO, t_out=frames_n)
+        mag = ops.spec_power(spec, 1)
+        feat = self.mel(mag) if use_mel else mag
+        target = self._target
+        dfeat = torch.empty_like(feat)
+        for i, (mode, eps, scale) in enumerate(terms):
+            ops.pair_bwd(feat, target, dfeat, mode, eps, scale, accumulate=i > 0)
+        if use_mel:
+            dmag = ops.conv1d(dfeat, self.fb_bwd, self.F, 1, pad_left=0, pad_mode=ops.PAD_ZERO, t_out=frames_n)
+        else:
+            dmag = dfeat
+        dspec = ops.spec_power_bwd(spec, dmag, 1)
+        dfr = ops.conv1d(dspec, self.basis_bwd, self.win, 1, pad_left=0, pad_mode=ops.PAD_ZERO, t_out=frames_n)
+        return ops.stft_frames_bwd(dfr, T, self.hop, self.n_fft // 2, self.off)
+
+
+class _SpectralLossFn(torch.autograd.Function):
+    """value = module._value(x, y); backward = d value / d x through the HIP adjoint kernels."""
+
+    @staticmethod
+    def forward(ctx, x, y, module):
+        ctx.module = module
+        ctx.save_for_backward(x, y)
+        return module._value(x.detach(), y.detach()).clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        x, y = ctx.saved_tensors
+        dx = ctx.module._grad_x(x.detach(), y.detach())
+        return (dx * g).reshape(x.shape), None, None
 
 
 class _LossBase(nn.Module):
@@ -79,16 +120,40 @@ class MelSpectrogramLoss(_LossBase):
         self.mel_fmin, self.mel_fmax, self.sample_rate = list(mel_fmin), list(mel_fmax), sample_rate
 
     def forward(self, x, y):
+        xa = getattr(x, "audio_data", x)
+        if torch.is_tensor(xa) and xa.requires_grad:
+            return _SpectralLossFn.apply(xa, getattr(y, "audio_data", y), self)
+        return self._value(x, y)
+
+    def _scale(self, device, sr, nm, fmin, fmax, w):
+        key = (device, w, nm, fmin, fmax, sr)
+        if key not in self._scales:
+            self._scales[key] = _SpectralScale(device, w, w, w // 4, dsp.mel_fbank_slaney(sr, w, nm, fmin, fmax))
+        return self._scales[key]
+
+    def _grad_x(self, x, y):
+        xs, ys = _audio(x).contiguous(), _audio(y).contiguous()
+        sr = self.sample_rate
+        dx = None
+        for nm, fmin, fmax, w in zip(self.n_mels, self.mel_fmin, self.mel_fmax, self.window_lengths):
+            sc = self._scale(xs.device, sr, nm, fmin, fmax, w)
+            sc._target = sc.mel(sc.spectrum(ys, 1))
+            n = sc._target.numel()
+            terms = [(1, self.clamp_eps, self.log_weight * self.pow / n)]
+            if self.mag_weight != 0.0:
+                terms.append((0, 0.0, self.mag_weight / n))
+            d = sc.backward_to_wave(xs, terms, use_mel=True)
+            dx = d if dx is None else ops.add(dx, d)
+        return dx
+
+    def _value(self, x, y):
         xs, ys = _audio(x), _audio(y)
         B = xs.shape[0]
         sr = getattr(x, "sample_rate", self.sample_rate)
         both = torch.cat([xs, ys], 0).contiguous()
         out, scratch = self._bufs(both.device)
         for nm, fmin, fmax, w in zip(self.n_mels, self.mel_fmin, self.mel_fmax, self.window_lengths):
-            key = (both.device, w, nm, fmin, fmax, sr)
-            if key not in self._scales:
-                self._scales[key] = _SpectralScale(both.device, w, w, w // 4, dsp.mel_fbank_slaney(sr, w, nm, fmin, fmax))
-            sc = self._scales[key]
+            sc = self._scale(both.device, sr, nm, fmin, fmax, w)
             mel = sc.mel(sc.spectrum(both, 1))                       # (2B, n_mels, frames)
             n = mel[:B].numel()
             # log10(clamp(m, eps)^pow) = pow * log10(max(m, eps))

@@ -579,3 +579,28 @@ def tanh_bwd(y, dy):
     dx = torch.empty_like(dy)
     _lib.check(_lib.load().fac_tanh_bwd(_ptr(y), _ptr(dy), _ptr(dx), dy.numel(), _stream()), "fac_tanh_bwd")
     return dx
+
+
+def pair_bwd(a, b, da, mode, eps, scale, accumulate):
+    a, b = _dev(a), _dev(b)
+    _lib.check(_lib.load().fac_pair_bwd(_ptr(a), _ptr(b), _ptr(da), a.numel(), mode, eps, scale, 1 if accumulate else 0,
+                                        _stream()), "fac_pair_bwd")
+    return da
+
+
+def spec_power_bwd(spec, dout, power):
+    spec, dout = _dev(spec), _dev(dout)
+    B, f2, nf = spec.shape
+    dspec = torch.empty_like(spec)
+    _lib.check(_lib.load().fac_spec_power_bwd(_ptr(spec), _ptr(dout), _ptr(dspec), B, f2 // 2, nf, power, _stream()),
+               "fac_spec_power_bwd")
+    return dspec
+
+
+def stft_frames_bwd(dframes, T, hop, pad, n_off):
+    dframes = _dev(dframes)
+    B, n_win, nf = dframes.shape
+    dwave = torch.empty(B, T, device=dframes.device, dtype=torch.float32)
+    _lib.check(_lib.load().fac_stft_frames_bwd(_ptr(dframes), _ptr(dwave), B, T, n_win, nf, hop, pad, n_off, _stream()),
+               "fac_stft_frames_bwd")
+    return dwave

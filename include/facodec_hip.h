@@ -181,6 +181,14 @@ int fac_lstm_gate_bwd(const float* dy_t, const float* rec, const float* gates_t,
                       float* dc, float* dgates_t, int H, int BP, int64_t rs, int first, fac_stream_t stream);
 /* dx = dy * (1 - y^2) */
 int fac_tanh_bwd(const float* y, const float* dy, float* dx, int64_t n, fac_stream_t stream);
+/* Backward of the spectral losses w.r.t. the estimate: da (+)= scale * d|a - b|/da (mode 0) or
+ * scale * d|log10 max(a,eps) - log10 max(b,eps)|/da (mode 1); spec_power and stft_frames adjoints. */
+int fac_pair_bwd(const float* a, const float* b, float* da, int64_t n, int mode, float eps, float scale, int accumulate,
+                 fac_stream_t stream);
+int fac_spec_power_bwd(const float* spec, const float* dout, float* dspec, int B, int F, int n_frames, int power,
+                       fac_stream_t stream);
+int fac_stft_frames_bwd(const float* dframes, float* dwave, int B, int T, int n_win, int n_frames, int hop, int pad,
+                        int n_off, fac_stream_t stream);
 /* Left-context buffer of a streaming causal conv: every row of buf (rows x cap) holds
  * [hist columns of history | n_prev columns appended last time]; moves the last `hist` columns to the
  * front (skipped when n_prev == 0) and appends src (rows x n_new, dense) behind them.  hist <= 2048. */

@@ -803,3 +803,20 @@ def test_decoder_backward_against_autograd(O, cuda):
     sd = synth.load_synthetic(dec, seed=5, prefix="decoder.")
     z = torch.randn(2, 64, 12, generator=_g(8))
     _grad_parity(dec, sd, lambda s, zz: O.decoder_forward(s, zz, rates=(6, 5, 5, 2), causal=True, lstm=2), z, cuda, 2e-4)
+
+
+def test_mel_loss_backward_against_autograd(O, cuda):
+    """d MelSpectrogramLoss / d estimate (train.py:155-163 configuration, 7 scales) against autograd through the
+    oracle's STFT / mel restatement.  L1 of logs has kinks; the bar is on the whole gradient field."""
+    from facodec_amd import losses
+    y = synth.synth_clips(2, 24000, seed=21)
+    x = (0.6 * y + 0.1 * synth.synth_clips(2, 24000, seed=22)).contiguous().requires_grad_()
+    ref = O.mel_spectrogram_loss(x, y)
+    ref.backward()
+    mel = losses.MelSpectrogramLoss(n_mels=[5, 10, 20, 40, 80, 160, 320], window_lengths=[32, 64, 128, 256, 512, 1024, 2048],
+                                    mel_fmin=[0] * 7, mel_fmax=[None] * 7, pow=1.0, mag_weight=0.0, clamp_eps=1e-5)
+    xg = x.detach().to(cuda).requires_grad_()
+    got = mel(xg, y.to(cuda))
+    assert abs(float(got) - float(ref)) / float(ref) < E2E_TOL
+    (3.0 * got).backward()
+    assert rel(xg.grad, 3.0 * x.grad) < 5e-4
