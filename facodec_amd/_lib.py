@@ -70,6 +70,10 @@ SIGNATURES = {
     "fac_pair_bwd": (_i, [_p, _p, _p, _i64, _i, C.c_float, C.c_float, _i, _p]),
     "fac_spec_power_bwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
     "fac_stft_frames_bwd": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "fac_vq_latent_bwd": (_i, [_p, _p, _p, _i64, _p, _p, _p, _p, _i, _i, _p]),
+    "fac_vq_codebook_grad": (_i, [_p, _p, _p, _i64, _p, _p, _i, _i, _i, _i, _p]),
+    "fac_layernorm_c_affine_bwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
+    "fac_rows_fma": (_i, [_p, _p, _p, _p, _i, _i64, _f, _p]),
     "fac_stream_push": (_i, [_p, _p, _i64, _i64, _i, _i, _i, _p]),
     "fac_vq_fwd": (_i, [C.POINTER(VqDesc), _p]),
     "fac_vq_search": (_i, [_p, _p, _p, _i64, _i, _p]),

@@ -191,3 +191,104 @@ def slstm(m, x):
         flat += [getattr(p, f"weight_ih_l{l}"), getattr(p, f"weight_hh_l{l}"), getattr(p, f"bias_ih_l{l}"),
                  getattr(p, f"bias_hh_l{l}")]
     return _LSTM.apply(x, m.skip, *flat)
+
+
+class _LayerNormAffine(Function):
+    """outs = LayerNorm_C(x) * gamma + beta with style = [gamma | beta] (modules/quantize.py:444-449)."""
+
+    @staticmethod
+    def forward(ctx, x, style):
+        ctx.save_for_backward(x, style)
+        return ops.layernorm_c_affine(x.detach(), style.detach().contiguous())
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, style = ctx.saved_tensors
+        return ops.layernorm_c_affine_bwd(x.detach(), style.detach().contiguous(), dout.contiguous())
+
+
+def layernorm_affine(x, style):
+    return _LayerNormAffine.apply(x, style)
+
+
+class _RVQ(Function):
+    """ResidualVectorQuantize.forward in training mode (dac/nn/quantize.py:127-198) with the per-sample quantizer
+    masks given explicitly (mask (n, B) of 0/1: the reference draws them from torch.randint, :163-168).
+    params per quantizer: in_proj (v, g, bias), codebook, out_proj (v, g, bias).
+    Returns z_q, commitment (scalar), codebook loss (scalar); codes via the `codes` buffer (B, n, T)."""
+
+    @staticmethod
+    def forward(ctx, z, mask, codes, *params):
+        n = len(params) // 7
+        B, D, T = z.shape
+        zd = z.detach()
+        z_q = torch.zeros_like(zd)
+        residuals, z_es = [], []
+        nt = (T + 63) // 64
+        lp = torch.empty(n, B, nt, device=z.device)
+        src = zd
+        for i in range(n):
+            v_in, g_in, b_in, cb, v_out, g_out, b_out = (p.detach() for p in params[7 * i: 7 * i + 7])
+            residuals.append(src)
+            z_e = torch.empty(B, 8, T, device=z.device)
+            nxt = torch.empty_like(zd)
+            ops.vq_step(src, ops.pack_conv_weight(v_in, g_in), b_in, cb, v_out, ops.wn_scale(v_out, g_out), b_out,
+                        codes[:, i], residual=nxt, zq_acc=z_q, mask=mask[i].contiguous(), z_e=z_e, loss_part=lp[i])
+            # the fused kernel writes nxt = src - z_q_i (reading src = z_in): keep src untouched for the backward
+            z_es.append(z_e)
+            src = nxt
+        per = lp.sum(2) / float(8 * T)                 # (n, B): mse per sample; commitment == codebook loss in value
+        loss = (per * mask).mean(1).sum()
+        ctx.n, ctx.dims = n, (B, D, T)
+        ctx.saved = (residuals, z_es, codes, mask)
+        ctx.save_for_backward(*params)
+        return z_q, loss, loss.clone()
+
+    @staticmethod
+    def backward(ctx, d_zq, g_commit, g_cb):
+        params = ctx.saved_tensors
+        residuals, z_es, codes, mask = ctx.saved
+        n = ctx.n
+        B, D, T = ctx.dims
+        d_zq = d_zq.contiguous()
+        grads = [None] * (7 * n)
+        d_res = None                                   # gradient w.r.t. the residual entering quantizer i+1
+        for i in reversed(range(n)):
+            v_in, g_in, b_in, cb, v_out, g_out, b_out = (p.detach() for p in params[7 * i: 7 * i + 7])
+            mi = mask[i].contiguous()
+            # upstream of z_q_i: the masked sum and (negatively) the residual chain
+            G = ops.rows_fma(d_zq, mi, d_res, -1.0)
+            ci = codes[:, i]
+            _, z_st = ops.vq_latent_bwd(z_es[i], cb, ci, want_dze=False, want_zst=True)
+            # out_proj (8 -> D, 1x1, weight-normed)
+            d_zst = ops.conv1d_bwd_data(G, v_out, g_out, T, pad_mode=ops.PAD_ZERO)
+            dw_out = ops.conv1d_bwd_weight(z_st, G, 1, pad_mode=ops.PAD_ZERO)
+            grads[7 * i + 4], grads[7 * i + 5] = ops.weight_norm_bwd(v_out, g_out, dw_out)
+            grads[7 * i + 6] = ops.bias_grad(G)
+            wc = (mi * (g_commit / B)).contiguous()
+            wb = (mi * (g_cb / B)).contiguous()
+            d_ze, _ = ops.vq_latent_bwd(z_es[i], cb, ci, d_zst=d_zst, wc=wc)
+            grads[7 * i + 3] = ops.vq_codebook_grad(z_es[i], cb, ci, wb)
+            # in_proj (D -> 8)
+            d_in = ops.conv1d_bwd_data(d_ze, v_in, g_in, T, pad_mode=ops.PAD_ZERO)
+            dw_in = ops.conv1d_bwd_weight(residuals[i], d_ze, 1, pad_mode=ops.PAD_ZERO)
+            grads[7 * i], grads[7 * i + 1] = ops.weight_norm_bwd(v_in, g_in, dw_in)
+            grads[7 * i + 2] = ops.bias_grad(d_ze)
+            d_res = d_in if d_res is None else ops.add(d_res, d_in)
+        return (d_res, None, None, *grads)
+
+
+def rvq(m, z, mask=None):
+    """ResidualVectorQuantize module `m` in training mode -> (z_q, codes, commitment, codebook_loss).
+    mask (n, B) float 0/1 (quantizer dropout); None = every quantizer active for every sample."""
+    n = m.n_codebooks
+    B, _, T = z.shape
+    if mask is None:
+        mask = torch.ones(n, B, device=z.device)
+    codes = torch.empty(B, n, T, device=z.device, dtype=torch.int64)
+    flat = []
+    for q in m.quantizers:
+        flat += [q.in_proj.weight_v, q.in_proj.weight_g, q.in_proj.bias, q.codebook.weight,
+                 q.out_proj.weight_v, q.out_proj.weight_g, q.out_proj.bias]
+    z_q, commit, cbl = _RVQ.apply(z, mask, codes, *flat)
+    return z_q, codes, commit, cbl

@@ -327,3 +327,178 @@ extern "C" int fac_bias_grad(const float* dy, float* db, int B, int C, int T, fa
   hipLaunchKernelGGL(fac::bias_grad_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, dy, db, B, C, T);
   return fac::check_launch("bias_grad");
 }
+
+// ------------------------------------------------------------------------------------------------------------
+// Quantizer backward (dac/nn/quantize.py:55-67): z_st = z_e + (codebook[idx] - z_e) feeds out_proj (straight-through:
+// d z_e += d z_st); commitment mse(z_e, z_q.detach()) and codebook mse(z_q, z_e.detach()) are means over the (8, T)
+// plane per sample, weighted per sample by wc[b] / wb[b] (quantizer-dropout mask, 1/B and the loss weight folded in).
+namespace fac {
+
+constexpr int VQB_CD = 8;
+
+__global__ void vq_latent_bwd_kernel(const float* __restrict__ z_e, const float* __restrict__ cb,
+                                     const long long* __restrict__ codes, long long codes_bs, const float* __restrict__ d_zst,
+                                     const float* __restrict__ wc, float* __restrict__ d_ze, float* __restrict__ z_st, int T,
+                                     long long n) {
+  const float inv = 2.0f / (float)(VQB_CD * T);
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const int t = (int)(i % T);
+    const long long r = i / T;
+    const int d = (int)(r % VQB_CD);
+    const int b = (int)(r / VQB_CD);
+    const float ze = z_e[i];
+    const float zq = cb[codes[(long long)b * codes_bs + t] * VQB_CD + d];
+    if (d_ze) d_ze[i] = (d_zst ? d_zst[i] : 0.f) + wc[b] * inv * (ze - zq);
+    if (z_st) z_st[i] = __fadd_rn(ze, __fsub_rn(zq, ze));
+  }
+}
+
+// one workgroup per code: gathers every position that chose it (deterministic, no atomics)
+__global__ __launch_bounds__(256) void vq_codebook_grad_kernel(const float* __restrict__ z_e, const float* __restrict__ cb,
+                                                               const long long* __restrict__ codes, long long codes_bs,
+                                                               const float* __restrict__ wb, float* __restrict__ dcb, int B,
+                                                               int T, int accumulate) {
+  __shared__ float red[VQB_CD][256];
+  const int k = blockIdx.x, tid = threadIdx.x;
+  const float inv = 2.0f / (float)(VQB_CD * T);
+  float s[VQB_CD];
+#pragma unroll
+  for (int d = 0; d < VQB_CD; ++d) s[d] = 0.f;
+  for (long long p = tid; p < (long long)B * T; p += 256) {
+    const int b = (int)(p / T), t = (int)(p - (long long)b * T);
+    if (codes[(long long)b * codes_bs + t] != k) continue;
+    const float w = wb[b] * inv;
+#pragma unroll
+    for (int d = 0; d < VQB_CD; ++d) s[d] += w * (cb[k * VQB_CD + d] - z_e[((long long)b * VQB_CD + d) * T + t]);
+  }
+#pragma unroll
+  for (int d = 0; d < VQB_CD; ++d) red[d][tid] = s[d];
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (tid < o)
+#pragma unroll
+      for (int d = 0; d < VQB_CD; ++d) red[d][tid] += red[d][tid + o];
+    __syncthreads();
+  }
+  if (tid < VQB_CD) dcb[k * VQB_CD + tid] = (accumulate ? dcb[k * VQB_CD + tid] : 0.f) + red[tid][0];
+}
+
+// LayerNorm over channels + per-clip affine (modules/quantize.py:444-449): out = xhat * gamma_b + beta_b.
+// Column kernel: dx; row kernel: dgamma / dbeta (sums over time, one workgroup per (b, c)).
+__global__ __launch_bounds__(256) void layernorm_c_bwd_x_kernel(const float* __restrict__ x, const float* __restrict__ style,
+                                                                const float* __restrict__ dout, float* __restrict__ dx, int C,
+                                                                int T) {
+  __shared__ float red[4][4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b = blockIdx.y, t = blockIdx.x * 64 + lane;
+  const bool tv = t < T;
+  const float* xb = x + (long long)b * C * T + t;
+  const float* db = dout + (long long)b * C * T + t;
+  const float* gm = style + (long long)b * 2 * C;
+  float s = 0.f;
+  for (int c = wave; c < C; c += 4) s += tv ? xb[(long long)c * T] : 0.f;
+  red[0][wave][lane] = s;
+  __syncthreads();
+  const float mean = ((red[0][0][lane] + red[0][1][lane]) + (red[0][2][lane] + red[0][3][lane])) / (float)C;
+  float vs = 0.f;
+  for (int c = wave; c < C; c += 4) {
+    const float d = tv ? xb[(long long)c * T] - mean : 0.f;
+    vs = fmaf(d, d, vs);
+  }
+  red[1][wave][lane] = vs;
+  __syncthreads();
+  const float var = ((red[1][0][lane] + red[1][1][lane]) + (red[1][2][lane] + red[1][3][lane])) / (float)C;
+  const float rstd = 1.0f / sqrtf(var + 1e-5f);
+  float s1 = 0.f, s2 = 0.f;          // sum of dxhat, sum of dxhat * xhat
+  for (int c = wave; c < C; c += 4) {
+    if (!tv) break;
+    const float xh = (xb[(long long)c * T] - mean) * rstd;
+    const float dxh = db[(long long)c * T] * gm[c];
+    s1 += dxh;
+    s2 = fmaf(dxh, xh, s2);
+  }
+  red[2][wave][lane] = s1;
+  red[3][wave][lane] = s2;
+  __syncthreads();
+  const float m1 = ((red[2][0][lane] + red[2][1][lane]) + (red[2][2][lane] + red[2][3][lane])) / (float)C;
+  const float m2 = ((red[3][0][lane] + red[3][1][lane]) + (red[3][2][lane] + red[3][3][lane])) / (float)C;
+  if (!tv) return;
+  float* ob = dx + (long long)b * C * T + t;
+  for (int c = wave; c < C; c += 4) {
+    const float xh = (xb[(long long)c * T] - mean) * rstd;
+    const float dxh = db[(long long)c * T] * gm[c];
+    ob[(long long)c * T] = rstd * (dxh - m1 - xh * m2);
+  }
+}
+
+// stats[b][t] = (mean, rstd) recomputed per column would cost C reads per element: instead the row kernel takes the
+// normalised tensor xhat it needs from a scratch written by ... nothing: it recomputes mean / rstd per column too
+// (C is 1024 and T small on this path; the quantizer runs at frame rate).
+__global__ __launch_bounds__(64) void layernorm_c_stats_kernel(const float* __restrict__ x, float* __restrict__ stats, int C, int T) {
+  const int b = blockIdx.y, t = blockIdx.x * 64 + threadIdx.x;
+  if (t >= T) return;
+  const float* xb = x + (long long)b * C * T + t;
+  float s = 0.f;
+  for (int c = 0; c < C; ++c) s += xb[(long long)c * T];
+  const float mean = s / (float)C;
+  float vs = 0.f;
+  for (int c = 0; c < C; ++c) { const float d = xb[(long long)c * T] - mean; vs = fmaf(d, d, vs); }
+  stats[((long long)b * T + t) * 2] = mean;
+  stats[((long long)b * T + t) * 2 + 1] = 1.0f / sqrtf(vs / (float)C + 1e-5f);
+}
+
+__global__ __launch_bounds__(64) void layernorm_c_bwd_style_kernel(const float* __restrict__ x, const float* __restrict__ stats,
+                                                                   const float* __restrict__ dout, float* __restrict__ dstyle,
+                                                                   int C, int T) {
+  const int c = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
+  const float* xr = x + ((long long)b * C + c) * T;
+  const float* dr = dout + ((long long)b * C + c) * T;
+  float sg = 0.f, sb = 0.f;
+  for (int t = lane; t < T; t += 64) {
+    const float mean = stats[((long long)b * T + t) * 2], rstd = stats[((long long)b * T + t) * 2 + 1];
+    const float g = dr[t];
+    sg = fmaf(g, (xr[t] - mean) * rstd, sg);
+    sb += g;
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    sg += __shfl_down(sg, o, 64);
+    sb += __shfl_down(sb, o, 64);
+  }
+  if (lane == 0) {
+    dstyle[(long long)b * 2 * C + c] = sg;
+    dstyle[(long long)b * 2 * C + C + c] = sb;
+  }
+}
+
+}  // namespace fac
+
+extern "C" int fac_vq_latent_bwd(const float* z_e, const float* codebook, const int64_t* codes, int64_t codes_bs,
+                                 const float* d_zst, const float* wc, float* d_ze, float* z_st, int B, int T,
+                                 fac_stream_t stream) {
+  using namespace fac;
+  FAC_REQUIRE(z_e && codebook && codes && (d_ze || z_st) && (!d_ze || wc) && B > 0 && T > 0, "vq_latent_bwd: bad arguments");
+  const long long n = (long long)B * VQB_CD * T;
+  const int blocks = (int)((n + 255) / 256 < 65535 ? (n + 255) / 256 : 65535);
+  hipLaunchKernelGGL(vq_latent_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, z_e, codebook,
+                     (const long long*)codes, (long long)codes_bs, d_zst, wc, d_ze, z_st, T, n);
+  return check_launch("vq_latent_bwd");
+}
+
+extern "C" int fac_vq_codebook_grad(const float* z_e, const float* codebook, const int64_t* codes, int64_t codes_bs,
+                                    const float* wb, float* dcb, int B, int T, int Kc, int accumulate, fac_stream_t stream) {
+  using namespace fac;
+  FAC_REQUIRE(z_e && codebook && codes && wb && dcb && B > 0 && T > 0 && Kc > 0, "vq_codebook_grad: bad arguments");
+  hipLaunchKernelGGL(vq_codebook_grad_kernel, dim3(Kc), dim3(256), 0, (hipStream_t)stream, z_e, codebook,
+                     (const long long*)codes, (long long)codes_bs, wb, dcb, B, T, accumulate);
+  return check_launch("vq_codebook_grad");
+}
+
+extern "C" int fac_layernorm_c_affine_bwd(const float* x, const float* style, const float* dout, float* dx, float* dstyle,
+                                          float* stats, int B, int C, int T, fac_stream_t stream) {
+  using namespace fac;
+  FAC_REQUIRE(x && style && dout && dx && dstyle && stats && B > 0 && C > 0 && T > 0, "layernorm_c_affine_bwd: bad arguments");
+  hipLaunchKernelGGL(layernorm_c_bwd_x_kernel, dim3((T + 63) / 64, B), dim3(256), 0, (hipStream_t)stream, x, style, dout, dx, C, T);
+  hipLaunchKernelGGL(layernorm_c_stats_kernel, dim3((T + 63) / 64, B), dim3(64), 0, (hipStream_t)stream, x, stats, C, T);
+  hipLaunchKernelGGL(layernorm_c_bwd_style_kernel, dim3(C, B), dim3(64), 0, (hipStream_t)stream, x, stats, dout, dstyle, C, T);
+  return check_launch("layernorm_c_affine_bwd");
+}

@@ -604,3 +604,43 @@ def stft_frames_bwd(dframes, T, hop, pad, n_off):
     _lib.check(_lib.load().fac_stft_frames_bwd(_ptr(dframes), _ptr(dwave), B, T, n_win, nf, hop, pad, n_off, _stream()),
                "fac_stft_frames_bwd")
     return dwave
+
+
+# --------------------------------------------------------------------------------- quantizer / LayerNorm backward
+def vq_latent_bwd(z_e, codebook, codes, d_zst=None, wc=None, want_dze=True, want_zst=False):
+    z_e = _dev(z_e)
+    B, _, T = z_e.shape
+    d_ze = torch.empty_like(z_e) if want_dze else None
+    z_st = torch.empty_like(z_e) if want_zst else None
+    _lib.check(_lib.load().fac_vq_latent_bwd(_ptr(z_e), _ptr(codebook), C.c_void_p(codes.data_ptr()), codes.stride(0),
+                                             _ptr(d_zst), _ptr(wc), _ptr(d_ze), _ptr(z_st), B, T, _stream()), "fac_vq_latent_bwd")
+    return d_ze, z_st
+
+
+def vq_codebook_grad(z_e, codebook, codes, wb):
+    z_e = _dev(z_e)
+    B, _, T = z_e.shape
+    dcb = torch.empty_like(codebook)
+    _lib.check(_lib.load().fac_vq_codebook_grad(_ptr(z_e), _ptr(codebook), C.c_void_p(codes.data_ptr()), codes.stride(0),
+                                                _ptr(wb), _ptr(dcb), B, T, codebook.shape[0], 0, _stream()), "fac_vq_codebook_grad")
+    return dcb
+
+
+def layernorm_c_affine_bwd(x, style, dout):
+    x, style, dout = _dev(x), _dev(style), _dev(dout)
+    B, c, T = x.shape
+    dx, dstyle = torch.empty_like(x), torch.empty_like(style)
+    stats = torch.empty(B * T * 2, device=x.device, dtype=torch.float32)
+    _lib.check(_lib.load().fac_layernorm_c_affine_bwd(_ptr(x), _ptr(style), _ptr(dout), _ptr(dx), _ptr(dstyle), _ptr(stats),
+                                                      B, c, T, _stream()), "fac_layernorm_c_affine_bwd")
+    return dx, dstyle
+
+
+def rows_fma(a, w=None, c=None, sign=1.0):
+    """a[b] * w[b] + sign * c[b] for (B, ...) tensors (w (B,), c like a; both optional)."""
+    a = _dev(a)
+    B = a.shape[0]
+    out = torch.empty_like(a)
+    _lib.check(_lib.load().fac_rows_fma(_ptr(a), _ptr(w), _ptr(_dev(c)), _ptr(out), B, a.numel() // B, sign, _stream()),
+               "fac_rows_fma")
+    return out

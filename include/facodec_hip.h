@@ -189,6 +189,20 @@ int fac_spec_power_bwd(const float* spec, const float* dout, float* dspec, int B
                        fac_stream_t stream);
 int fac_stft_frames_bwd(const float* dframes, float* dwave, int B, int T, int n_win, int n_frames, int hop, int pad,
                         int n_off, fac_stream_t stream);
+/* Quantizer backward (dac/nn/quantize.py:55-67).  fac_vq_latent_bwd: d_ze = d_zst (straight-through, may be NULL) +
+ * wc[b] * 2/(8T) * (z_e - codebook[idx]) (commitment term) and / or z_st = z_e + (codebook[idx] - z_e) (the out_proj
+ * input the weight gradient needs).  fac_vq_codebook_grad: dcb[k] (+)= sum over positions that chose k of
+ * wb[b] * 2/(8T) * (codebook[k] - z_e) (deterministic gather, one workgroup per code). */
+int fac_vq_latent_bwd(const float* z_e, const float* codebook, const int64_t* codes, int64_t codes_bs, const float* d_zst,
+                      const float* wc, float* d_ze, float* z_st, int B, int T, fac_stream_t stream);
+int fac_vq_codebook_grad(const float* z_e, const float* codebook, const int64_t* codes, int64_t codes_bs, const float* wb,
+                         float* dcb, int B, int T, int Kc, int accumulate, fac_stream_t stream);
+/* Backward of fac_layernorm_c_affine: dx (B,C,T), dstyle (B, 2C) = [dgamma | dbeta]; stats: scratch of 2*B*T floats. */
+int fac_layernorm_c_affine_bwd(const float* x, const float* style, const float* dout, float* dx, float* dstyle, float* stats,
+                               int B, int C, int T, fac_stream_t stream);
+/* out[b][i] = a[b][i] * w[b] + sign * c[b][i] over B rows of `per` elements (w and c may be NULL). */
+int fac_rows_fma(const float* a, const float* w, const float* c, float* out, int B, int64_t per, float sign,
+                 fac_stream_t stream);
 /* Left-context buffer of a streaming causal conv: every row of buf (rows x cap) holds
  * [hist columns of history | n_prev columns appended last time]; moves the last `hist` columns to the
  * front (skipped when n_prev == 0) and appends src (rows x n_new, dense) behind them.  hist <= 2048. */

@@ -208,6 +208,38 @@ def vq_forward(z, sd, p):
     return out, commit, cbl, idx, z_e
 
 
+def vq_forward_train(z, sd, p):
+    """VectorQuantize.forward dac/nn/quantize.py:55-67 with its detach placements (for autograd references):
+    commitment = mse(z_e, z_q.detach()), codebook = mse(z_q, z_e.detach()), straight-through z_e + (z_q - z_e).detach()."""
+    z_e = F.conv1d(z, conv_weight(sd, p + "in_proj."), sd[p + "in_proj.bias"])
+    with torch.no_grad():
+        _, idx = vq_nearest(z_e, sd[p + "codebook.weight"])
+    z_q = F.embedding(idx, sd[p + "codebook.weight"]).transpose(1, 2)
+    commit = (z_e - z_q.detach()).pow(2).mean([1, 2])
+    cbl = (z_q - z_e.detach()).pow(2).mean([1, 2])
+    z_st = z_e + (z_q - z_e).detach()
+    out = F.conv1d(z_st, conv_weight(sd, p + "out_proj."), sd[p + "out_proj.bias"])
+    return out, commit, cbl, idx, z_e
+
+
+def rvq_forward_train(z, sd, p, n_codebooks, mask):
+    """ResidualVectorQuantize.forward in training mode (dac/nn/quantize.py:171-196) with the per-sample quantizer
+    masks (n, B) given instead of drawn (:163-168)."""
+    z_q = torch.zeros_like(z)
+    residual = z
+    commit = torch.zeros(())
+    cbl = torch.zeros(())
+    codes = []
+    for i in range(n_codebooks):
+        out, c_i, cb_i, idx, _ = vq_forward_train(residual, sd, f"{p}quantizers.{i}.")
+        z_q = z_q + out * mask[i][:, None, None]
+        residual = residual - out
+        commit = commit + (c_i * mask[i]).mean()
+        cbl = cbl + (cb_i * mask[i]).mean()
+        codes.append(idx)
+    return z_q, torch.stack(codes, 1), commit, cbl
+
+
 def rvq_forward(z, sd, p, n_codebooks, n_quantizers=None):
     """ResidualVectorQuantize.forward dac/nn/quantize.py:127-198, eval mode (no quantizer dropout:
     the torch.randint mask of :166-171 only exists under self.training)."""

@@ -820,3 +820,45 @@ def test_mel_loss_backward_against_autograd(O, cuda):
     assert abs(float(got) - float(ref)) / float(ref) < E2E_TOL
     (3.0 * got).backward()
     assert rel(xg.grad, 3.0 * x.grad) < 5e-4
+
+
+def test_rvq_backward_against_autograd(O, cuda):
+    """Training-mode RVQ (3 quantizers, quantizer-dropout masks, straight-through, commitment 0.25 + codebook 1.0 as
+    in train.py:357-358): gradients of the input and of every in_proj / codebook / out_proj parameter."""
+    from facodec_amd import autograd as A
+    from facodec_amd.quantize import ResidualVectorQuantize
+    rvq = ResidualVectorQuantize(256, 3, 1024, 8)
+    sd = synth.load_synthetic(rvq, seed=13)
+    g = _g(31)
+    z = torch.randn(4, 256, 150, generator=g)
+    mask = torch.tensor([[1, 1, 1, 1], [1, 0, 1, 1], [0, 0, 1, 1]], dtype=torch.float32)
+    r = torch.randn(4, 256, 150, generator=g)
+    leaves = {k: v.clone().requires_grad_() for k, v in sd.items()}
+    zr = z.clone().requires_grad_()
+    zq_ref, codes_ref, c_ref, cb_ref = O.rvq_forward_train(zr, leaves, "", 3, mask)
+    ((zq_ref * r).sum() + 0.25 * c_ref + 1.0 * cb_ref).backward()
+    rvq.to(cuda).train()
+    zg = z.to(cuda).requires_grad_()
+    zq, codes, c, cb = A.rvq(rvq, zg, mask.to(cuda))
+    assert torch.equal(codes.cpu(), codes_ref)
+    assert rel(zq, zq_ref) < OP_TOL and abs(float(c) - float(c_ref)) / float(c_ref) < 1e-5
+    ((zq * r.to(cuda)).sum() + 0.25 * c + 1.0 * cb).backward()
+    assert rel(zg.grad, zr.grad) < BWD_TOL
+    for n, p in rvq.named_parameters():
+        assert rel(p.grad, leaves[n].grad) < BWD_TOL, n
+
+
+def test_layernorm_affine_backward_against_autograd(O, cuda):
+    from facodec_amd import autograd as A
+    g = _g(41)
+    x = torch.randn(3, 1024, 50, generator=g, requires_grad=True)
+    style = torch.randn(3, 2048, generator=g, requires_grad=True)
+    gamma, beta = style[:, :1024, None], style[:, 1024:, None]
+    y = torch.nn.functional.layer_norm(x.transpose(1, 2), (1024,), eps=1e-5).transpose(1, 2) * gamma + beta
+    r = torch.randn(3, 1024, 50, generator=g)
+    (y * r).sum().backward()
+    xg, sg = x.detach().to(cuda).requires_grad_(), style.detach().to(cuda).requires_grad_()
+    out = A.layernorm_affine(xg, sg)
+    assert rel(out, y) < OP_TOL
+    (out * r.to(cuda)).sum().backward()
+    assert rel(xg.grad, x.grad) < BWD_TOL and rel(sg.grad, style.grad) < BWD_TOL
