@@ -74,6 +74,8 @@ SIGNATURES = {
     "fac_vq_codebook_grad": (_i, [_p, _p, _p, _i64, _p, _p, _i, _i, _i, _i, _p]),
     "fac_layernorm_c_affine_bwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
     "fac_rows_fma": (_i, [_p, _p, _p, _p, _i, _i64, _f, _p]),
+    "fac_grad_norm_clip": (_i, [_p, _i64, _f, _p, _p, _p]),
+    "fac_adamw_step": (_i, [_p, _p, _p, _p, _i64, _f, _f, _f, _f, _f, _i64, _p, _p]),
     "fac_stream_push": (_i, [_p, _p, _i64, _i64, _i, _i, _i, _p]),
     "fac_vq_fwd": (_i, [C.POINTER(VqDesc), _p]),
     "fac_vq_search": (_i, [_p, _p, _p, _i64, _i, _p]),

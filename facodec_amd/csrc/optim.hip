@@ -1,0 +1,81 @@
+// Optimiser step of the training path on flat parameter / gradient arenas (reference: optimizers.py:72-108 builds one
+// torch AdamW(lr, betas (0.9, 0.98), eps 1e-9, weight_decay 0.1) + ExponentialLR per model key; train.py:362-374 clips
+// each key's gradient norm to 1000 and steps).  One launch per key instead of ~10 ATen kernels per tensor.
+#include "common.h"
+#include "../../include/facodec_hip.h"
+
+namespace fac {
+
+constexpr int SUMSQ_BLOCKS = 1024;
+
+__global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* __restrict__ g, long long n, float* __restrict__ part) {
+  __shared__ float red[256];
+  float s = 0.f;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) s = fmaf(g[i], g[i], s);
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) part[blockIdx.x] = red[0];
+}
+
+// norm_out[0] = ||g||, norm_out[1] = clip coefficient min(1, max_norm / (norm + 1e-6))  (torch clip_grad_norm_)
+__global__ __launch_bounds__(256) void sumsq_final_kernel(const float* __restrict__ part, int n_part, float max_norm,
+                                                          float* __restrict__ norm_out) {
+  __shared__ float red[256];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n_part; i += 256) s += part[i];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const float nrm = sqrtf(red[0]);
+    norm_out[0] = nrm;
+    const float c = max_norm / (nrm + 1e-6f);
+    norm_out[1] = c < 1.f ? c : 1.f;
+  }
+}
+
+// torch.optim.AdamW (decoupled weight decay): p *= 1 - lr*wd; m, v EMAs; p -= lr/bc1 * m / (sqrt(v)/sqrt(bc2) + eps)
+__global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                             long long n, float lr, float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt,
+                             const float* __restrict__ clip) {
+  const float gs = clip ? clip[1] : 1.f;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const float gi = g[i] * gs;
+    float pi = p[i] * (1.f - lr * wd);
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    pi -= (lr / bc1) * mi / (sqrtf(vi) / bc2_sqrt + eps);
+    p[i] = pi;
+  }
+}
+
+}  // namespace fac
+
+extern "C" int fac_grad_norm_clip(const float* g, int64_t n, float max_norm, float* scratch, float* norm_out, fac_stream_t stream) {
+  using namespace fac;
+  FAC_REQUIRE(g && scratch && norm_out && n > 0, "grad_norm_clip: bad arguments");
+  hipLaunchKernelGGL(sumsq_partial_kernel, dim3(SUMSQ_BLOCKS), dim3(256), 0, (hipStream_t)stream, g, (long long)n, scratch);
+  hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, scratch, SUMSQ_BLOCKS, max_norm, norm_out);
+  return check_launch("grad_norm_clip");
+}
+
+extern "C" int fac_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                              float eps, float weight_decay, int64_t step, const float* clip, fac_stream_t stream) {
+  using namespace fac;
+  FAC_REQUIRE(p && g && m && v && n > 0 && step >= 1, "adamw_step: bad arguments");
+  const float bc1 = 1.f - powf(beta1, (float)step);
+  const float bc2_sqrt = sqrtf(1.f - powf(beta2, (float)step));
+  const int blocks = (int)((n + 255) / 256 < 65535 ? (n + 255) / 256 : 65535);
+  hipLaunchKernelGGL(adamw_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (long long)n, lr, beta1, beta2,
+                     eps, weight_decay, bc1, bc2_sqrt, clip);
+  return check_launch("adamw_step");
+}

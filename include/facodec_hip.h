@@ -203,6 +203,13 @@ int fac_layernorm_c_affine_bwd(const float* x, const float* style, const float* 
 /* out[b][i] = a[b][i] * w[b] + sign * c[b][i] over B rows of `per` elements (w and c may be NULL). */
 int fac_rows_fma(const float* a, const float* w, const float* c, float* out, int B, int64_t per, float sign,
                  fac_stream_t stream);
+/* Optimiser step on flat arenas (optimizers.py:72-108, train.py:362-374).  fac_grad_norm_clip: norm_out[0] = ||g||_2,
+ * norm_out[1] = min(1, max_norm / (norm + 1e-6)) (torch clip_grad_norm_), scratch: 1024 floats.  fac_adamw_step: torch
+ * AdamW with decoupled weight decay and bias correction for `step` (1-based); clip: norm_out of the call above (the
+ * gradient is scaled by clip[1]) or NULL. */
+int fac_grad_norm_clip(const float* g, int64_t n, float max_norm, float* scratch, float* norm_out, fac_stream_t stream);
+int fac_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                   float weight_decay, int64_t step, const float* clip, fac_stream_t stream);
 /* Left-context buffer of a streaming causal conv: every row of buf (rows x cap) holds
  * [hist columns of history | n_prev columns appended last time]; moves the last `hist` columns to the
  * front (skipped when n_prev == 0) and appends src (rows x n_new, dense) behind them.  hist <= 2048. */

@@ -862,3 +862,27 @@ def test_layernorm_affine_backward_against_autograd(O, cuda):
     assert rel(out, y) < OP_TOL
     (out * r.to(cuda)).sum().backward()
     assert rel(xg.grad, x.grad) < BWD_TOL and rel(sg.grad, style.grad) < BWD_TOL
+
+
+def test_flat_adamw_matches_torch(cuda):
+    """Fused arena AdamW + clip + ExponentialLR against torch.optim.AdamW / clip_grad_norm_ / ExponentialLR on CPU."""
+    from facodec_amd.optim import FlatAdamW
+    g = _g(77)
+    shapes = [(64, 32, 7), (64, 1, 1), (64,), (1, 96, 1), (300, 17)]
+    ref = [torch.randn(*s, generator=g).requires_grad_() for s in shapes]
+    ours = [r.detach().clone().to(cuda).requires_grad_() for r in ref]
+    opt_ref = torch.optim.AdamW(ref, lr=1e-3, betas=(0.9, 0.98), eps=1e-9, weight_decay=0.1)
+    sch = torch.optim.lr_scheduler.ExponentialLR(opt_ref, gamma=0.99)
+    opt = FlatAdamW(ours, lr=1e-3, gamma=0.99, max_norm=2.0)
+    for it in range(4):
+        grads = [torch.randn(*s, generator=g) * (3.0 if it % 2 else 0.01) for s in shapes]
+        for r, o, gr in zip(ref, ours, grads):
+            r.grad = gr.clone()
+            o.grad = gr.to(cuda)
+        nrm = torch.nn.utils.clip_grad_norm_(ref, 2.0)
+        opt_ref.step()
+        sch.step()
+        opt.step()
+        assert abs(float(opt.grad_norm()) - float(nrm)) / float(nrm) < 1e-5
+    for r, o in zip(ref, ours):
+        assert rel(o, r) < 1e-5
