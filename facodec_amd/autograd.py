@@ -292,3 +292,54 @@ def rvq(m, z, mask=None):
                  q.out_proj.weight_v, q.out_proj.weight_g, q.out_proj.bias]
     z_q, commit, cbl = _RVQ.apply(z, mask, codes, *flat)
     return z_q, codes, commit, cbl
+
+
+class _SubDetached(Function):
+    """x - a - b where a and b are treated as constants (modules/quantize.py:411: x - z_p.detach() - z_c.detach())."""
+
+    @staticmethod
+    def forward(ctx, x, a, b):
+        return ops.sub2(x.detach(), a.detach(), b.detach())
+
+    @staticmethod
+    def backward(ctx, d):
+        return d, None, None
+
+
+class _MixOuts(Function):
+    """outs = z_p.detach() + z_c.detach() + z_r * res_mask[b]  (modules/quantize.py:402-435): only z_r carries gradient."""
+
+    @staticmethod
+    def forward(ctx, z_p, z_c, z_r, res_mask):
+        ctx.save_for_backward(res_mask)
+        return ops.add(ops.add(z_p.detach(), z_c.detach()), ops.rows_fma(z_r.detach(), res_mask))
+
+    @staticmethod
+    def backward(ctx, d):
+        (res_mask,) = ctx.saved_tensors
+        return None, None, ops.rows_fma(d.contiguous(), res_mask), None
+
+
+def sub_detached(x, a, b):
+    return _SubDetached.apply(x, a, b)
+
+
+def mix_outs(z_p, z_c, z_r, res_mask):
+    return _MixOuts.apply(z_p, z_c, z_r, res_mask)
+
+
+def linear(m, x):
+    """_Linear module (weight (out, in), bias) with autograd, as a 1x1 conv on the (B, C, 1) view."""
+    y = _Conv.apply(x.reshape(x.shape[0], x.shape[1], 1), m.weight.unsqueeze(-1), None, m.bias,
+                    (1, 1, 1, ops.PAD_ZERO, True, ops.ACT_NONE))
+    return y.reshape(x.shape[0], -1)
+
+
+def draw_quantizer_masks(n_codebooks, batch, dropout=0.5, generator=None):
+    """The per-sample quantizer-dropout masks of ResidualVectorQuantize.forward in training mode
+    (dac/nn/quantize.py:163-168, 181-183) as a (n, B) float tensor."""
+    nq = torch.ones(batch) * n_codebooks + 1
+    drop = torch.randint(1, n_codebooks + 1, (batch,), generator=generator)
+    n_drop = int(batch * dropout)
+    nq[:n_drop] = drop[:n_drop].to(nq.dtype)
+    return torch.stack([(torch.full((batch,), float(i)) < nq).to(torch.float32) for i in range(n_codebooks)])

@@ -297,9 +297,63 @@ class FAquantizer(nn.Module):
     def preprocess(self, wave_tensor, n_bins=20):
         return self.to_mel(wave_tensor)[:, :n_bins]
 
-    def forward(self, x, wave_segments, n_c=1, n_t=2, full_waves=None, wave_lens=None, return_codes=False):
+    prob_random_mask_residual = 0.75     # modules/quantize.py:217
+
+    def _forward_train(self, x, wave_segments, full_waves, wave_lens, return_codes, masks=None):
+        """forward_v2 in training mode (modules/quantize.py:375-454) with HIP forward + backward.
+        Gradient coverage this round: the three RVQs (straight-through, commitment / codebook losses, quantizer
+        dropout), the residual path into the encoder latent, LayerNorm + timbre_linear.  The timbre encoder and the
+        prosody WaveNet run forward-only (their attention / gate backward kernels are the next step), so their
+        parameters receive no gradient yet; WaveNet dropout (p = 0.2) is likewise not applied.
+        masks: optional dict(p=, c=, r= (n, B) quantizer-dropout masks, res= (B,) residual mask) for reproducible
+        steps; drawn like the reference otherwise (torch.randint / np.random.choice)."""
+        from . import autograd as A
+        import numpy as np
+        B = x.shape[0]
+        dev = x.device
+        with torch.no_grad():
+            mel = self.to_mel(wave_segments)
+            if full_waves is None:
+                timbre = self.timbre_encoder(mel, None)
+            else:
+                mel_full = self.to_mel(full_waves)
+                m = sequence_mask(wave_lens // self.hop_length, mel_full.shape[-1]).to(torch.float32).contiguous()
+                timbre = self.timbre_encoder(mel_full, m)
+            f0 = ops.conv1d(mel[:, :20], self.melspec_linear.w.packed(), 256, 1, bias=self.melspec_linear.w.bias,
+                            pad_left=0, pad_mode=ops.PAD_ZERO, t_out=mel.shape[-1])
+            f0 = self.melspec_linear2.run(self.melspec_encoder(f0))
+        n = min(f0.shape[2], x.shape[2])
+        if f0.shape[2] != n:
+            f0 = f0[:, :, :n].contiguous()
+        if x.shape[2] != n:
+            x = x[:, :, :n].contiguous()
+        masks = masks or {}
+
+        def qmask(key, rvq):
+            mk = masks.get(key)
+            if mk is None:
+                mk = A.draw_quantizer_masks(rvq.n_codebooks, B, rvq.quantizer_dropout)
+            return mk.to(dev)
+
+        z_p, codes_p, cm_p, cb_p = A.rvq(self.prosody_quantizer, f0, qmask("p", self.prosody_quantizer))
+        z_c, codes_c, cm_c, cb_c = A.rvq(self.content_quantizer, x, qmask("c", self.content_quantizer))
+        z_r, codes_r, cm_r, cb_r = A.rvq(self.residual_quantizer, A.sub_detached(x, z_p, z_c), qmask("r", self.residual_quantizer))
+        res = masks.get("res")
+        if res is None:
+            res = torch.from_numpy(np.random.choice([0, 1], size=B, p=[self.prob_random_mask_residual,
+                                                                       1 - self.prob_random_mask_residual]))
+        res = res.to(device=dev, dtype=torch.float32).contiguous()
+        outs = A.mix_outs(z_p, z_c, z_r, res)
+        outs = A.layernorm_affine(outs, A.linear(self.timbre_linear, timbre))
+        quantized = [z_p, z_c, z_r]
+        commitment, codebook = cm_p + cm_c + cm_r, cb_p + cb_c + cb_r
+        if return_codes:
+            return outs, quantized, commitment, codebook, timbre, [codes_p, codes_c, codes_r]
+        return outs, quantized, commitment, codebook, timbre
+
+    def forward(self, x, wave_segments, n_c=1, n_t=2, full_waves=None, wave_lens=None, return_codes=False, masks=None):
         if self.training:
-            raise NotImplementedError("train-mode forward (residual mask / dropout / backward) is not built yet")
+            return self._forward_train(x, wave_segments, full_waves, wave_lens, return_codes, masks)
         mel = self.to_mel(wave_segments)                      # (B, 80, F) computed once
         if full_waves is None:
             timbre = self.timbre_encoder(mel, None)

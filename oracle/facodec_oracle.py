@@ -471,6 +471,32 @@ def quantizer_forward(sd, z, wave, n_c=2, full_waves=None, wave_lens=None, hop=3
     return outs, [z_p, z_c, z_r], cm_p + cm_c + cm_r, cb_p + cb_c + cb_r, timbre, [codes_p, codes_c, codes_r]
 
 
+def quantizer_forward_train(sd, z, wave, masks, side_branches_no_grad=True):
+    """FAquantizer.forward_v2 in training mode (modules/quantize.py:375-454) with its detach placements (:402-411),
+    the quantizer-dropout masks (dac/nn/quantize.py:163-183) and the residual mask (:419-435) given explicitly.
+    side_branches_no_grad mirrors the product's current gradient coverage (timbre encoder and prosody WaveNet run
+    forward-only); WaveNet dropout is not applied on either side."""
+    ctx = torch.no_grad() if side_branches_no_grad else torch.enable_grad()
+    with ctx:
+        mel = logmel_frontend(wave, 80)
+        timbre = style_encoder_forward(mel, sd, "timbre_encoder.")
+        f0 = logmel_frontend(wave, 20)
+        f0 = sconv1d(f0, sd["melspec_linear.conv.conv.weight"], sd["melspec_linear.conv.conv.bias"])
+        f0 = wavenet_forward(f0, sd, "melspec_encoder.", hidden=256, n_layers=8)
+        f0 = sconv1d(f0, sd["melspec_linear2.conv.conv.weight"], sd["melspec_linear2.conv.conv.bias"])
+    n = min(f0.shape[2], z.shape[2])
+    f0, x = f0[:, :, :n], z[:, :, :n]
+    z_p, codes_p, cm_p, cb_p = rvq_forward_train(f0, sd, "prosody_quantizer.", 1, masks["p"])
+    z_c, codes_c, cm_c, cb_c = rvq_forward_train(x, sd, "content_quantizer.", _count(sd, "content_quantizer."), masks["c"])
+    z_r, codes_r, cm_r, cb_r = rvq_forward_train(x - z_p.detach() - z_c.detach(), sd, "residual_quantizer.", 3, masks["r"])
+    outs = z_p.detach() + z_c.detach() + z_r * masks["res"].to(z.dtype)[:, None, None]
+    style = F.linear(timbre, sd["timbre_linear.weight"], sd["timbre_linear.bias"]).unsqueeze(2)
+    gamma, beta = style.chunk(2, 1)
+    outs = F.layer_norm(outs.transpose(1, 2), (outs.shape[1],)).transpose(1, 2)
+    outs = outs * gamma + beta
+    return outs, [z_p, z_c, z_r], cm_p + cm_c + cm_r, cb_p + cb_c + cb_r, timbre, [codes_p, codes_c, codes_r]
+
+
 def _count(sd, p):
     n = 0
     while f"{p}quantizers.{n}.codebook.weight" in sd:

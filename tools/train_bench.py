@@ -1,0 +1,56 @@
+#!/usr/bin/env python
+"""Generator training step timing (BASELINE.json configs[2] shape: batch 16 x 2 s per GPU; generator half only --
+see facodec_amd/train.py for what the step covers this round).
+
+    python tools/train_bench.py [--batch 16] [--steps 3]
+    python -m torch.distributed.run --nproc-per-node N tools/train_bench.py   (one rank per GPU, RCCL all-reduce)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from facodec_amd import benchutil, synth  # noqa: E402
+from facodec_amd.commons import build_model, default_model_params  # noqa: E402
+from facodec_amd.train import GeneratorStep  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=16)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    a = ap.parse_args()
+    rank, local_rank, world = benchutil.init_distributed()
+    dev = torch.device(f"cuda:{local_rank % torch.cuda.device_count()}")
+    torch.cuda.set_device(dev)
+    model = build_model(default_model_params())
+    for k in ("encoder", "quantizer", "decoder"):
+        synth.load_synthetic(model[k], seed=0, prefix=k + ".")
+        model[k].to(dev)
+    step = GeneratorStep(model)
+    wave = synth.synth_clips(a.batch, 48000, seed=0, rank=rank).to(dev)
+    for _ in range(a.warmup):
+        out = step(wave)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        out = step(wave)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / a.steps
+    if rank == 0:
+        print(json.dumps({"metric": "generator training step (encoder + RVQs + decoder fwd/bwd, mel + VQ losses, AdamW)",
+                          "batch_per_gpu": a.batch, "n_gpus": world, "ms_per_step": round(1e3 * dt, 1),
+                          "audio_s_per_s": round(world * a.batch * 2.0 / dt, 2), "loss": float(out["loss"]),
+                          "mel": float(out["mel"]), "grad_norm": {k: float(v) for k, v in out["grad_norm"].items()},
+                          "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)}))
+    if torch.distributed.is_initialized():
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
