@@ -65,3 +65,44 @@ def test_shard_clips_edge_cases():
     assert [shard_clips(5, 8, r) for r in range(8)] == [(0, 1), (1, 2), (2, 3), (3, 4), (4, 5), (5, 5), (5, 5), (5, 5)]
     assert shard_clips(0, 2, 1) == (0, 0)
     assert [shard_clips(64, 2, r) for r in range(2)] == [(0, 32), (32, 64)]
+
+
+def _grad_worker(rank, world, port, q):
+    sys.path.insert(0, REPO)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from facodec_amd import benchutil
+    from facodec_amd.optim import FlatAdamW
+    benchutil.init_distributed("gloo")
+    torch.manual_seed(0)
+    params = [torch.nn.Parameter(torch.randn(5, 3)), torch.nn.Parameter(torch.randn(7)), torch.nn.Parameter(torch.randn(2, 2))]
+    opt = FlatAdamW(params)
+    assert params[0].data.data_ptr() == opt.p.data_ptr()          # parameters live in the arena
+    params[0].grad = torch.full((5, 3), float(rank + 1))
+    params[1].grad = torch.arange(7, dtype=torch.float32) * (rank + 1)
+    # params[2] has no gradient on any rank: counts as zeros
+    opt.gather_grads()
+    opt.all_reduce_mean()                                           # ONE collective over the whole arena
+    q.put((rank, opt.g.clone()))
+    torch.distributed.destroy_process_group()
+
+
+def test_two_rank_gradient_arena_all_reduce():
+    """Data-parallel exchange of the training step (facodec_amd/optim.py): every rank ends with the mean gradient,
+    one all-reduce per model key, unused parameters as zeros."""
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_grad_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((r, g) for r, g in (q.get(timeout=120) for _ in range(world)))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    g0, g1 = res[0][1], res[1][1]
+    assert torch.equal(g0, g1)
+    assert torch.allclose(g0[:15], torch.full((15,), 1.5))
+    assert torch.allclose(g0[15:22], torch.arange(7, dtype=torch.float32) * 1.5)
+    assert torch.equal(g0[22:], torch.zeros(4))
