@@ -76,6 +76,16 @@ SIGNATURES = {
     "fac_rows_fma": (_i, [_p, _p, _p, _p, _i, _i64, _f, _p]),
     "fac_grad_norm_clip": (_i, [_p, _i64, _f, _p, _p, _p]),
     "fac_adamw_step": (_i, [_p, _p, _p, _p, _i64, _f, _f, _f, _f, _f, _i64, _p, _p]),
+    "fac_gate_bwd": (_i, [_p, _p, _p, _i, _i, _i, _p]),
+    "fac_mish_fwd": (_i, [_p, _p, _i64, _p]),
+    "fac_mish_bwd": (_i, [_p, _p, _p, _i64, _p]),
+    "fac_glu_bwd": (_i, [_p, _p, _p, _i, _i, _i, _p]),
+    "fac_mul_scaled": (_i, [_p, _p, _p, _f, _i64, _p]),
+    "fac_masked_mean_bwd": (_i, [_p, _p, _p, _i, _i, _i, _p]),
+    "fac_attention_probs": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p]),
+    "fac_attention_pv": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
+    "fac_attention_bwd_pv": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
+    "fac_attention_bwd_qk": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "fac_stream_push": (_i, [_p, _p, _i64, _i64, _i, _i, _i, _p]),
     "fac_vq_fwd": (_i, [C.POINTER(VqDesc), _p]),
     "fac_vq_search": (_i, [_p, _p, _p, _i64, _i, _p]),

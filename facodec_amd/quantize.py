@@ -301,27 +301,26 @@ class FAquantizer(nn.Module):
 
     def _forward_train(self, x, wave_segments, full_waves, wave_lens, return_codes, masks=None):
         """forward_v2 in training mode (modules/quantize.py:375-454) with HIP forward + backward.
-        Gradient coverage this round: the three RVQs (straight-through, commitment / codebook losses, quantizer
-        dropout), the residual path into the encoder latent, LayerNorm + timbre_linear.  The timbre encoder and the
-        prosody WaveNet run forward-only (their attention / gate backward kernels are the next step), so their
-        parameters receive no gradient yet; WaveNet dropout (p = 0.2) is likewise not applied.
-        masks: optional dict(p=, c=, r= (n, B) quantizer-dropout masks, res= (B,) residual mask) for reproducible
-        steps; drawn like the reference otherwise (torch.randint / np.random.choice)."""
+        Every branch carries gradient: the three RVQs (straight-through, commitment / codebook losses, quantizer
+        dropout), the residual path into the encoder latent, LayerNorm + timbre_linear, the timbre encoder
+        (Mish / GLU / attention / masked mean, dropout 0.1) and the prosody WaveNet (gates, dropout 0.2).
+        masks: optional dict(p=, c=, r= (n, B) quantizer-dropout masks, res= (B,) residual mask, dropout=False to
+        switch the Bernoulli dropouts off) for reproducible steps; drawn like the reference otherwise."""
         from . import autograd as A
+        from . import autograd_quant as AQ
         import numpy as np
         B = x.shape[0]
         dev = x.device
-        with torch.no_grad():
-            mel = self.to_mel(wave_segments)
-            if full_waves is None:
-                timbre = self.timbre_encoder(mel, None)
-            else:
-                mel_full = self.to_mel(full_waves)
-                m = sequence_mask(wave_lens // self.hop_length, mel_full.shape[-1]).to(torch.float32).contiguous()
-                timbre = self.timbre_encoder(mel_full, m)
-            f0 = ops.conv1d(mel[:, :20], self.melspec_linear.w.packed(), 256, 1, bias=self.melspec_linear.w.bias,
-                            pad_left=0, pad_mode=ops.PAD_ZERO, t_out=mel.shape[-1])
-            f0 = self.melspec_linear2.run(self.melspec_encoder(f0))
+        use_drop = bool((masks or {}).get("dropout", True))      # WaveNet p = 0.2, StyleEncoder p = 0.1
+        mel = self.to_mel(wave_segments)                           # constant input features (no gradient)
+        if full_waves is None:
+            timbre = AQ.style_encoder(self.timbre_encoder, mel, None, use_dropout=use_drop)
+        else:
+            mel_full = self.to_mel(full_waves)
+            m = sequence_mask(wave_lens // self.hop_length, mel_full.shape[-1]).to(torch.float32).contiguous()
+            timbre = AQ.style_encoder(self.timbre_encoder, mel_full, m, use_dropout=use_drop)
+        f0 = A.conv(self.melspec_linear, mel[:, :20].contiguous())
+        f0 = A.conv(self.melspec_linear2, AQ.wavenet(self.melspec_encoder, f0, use_dropout=use_drop))
         n = min(f0.shape[2], x.shape[2])
         if f0.shape[2] != n:
             f0 = f0[:, :, :n].contiguous()

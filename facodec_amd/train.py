@@ -4,9 +4,9 @@
     loss = 15 * mel_loss(wave_hat, wave) + 0.25 * commitment + 1.0 * codebook
     backward;  per model key: average gradients across ranks (one all-reduce), clip at 1000, AdamW, ExponentialLR
 
-Not in this round: the discriminator terms (feature matching + adversarial), the predictor heads' losses
-(they need external phoneme / F0 / speaker targets) and the gradients of the timbre encoder / prosody WaveNet (see
-FAquantizer._forward_train).  The step therefore trains encoder, decoder, the three RVQs and timbre_linear."""
+Not in this round: the discriminator terms (feature matching + adversarial) and the predictor heads'
+losses (they need external phoneme / F0 / speaker targets).  Every parameter of encoder, quantizer and decoder that
+the remaining loss reaches is trained."""
 import torch
 
 from . import losses, optim
@@ -20,11 +20,8 @@ class GeneratorStep:
         self.mel = losses.MelSpectrogramLoss(n_mels=[5, 10, 20, 40, 80, 160, 320], window_lengths=[32, 64, 128, 256, 512, 1024, 2048],
                                              mel_fmin=[0] * 7, mel_fmax=[None] * 7, pow=1.0, mag_weight=0.0, clamp_eps=1e-5,
                                              sample_rate=sample_rate)          # train.py:155-163
-        q = model.quantizer
-        q_params = (list(q.prosody_quantizer.parameters()) + list(q.content_quantizer.parameters()) +
-                    list(q.residual_quantizer.parameters()) + list(q.timbre_linear.parameters()))
         self.opt = {"encoder": optim.FlatAdamW(model.encoder.parameters(), lr=lr),
-                    "quantizer": optim.FlatAdamW(q_params, lr=lr),
+                    "quantizer": optim.FlatAdamW(model.quantizer.parameters(), lr=lr),
                     "decoder": optim.FlatAdamW(model.decoder.parameters(), lr=lr)}
 
     def forward_backward(self, wave, masks=None):

@@ -210,6 +210,23 @@ int fac_rows_fma(const float* a, const float* w, const float* c, float* out, int
 int fac_grad_norm_clip(const float* g, int64_t n, float max_norm, float* scratch, float* norm_out, fac_stream_t stream);
 int fac_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
                    float weight_decay, int64_t step, const float* clip, fac_stream_t stream);
+/* Training path of the FA-quantizer's side branches (modules/wavenet.py gate, modules/style_encoder.py Mish / GLU /
+ * masked mean, modules/attentions.py attention): elementwise backward kernels, and attention with the probability
+ * matrix P (B, H, T, T) kept in HBM so that dropout on it and the softmax backward are row kernels.
+ * q, k, v, o are (B, H*dk, T); mask (B, T) float 0/1 or NULL. */
+int fac_gate_bwd(const float* a, const float* d, float* da, int B, int C, int T, fac_stream_t stream);
+int fac_mish_fwd(const float* x, float* y, int64_t n, fac_stream_t stream);
+int fac_mish_bwd(const float* x, const float* d, float* dx, int64_t n, fac_stream_t stream);
+int fac_glu_bwd(const float* a, const float* d, float* da, int B, int C, int T, fac_stream_t stream);
+int fac_mul_scaled(const float* a, const float* b, float* out, float scale, int64_t n, fac_stream_t stream);
+int fac_masked_mean_bwd(const float* dout, const float* mask, float* dx, int B, int C, int T, fac_stream_t stream);
+int fac_attention_probs(const float* q, const float* k, const float* mask, float* P, int B, int H, int dk, int T,
+                        fac_stream_t stream);
+int fac_attention_pv(const float* P, const float* v, float* o, int B, int H, int dk, int T, fac_stream_t stream);
+int fac_attention_bwd_pv(const float* P_used, const float* v, const float* dO, float* dv, float* dP, int B, int H, int dk,
+                         int T, fac_stream_t stream);
+int fac_attention_bwd_qk(const float* P, float* dP, const float* q, const float* k, const float* mask, float* dq, float* dk_,
+                         int B, int H, int dk, int T, fac_stream_t stream);
 /* Left-context buffer of a streaming causal conv: every row of buf (rows x cap) holds
  * [hist columns of history | n_prev columns appended last time]; moves the last `hist` columns to the
  * front (skipped when n_prev == 0) and appends src (rows x n_new, dense) behind them.  hist <= 2048. */
