@@ -176,24 +176,29 @@ __global__ __launch_bounds__(256) void weight_norm_bwd_kernel(const float* __res
 }
 
 // y = x + sin^2(a x)/(a + 1e-9):  dy/dx = 1 + a sin(2 a x)/(a + 1e-9);  dy/da = (x sin(2 a x)(a+eps) - sin^2(a x))/(a+eps)^2
-// One workgroup per channel (deterministic tree for d alpha).
+// grid (C, NS): workgroup (c, s) covers a slice of the (b, t) positions of channel c and leaves one partial sum of
+// d alpha; channel_reduce_kernel adds the NS partials in order (deterministic).  Same scheme for the bias gradient.
+constexpr int RED_NS = 32;
+
 __global__ __launch_bounds__(256) void snake_bwd_kernel(const float* __restrict__ x, const float* __restrict__ alpha,
                                                         const float* __restrict__ dy, float* __restrict__ dx,
-                                                        float* __restrict__ dalpha, int B, int C, int T) {
+                                                        float* __restrict__ part, int B, int C, int T) {
   __shared__ float red[256];
-  const int c = blockIdx.x, tid = threadIdx.x;
+  const int c = blockIdx.x, sl = blockIdx.y, tid = threadIdx.x;
   const float al = alpha[c], ae = al + 1e-9f;
+  const long long n = (long long)B * T;
+  const long long per = (n + RED_NS - 1) / RED_NS;
+  const long long lo = sl * per, hi = lo + per < n ? lo + per : n;
   float s = 0.f;
-  for (int b = 0; b < B; ++b) {
-    const long long base = ((long long)b * C + c) * T;
-    for (int t = tid; t < T; t += 256) {
-      const float xv = x[base + t], g = dy[base + t];
-      const float ax = al * xv;
-      const float sn = sinf(ax), cs = cosf(ax);
-      const float s2 = 2.f * sn * cs;
-      dx[base + t] = g * (1.f + al * s2 / ae);
-      s += g * (xv * s2 * ae - sn * sn) / (ae * ae);
-    }
+  for (long long p = lo + tid; p < hi; p += 256) {
+    const long long b = p / T, t = p - b * T;
+    const long long o = (b * C + c) * T + t;
+    const float xv = x[o], g = dy[o];
+    const float ax = al * xv;
+    const float sn = sinf(ax), cs = cosf(ax);
+    const float s2 = 2.f * sn * cs;
+    dx[o] = g * (1.f + al * s2 / ae);
+    s += g * (xv * s2 * ae - sn * sn) / (ae * ae);
   }
   red[tid] = s;
   __syncthreads();
@@ -201,16 +206,19 @@ __global__ __launch_bounds__(256) void snake_bwd_kernel(const float* __restrict_
     if (tid < o) red[tid] += red[tid + o];
     __syncthreads();
   }
-  if (tid == 0 && dalpha) dalpha[c] = red[0];
+  if (tid == 0) part[c * RED_NS + sl] = red[0];
 }
 
-__global__ __launch_bounds__(256) void bias_grad_kernel(const float* __restrict__ dy, float* __restrict__ db, int B, int C, int T) {
+__global__ __launch_bounds__(256) void bias_grad_kernel(const float* __restrict__ dy, float* __restrict__ part, int B, int C, int T) {
   __shared__ float red[256];
-  const int c = blockIdx.x, tid = threadIdx.x;
+  const int c = blockIdx.x, sl = blockIdx.y, tid = threadIdx.x;
+  const long long n = (long long)B * T;
+  const long long per = (n + RED_NS - 1) / RED_NS;
+  const long long lo = sl * per, hi = lo + per < n ? lo + per : n;
   float s = 0.f;
-  for (int b = 0; b < B; ++b) {
-    const float* p = dy + ((long long)b * C + c) * T;
-    for (int t = tid; t < T; t += 256) s += p[t];
+  for (long long p = lo + tid; p < hi; p += 256) {
+    const long long b = p / T, t = p - b * T;
+    s += dy[(b * C + c) * T + t];
   }
   red[tid] = s;
   __syncthreads();
@@ -218,7 +226,15 @@ __global__ __launch_bounds__(256) void bias_grad_kernel(const float* __restrict_
     if (tid < o) red[tid] += red[tid + o];
     __syncthreads();
   }
-  if (tid == 0) db[c] = red[0];
+  if (tid == 0) part[c * RED_NS + sl] = red[0];
+}
+
+__global__ void channel_reduce_kernel(const float* __restrict__ part, float* __restrict__ out, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float s = 0.f;
+  for (int i = 0; i < RED_NS; ++i) s += part[c * RED_NS + i];
+  out[c] = s;
 }
 
 static int wgrad_geometry(int B, int C_in, int C_out, int T_out, int K, int* cit, int* splits, int* n_tt, int* per) {
@@ -227,9 +243,13 @@ static int wgrad_geometry(int B, int C_in, int C_out, int T_out, int K, int* cit
   *n_tt = (T_out + WG_TT - 1) / WG_TT;
   const long long tiles = (long long)B * *n_tt;
   const long long wgs = (long long)((C_out + 63) / 64) * ((C_in + *cit - 1) / *cit);
+  // few-channel layers have only a handful of (co, ci) tiles: split their long (b, t) range across many more
+  // workgroups (the partial buffers stay small exactly there); bounded by 512 MB of partials
   long long S = (2048 + wgs - 1) / wgs;
   if (S > tiles) S = tiles;
-  if (S > 64) S = 64;
+  if (S > 1024) S = 1024;
+  const long long per_split_bytes = (long long)C_out * C_in * K * 4;
+  if (S * per_split_bytes > (512ll << 20)) S = (512ll << 20) / per_split_bytes;
   if (S < 1) S = 1;
   *per = (int)((tiles + S - 1) / S);
   *splits = (int)((tiles + *per - 1) / *per);
@@ -315,17 +335,21 @@ extern "C" int fac_weight_norm_bwd(const float* v, const float* g, const float* 
   return fac::check_launch("weight_norm_bwd");
 }
 
-extern "C" int fac_snake_bwd(const float* x, const float* alpha, const float* dy, float* dx, float* dalpha, int B, int C,
-                             int T, fac_stream_t stream) {
-  FAC_REQUIRE(x && alpha && dy && dx && B > 0 && C > 0 && T > 0, "snake_bwd: bad arguments");
-  hipLaunchKernelGGL(fac::snake_bwd_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, x, alpha, dy, dx, dalpha, B, C, T);
-  return fac::check_launch("snake_bwd");
+extern "C" int fac_snake_bwd(const float* x, const float* alpha, const float* dy, float* dx, float* dalpha, float* scratch,
+                             int B, int C, int T, fac_stream_t stream) {
+  using namespace fac;
+  FAC_REQUIRE(x && alpha && dy && dx && dalpha && scratch && B > 0 && C > 0 && T > 0, "snake_bwd: bad arguments");
+  hipLaunchKernelGGL(snake_bwd_kernel, dim3(C, RED_NS), dim3(256), 0, (hipStream_t)stream, x, alpha, dy, dx, scratch, B, C, T);
+  hipLaunchKernelGGL(channel_reduce_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, scratch, dalpha, C);
+  return check_launch("snake_bwd");
 }
 
-extern "C" int fac_bias_grad(const float* dy, float* db, int B, int C, int T, fac_stream_t stream) {
-  FAC_REQUIRE(dy && db && B > 0 && C > 0 && T > 0, "bias_grad: bad arguments");
-  hipLaunchKernelGGL(fac::bias_grad_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, dy, db, B, C, T);
-  return fac::check_launch("bias_grad");
+extern "C" int fac_bias_grad(const float* dy, float* db, float* scratch, int B, int C, int T, fac_stream_t stream) {
+  using namespace fac;
+  FAC_REQUIRE(dy && db && scratch && B > 0 && C > 0 && T > 0, "bias_grad: bad arguments");
+  hipLaunchKernelGGL(bias_grad_kernel, dim3(C, RED_NS), dim3(256), 0, (hipStream_t)stream, dy, scratch, B, C, T);
+  hipLaunchKernelGGL(channel_reduce_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, scratch, db, C);
+  return check_launch("bias_grad");
 }
 
 // ------------------------------------------------------------------------------------------------------------

@@ -538,8 +538,9 @@ def snake_bwd(x, alpha, dy):
     x, dy = _dev(x, "x"), _dev(dy, "dy")
     B, c, t = x.shape
     dx, dalpha = torch.empty_like(x), torch.empty(c, device=x.device, dtype=torch.float32)
-    _lib.check(_lib.load().fac_snake_bwd(_ptr(x), _ptr(alpha), _ptr(dy), _ptr(dx), _ptr(dalpha), B, c, t, _stream()),
-               "fac_snake_bwd")
+    scratch = torch.empty(32 * c, device=x.device, dtype=torch.float32)
+    _lib.check(_lib.load().fac_snake_bwd(_ptr(x), _ptr(alpha), _ptr(dy), _ptr(dx), _ptr(dalpha), _ptr(scratch), B, c, t,
+                                         _stream()), "fac_snake_bwd")
     return dx, dalpha
 
 
@@ -547,7 +548,8 @@ def bias_grad(dy):
     dy = _dev(dy, "dy")
     B, c, t = dy.shape
     db = torch.empty(c, device=dy.device, dtype=torch.float32)
-    _lib.check(_lib.load().fac_bias_grad(_ptr(dy), _ptr(db), B, c, t, _stream()), "fac_bias_grad")
+    scratch = torch.empty(32 * c, device=dy.device, dtype=torch.float32)
+    _lib.check(_lib.load().fac_bias_grad(_ptr(dy), _ptr(db), _ptr(scratch), B, c, t, _stream()), "fac_bias_grad")
     return db
 
 

@@ -257,11 +257,12 @@ int fac_conv1d_bwd_weight(const float* x, const float* dy, float* dw, void* ws, 
 /* w = g*v/||v|| per row (n_rows x row_len): dv, dg from dW. */
 int fac_weight_norm_bwd(const float* v, const float* g, const float* dw, float* dv, float* dg, int n_rows, int row_len,
                         fac_stream_t stream);
-/* y = x + sin^2(alpha x)/(alpha + 1e-9): dx (B,C,T) and dalpha (C) (dalpha may be NULL). */
-int fac_snake_bwd(const float* x, const float* alpha, const float* dy, float* dx, float* dalpha, int B, int C, int T,
-                  fac_stream_t stream);
-/* db[c] = sum over (b, t) of dy. */
-int fac_bias_grad(const float* dy, float* db, int B, int C, int T, fac_stream_t stream);
+/* y = x + sin^2(alpha x)/(alpha + 1e-9): dx (B,C,T) and dalpha (C).  scratch: 32*C floats (partial sums of the
+ * two-stage, fixed-order channel reductions). */
+int fac_snake_bwd(const float* x, const float* alpha, const float* dy, float* dx, float* dalpha, float* scratch, int B, int C,
+                  int T, fac_stream_t stream);
+/* db[c] = sum over (b, t) of dy; scratch: 32*C floats. */
+int fac_bias_grad(const float* dy, float* db, float* scratch, int B, int C, int T, fac_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * K7  factorized VQ step (dac/nn/quantize.py:34-94 VectorQuantize.forward + the residual
