@@ -19,6 +19,11 @@ from torch.autograd import Function
 from . import ops
 
 
+def _split_ok(c_out, c_in, k, stride, x):
+    return (ops.BF16_SPLIT and k == 7 and stride == 1 and c_in % 16 == 0 and c_out % 16 == 0 and c_out > 2
+            and x.shape[0] * x.shape[-1] > 640)
+
+
 def _wn(w):
     """(v, g) of a ConvWeights holder (g None for a plain weight)."""
     return (w.weight_v, w.weight_g) if w.weight_norm else (w.weight, None)
@@ -29,8 +34,12 @@ class _Conv(Function):
     def forward(ctx, x, v, g, bias, cfg):
         k, stride, dilation, pad_mode, causal, act = cfg
         vd, gd = v.detach(), (g.detach() if g is not None else None)
-        y = ops.conv1d(x.detach(), ops.pack_conv_weight(vd, gd), v.shape[0], k, bias=bias.detach() if bias is not None else None,
-                       stride=stride, dilation=dilation, pad_mode=pad_mode, causal=causal, act=act)
+        if _split_ok(v.shape[0], v.shape[1], k, stride, x):       # k = 7 convs: fp32-exact split on the bf16 pipe
+            wp, ws = None, ops.pack_conv_weight_split(vd, gd)
+        else:
+            wp, ws = ops.pack_conv_weight(vd, gd), None
+        y = ops.conv1d(x.detach(), wp, v.shape[0], k, bias=bias.detach() if bias is not None else None,
+                       stride=stride, dilation=dilation, pad_mode=pad_mode, causal=causal, act=act, w_split=ws)
         ctx.cfg = cfg
         ctx.save_for_backward(x, v, g, bias, y if act == ops.ACT_TANH else None)
         return y

@@ -494,7 +494,13 @@ def conv1d_bwd_data(dy, v, g, t_in, stride=1, dilation=1, pad_mode=PAD_REFLECT, 
     pad_left = padding_total if causal else padding_total - padding_total // 2
     pad_right = (padding_total - pad_left) + extra
     tp = pad_left + t_in + pad_right
-    if stride == 1:
+    if stride == 1 and BF16_SPLIT and k == 7 and c_in % 16 == 0 and c_out % 16 == 0 and B * tp > 640:
+        # the flipped / transposed conv on the bf16 pipe too: materialise w = g v/||v||, swap channels, flip taps
+        w = rows_fma(v, wn_scale(v, g)) if g is not None else v
+        wt = w.permute(1, 0, 2).flip(2).contiguous()                       # (C_in, C_out, K) = weights of the bwd conv
+        dxpad = conv1d(dy, None, c_in, k, dilation=dilation, pad_left=(k - 1) * dilation, pad_mode=PAD_ZERO, t_out=tp,
+                       w_split=pack_conv_weight_split(wt))
+    elif stride == 1:
         dxpad = conv1d(dy, pack_conv_weight_bwd(v, g), c_in, k, dilation=dilation, pad_left=(k - 1) * dilation,
                        pad_mode=PAD_ZERO, t_out=tp)
     else:
