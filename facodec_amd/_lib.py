@@ -86,6 +86,7 @@ SIGNATURES = {
     "fac_attention_pv": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
     "fac_attention_bwd_pv": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "fac_attention_bwd_qk": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
+    "fac_aa_snakebeta_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
     "fac_stream_push": (_i, [_p, _p, _i64, _i64, _i, _i, _i, _p]),
     "fac_vq_fwd": (_i, [C.POINTER(VqDesc), _p]),
     "fac_vq_search": (_i, [_p, _p, _p, _i64, _i, _p]),

@@ -143,6 +143,9 @@ class FApredictors(nn.Module):
         return acc if acc is not None else torch.zeros_like(like)
 
     def forward(self, quantized, timbre):
+        if self.training:            # HIP forward + backward (facodec_amd/autograd_pred.py)
+            from . import autograd_pred
+            return autograd_pred.predictors(self, quantized, timbre)
         prosody, content, residual = quantized[0], quantized[1], quantized[2]
         content_pred = self.phone_predictor(content)[0]
         spk_pred = self.timbre_predictor(timbre)

@@ -227,6 +227,10 @@ int fac_attention_bwd_pv(const float* P_used, const float* v, const float* dO, f
                          int T, fac_stream_t stream);
 int fac_attention_bwd_qk(const float* P, float* dP, const float* q, const float* k, const float* mask, float* dq, float* dk_,
                          int B, int H, int dk, int T, fac_stream_t stream);
+/* Backward of fac_aa_snakebeta_fwd: dx (B,C,T), dalpha / dbeta (C) w.r.t. the log-scale parameters;
+ * scratch: 2 * B * C * ceil(T/256) floats. */
+int fac_aa_snakebeta_bwd(const float* x, const float* alpha_log, const float* beta_log, const float* filter12, const float* dy,
+                         float* dx, float* dalpha, float* dbeta, float* scratch, int B, int C, int T, fac_stream_t stream);
 /* Left-context buffer of a streaming causal conv: every row of buf (rows x cap) holds
  * [hist columns of history | n_prev columns appended last time]; moves the last `hist` columns to the
  * front (skipped when n_prev == 0) and appends src (rows x n_new, dense) behind them.  hist <= 2048. */

@@ -976,3 +976,32 @@ def test_style_encoder_and_wavenet_backward_against_autograd(O, cuda):
     assert rel(xg.grad, x.grad) < BWD_TOL
     for n, p in wn.named_parameters():
         assert rel(p.grad, lw[n].grad) < BWD_TOL, n
+
+
+def test_predictor_heads_backward_against_autograd(O, cuda):
+    """A CNNLSTM head (3 anti-aliased-SnakeBeta residual units + Linear heads) in training mode: input and parameter
+    gradients against autograd through the oracle; plus the gradient-reversal sign."""
+    from facodec_amd import autograd_pred as AP
+    from facodec_amd.predictors import CNNLSTM
+    head = CNNLSTM(64, 5, 2)
+    synth.load_synthetic(head, seed=21)
+    params = {n for n, _ in head.named_parameters()}
+    x = torch.randn(2, 64, 300, generator=_g(9), requires_grad=True)
+    leaves = {k: (v.clone().requires_grad_() if k in params else v.clone()) for k, v in head.state_dict().items()}
+    refs = O.cnnlstm_forward(x, leaves, "", 2)
+    rs = [torch.randn(*r.shape, generator=_g(10 + i)) for i, r in enumerate(refs)]
+    sum((r * w).sum() for r, w in zip(refs, rs)).backward()
+    head.to(cuda).train()
+    xg = x.detach().to(cuda).requires_grad_()
+    outs = AP.cnnlstm(head, xg)
+    for o, r in zip(outs, refs):
+        assert rel(o, r) < OP_TOL
+    sum((o * w.to(cuda)).sum() for o, w in zip(outs, rs)).backward()
+    assert rel(xg.grad, x.grad) < BWD_TOL
+    for n, p in head.named_parameters():
+        assert rel(p.grad, leaves[n].grad) < BWD_TOL, n
+    # gradient reversal: identity forward, negated gradient
+    z = torch.randn(2, 8, 5, device=cuda, requires_grad=True)
+    y = AP._GradReverse.apply(z, 1.0)
+    y.sum().backward()
+    assert torch.equal(y.detach(), z.detach()) and torch.allclose(z.grad, -torch.ones_like(z))
