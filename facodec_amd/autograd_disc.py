@@ -1,0 +1,205 @@
+"""Autograd Functions of the discriminator path (dac/model/discriminator.py; train.py:280-312) over the HIP C ABI."""
+import ctypes as C
+
+import torch
+from torch.autograd import Function
+
+from . import _lib, ops
+
+
+def _call(name, *args):
+    _lib.check(getattr(_lib.load(), name)(*args, ops._stream()), name)
+
+
+_p = ops._ptr
+
+
+class PlainConv(Function):
+    """torch-semantics Conv1d (zero padding `pad` both sides, stride) with optional weight-norm gain g (C_out,1,1)."""
+
+    @staticmethod
+    def forward(ctx, x, v, g, bias, k, stride, pad):
+        B, c_in, t_in = x.shape
+        t_out = (t_in + 2 * pad - k) // stride + 1
+        vd, gd = v.detach().contiguous(), (g.detach().contiguous() if g is not None else None)
+        y = ops.conv1d(x.detach(), ops.pack_conv_weight(vd, gd), v.shape[0], k, bias=bias.detach() if bias is not None else None,
+                       stride=stride, pad_left=pad, pad_mode=ops.PAD_ZERO, t_out=t_out)
+        ctx.cfg = (k, stride, pad, t_in, t_out)
+        ctx.save_for_backward(x, v, g, bias)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, v, g, bias = ctx.saved_tensors
+        k, stride, pad, t_in, t_out = ctx.cfg
+        dy = dy.contiguous()
+        B, c_out, _ = dy.shape
+        c_in = v.shape[1]
+        vd, gd = v.detach().contiguous(), (g.detach().contiguous() if g is not None else None)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            up = dy
+            if stride > 1:            # strided conv: zero-insert, then the stride-1 flipped-weight conv
+                tu = (t_out - 1) * stride + 1
+                up = torch.empty(B, c_out, tu, device=dy.device)
+                _call("fac_zero_insert", _p(dy), _p(up), B * c_out, t_out, stride)
+            tp = up.shape[-1] + k - 1
+            dxp = ops.conv1d(up, ops.pack_conv_weight_bwd(vd, gd), c_in, k, pad_left=k - 1, pad_mode=ops.PAD_ZERO, t_out=tp)
+            if tp < pad + t_in:       # trailing inputs no window reads
+                dxp = torch.cat([dxp, torch.zeros(B, c_in, pad + t_in - tp, device=dy.device)], dim=2)
+            dx = dxp[:, :, pad:pad + t_in].contiguous()
+        dw = ops.conv1d_bwd_weight(x.detach(), dy, k, stride=stride, pad_mode=ops.PAD_ZERO, pad_left=pad)
+        if g is not None:
+            dv, dg = ops.weight_norm_bwd(vd, gd, dw)
+        else:
+            dv, dg = dw, None
+        db = ops.bias_grad(dy) if bias is not None else None
+        return dx, dv, dg, db, None, None, None
+
+
+class LeakyReLU(Function):
+    @staticmethod
+    def forward(ctx, x, slope):
+        ctx.save_for_backward(x)
+        ctx.slope = slope
+        y = torch.empty_like(x)
+        _call("fac_leaky_relu", _p(x.detach().contiguous()), _p(None), _p(y), x.numel(), C.c_float(slope))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        dx = torch.empty_like(x)
+        _call("fac_leaky_relu", _p(x.detach().contiguous()), _p(dy.contiguous()), _p(dx), x.numel(), C.c_float(ctx.slope))
+        return dx, None
+
+
+class PeriodFold(Function):
+    """(B, 1, T) -> (B * period, 1, L): MPD.pad_to_period + rearrange (discriminator.py:39-48), period as batch."""
+
+    @staticmethod
+    def forward(ctx, x, period):
+        B, _, T = x.shape
+        L = (T + (period - T % period)) // period
+        out = torch.empty(B * period, 1, L, device=x.device)
+        _call("fac_period_fold", _p(x.detach().contiguous()), _p(out), B, T, period, L, 0)
+        ctx.cfg = (B, T, period, L)
+        return out
+
+    @staticmethod
+    def backward(ctx, d):
+        B, T, period, L = ctx.cfg
+        dx = torch.empty(B, 1, T, device=d.device)
+        _call("fac_period_fold", _p(d.contiguous()), _p(dx), B, T, period, L, 1)
+        return dx, None
+
+
+class RowStack3(Function):
+    """(B*T, C, F) -> (B*T, 3C, F): the three time rows a (3, k) Conv2d reads, stacked into channels."""
+
+    @staticmethod
+    def forward(ctx, x, T):
+        rows, c, f = x.shape
+        out = torch.empty(rows, 3 * c, f, device=x.device)
+        _call("fac_row_stack3", _p(x.detach().contiguous()), _p(out), rows, T, c, f, 0)
+        ctx.cfg = (rows, T, c, f)
+        return out
+
+    @staticmethod
+    def backward(ctx, d):
+        rows, T, c, f = ctx.cfg
+        dx = torch.empty(rows, c, f, device=d.device)
+        _call("fac_row_stack3", _p(d.contiguous()), _p(dx), rows, T, c, f, 1)
+        return dx, None
+
+
+class Spectrogram(Function):
+    """wave (B, T) -> complex STFT with audiotools' match_stride framing (discriminator.py:121-125,150-151) as
+    (B, 2F, frames) = [re | im] rows: reflect pad, plain framing (the centre padding of torch.stft is exactly the two
+    frames dropped at either end when hop = window / 4), windowed-DFT GEMM."""
+
+    @staticmethod
+    def forward(ctx, wave, scale):
+        B, T = wave.shape
+        L, hop = scale.win, scale.hop
+        pad = (L - hop) // 2
+        right = -(-T // hop) * hop - T
+        T1 = T + 2 * pad + right
+        xp = torch.empty(B, T1, device=wave.device)
+        _call("fac_pad_reflect", _p(wave.detach().contiguous()), _p(xp), B, T, pad, pad + right)
+        nf = T1 // hop + 1 - 4
+        frames = ops.stft_frames(xp, L, nf, hop, 0, 0)
+        spec = ops.conv1d(frames, scale.basis, 2 * scale.F, 1, pad_left=0, pad_mode=ops.PAD_ZERO, t_out=nf)
+        ctx.cfg = (scale, B, T, T1, pad, nf)
+        return spec
+
+    @staticmethod
+    def backward(ctx, dspec):
+        scale, B, T, T1, pad, nf = ctx.cfg
+        dfr = ops.conv1d(dspec.contiguous(), scale.basis_bwd, scale.win, 1, pad_left=0, pad_mode=ops.PAD_ZERO, t_out=nf)
+        dxp = ops.stft_frames_bwd(dfr, T1, scale.hop, 0, 0)
+        dx = torch.empty(B, 1, T, device=dspec.device)
+        _lib.check(_lib.load().fac_pad_fold_bwd(_p(dxp), _p(dx), B, 1, T, T1, pad, ops.PAD_REFLECT, ops._stream()), "fac_pad_fold_bwd")
+        return dx.reshape(B, T), None
+
+
+class SpecBand(Function):
+    """One frequency band of the spectrogram as conv rows: (B, 2F, T) -> (B*T, 2, Fb)."""
+
+    @staticmethod
+    def forward(ctx, spec, f0, fb):
+        B, f2, T = spec.shape
+        out = torch.empty(B * T, 2, fb, device=spec.device)
+        _call("fac_spec_to_rows", _p(spec.detach().contiguous()), _p(out), B, f2 // 2, T, f0, fb, 0)
+        ctx.cfg = (B, f2 // 2, T, f0, fb)
+        return out
+
+    @staticmethod
+    def backward(ctx, d):
+        B, Ft, T, f0, fb = ctx.cfg
+        dspec = torch.zeros(B, 2 * Ft, T, device=d.device)
+        _call("fac_spec_to_rows", _p(d.contiguous()), _p(dspec), B, Ft, T, f0, fb, 1)
+        return dspec, None, None
+
+
+class Preprocess(Function):
+    """Discriminator.preprocess (discriminator.py:200-205)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        B, _, T = x.shape
+        xd = x.detach().contiguous()
+        z = torch.empty_like(xd)
+        stats = torch.empty(B * 4, device=x.device)
+        _call("fac_disc_preprocess", _p(xd), _p(None), _p(z), _p(stats), B, T)
+        ctx.save_for_backward(xd, stats)
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        xd, stats = ctx.saved_tensors
+        B, _, T = xd.shape
+        dx = torch.empty_like(xd)
+        _call("fac_disc_preprocess", _p(xd), _p(dz.contiguous()), _p(dx), _p(stats), B, T)
+        return dx
+
+
+class PairMean(Function):
+    """mean over elements of |a - b| (mode 0) or (a - b)^2 (mode 2); gradient to `a` only."""
+
+    @staticmethod
+    def forward(ctx, a, b, mode):
+        ad, bd = a.detach().contiguous(), b.detach().contiguous()
+        out = torch.zeros(1, device=a.device)
+        scratch = torch.empty(1024, device=a.device)
+        ops.reduce_pair(ad, bd, out, scratch, mode, 0.0, 1.0 / ad.numel(), False)
+        ctx.save_for_backward(ad, bd)
+        ctx.mode = mode
+        return out[0].clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        ad, bd = ctx.saved_tensors
+        da = torch.empty_like(ad)
+        ops.pair_bwd(ad, bd, da, ctx.mode, 0.0, 1.0 / ad.numel(), False)
+        return ops.rows_fma(da.reshape(1, -1), g.reshape(1).to(da.dtype)).reshape(ad.shape), None, None

@@ -380,6 +380,8 @@ __global__ void pair_bwd_kernel(const float* __restrict__ a, const float* __rest
     float g;
     if (mode == 0) {
       g = av > bv ? 1.f : (av < bv ? -1.f : 0.f);
+    } else if (mode == 2) {
+      g = 2.f * (av - bv);
     } else {
       const float d = log10f(fmaxf(av, eps)) - log10f(fmaxf(bv, eps));
       const float sgn = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
@@ -744,7 +746,7 @@ extern "C" int fac_aa_snakebeta_fwd(const float* x, const float* alpha_log, cons
 
 extern "C" int fac_pair_bwd(const float* a, const float* b, float* da, int64_t n, int mode, float eps, float scale,
                             int accumulate, fac_stream_t stream) {
-  FAC_REQUIRE(a && b && da && n > 0 && (mode == 0 || mode == 1), "pair_bwd: bad arguments");
+  FAC_REQUIRE(a && b && da && n > 0 && mode >= 0 && mode <= 2, "pair_bwd: bad arguments");
   EW_LAUNCH(pair_bwd_kernel, n, a, b, da, (long long)n, mode, eps, scale, accumulate);
   return check_launch("pair_bwd");
 }

@@ -1,0 +1,223 @@
+// Layout / elementwise kernels of the discriminator path (dac/model/discriminator.py; train.py:280-312).  The
+// discriminators' convolutions themselves run on the 1-D conv kernels: an MPD (k,1) Conv2d is a 1-D conv along the
+// folded time axis with the period as extra batch; an MRD (3,k) Conv2d is a 1-D conv along frequency over the three
+// neighbouring time rows stacked into the channel axis.
+#include "common.h"
+#include "../../include/facodec_hip.h"
+
+namespace fac {
+
+#define GRID_STRIDE(i, n) for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < (n); i += (long long)gridDim.x * blockDim.x)
+static inline int grid_for(long long n) { return (int)((n + 255) / 256 < 65535 ? (n + 255) / 256 : 65535); }
+
+__global__ void leaky_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, float slope, long long n) {
+  GRID_STRIDE(i, n) { const float v = x[i]; y[i] = v > 0.f ? v : v * slope; }
+}
+__global__ void leaky_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dx, float slope, long long n) {
+  GRID_STRIDE(i, n) dx[i] = x[i] > 0.f ? dy[i] : dy[i] * slope;
+}
+
+// out[(b*p + j)][l] = xr[l*p + j], xr = x reflect-extended on the right to L*p samples (MPD.pad_to_period + rearrange)
+__global__ void period_fold_kernel(const float* __restrict__ x, float* __restrict__ out, int T, int p, int L, long long n) {
+  GRID_STRIDE(i, n) {
+    const int l = (int)(i % L);
+    const long long r = i / L;
+    const int j = (int)(r % p);
+    const long long b = r / p;
+    int s = l * p + j;
+    if (s >= T) s = 2 * (T - 1) - s;
+    out[i] = x[b * T + s];
+  }
+}
+__global__ void period_fold_bwd_kernel(const float* __restrict__ dout, float* __restrict__ dx, int T, int p, int L, long long n) {
+  GRID_STRIDE(i, n) {
+    const int s = (int)(i % T);
+    const long long b = i / T;
+    float g = dout[(b * p + s % p) * L + s / p];
+    const int s2 = 2 * (T - 1) - s;            // the reflected copy of sample s, if it lies in the padded tail
+    if (s2 >= T && s2 < L * p) g += dout[(b * p + s2 % p) * L + s2 / p];
+    dx[i] = g;
+  }
+}
+
+// dy (rows, T) -> up (rows, (T-1)*s + 1) with zeros between samples (data gradient of a strided conv as a stride-1 conv)
+__global__ void zero_insert_kernel(const float* __restrict__ dy, float* __restrict__ up, int T, int s, int Tu, long long n) {
+  GRID_STRIDE(i, n) {
+    const int u = (int)(i % Tu);
+    const long long r = i / Tu;
+    up[i] = (u % s == 0) ? dy[r * T + u / s] : 0.f;
+  }
+}
+
+// rows = (b, t) of a (B*T, C, F) tensor: stk[(b,t)][dt*C + c][f] = x[(b, t+dt-1)][c][f] (zero outside 0 <= t+dt-1 < T)
+__global__ void row_stack3_kernel(const float* __restrict__ x, float* __restrict__ stk, int T, int C, int F, long long n) {
+  const long long cf = (long long)C * F;
+  GRID_STRIDE(i, n) {
+    const long long row = i / (3 * cf);
+    const long long r = i - row * 3 * cf;
+    const int dt = (int)(r / cf);
+    const long long rest = r - dt * cf;
+    const int t = (int)(row % T) + dt - 1;
+    stk[i] = (t >= 0 && t < T) ? x[(row + dt - 1) * cf + rest] : 0.f;
+  }
+}
+__global__ void row_stack3_bwd_kernel(const float* __restrict__ dstk, float* __restrict__ dx, int T, int C, int F, long long n) {
+  const long long cf = (long long)C * F;
+  GRID_STRIDE(i, n) {
+    const long long row = i / cf;
+    const long long rest = i - row * cf;
+    const int t = (int)(row % T);
+    float g = 0.f;
+#pragma unroll
+    for (int dt = 0; dt < 3; ++dt) {
+      const int ts = t - dt + 1;               // the stacked row that read x[row] through its tap dt
+      if (ts >= 0 && ts < T) g += dstk[((row - dt + 1) * 3 + dt) * cf + rest];
+    }
+    dx[i] = g;
+  }
+}
+
+// spec (B, 2*Ft, T) = [re | im] rows -> rows[(b*T + t)][c][f] = spec[b][c*Ft + f0 + f][t], f < Fb (one frequency band)
+__global__ void spec_to_rows_kernel(const float* __restrict__ spec, float* __restrict__ rows, int Ft, int T, int f0, int Fb, long long n) {
+  GRID_STRIDE(i, n) {
+    const int f = (int)(i % Fb);
+    const long long r = i / Fb;
+    const int c = (int)(r & 1);
+    const long long bt = r >> 1;
+    const long long b = bt / T;
+    const int t = (int)(bt - b * T);
+    rows[i] = spec[(b * 2 * Ft + (long long)c * Ft + f0 + f) * T + t];
+  }
+}
+// adjoint, accumulating the band into dspec (bands are disjoint: plain stores into a zero-initialised buffer)
+__global__ void spec_to_rows_bwd_kernel(const float* __restrict__ drows, float* __restrict__ dspec, int Ft, int T, int f0, int Fb, long long n) {
+  GRID_STRIDE(i, n) {
+    const int f = (int)(i % Fb);
+    const long long r = i / Fb;
+    const int c = (int)(r & 1);
+    const long long bt = r >> 1;
+    const long long b = bt / T;
+    const int t = (int)(bt - b * T);
+    dspec[(b * 2 * Ft + (long long)c * Ft + f0 + f) * T + t] = drows[i];
+  }
+}
+
+// out[b][i] = x[b][reflect(i - pad_l)], i < T + pad_l + pad_r
+__global__ void pad_reflect_kernel(const float* __restrict__ x, float* __restrict__ out, int T, int pad_l, int Tp, long long n) {
+  GRID_STRIDE(i, n) {
+    const int u = (int)(i % Tp);
+    const long long b = i / Tp;
+    int s = u - pad_l;
+    if (s < 0) s = -s;
+    if (s >= T) s = 2 * (T - 1) - s;
+    out[i] = x[b * T + s];
+  }
+}
+
+// Discriminator.preprocess: z = 0.8 (x - mean) / (max|x - mean| + 1e-9); stats[b] = (mean, max, argmax, sign)
+__global__ __launch_bounds__(256) void disc_pre_fwd_kernel(const float* __restrict__ x, float* __restrict__ z, float* __restrict__ stats, int T) {
+  __shared__ float red[256];
+  __shared__ int redi[256];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const float* xr = x + (long long)b * T;
+  float s = 0.f;
+  for (int t = tid; t < T; t += 256) s += xr[t];
+  red[tid] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) { if (tid < o) red[tid] += red[tid + o]; __syncthreads(); }
+  const float mean = red[0] / (float)T;
+  __syncthreads();
+  float m = -1.f;
+  int mi = 0;
+  for (int t = tid; t < T; t += 256) { const float a = fabsf(xr[t] - mean); if (a > m) { m = a; mi = t; } }
+  red[tid] = m;
+  redi[tid] = mi;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (tid < o && (red[tid + o] > red[tid] || (red[tid + o] == red[tid] && redi[tid + o] < redi[tid]))) { red[tid] = red[tid + o]; redi[tid] = redi[tid + o]; }
+    __syncthreads();
+  }
+  const float mx = red[0];
+  const int am = redi[0];
+  const float c = 0.8f / (mx + 1e-9f);
+  for (int t = tid; t < T; t += 256) z[(long long)b * T + t] = (xr[t] - mean) * c;
+  if (tid == 0) { stats[b * 4] = mean; stats[b * 4 + 1] = mx; stats[b * 4 + 2] = (float)am; stats[b * 4 + 3] = (xr[am] - mean) >= 0.f ? 1.f : -1.f; }
+}
+
+__global__ __launch_bounds__(256) void disc_pre_bwd_kernel(const float* __restrict__ x, const float* __restrict__ stats,
+                                                           const float* __restrict__ dz, float* __restrict__ dx, int T) {
+  __shared__ float red[2][256];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const float* xr = x + (long long)b * T;
+  const float* dr = dz + (long long)b * T;
+  const float mean = stats[b * 4], mx = stats[b * 4 + 1], sgn = stats[b * 4 + 3];
+  const int am = (int)stats[b * 4 + 2];
+  const float c = 0.8f / (mx + 1e-9f);
+  float s1 = 0.f, s2 = 0.f;                      // sum dz * y0, sum dz
+  for (int t = tid; t < T; t += 256) { s1 = fmaf(dr[t], xr[t] - mean, s1); s2 += dr[t]; }
+  red[0][tid] = s1;
+  red[1][tid] = s2;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) { if (tid < o) { red[0][tid] += red[0][tid + o]; red[1][tid] += red[1][tid + o]; } __syncthreads(); }
+  // dy0_j = c dz_j - [j = am] sgn * 0.8 / (mx+eps)^2 * S1;   dx = dy0 - mean(dy0)
+  const float spike = sgn * (0.8f / ((mx + 1e-9f) * (mx + 1e-9f))) * red[0][0];
+  const float mean_dy0 = (c * red[1][0] - spike) / (float)T;
+  for (int t = tid; t < T; t += 256) dx[(long long)b * T + t] = c * dr[t] - (t == am ? spike : 0.f) - mean_dy0;
+}
+
+}  // namespace fac
+
+#define L1(kern, n, ...) hipLaunchKernelGGL(fac::kern, dim3(fac::grid_for(n)), dim3(256), 0, (hipStream_t)stream, __VA_ARGS__)
+
+extern "C" int fac_leaky_relu(const float* x, const float* dy, float* out, int64_t n, float slope, fac_stream_t stream) {
+  FAC_REQUIRE(x && out && n > 0, "leaky_relu: bad arguments");
+  if (dy) L1(leaky_bwd_kernel, n, x, dy, out, slope, (long long)n);
+  else L1(leaky_fwd_kernel, n, x, out, slope, (long long)n);
+  return fac::check_launch("leaky_relu");
+}
+
+extern "C" int fac_period_fold(const float* x, float* out, int B, int T, int period, int L, int backward, fac_stream_t stream) {
+  FAC_REQUIRE(x && out && B > 0 && T > 1 && period > 0 && (long long)L * period >= T && (long long)L * period <= 2ll * T - 1,
+              "period_fold: bad arguments");
+  if (backward) { const long long n = (long long)B * T; L1(period_fold_bwd_kernel, n, x, out, T, period, L, n); }
+  else { const long long n = (long long)B * period * L; L1(period_fold_kernel, n, x, out, T, period, L, n); }
+  return fac::check_launch("period_fold");
+}
+
+extern "C" int fac_zero_insert(const float* dy, float* up, int64_t rows, int T, int stride, fac_stream_t stream) {
+  FAC_REQUIRE(dy && up && rows > 0 && T > 0 && stride > 0, "zero_insert: bad arguments");
+  const int Tu = (T - 1) * stride + 1;
+  const long long n = (long long)rows * Tu;
+  L1(zero_insert_kernel, n, dy, up, T, stride, Tu, n);
+  return fac::check_launch("zero_insert");
+}
+
+extern "C" int fac_row_stack3(const float* x, float* out, int64_t rows, int T, int C, int F, int backward, fac_stream_t stream) {
+  FAC_REQUIRE(x && out && rows > 0 && T > 0 && rows % T == 0 && C > 0 && F > 0, "row_stack3: bad arguments");
+  if (backward) { const long long n = (long long)rows * C * F; L1(row_stack3_bwd_kernel, n, x, out, T, C, F, n); }
+  else { const long long n = (long long)rows * 3 * C * F; L1(row_stack3_kernel, n, x, out, T, C, F, n); }
+  return fac::check_launch("row_stack3");
+}
+
+extern "C" int fac_spec_to_rows(const float* src, float* dst, int B, int Ft, int T, int f0, int Fb, int backward, fac_stream_t stream) {
+  FAC_REQUIRE(src && dst && B > 0 && Ft > 0 && T > 0 && f0 >= 0 && Fb > 0 && f0 + Fb <= Ft, "spec_to_rows: bad arguments");
+  const long long n = (long long)B * T * 2 * Fb;
+  if (backward) L1(spec_to_rows_bwd_kernel, n, src, dst, Ft, T, f0, Fb, n);
+  else L1(spec_to_rows_kernel, n, src, dst, Ft, T, f0, Fb, n);
+  return fac::check_launch("spec_to_rows");
+}
+
+extern "C" int fac_pad_reflect(const float* x, float* out, int B, int T, int pad_l, int pad_r, fac_stream_t stream) {
+  FAC_REQUIRE(x && out && B > 0 && T > 1 && pad_l >= 0 && pad_r >= 0 && pad_l < T && pad_r < T, "pad_reflect: bad arguments");
+  const int Tp = T + pad_l + pad_r;
+  const long long n = (long long)B * Tp;
+  L1(pad_reflect_kernel, n, x, out, T, pad_l, Tp, n);
+  return fac::check_launch("pad_reflect");
+}
+
+extern "C" int fac_disc_preprocess(const float* x, const float* dz, float* out, float* stats, int B, int T, fac_stream_t stream) {
+  FAC_REQUIRE(x && out && stats && B > 0 && T > 0, "disc_preprocess: bad arguments");
+  if (dz) hipLaunchKernelGGL(fac::disc_pre_bwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, x, stats, dz, out, T);
+  else hipLaunchKernelGGL(fac::disc_pre_fwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, x, out, stats, T);
+  return fac::check_launch("disc_preprocess");
+}

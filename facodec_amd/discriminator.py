@@ -1,0 +1,160 @@
+"""Discriminator of the training step (reference: dac/model/discriminator.py; built by modules/commons.py:334-340 with
+rates=[], periods [2,3,5,7,11], fft_sizes [2048,1024,512]; used by train.py:280-312), HIP forward and backward.
+
+State-dict keys equal the reference's (`discriminators.N.convs.i.0.{weight_g,weight_v,bias}`, `...conv_post.*`,
+`discriminators.N.band_convs.b.i.0.*`; Conv2d weights 4-D, old-style weight_norm).
+
+Execution: every Conv2d here has one trivial kernel dimension, so it runs on the 1-D conv kernels --
+  MPD  (k,1) convs: 1-D along the folded time axis, the period folded into the batch: tensors (B*period, C, L);
+  MRD  (3,k) convs: 1-D along frequency over the three neighbouring time rows stacked into channels: tensors (B*T, C, F).
+Feature maps are returned in these internal layouts: the losses that consume them (LSGAN on the logits, L1 feature
+matching: train.py:282-312) are means over all elements, hence layout-independent; `reference_layout()` converts a map
+for callers that want the reference's (B, C, L, period) / (B, C, T, F)."""
+import torch
+from torch import nn
+
+from . import autograd_disc as AD
+from . import losses
+
+BANDS = ((0.0, 0.1), (0.1, 0.25), (0.25, 0.5), (0.5, 0.75), (0.75, 1.0))
+
+
+class _WNConv2d(nn.Module):
+    """weight_norm(nn.Conv2d) parameters (old-style names)."""
+
+    def __init__(self, c_in, c_out, kh, kw):
+        super().__init__()
+        w = torch.empty(c_out, c_in, kh, kw)
+        nn.init.kaiming_uniform_(w, a=5 ** 0.5)
+        self.weight_g = nn.Parameter(w.flatten(1).norm(dim=1).view(-1, 1, 1, 1))
+        self.weight_v = nn.Parameter(w)
+        bound = 1.0 / (c_in * kh * kw) ** 0.5
+        self.bias = nn.Parameter(torch.empty(c_out).uniform_(-bound, bound))
+
+
+def _seq(conv):
+    """Sequential(conv, LeakyReLU) naming level: key `...0.weight_g`."""
+    return nn.Sequential(conv)
+
+
+class MPD(nn.Module):
+    """discriminator.py:27-60."""
+
+    def __init__(self, period):
+        super().__init__()
+        self.period = period
+        ch = [1, 32, 128, 512, 1024, 1024]
+        self.convs = nn.ModuleList([_seq(_WNConv2d(ch[i], ch[i + 1], 5, 1)) for i in range(5)])
+        self.conv_post = _WNConv2d(1024, 1, 3, 1)
+        self.strides = (3, 3, 3, 3, 1)
+
+    def forward(self, x):
+        """x (B, 1, T) preprocessed -> 6 feature maps (B*period, C, L)."""
+        x = AD.PeriodFold.apply(x, self.period)
+        fmap = []
+        for seq, s in zip(self.convs, self.strides):
+            c = seq[0]
+            x = AD.PlainConv.apply(x, c.weight_v.squeeze(-1), c.weight_g.squeeze(-1), c.bias, 5, s, 2)
+            x = AD.LeakyReLU.apply(x, 0.1)
+            fmap.append(x)
+        c = self.conv_post
+        x = AD.PlainConv.apply(x, c.weight_v.squeeze(-1), c.weight_g.squeeze(-1), c.bias, 3, 1, 1)
+        fmap.append(x)
+        return fmap
+
+
+class MRD(nn.Module):
+    """discriminator.py:101-170."""
+
+    def __init__(self, window_length, sample_rate=24000, bands=BANDS):
+        super().__init__()
+        self.window_length = window_length
+        n_fft = window_length // 2 + 1
+        self.bands = [(int(lo * n_fft), int(hi * n_fft)) for lo, hi in bands]
+        ch = 32
+        stack = lambda: nn.ModuleList([_seq(_WNConv2d(2, ch, 3, 9)), _seq(_WNConv2d(ch, ch, 3, 9)), _seq(_WNConv2d(ch, ch, 3, 9)),   # noqa: E731
+                                       _seq(_WNConv2d(ch, ch, 3, 9)), _seq(_WNConv2d(ch, ch, 3, 3))])
+        self.band_convs = nn.ModuleList([stack() for _ in self.bands])
+        self.conv_post = _WNConv2d(ch, 1, 3, 3)
+        self.fstrides = (1, 2, 2, 2, 1)
+        self._scale = None
+
+    def _conv(self, c, rows, T, kf, sf):
+        co, ci = c.weight_v.shape[0], c.weight_v.shape[1]
+        v = c.weight_v.permute(0, 2, 1, 3).reshape(co, 3 * ci, kf)       # channel axis of the stacked rows: (dt, ci)
+        return AD.PlainConv.apply(AD.RowStack3.apply(rows, T), v, c.weight_g.reshape(co, 1, 1), c.bias, kf, sf, kf // 2)
+
+    def forward(self, x):
+        """x (B, 1, T) preprocessed -> 26 feature maps (B*T_frames, C, F)."""
+        B = x.shape[0]
+        dev = x.device
+        if self._scale is None or self._scale.basis.device != dev:
+            self._scale = losses._SpectralScale(dev, self.window_length, self.window_length, self.window_length // 4)
+        spec = AD.Spectrogram.apply(x.reshape(B, x.shape[-1]), self._scale)     # (B, 2F, T')
+        T = spec.shape[-1]
+        fmap, outs = [], []
+        for (lo, hi), stack in zip(self.bands, self.band_convs):
+            rows = AD.SpecBand.apply(spec, lo, hi - lo)
+            for seq, sf in zip(stack, self.fstrides):
+                c = seq[0]
+                rows = AD.LeakyReLU.apply(self._conv(c, rows, T, c.weight_v.shape[-1], sf), 0.1)
+                fmap.append(rows)
+            outs.append(rows)
+        y = self._conv(self.conv_post, torch.cat(outs, dim=2), T, 3, 1)
+        fmap.append(y)
+        self.last_frames = T
+        return fmap
+
+
+class Discriminator(nn.Module):
+    """discriminator.py:173-210 (rates = [] only: the MSD branch resamples through audiotools and is unused by the model)."""
+
+    def __init__(self, rates=(), periods=(2, 3, 5, 7, 11), fft_sizes=(2048, 1024, 512), sample_rate=24000, bands=BANDS):
+        super().__init__()
+        if len(rates):
+            raise NotImplementedError("MSD (rates != []) is not used by build_model and is not built")
+        self.discriminators = nn.ModuleList([MPD(p) for p in periods] + [MRD(f, sample_rate, bands) for f in fft_sizes])
+
+    def preprocess(self, y):
+        return AD.Preprocess.apply(y)
+
+    def forward(self, x):
+        x = self.preprocess(x)
+        return [d(x) for d in self.discriminators]
+
+
+def reference_layout(disc, fmaps, batch):
+    """Internal feature maps -> the reference's (B, C, L, period) / (B, C, T, F) tensors."""
+    out = []
+    for d, maps in zip(disc.discriminators, fmaps):
+        conv = []
+        for m in maps:
+            if isinstance(d, MPD):
+                bp, c, L = m.shape
+                conv.append(m.reshape(batch, d.period, c, L).permute(0, 2, 3, 1).contiguous())
+            else:
+                rows, c, f = m.shape
+                conv.append(m.reshape(batch, rows // batch, c, f).permute(0, 2, 1, 3).contiguous())
+        out.append(conv)
+    return out
+
+
+def gan_losses(d_fake, d_real):
+    """train.py:282-285 and :304-312 -> (loss_d, loss_g, loss_feature) as autograd scalars."""
+    one = {}
+
+    def ones_like(t):
+        k = (t.shape, t.device)
+        if k not in one:
+            one[k] = torch.ones_like(t)
+        return one[k]
+
+    loss_d = loss_g = loss_f = None
+    acc = lambda a, b: b if a is None else a + b     # noqa: E731  (scalar adds: bookkeeping)
+    for xf, xr in zip(d_fake, d_real):
+        zf = torch.zeros_like(xf[-1])
+        loss_d = acc(loss_d, AD.PairMean.apply(xf[-1], zf, 2) + AD.PairMean.apply(xr[-1], ones_like(xr[-1]), 2))
+        loss_g = acc(loss_g, AD.PairMean.apply(xf[-1], ones_like(xf[-1]), 2))
+        for j in range(len(xf) - 1):
+            loss_f = acc(loss_f, AD.PairMean.apply(xf[j], xr[j].detach(), 0))
+    return loss_d, loss_g, loss_f

@@ -515,13 +515,14 @@ def conv1d_bwd_data(dy, v, g, t_in, stride=1, dilation=1, pad_mode=PAD_REFLECT, 
     return dx
 
 
-def conv1d_bwd_weight(x, dy, k, stride=1, dilation=1, pad_mode=PAD_REFLECT, causal=True):
-    """dW (C_out, C_in, K) of SConv1d."""
+def conv1d_bwd_weight(x, dy, k, stride=1, dilation=1, pad_mode=PAD_REFLECT, causal=True, pad_left=None):
+    """dW (C_out, C_in, K) of SConv1d (or of a plain conv when pad_left is given explicitly)."""
     x, dy = _dev(x, "x"), _dev(dy, "dy")
     B, c_in, t_in = x.shape
     _, c_out, t_out = dy.shape
-    _, padding_total, _ = conv_out_len(t_in, k, stride, dilation)
-    pad_left = padding_total if causal else padding_total - padding_total // 2
+    if pad_left is None:
+        _, padding_total, _ = conv_out_len(t_in, k, stride, dilation)
+        pad_left = padding_total if causal else padding_total - padding_total // 2
     lib = _lib.load()
     nbytes = lib.fac_conv1d_bwd_weight_ws_bytes(B, c_in, c_out, t_out, k)
     ws = torch.empty(nbytes // 4, device=x.device, dtype=torch.float32)

@@ -231,6 +231,23 @@ int fac_attention_bwd_qk(const float* P, float* dP, const float* q, const float*
  * scratch: 2 * B * C * ceil(T/256) floats. */
 int fac_aa_snakebeta_bwd(const float* x, const float* alpha_log, const float* beta_log, const float* filter12, const float* dy,
                          float* dx, float* dalpha, float* dbeta, float* scratch, int B, int C, int T, fac_stream_t stream);
+/* Discriminator path (dac/model/discriminator.py): layout / elementwise kernels; the convolutions run on
+ * fac_conv1d_fwd (MPD: 1-D along the folded time axis, period as batch; MRD: 1-D along frequency over three stacked
+ * time rows).  A non-NULL dy / non-zero `backward` selects the adjoint.
+ *   leaky_relu: out = x > 0 ? x : slope*x   (backward: out = x > 0 ? dy : slope*dy)
+ *   period_fold: (B, T) -> (B*period, L), reflect-extended on the right to L*period samples
+ *   zero_insert: (rows, T) -> (rows, (T-1)*stride + 1), zeros between samples (strided conv data gradient)
+ *   row_stack3: (rows = B*T, C, F) -> (rows, 3C, F): time rows t-1, t, t+1 stacked (zero outside a clip)
+ *   spec_to_rows: one frequency band [f0, f0+Fb) of spec (B, 2*Ft, T) = [re|im] -> (B*T, 2, Fb)
+ *   pad_reflect: (B, T) -> (B, pad_l + T + pad_r)
+ *   disc_preprocess: z = 0.8 (x - mean)/(max|x - mean| + 1e-9) per clip; stats: 4*B floats kept for the backward */
+int fac_leaky_relu(const float* x, const float* dy, float* out, int64_t n, float slope, fac_stream_t stream);
+int fac_period_fold(const float* x, float* out, int B, int T, int period, int L, int backward, fac_stream_t stream);
+int fac_zero_insert(const float* dy, float* up, int64_t rows, int T, int stride, fac_stream_t stream);
+int fac_row_stack3(const float* x, float* out, int64_t rows, int T, int C, int F, int backward, fac_stream_t stream);
+int fac_spec_to_rows(const float* src, float* dst, int B, int Ft, int T, int f0, int Fb, int backward, fac_stream_t stream);
+int fac_pad_reflect(const float* x, float* out, int B, int T, int pad_l, int pad_r, fac_stream_t stream);
+int fac_disc_preprocess(const float* x, const float* dz, float* out, float* stats, int B, int T, fac_stream_t stream);
 /* Left-context buffer of a streaming causal conv: every row of buf (rows x cap) holds
  * [hist columns of history | n_prev columns appended last time]; moves the last `hist` columns to the
  * front (skipped when n_prev == 0) and appends src (rows x n_new, dense) behind them.  hist <= 2048. */

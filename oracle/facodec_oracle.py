@@ -642,3 +642,89 @@ def reconstruction_loss(x, g_x, eps=1e-7):
         l2 = (((torch.log(sx.abs() + eps) - torch.log(sg.abs() + eps)) ** 2).mean(dim=-2) ** 0.5).mean()
         loss = loss + l1 + (s / 2) ** 0.5 * l2
     return loss
+
+
+# ---------------------------------------------------------------------------------------------
+# discriminator (dac/model/discriminator.py), train-step only: 5 multi-period + 3 multi-resolution
+# complex-spectrogram discriminators.  The STFT of MRD goes through descript-audiotools (not vendored): its
+# semantics are restated from SURVEY.md 8c ([upstream]) -- parity of that front-end is unpinned, like the losses'.
+BANDS = ((0.0, 0.1), (0.1, 0.25), (0.25, 0.5), (0.5, 0.75), (0.75, 1.0))
+
+
+def discriminator_preprocess(y):
+    """Discriminator.preprocess :200-205: remove DC, peak-normalise to 0.8."""
+    y = y - y.mean(dim=-1, keepdim=True)
+    return 0.8 * y / (y.abs().max(dim=-1, keepdim=True)[0] + 1e-9)
+
+
+def _wn2d(sd, p):
+    v, g = sd[p + "weight_v"], sd[p + "weight_g"]
+    return g * v / v.flatten(1).norm(dim=1).view(-1, 1, 1, 1)
+
+
+def mpd_forward(x, sd, p, period):
+    """MPD.forward :44-60: reflect-pad to a multiple of the period (a full period when already aligned, :40-42),
+    fold to (B, 1, L, period), five (5,1) convs with LeakyReLU(0.1), (3,1) post conv.  Returns the 6 feature maps."""
+    t = x.shape[-1]
+    x = F.pad(x, (0, period - t % period), mode="reflect")
+    x = x.view(x.shape[0], 1, -1, period)
+    fmap = []
+    for i, stride in enumerate((3, 3, 3, 3, 1)):
+        q = f"{p}convs.{i}.0."
+        x = F.leaky_relu(F.conv2d(x, _wn2d(sd, q), sd[q + "bias"], stride=(stride, 1), padding=(2, 0)), 0.1)
+        fmap.append(x)
+    q = f"{p}conv_post."
+    x = F.conv2d(x, _wn2d(sd, q), sd[q + "bias"], padding=(1, 0))
+    fmap.append(x)
+    return fmap
+
+
+def stft_match_stride(wave2d, window_length):
+    """audiotools AudioSignal.stft with STFTParams(window_length, hop = window_length // 4, match_stride=True):
+    reflect-pad (pad, pad + right_pad) with pad = (window - hop) // 2, right_pad = ceil(T / hop) * hop - T; periodic
+    Hann; torch.stft(centre, reflect); drop two frames at either end.  -> complex (N, F, T_frames)."""
+    hop = window_length // 4
+    T = wave2d.shape[-1]
+    right_pad = math.ceil(T / hop) * hop - T
+    pad = (window_length - hop) // 2
+    x = F.pad(wave2d.unsqueeze(1), (pad, pad + right_pad), mode="reflect").squeeze(1)
+    win = torch.as_tensor(hann_periodic(window_length), dtype=torch.float32)
+    s = torch.stft(x, n_fft=window_length, hop_length=hop, window=win, center=True, pad_mode="reflect", return_complex=True)
+    return s[..., 2:-2]
+
+
+def mrd_forward(x, sd, p, window_length, bands=BANDS):
+    """MRD.forward :151-170: complex spectrogram (B, 2, T, F) split into 5 frequency bands, per band four (3,9) convs
+    (frequency strides 1, 2, 2, 2) and a (3,3) conv, LeakyReLU(0.1); bands concatenated along frequency; (3,3) post conv.
+    Returns the 26 feature maps in the reference's order."""
+    s = torch.view_as_real(stft_match_stride(x.reshape(x.shape[0], x.shape[-1]), window_length))   # (B, F, T, 2)
+    s = s.permute(0, 3, 2, 1)                                                                           # (B, 2, T, F)
+    n_fft = window_length // 2 + 1
+    fmap, outs = [], []
+    for bi, (lo, hi) in enumerate(bands):
+        band = s[..., int(lo * n_fft): int(hi * n_fft)]
+        for i, (kf, sf) in enumerate(((9, 1), (9, 2), (9, 2), (9, 2), (3, 1))):
+            q = f"{p}band_convs.{bi}.{i}.0."
+            band = F.leaky_relu(F.conv2d(band, _wn2d(sd, q), sd[q + "bias"], stride=(1, sf), padding=(1, kf // 2)), 0.1)
+            fmap.append(band)
+        outs.append(band)
+    q = f"{p}conv_post."
+    y = F.conv2d(torch.cat(outs, dim=-1), _wn2d(sd, q), sd[q + "bias"], padding=(1, 1))
+    fmap.append(y)
+    return fmap
+
+
+def discriminator_forward(sd, x, periods=(2, 3, 5, 7, 11), fft_sizes=(2048, 1024, 512)):
+    """Discriminator.forward :207-210 (rates = []): list of 8 lists of feature maps; the last map of each is the logit."""
+    x = discriminator_preprocess(x)
+    out = [mpd_forward(x, sd, f"discriminators.{i}.", p) for i, p in enumerate(periods)]
+    out += [mrd_forward(x, sd, f"discriminators.{len(periods) + i}.", w) for i, w in enumerate(fft_sizes)]
+    return out
+
+
+def gan_losses(d_fake, d_real):
+    """train.py:282-285 (discriminator), :304-312 (generator: adversarial + feature matching)."""
+    loss_d = sum((xf[-1] ** 2).mean() + ((1 - xr[-1]) ** 2).mean() for xf, xr in zip(d_fake, d_real))
+    loss_g = sum(((1 - xf[-1]) ** 2).mean() for xf in d_fake)
+    loss_feat = sum(F.l1_loss(xf[j], xr[j].detach()) for xf, xr in zip(d_fake, d_real) for j in range(len(xf) - 1))
+    return loss_d, loss_g, loss_feat

@@ -76,13 +76,19 @@ def install_shims():
     class AudioSignal:
         """Only what dac/nn/loss.py touches: stft(), .magnitude, mel_spectrogram(), audio_data."""
 
-        def __init__(self, audio, sample_rate):
+        def __init__(self, audio, sample_rate, stft_params=None):
             self.audio_data = audio
             self.sample_rate = sample_rate
+            self.stft_params = stft_params
             self.stft_data = None
 
-        def stft(self, window_length, hop_length, window_type=None, **kw):
+        def stft(self, window_length=None, hop_length=None, window_type=None, **kw):
             b, c, t = self.audio_data.shape
+            p = self.stft_params
+            if window_length is None and p is not None and p.match_stride:     # MRD front-end (discriminator.py:150-151)
+                s = O.stft_match_stride(self.audio_data.reshape(-1, t), p.window_length)
+                self.stft_data = s.reshape(b, c, s.shape[-2], s.shape[-1])
+                return self.stft_data
             s = O.stft_complex(self.audio_data.reshape(-1, t), window_length, hop_length)
             self.stft_data = s.reshape(b, c, s.shape[-2], s.shape[-1])
             return self.stft_data
@@ -247,6 +253,20 @@ def main():
         report["e2e_codes_oracle_pipeline_mismatch"] = int(sum((a != b).sum() for a, b in zip(o_codes2, codes)))
 
         probe_t_early = np.arange(0, 48000, 47)
+        # discriminator (train.py:280-312): the real dac/model/discriminator.py over the audiotools shim
+        from dac.model.discriminator import Discriminator
+        disc = Discriminator(rates=[], periods=[2, 3, 5, 7, 11], fft_sizes=[2048, 1024, 512], sample_rate=24000).eval()
+        sd_d = synth.load_synthetic(disc, seed=0, prefix="discriminator.")
+        xd = synth.synth_clips(2, 24000, seed=5)
+        fm_ref = disc(xd)
+        fm_or = O.discriminator_forward(sd_d, xd)
+        report["discriminator_oracle_rel_max"] = max(rel_err(a, b) for fr, fo in zip(fm_ref, fm_or) for a, b in zip(fo, fr))
+        shapes["discriminator"] = {n: list(v.shape) for n, v in disc.state_dict().items()}
+        json.dump(shapes, open(os.path.join(HERE, "state_shapes.json"), "w"), indent=0, sort_keys=True)
+        np.savez_compressed(os.path.join(HERE, "discriminator.npz"),
+                            **{f"logit{i}": fr[-1].numpy() for i, fr in enumerate(fm_ref)},
+                            **{f"fmap{i}_mean_abs": np.array([float(f.abs().mean()) for f in fr], np.float32) for i, fr in enumerate(fm_ref)})
+
         # predictor heads (train.py:270), eval mode, on the quantizer's outputs
         model.fa_predictors.eval()
         sd_p = synth.load_synthetic(model.fa_predictors, seed=0, prefix="fa_predictors.")
