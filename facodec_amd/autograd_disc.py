@@ -48,12 +48,15 @@ class PlainConv(Function):
             if tp < pad + t_in:       # trailing inputs no window reads
                 dxp = torch.cat([dxp, torch.zeros(B, c_in, pad + t_in - tp, device=dy.device)], dim=2)
             dx = dxp[:, :, pad:pad + t_in].contiguous()
-        dw = ops.conv1d_bwd_weight(x.detach(), dy, k, stride=stride, pad_mode=ops.PAD_ZERO, pad_left=pad)
-        if g is not None:
-            dv, dg = ops.weight_norm_bwd(vd, gd, dw)
-        else:
-            dv, dg = dw, None
-        db = ops.bias_grad(dy) if bias is not None else None
+        dv = dg = db = None
+        if ctx.needs_input_grad[1]:       # frozen discriminator (generator step): no weight gradients
+            dw = ops.conv1d_bwd_weight(x.detach(), dy, k, stride=stride, pad_mode=ops.PAD_ZERO, pad_left=pad)
+            if g is not None:
+                dv, dg = ops.weight_norm_bwd(vd, gd, dw)
+            else:
+                dv = dw
+        if bias is not None and ctx.needs_input_grad[3]:
+            db = ops.bias_grad(dy)
         return dx, dv, dg, db, None, None, None
 
 

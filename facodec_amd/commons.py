@@ -33,9 +33,8 @@ def recursive_munch(d):
 
 
 def build_model(args, stage="codec"):
-    """modules/commons.py:283-348.  Returns Munch(encoder, quantizer, decoder, fa_predictors).  The
-    reference also builds `discriminator` (train-step only): next row of the scope table (SURVEY.md
-    section 8f), reported as missing rather than silently faked."""
+    """modules/commons.py:283-348.  Returns Munch(encoder, quantizer, decoder, discriminator, fa_predictors)
+    with the reference's key order."""
     from .dac_model import Encoder, Decoder
     from .quantize import FAquantizer
 
@@ -70,7 +69,11 @@ def build_model(args, stage="codec"):
                                  use_gr_timbre_prosody=args.use_gr_timbre_prosody, use_gr_x_timbre=True,
                                  norm_f0=args.norm_f0, timbre_norm=args.timbre_norm,
                                  use_gr_content_global_f0=args.use_gr_content_global_f0)
-    return Munch(encoder=encoder, quantizer=quantizer, decoder=decoder, fa_predictors=fa_predictors)
+    from .discriminator import Discriminator
+    discriminator = Discriminator(rates=[], periods=[2, 3, 5, 7, 11], fft_sizes=[2048, 1024, 512],
+                                  sample_rate=args.DAC.sr)                      # modules/commons.py:334-340
+    return Munch(encoder=encoder, quantizer=quantizer, decoder=decoder, discriminator=discriminator,
+                 fa_predictors=fa_predictors)
 
 
 def default_model_params():

@@ -40,3 +40,48 @@ class GeneratorStep:
             self.opt[k].step()
         out["grad_norm"] = {k: self.opt[k].grad_norm() for k in self.opt}
         return out
+
+
+class TrainStep(GeneratorStep):
+    """Both halves of train.py's iteration (:265-374) minus the predictor-head losses:
+
+        pred = decoder(quantizer(encoder(wave)))
+        discriminator:  loss_d = sum_k mean(D_k(pred.detach())^2) + mean((1 - D_k(wave))^2);  clip 10;  AdamW
+        generator:      15 mel + feature matching + adversarial + 0.25 commitment + codebook;  clip 1000;  AdamW x3
+    """
+
+    def __init__(self, model, lr=1e-4, sample_rate=24000):
+        super().__init__(model, lr, sample_rate)
+        model.discriminator.train()
+        self.opt["discriminator"] = optim.FlatAdamW(model.discriminator.parameters(), lr=lr, max_norm=10.0)
+
+    def __call__(self, wave, masks=None):
+        from .discriminator import gan_losses
+        m = self.model
+        z = m.encoder(wave)
+        outs, _, commitment, codebook, _ = m.quantizer(z, wave, n_c=2, masks=masks)
+        pred = m.decoder(outs)
+        # ---- discriminator step (train.py:279-292)
+        d_fake, d_real = m.discriminator(pred.detach()), m.discriminator(wave)
+        loss_d, _, _ = gan_losses(d_fake, d_real)
+        loss_d.backward()
+        self.opt["discriminator"].step()
+        # ---- generator step (:295-374): the discriminator is only differentiated w.r.t. its input
+        for p in self.opt["discriminator"].params:
+            p.requires_grad_(False)
+        try:
+            d_fake = m.discriminator(pred)
+            with torch.no_grad():
+                d_real = m.discriminator(wave)
+            _, loss_g, loss_feat = gan_losses(d_fake, d_real)
+            mel = self.mel(pred, wave)
+            loss = 15.0 * mel + 1.0 * loss_feat + 1.0 * loss_g + 0.25 * commitment + 1.0 * codebook
+            loss.backward()
+        finally:
+            for p in self.opt["discriminator"].params:
+                p.requires_grad_(True)
+        for k in ("encoder", "decoder", "quantizer"):
+            self.opt[k].step()
+        return dict(loss=loss.detach(), loss_d=loss_d.detach(), loss_g=loss_g.detach(), feature=loss_feat.detach(),
+                    mel=mel.detach(), commitment=commitment.detach(), codebook=codebook.detach(),
+                    grad_norm={k: self.opt[k].grad_norm() for k in self.opt})

@@ -12,10 +12,10 @@ from facodec_amd.commons import (Munch, build_model, default_model_params, defau
 def test_state_dict_keys_and_shapes_match_reference(golden_dir):
     ref = json.load(open(os.path.join(golden_dir, "state_shapes.json")))
     model = build_model(default_model_params())
-    assert set(model.keys()) == {"encoder", "quantizer", "decoder", "fa_predictors"}
+    assert list(model.keys()) == ["encoder", "quantizer", "decoder", "discriminator", "fa_predictors"]   # commons.py:342-348
     # buffers real torchaudio checkpoints carry (SURVEY 3.3 [upstream]); absent from the shimmed dump
     extra_ok = {"to_mel.spectrogram.window", "to_mel.mel_scale.fb"}
-    for k in ("encoder", "quantizer", "decoder", "fa_predictors"):
+    for k in ("encoder", "quantizer", "decoder", "discriminator", "fa_predictors"):
         own = {n: list(v.shape) for n, v in model[k].state_dict().items()}
         assert set(ref[k]) - set(own) == set(), k
         assert set(own) - set(ref[k]) <= extra_ok, k

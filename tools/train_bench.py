@@ -16,7 +16,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from facodec_amd import benchutil, synth  # noqa: E402
 from facodec_amd.commons import build_model, default_model_params  # noqa: E402
-from facodec_amd.train import GeneratorStep  # noqa: E402
+from facodec_amd.train import GeneratorStep, TrainStep  # noqa: E402
 
 
 def main():
@@ -24,15 +24,16 @@ def main():
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--generator-only", action="store_true", help="skip the discriminator step and the GAN terms")
     a = ap.parse_args()
     rank, local_rank, world = benchutil.init_distributed()
     dev = torch.device(f"cuda:{local_rank % torch.cuda.device_count()}")
     torch.cuda.set_device(dev)
     model = build_model(default_model_params())
-    for k in ("encoder", "quantizer", "decoder"):
+    for k in ("encoder", "quantizer", "decoder", "discriminator"):
         synth.load_synthetic(model[k], seed=0, prefix=k + ".")
         model[k].to(dev)
-    step = GeneratorStep(model)
+    step = GeneratorStep(model) if a.generator_only else TrainStep(model)
     wave = synth.synth_clips(a.batch, 48000, seed=0, rank=rank).to(dev)
     for _ in range(a.warmup):
         out = step(wave)
@@ -43,7 +44,9 @@ def main():
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / a.steps
     if rank == 0:
-        print(json.dumps({"metric": "generator training step (encoder + RVQs + decoder fwd/bwd, mel + VQ losses, AdamW)",
+        print(json.dumps({"metric": ("generator training step (encoder + FA-quantizer + decoder fwd/bwd, mel + VQ losses, AdamW)"
+                                     if a.generator_only else
+                                     "training step: discriminator step + generator step (mel + feature matching + adversarial + VQ losses), 4 x AdamW"),
                           "batch_per_gpu": a.batch, "n_gpus": world, "ms_per_step": round(1e3 * dt, 1),
                           "audio_s_per_s": round(world * a.batch * 2.0 / dt, 2), "loss": float(out["loss"]),
                           "mel": float(out["mel"]), "grad_norm": {k: float(v) for k, v in out["grad_norm"].items()},
