@@ -188,7 +188,7 @@ class Preprocess(Function):
 
 
 class PairMean(Function):
-    """mean over elements of |a - b| (mode 0) or (a - b)^2 (mode 2); gradient to `a` only."""
+    """mean over elements of |a - b| (mode 0), (a - b)^2 (mode 2) or smooth-L1 (mode 3); gradient to `a` only."""
 
     @staticmethod
     def forward(ctx, a, b, mode):
@@ -206,3 +206,26 @@ class PairMean(Function):
         da = torch.empty_like(ad)
         ops.pair_bwd(ad, bd, da, ctx.mode, 0.0, 1.0 / ad.numel(), False)
         return ops.rows_fma(da.reshape(1, -1), g.reshape(1).to(da.dtype)).reshape(ad.shape), None, None
+
+
+class CrossEntropy(Function):
+    """F.cross_entropy(logits (N, C), labels (N)), mean reduction."""
+
+    @staticmethod
+    def forward(ctx, logits, labels):
+        ld = logits.detach().contiguous()
+        N, Cn = ld.shape
+        loss = torch.zeros(1, device=ld.device)
+        scratch = torch.empty(N, device=ld.device)
+        _call("fac_cross_entropy", _p(ld), C.c_void_p(labels.data_ptr()), _p(loss), _p(None), _p(scratch), N, Cn, C.c_float(0.0))
+        ctx.save_for_backward(ld, labels)
+        return loss[0].clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        ld, labels = ctx.saved_tensors
+        N, Cn = ld.shape
+        dl = torch.empty_like(ld)
+        scratch = torch.empty(N, device=ld.device)
+        _call("fac_cross_entropy", _p(ld), C.c_void_p(labels.data_ptr()), _p(None), _p(dl), _p(scratch), N, Cn, C.c_float(1.0 / N))
+        return ops.rows_fma(dl.reshape(1, -1), g.reshape(1).to(dl.dtype)).reshape(ld.shape), None

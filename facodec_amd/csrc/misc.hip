@@ -382,6 +382,9 @@ __global__ void pair_bwd_kernel(const float* __restrict__ a, const float* __rest
       g = av > bv ? 1.f : (av < bv ? -1.f : 0.f);
     } else if (mode == 2) {
       g = 2.f * (av - bv);
+    } else if (mode == 3) {
+      const float d = av - bv;
+      g = fabsf(d) < 1.f ? d : (d > 0.f ? 1.f : -1.f);
     } else {
       const float d = log10f(fmaxf(av, eps)) - log10f(fmaxf(bv, eps));
       const float sgn = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
@@ -447,6 +450,7 @@ __device__ __forceinline__ float pair_term(float a, float b, int mode, float eps
   if (mode == 0) return fabsf(a - b);
   if (mode == 1) return fabsf(log10f(fmaxf(a, eps)) - log10f(fmaxf(b, eps)));
   const float d = a - b;
+  if (mode == 3) { const float ad = fabsf(d); return ad < 1.f ? 0.5f * d * d : ad - 0.5f; }   // smooth L1, beta = 1
   return d * d;
 }
 
@@ -710,7 +714,7 @@ extern "C" int fac_spec_power(const float* spec, float* out, int B, int F, int n
 extern "C" int fac_reduce_pair(const float* a, const float* b, float* out, float* scratch,
                                int64_t n, int mode, float eps, float scale, int accumulate,
                                fac_stream_t stream) {
-  FAC_REQUIRE(a && b && out && scratch && n > 0 && mode >= 0 && mode <= 2, "reduce_pair: bad arguments");
+  FAC_REQUIRE(a && b && out && scratch && n > 0 && mode >= 0 && mode <= 3, "reduce_pair: bad arguments");
   long long g = (n + 255) / 256;
   if (g > 1024) g = 1024;
   hipLaunchKernelGGL(reduce_pair_stage1, dim3((int)g), dim3(256), 0, (hipStream_t)stream, a, b,
@@ -746,7 +750,7 @@ extern "C" int fac_aa_snakebeta_fwd(const float* x, const float* alpha_log, cons
 
 extern "C" int fac_pair_bwd(const float* a, const float* b, float* da, int64_t n, int mode, float eps, float scale,
                             int accumulate, fac_stream_t stream) {
-  FAC_REQUIRE(a && b && da && n > 0 && mode >= 0 && mode <= 2, "pair_bwd: bad arguments");
+  FAC_REQUIRE(a && b && da && n > 0 && mode >= 0 && mode <= 3, "pair_bwd: bad arguments");
   EW_LAUNCH(pair_bwd_kernel, n, a, b, da, (long long)n, mode, eps, scale, accumulate);
   return check_launch("pair_bwd");
 }

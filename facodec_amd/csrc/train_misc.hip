@@ -26,3 +26,56 @@ extern "C" int fac_rows_fma(const float* a, const float* w, const float* c, floa
   hipLaunchKernelGGL(rows_fma_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a, w, c, out, (long long)per, sign, n);
   return check_launch("rows_fma");
 }
+
+// Softmax cross-entropy over rows (N, C) with int64 labels (F.cross_entropy, mean reduction): one workgroup per row.
+// loss_row[n] = logsumexp(x_n) - x_n[label];  dlogits = (softmax - onehot) * scale  (scale = upstream / N).
+namespace fac {
+
+__global__ __launch_bounds__(256) void ce_row_kernel(const float* __restrict__ x, const long long* __restrict__ label,
+                                                     float* __restrict__ loss_row, float* __restrict__ dx, int Cn, float scale) {
+  __shared__ float red[256];
+  const long long n = blockIdx.x;
+  const int tid = threadIdx.x;
+  const float* xr = x + n * Cn;
+  float mx = -INFINITY;
+  for (int c = tid; c < Cn; c += 256) mx = fmaxf(mx, xr[c]);
+  red[tid] = mx;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) { if (tid < o) red[tid] = fmaxf(red[tid], red[tid + o]); __syncthreads(); }
+  mx = red[0];
+  __syncthreads();
+  float s = 0.f;
+  for (int c = tid; c < Cn; c += 256) s += expf(xr[c] - mx);
+  red[tid] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) { if (tid < o) red[tid] += red[tid + o]; __syncthreads(); }
+  s = red[0];
+  const long long lb = label[n];
+  if (tid == 0 && loss_row) loss_row[n] = logf(s) + mx - xr[lb];
+  if (dx) {
+    float* dr = dx + n * Cn;
+    for (int c = tid; c < Cn; c += 256) dr[c] = (expf(xr[c] - mx) / s - (c == lb ? 1.f : 0.f)) * scale;
+  }
+}
+
+__global__ __launch_bounds__(256) void sum_rows_kernel(const float* __restrict__ v, float* __restrict__ out, long long n, float scale) {
+  __shared__ float red[256];
+  float s = 0.f;
+  for (long long i = threadIdx.x; i < n; i += 256) s += v[i];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
+  if (threadIdx.x == 0) out[0] = red[0] * scale;
+}
+
+}  // namespace fac
+
+extern "C" int fac_cross_entropy(const float* logits, const int64_t* labels, float* loss, float* dlogits, float* scratch,
+                                 int64_t N, int C, float grad_scale, fac_stream_t stream) {
+  using namespace fac;
+  FAC_REQUIRE(logits && labels && scratch && (loss || dlogits) && N > 0 && C > 0, "cross_entropy: bad arguments");
+  hipLaunchKernelGGL(ce_row_kernel, dim3((unsigned)N), dim3(256), 0, (hipStream_t)stream, logits, (const long long*)labels,
+                     loss ? scratch : nullptr, dlogits, C, grad_scale);
+  if (loss) hipLaunchKernelGGL(sum_rows_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, scratch, loss, (long long)N, 1.0f / (float)N);
+  return check_launch("cross_entropy");
+}

@@ -248,6 +248,10 @@ int fac_row_stack3(const float* x, float* out, int64_t rows, int T, int C, int F
 int fac_spec_to_rows(const float* src, float* dst, int B, int Ft, int T, int f0, int Fb, int backward, fac_stream_t stream);
 int fac_pad_reflect(const float* x, float* out, int B, int T, int pad_l, int pad_r, fac_stream_t stream);
 int fac_disc_preprocess(const float* x, const float* dz, float* out, float* stats, int B, int T, fac_stream_t stream);
+/* F.cross_entropy (mean) over rows: logits (N, C), labels (N) int64.  loss (1 float) and / or dlogits = (softmax -
+ * onehot) * grad_scale; scratch: N floats. */
+int fac_cross_entropy(const float* logits, const int64_t* labels, float* loss, float* dlogits, float* scratch, int64_t N,
+                      int C, float grad_scale, fac_stream_t stream);
 /* Left-context buffer of a streaming causal conv: every row of buf (rows x cap) holds
  * [hist columns of history | n_prev columns appended last time]; moves the last `hist` columns to the
  * front (skipped when n_prev == 0) and appends src (rows x n_new, dense) behind them.  hist <= 2048. */

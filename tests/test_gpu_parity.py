@@ -1064,3 +1064,44 @@ def test_full_train_step_runs(cuda):
     for k in step.opt:
         assert torch.isfinite(step.opt[k].p).all() and not torch.equal(step.opt[k].p, before[k]), k
         assert float(out["grad_norm"][k]) > 0
+
+
+def test_cross_entropy_and_smooth_l1_against_torch(cuda):
+    from facodec_amd import autograd_disc as AD
+    g = _g(61)
+    logits = torch.randn(37, 1024, generator=g, requires_grad=True)
+    labels = torch.randint(0, 1024, (37,), generator=g)
+    ref = torch.nn.functional.cross_entropy(logits, labels)
+    (2.0 * ref).backward()
+    lg = logits.detach().to(cuda).requires_grad_()
+    got = AD.CrossEntropy.apply(lg, labels.to(cuda))
+    (2.0 * got).backward()
+    assert abs(float(got.detach()) - float(ref.detach())) < 1e-5 and rel(lg.grad, logits.grad) < 1e-5
+    a = (3 * torch.randn(5, 40, generator=g)).requires_grad_()
+    b = torch.randn(5, 40, generator=g)
+    r2 = torch.nn.functional.smooth_l1_loss(b, a)
+    r2.backward()
+    ag = a.detach().to(cuda).requires_grad_()
+    g2 = AD.PairMean.apply(ag, b.to(cuda), 3)
+    g2.backward()
+    assert abs(float(g2.detach()) - float(r2.detach())) < 1e-6 and rel(ag.grad, a.grad) < 1e-5
+
+
+def test_full_train_step_with_predictor_targets(cuda):
+    """The complete loss of train.py:357-358 with caller-supplied predictor targets: runs, finite, all five optimisers step."""
+    from facodec_amd.commons import build_model, default_model_params
+    from facodec_amd.train import TrainStep
+    model = build_model(default_model_params())
+    for k in model:
+        synth.load_synthetic(model[k], seed=0, prefix=k + ".")
+        model[k].to(cuda)
+    step = TrainStep(model, with_predictors=True)
+    B, T = 2, 12000
+    F_ = T // 300
+    g = _g(71)
+    targets = dict(f0=torch.randn(B, F_, generator=g).to(cuda), uv=torch.randn(B, F_, generator=g).to(cuda),
+                   phones=torch.randint(0, 1024, (B, F_), generator=g).to(cuda), speaker=torch.randint(0, 20000, (B,), generator=g).to(cuda))
+    before = step.opt["fa_predictors"].p.clone()
+    out = step(synth.synth_clips(B, T, seed=3).to(cuda), targets=targets)
+    assert torch.isfinite(out["loss"]).all() and float(out["grad_norm"]["fa_predictors"]) > 0
+    assert not torch.equal(step.opt["fa_predictors"].p, before)
