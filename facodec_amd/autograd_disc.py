@@ -14,6 +14,11 @@ def _call(name, *args):
 _p = ops._ptr
 
 
+def _split_ok(k, stride, c_in, c_out, ncol):
+    """k = 5 / 7 stride-1 convs with enough channels and columns: fp32-exact split on the bf16 pipe."""
+    return ops.BF16_SPLIT and k in (5, 7) and stride == 1 and c_in % 16 == 0 and c_out % 16 == 0 and c_out > 2 and ncol > 640
+
+
 class PlainConv(Function):
     """torch-semantics Conv1d (zero padding `pad` both sides, stride) with optional weight-norm gain g (C_out,1,1)."""
 
@@ -22,8 +27,12 @@ class PlainConv(Function):
         B, c_in, t_in = x.shape
         t_out = (t_in + 2 * pad - k) // stride + 1
         vd, gd = v.detach().contiguous(), (g.detach().contiguous() if g is not None else None)
-        y = ops.conv1d(x.detach(), ops.pack_conv_weight(vd, gd), v.shape[0], k, bias=bias.detach() if bias is not None else None,
-                       stride=stride, pad_left=pad, pad_mode=ops.PAD_ZERO, t_out=t_out)
+        if _split_ok(k, stride, c_in, v.shape[0], B * t_out):
+            wp, ws = None, ops.pack_conv_weight_split(vd, gd)
+        else:
+            wp, ws = ops.pack_conv_weight(vd, gd), None
+        y = ops.conv1d(x.detach(), wp, v.shape[0], k, bias=bias.detach() if bias is not None else None,
+                       stride=stride, pad_left=pad, pad_mode=ops.PAD_ZERO, t_out=t_out, w_split=ws)
         ctx.cfg = (k, stride, pad, t_in, t_out)
         ctx.save_for_backward(x, v, g, bias)
         return y
@@ -44,7 +53,12 @@ class PlainConv(Function):
                 up = torch.empty(B, c_out, tu, device=dy.device)
                 _call("fac_zero_insert", _p(dy), _p(up), B * c_out, t_out, stride)
             tp = up.shape[-1] + k - 1
-            dxp = ops.conv1d(up, ops.pack_conv_weight_bwd(vd, gd), c_in, k, pad_left=k - 1, pad_mode=ops.PAD_ZERO, t_out=tp)
+            if _split_ok(k, 1, c_out, c_in, B * tp):
+                w = ops.rows_fma(vd, ops.wn_scale(vd, gd)) if gd is not None else vd
+                ws = ops.pack_conv_weight_split(w.permute(1, 0, 2).flip(2).contiguous())
+                dxp = ops.conv1d(up, None, c_in, k, pad_left=k - 1, pad_mode=ops.PAD_ZERO, t_out=tp, w_split=ws)
+            else:
+                dxp = ops.conv1d(up, ops.pack_conv_weight_bwd(vd, gd), c_in, k, pad_left=k - 1, pad_mode=ops.PAD_ZERO, t_out=tp)
             if tp < pad + t_in:       # trailing inputs no window reads
                 dxp = torch.cat([dxp, torch.zeros(B, c_in, pad + t_in - tp, device=dy.device)], dim=2)
             dx = dxp[:, :, pad:pad + t_in].contiguous()

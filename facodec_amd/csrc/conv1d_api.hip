@@ -125,7 +125,7 @@ extern "C" int fac_conv1d_variant(const fac_conv_desc* d, char* name, int name_l
     a.alpha_in = d->alpha_in; a.w1 = d->w_k1; a.w_batched = d->w_batched; a.C_in = d->C_in; a.dil = d->dilation;
     a.B = d->B; a.T_out = d->T_out;
     if (conv_bsplit_ok(a)) {
-      if (name && name_len > 0) snprintf(name, name_len, "conv1d_bsplit_kernel<7> 64x256 (bf16x3 split, fp32-exact)");
+      if (name && name_len > 0) snprintf(name, name_len, "conv1d_bsplit_kernel<%d> 64x256 (bf16x3 split, fp32-exact)", d->K);
       return 11;
     }
   }

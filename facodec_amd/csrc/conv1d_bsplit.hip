@@ -380,10 +380,11 @@ __global__ __launch_bounds__((NMW + NSW) * 64, (NMW + NSW) / 4) void conv1d_bspl
 }
 
 bool conv_bsplit_ok(const ConvArgs& a) {
-  if (!(a.K == 7 && a.stride == 1 && a.n_phase == 1 && a.phase_shift == 0 && a.y_tstride == 1 && !a.alpha_in &&
+  if (!((a.K == 7 || a.K == 5) && a.stride == 1 && a.n_phase == 1 && a.phase_shift == 0 && a.y_tstride == 1 && !a.alpha_in &&
         !a.w1 && !a.w_batched && (long long)a.B * a.T_out > 640))
     return false;
-  const int G = bs_group(a.C_in), tt = G == 2 ? 256 : 512, kp = G == 2 ? 6 : 7;   // G = 1 also reads the zero tap
+  const int G = bs_group(a.C_in), tt = G == 2 ? 256 : 512;
+  const int kp = G == 2 ? a.K - 1 : ((a.K + 1) & ~1) - 1;                        // G = 1 also reads the zero tap
   return a.C_in % (8 * G) == 0 && G * ((tt + kp * a.dil + 63) / 64) <= BS_NSW * BS_XU &&
          a.x_cs * (long long)a.C_in < (1ll << 31);
 }
@@ -417,6 +418,8 @@ static int bsplit_launch(ConvArgs& a, hipStream_t s) {
 }
 
 int conv_dispatch_bsplit(ConvArgs& a, hipStream_t s) {
+  if (a.K == 5)   // the discriminators' (5,1) convs and their data gradients
+    return bs_group(a.C_in) == 2 ? bsplit_launch<5, 2, 4, BS_NSW_WIDE>(a, s) : bsplit_launch<5, 1, 8, BS_NSW>(a, s);
   return bs_group(a.C_in) == 2 ? bsplit_launch<7, 2, 4, BS_NSW_WIDE>(a, s) : bsplit_launch<7, 1, 8, BS_NSW>(a, s);
 }
 
