@@ -128,3 +128,46 @@ def test_reflect_short_input_matches_pad1d():
     y = O.sconv1d(x, w, None)
     assert y.shape[-1] == 5
     assert torch.allclose(y[0, 0], torch.tensor([0.0, 0.0, 5.0, 4.0, 3.0]))
+
+
+def test_pinning_report_covers_redecoder_and_discriminator(golden_dir):
+    r = json.load(open(os.path.join(golden_dir, "oracle_pinning_report.json")))
+    assert r["redecoder_oracle_rel"] < 1e-5 and r["redecoder_decoder_oracle_rel"] < 1e-5
+    assert r["discriminator_oracle_rel_max"] < 1e-5
+
+
+def test_discriminator_oracle_against_reference_logits(golden_dir):
+    """5 MPD + 3 MRD logits of the REAL dac/model/discriminator.py (over the audiotools STFT restatement) on two 1 s
+    clips with formula weights: the oracle reproduces them from the committed fixture alone."""
+    shapes = _shapes(golden_dir, "discriminator")
+    sd = synth.synth_state_dict(shapes, 0, "discriminator.")
+    x = synth.synth_clips(2, 24000, seed=5)
+    gold = np.load(os.path.join(golden_dir, "discriminator.npz"))
+    with torch.no_grad():
+        fm = O.discriminator_forward(sd, x)
+    assert [len(f) for f in fm] == [6] * 5 + [26] * 3
+    for i, f in enumerate(fm):
+        assert rel(f[-1], gold[f"logit{i}"]) < 1e-5, i
+        ma = np.array([float(t.abs().mean()) for t in f], np.float32)
+        assert np.allclose(ma, gold[f"fmap{i}_mean_abs"], rtol=1e-4), i
+
+
+def test_quantizer_dropout_masks_follow_reference_rule():
+    """dac/nn/quantize.py:163-183: the first int(B * dropout) samples draw n in [1, n_codebooks], the rest use all."""
+    from facodec_amd.autograd import draw_quantizer_masks
+    g = torch.Generator().manual_seed(5)
+    m = draw_quantizer_masks(3, 8, 0.5, g)
+    assert m.shape == (3, 8) and torch.all(m[:, 4:] == 1)            # undropped half: every quantizer
+    assert torch.all(m[0] == 1)                                       # at least one quantizer for everyone
+    assert torch.all(m[1:] <= m[:-1])                                 # masks are prefixes: i < n_quantizers
+    g2 = torch.Generator().manual_seed(5)
+    drop = torch.randint(1, 4, (8,), generator=g2)
+    assert torch.equal(m[:, :4].sum(0).long(), drop[:4])
+
+
+def test_gan_and_train_losses_restated_like_train_py():
+    """train.py:282-285, 304-312 on toy feature maps."""
+    fake = [[torch.full((2, 3), 0.5), torch.full((2, 1), 0.25)]]
+    real = [[torch.full((2, 3), 1.5), torch.full((2, 1), 0.75)]]
+    ld, lg, lf = O.gan_losses(fake, real)
+    assert abs(float(ld) - (0.25 ** 2 + 0.25 ** 2)) < 1e-7 and abs(float(lg) - 0.75 ** 2) < 1e-7 and abs(float(lf) - 1.0) < 1e-7
