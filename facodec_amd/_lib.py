@@ -87,8 +87,8 @@ SIGNATURES = {
     "fac_attention_bwd_pv": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "fac_attention_bwd_qk": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "fac_aa_snakebeta_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
-    "fac_leaky_relu": (_i, [_p, _p, _p, _i64, _f, _p]),
-    "fac_period_fold": (_i, [_p, _p, _i, _i, _i, _i, _i, _p]),
+    "fac_leaky_relu": (_i, [_p, _p, _p, _i64, _f, _i, _i, _i, _p]),
+    "fac_period_fold": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "fac_zero_insert": (_i, [_p, _p, _i64, _i, _i, _p]),
     "fac_row_stack3": (_i, [_p, _p, _i64, _i, _i, _i, _i, _p]),
     "fac_spec_to_rows": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _p]),

@@ -75,40 +75,45 @@ class PlainConv(Function):
 
 
 class LeakyReLU(Function):
+    """LeakyReLU; with rows = (pitch, valid) also zeroes the gap columns of a row-concatenated signal."""
+
     @staticmethod
-    def forward(ctx, x, slope):
+    def forward(ctx, x, slope, rows=None):
         ctx.save_for_backward(x)
-        ctx.slope = slope
+        pitch, valid = rows if rows is not None else (0, 0)
+        ctx.cfg = (slope, x.shape[-1], pitch, valid)
         y = torch.empty_like(x)
-        _call("fac_leaky_relu", _p(x.detach().contiguous()), _p(None), _p(y), x.numel(), C.c_float(slope))
+        _call("fac_leaky_relu", _p(x.detach().contiguous()), _p(None), _p(y), x.numel(), C.c_float(slope), x.shape[-1], pitch, valid)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         (x,) = ctx.saved_tensors
+        slope, T, pitch, valid = ctx.cfg
         dx = torch.empty_like(x)
-        _call("fac_leaky_relu", _p(x.detach().contiguous()), _p(dy.contiguous()), _p(dx), x.numel(), C.c_float(ctx.slope))
-        return dx, None
+        _call("fac_leaky_relu", _p(x.detach().contiguous()), _p(dy.contiguous()), _p(dx), x.numel(), C.c_float(slope), T, pitch, valid)
+        return dx, None, None
 
 
 class PeriodFold(Function):
-    """(B, 1, T) -> (B * period, 1, L): MPD.pad_to_period + rearrange (discriminator.py:39-48), period as batch."""
+    """(B, 1, T) -> (1, 1, B*period*pitch): MPD.pad_to_period + rearrange (discriminator.py:39-48) with the B*period
+    rows laid one after another, `pitch` columns each (L data columns, then zeros standing in for the convs' padding)."""
 
     @staticmethod
-    def forward(ctx, x, period):
+    def forward(ctx, x, period, pitch):
         B, _, T = x.shape
         L = (T + (period - T % period)) // period
-        out = torch.empty(B * period, 1, L, device=x.device)
-        _call("fac_period_fold", _p(x.detach().contiguous()), _p(out), B, T, period, L, 0)
-        ctx.cfg = (B, T, period, L)
+        out = torch.empty(1, 1, B * period * pitch, device=x.device)
+        _call("fac_period_fold", _p(x.detach().contiguous()), _p(out), B, T, period, L, pitch, 0)
+        ctx.cfg = (B, T, period, L, pitch)
         return out
 
     @staticmethod
     def backward(ctx, d):
-        B, T, period, L = ctx.cfg
+        B, T, period, L, pitch = ctx.cfg
         dx = torch.empty(B, 1, T, device=d.device)
-        _call("fac_period_fold", _p(d.contiguous()), _p(dx), B, T, period, L, 1)
-        return dx, None
+        _call("fac_period_fold", _p(d.contiguous()), _p(dx), B, T, period, L, pitch, 1)
+        return dx, None, None
 
 
 class RowStack3(Function):
@@ -205,11 +210,13 @@ class PairMean(Function):
     """mean over elements of |a - b| (mode 0), (a - b)^2 (mode 2) or smooth-L1 (mode 3); gradient to `a` only."""
 
     @staticmethod
-    def forward(ctx, a, b, mode):
+    def forward(ctx, a, b, mode, count=None):
+        """count: number of elements the mean runs over (default all; smaller when a and b carry zero gap columns)."""
         ad, bd = a.detach().contiguous(), b.detach().contiguous()
         out = torch.zeros(1, device=a.device)
         scratch = torch.empty(1024, device=a.device)
-        ops.reduce_pair(ad, bd, out, scratch, mode, 0.0, 1.0 / ad.numel(), False)
+        ctx.inv = 1.0 / (count if count is not None else ad.numel())
+        ops.reduce_pair(ad, bd, out, scratch, mode, 0.0, ctx.inv, False)
         ctx.save_for_backward(ad, bd)
         ctx.mode = mode
         return out[0].clone()
@@ -218,8 +225,8 @@ class PairMean(Function):
     def backward(ctx, g):
         ad, bd = ctx.saved_tensors
         da = torch.empty_like(ad)
-        ops.pair_bwd(ad, bd, da, ctx.mode, 0.0, 1.0 / ad.numel(), False)
-        return ops.rows_fma(da.reshape(1, -1), g.reshape(1).to(da.dtype)).reshape(ad.shape), None, None
+        ops.pair_bwd(ad, bd, da, ctx.mode, 0.0, ctx.inv, False)
+        return ops.rows_fma(da.reshape(1, -1), g.reshape(1).to(da.dtype)).reshape(ad.shape), None, None, None
 
 
 class CrossEntropy(Function):

@@ -10,32 +10,43 @@ namespace fac {
 #define GRID_STRIDE(i, n) for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < (n); i += (long long)gridDim.x * blockDim.x)
 static inline int grid_for(long long n) { return (int)((n + 255) / 256 < 65535 ? (n + 255) / 256 : 65535); }
 
-__global__ void leaky_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, float slope, long long n) {
-  GRID_STRIDE(i, n) { const float v = x[i]; y[i] = v > 0.f ? v : v * slope; }
+// Optional position mask for row-concatenated signals (MPD): only positions t with t % pitch < valid inside each
+// channel row of length T carry data; the rest are the zero gaps that stand in for the convs' padding.
+__global__ void leaky_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, float slope, int T, int pitch, int valid, long long n) {
+  GRID_STRIDE(i, n) {
+    const float v = x[i];
+    const bool ok = pitch == 0 || (int)((i % T) % pitch) < valid;
+    y[i] = ok ? (v > 0.f ? v : v * slope) : 0.f;
+  }
 }
-__global__ void leaky_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dx, float slope, long long n) {
-  GRID_STRIDE(i, n) dx[i] = x[i] > 0.f ? dy[i] : dy[i] * slope;
+__global__ void leaky_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dx, float slope, int T, int pitch,
+                                 int valid, long long n) {
+  GRID_STRIDE(i, n) {
+    const bool ok = pitch == 0 || (int)((i % T) % pitch) < valid;
+    dx[i] = ok ? (x[i] > 0.f ? dy[i] : dy[i] * slope) : 0.f;
+  }
 }
 
-// out[(b*p + j)][l] = xr[l*p + j], xr = x reflect-extended on the right to L*p samples (MPD.pad_to_period + rearrange)
-__global__ void period_fold_kernel(const float* __restrict__ x, float* __restrict__ out, int T, int p, int L, long long n) {
+// out[(b*p + j)*pitch + l] = xr[l*p + j] for l < L (zero for L <= l < pitch), xr = x reflect-extended on the right to
+// L*p samples (MPD.pad_to_period + rearrange); rows (b, j) laid one after another with `pitch` columns each
+__global__ void period_fold_kernel(const float* __restrict__ x, float* __restrict__ out, int T, int p, int L, int pitch, long long n) {
   GRID_STRIDE(i, n) {
-    const int l = (int)(i % L);
-    const long long r = i / L;
+    const int l = (int)(i % pitch);
+    const long long r = i / pitch;
     const int j = (int)(r % p);
     const long long b = r / p;
     int s = l * p + j;
     if (s >= T) s = 2 * (T - 1) - s;
-    out[i] = x[b * T + s];
+    out[i] = l < L ? x[b * T + s] : 0.f;
   }
 }
-__global__ void period_fold_bwd_kernel(const float* __restrict__ dout, float* __restrict__ dx, int T, int p, int L, long long n) {
+__global__ void period_fold_bwd_kernel(const float* __restrict__ dout, float* __restrict__ dx, int T, int p, int L, int pitch, long long n) {
   GRID_STRIDE(i, n) {
     const int s = (int)(i % T);
     const long long b = i / T;
-    float g = dout[(b * p + s % p) * L + s / p];
+    float g = dout[(b * p + s % p) * pitch + s / p];
     const int s2 = 2 * (T - 1) - s;            // the reflected copy of sample s, if it lies in the padded tail
-    if (s2 >= T && s2 < L * p) g += dout[(b * p + s2 % p) * L + s2 / p];
+    if (s2 >= T && s2 < L * p) g += dout[(b * p + s2 % p) * pitch + s2 / p];
     dx[i] = g;
   }
 }
@@ -169,18 +180,21 @@ __global__ __launch_bounds__(256) void disc_pre_bwd_kernel(const float* __restri
 
 #define L1(kern, n, ...) hipLaunchKernelGGL(fac::kern, dim3(fac::grid_for(n)), dim3(256), 0, (hipStream_t)stream, __VA_ARGS__)
 
-extern "C" int fac_leaky_relu(const float* x, const float* dy, float* out, int64_t n, float slope, fac_stream_t stream) {
-  FAC_REQUIRE(x && out && n > 0, "leaky_relu: bad arguments");
-  if (dy) L1(leaky_bwd_kernel, n, x, dy, out, slope, (long long)n);
-  else L1(leaky_fwd_kernel, n, x, out, slope, (long long)n);
+extern "C" int fac_leaky_relu(const float* x, const float* dy, float* out, int64_t n, float slope, int T, int pitch, int valid,
+                              fac_stream_t stream) {
+  FAC_REQUIRE(x && out && n > 0 && (pitch == 0 || (T > 0 && valid > 0 && valid <= pitch)), "leaky_relu: bad arguments");
+  if (dy) L1(leaky_bwd_kernel, n, x, dy, out, slope, T > 0 ? T : 1, pitch, valid, (long long)n);
+  else L1(leaky_fwd_kernel, n, x, out, slope, T > 0 ? T : 1, pitch, valid, (long long)n);
   return fac::check_launch("leaky_relu");
 }
 
-extern "C" int fac_period_fold(const float* x, float* out, int B, int T, int period, int L, int backward, fac_stream_t stream) {
-  FAC_REQUIRE(x && out && B > 0 && T > 1 && period > 0 && (long long)L * period >= T && (long long)L * period <= 2ll * T - 1,
+extern "C" int fac_period_fold(const float* x, float* out, int B, int T, int period, int L, int pitch, int backward,
+                               fac_stream_t stream) {
+  FAC_REQUIRE(x && out && B > 0 && T > 1 && period > 0 && (long long)L * period >= T && (long long)L * period <= 2ll * T - 1 &&
+                  pitch >= L,
               "period_fold: bad arguments");
-  if (backward) { const long long n = (long long)B * T; L1(period_fold_bwd_kernel, n, x, out, T, period, L, n); }
-  else { const long long n = (long long)B * period * L; L1(period_fold_kernel, n, x, out, T, period, L, n); }
+  if (backward) { const long long n = (long long)B * T; L1(period_fold_bwd_kernel, n, x, out, T, period, L, pitch, n); }
+  else { const long long n = (long long)B * period * pitch; L1(period_fold_kernel, n, x, out, T, period, L, pitch, n); }
   return fac::check_launch("period_fold");
 }
 

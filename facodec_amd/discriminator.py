@@ -48,17 +48,36 @@ class MPD(nn.Module):
         self.conv_post = _WNConv2d(1024, 1, 3, 1)
         self.strides = (3, 3, 3, 3, 1)
 
+    def geometry(self, T):
+        """Row lengths L_i and pitches P_i of the six tensors x0..x5 (+ logits) for an input of T samples.  All
+        B*period rows are laid one after another inside ONE long signal (so the convs run as big single-batch
+        launches instead of one short launch tile per row); a row of x_i owns P_i columns, L_i of data followed by zeros
+        that act as the convs' zero padding.  P_i = stride_i * P_{i+1} keeps every row aligned to its conv's stride."""
+        L = [(T + (self.period - T % self.period)) // self.period]
+        for s in self.strides:
+            L.append((L[-1] + 4 - 5) // s + 1)
+        P = [L[5] + 2] * 6                      # x5 / x4 (stride 1): gap of 2 zeros covers k = 5 and k = 3
+        for i in (3, 2, 1, 0):
+            P[i] = self.strides[i] * P[i + 1]
+        return L, P
+
     def forward(self, x):
-        """x (B, 1, T) preprocessed -> 6 feature maps (B*period, C, L)."""
-        x = AD.PeriodFold.apply(x, self.period)
+        """x (B, 1, T) preprocessed -> 6 feature maps (1, C, B*period*P_i) with `.rows = (pitch, valid, n_rows)`."""
+        B, _, T = x.shape
+        L, P = self.geometry(T)
+        R = B * self.period
+        x = AD.PeriodFold.apply(x, self.period, P[0])
         fmap = []
-        for seq, s in zip(self.convs, self.strides):
+        for i, (seq, s) in enumerate(zip(self.convs, self.strides)):
             c = seq[0]
             x = AD.PlainConv.apply(x, c.weight_v.squeeze(-1), c.weight_g.squeeze(-1), c.bias, 5, s, 2)
-            x = AD.LeakyReLU.apply(x, 0.1)
+            x = AD.LeakyReLU.apply(x, 0.1, (P[i + 1], L[i + 1]))
+            x.rows = (P[i + 1], L[i + 1], R)
             fmap.append(x)
         c = self.conv_post
         x = AD.PlainConv.apply(x, c.weight_v.squeeze(-1), c.weight_g.squeeze(-1), c.bias, 3, 1, 1)
+        x = AD.LeakyReLU.apply(x, 1.0, (P[5], L[5]))      # identity on the data columns, zero in the gaps
+        x.rows = (P[5], L[5], R)
         fmap.append(x)
         return fmap
 
@@ -130,8 +149,10 @@ def reference_layout(disc, fmaps, batch):
         conv = []
         for m in maps:
             if isinstance(d, MPD):
-                bp, c, L = m.shape
-                conv.append(m.reshape(batch, d.period, c, L).permute(0, 2, 3, 1).contiguous())
+                pitch, valid, rows = m.rows
+                c = m.shape[1]
+                v = m.reshape(c, rows, pitch)[:, :, :valid]                       # (C, B*period, L)
+                conv.append(v.reshape(c, batch, d.period, valid).permute(1, 0, 3, 2).contiguous())
             else:
                 rows, c, f = m.shape
                 conv.append(m.reshape(batch, rows // batch, c, f).permute(0, 2, 1, 3).contiguous())
@@ -139,22 +160,34 @@ def reference_layout(disc, fmaps, batch):
     return out
 
 
+_MASKS = {}
+
+
+def _row_mask(t):
+    """1 on the data columns of a row-concatenated map, 0 in the gaps (None for plain tensors) + the data count."""
+    rows = getattr(t, "rows", None)
+    if rows is None:
+        return None, t.numel()
+    pitch, valid, n_rows = rows
+    key = (t.shape, pitch, valid, t.device)
+    if key not in _MASKS:
+        m = (torch.arange(t.shape[-1], device=t.device) % pitch < valid).to(torch.float32)
+        _MASKS[key] = m.reshape(1, 1, -1).expand(t.shape).contiguous()
+    return _MASKS[key], t.shape[1] * n_rows * valid
+
+
 def gan_losses(d_fake, d_real):
-    """train.py:282-285 and :304-312 -> (loss_d, loss_g, loss_feature) as autograd scalars."""
-    one = {}
-
-    def ones_like(t):
-        k = (t.shape, t.device)
-        if k not in one:
-            one[k] = torch.ones_like(t)
-        return one[k]
-
+    """train.py:282-285 and :304-312 -> (loss_d, loss_g, loss_feature) as autograd scalars.  Means run over the data
+    elements only (gap columns of the row-concatenated MPD maps are zero in both operands)."""
     loss_d = loss_g = loss_f = None
     acc = lambda a, b: b if a is None else a + b     # noqa: E731  (scalar adds: bookkeeping)
     for xf, xr in zip(d_fake, d_real):
-        zf = torch.zeros_like(xf[-1])
-        loss_d = acc(loss_d, AD.PairMean.apply(xf[-1], zf, 2) + AD.PairMean.apply(xr[-1], ones_like(xr[-1]), 2))
-        loss_g = acc(loss_g, AD.PairMean.apply(xf[-1], ones_like(xf[-1]), 2))
+        mask, cnt = _row_mask(xf[-1])
+        one = mask if mask is not None else torch.ones_like(xf[-1])
+        zero = torch.zeros_like(xf[-1])
+        loss_d = acc(loss_d, AD.PairMean.apply(xf[-1], zero, 2, cnt) + AD.PairMean.apply(xr[-1], one, 2, cnt))
+        loss_g = acc(loss_g, AD.PairMean.apply(xf[-1], one, 2, cnt))
         for j in range(len(xf) - 1):
-            loss_f = acc(loss_f, AD.PairMean.apply(xf[j], xr[j].detach(), 0))
+            _, cj = _row_mask(xf[j])
+            loss_f = acc(loss_f, AD.PairMean.apply(xf[j], xr[j].detach(), 0, cj))
     return loss_d, loss_g, loss_f

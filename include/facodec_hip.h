@@ -234,15 +234,18 @@ int fac_aa_snakebeta_bwd(const float* x, const float* alpha_log, const float* be
 /* Discriminator path (dac/model/discriminator.py): layout / elementwise kernels; the convolutions run on
  * fac_conv1d_fwd (MPD: 1-D along the folded time axis, period as batch; MRD: 1-D along frequency over three stacked
  * time rows).  A non-NULL dy / non-zero `backward` selects the adjoint.
- *   leaky_relu: out = x > 0 ? x : slope*x   (backward: out = x > 0 ? dy : slope*dy)
- *   period_fold: (B, T) -> (B*period, L), reflect-extended on the right to L*period samples
+ *   leaky_relu: out = x > 0 ? x : slope*x   (backward: out = x > 0 ? dy : slope*dy); with pitch > 0 only positions
+ *               t % pitch < valid of every length-T row are kept, the rest set to zero (row-concatenated MPD signals)
+ *   period_fold: (B, T) -> B*period rows of `pitch` columns laid one after another (L data columns, then zeros),
+ *               reflect-extended on the right to L*period samples
  *   zero_insert: (rows, T) -> (rows, (T-1)*stride + 1), zeros between samples (strided conv data gradient)
  *   row_stack3: (rows = B*T, C, F) -> (rows, 3C, F): time rows t-1, t, t+1 stacked (zero outside a clip)
  *   spec_to_rows: one frequency band [f0, f0+Fb) of spec (B, 2*Ft, T) = [re|im] -> (B*T, 2, Fb)
  *   pad_reflect: (B, T) -> (B, pad_l + T + pad_r)
  *   disc_preprocess: z = 0.8 (x - mean)/(max|x - mean| + 1e-9) per clip; stats: 4*B floats kept for the backward */
-int fac_leaky_relu(const float* x, const float* dy, float* out, int64_t n, float slope, fac_stream_t stream);
-int fac_period_fold(const float* x, float* out, int B, int T, int period, int L, int backward, fac_stream_t stream);
+int fac_leaky_relu(const float* x, const float* dy, float* out, int64_t n, float slope, int T, int pitch, int valid,
+                   fac_stream_t stream);
+int fac_period_fold(const float* x, float* out, int B, int T, int period, int L, int pitch, int backward, fac_stream_t stream);
 int fac_zero_insert(const float* dy, float* up, int64_t rows, int T, int stride, fac_stream_t stream);
 int fac_row_stack3(const float* x, float* out, int64_t rows, int T, int C, int F, int backward, fac_stream_t stream);
 int fac_spec_to_rows(const float* src, float* dst, int B, int Ft, int T, int f0, int Fb, int backward, fac_stream_t stream);
