@@ -6,14 +6,22 @@ Workload at N=1 = BASELINE.json configs[1]: batch 32 x 2 s @ 24 kHz, forward-onl
 encoder -> FVQ (6 codebooks, codes returned) -> decoder, synthetic clips resident in HBM,
 formula-generated weights of the shipped architecture (configs/config.yml model_params),
 fp32 throughout (fp32 MFMA; bf16 cannot hold bit-exact codes -- SURVEY.md 0.5).
-N>1: one process per GPU (torch.distributed.run), every rank runs the same per-GPU batch on its
-own clips (weak scaling, no data-path collective: clips are independent units).
+N>1: one process per GPU, every rank runs the same per-GPU batch on its own clips (weak scaling, no
+data-path collective in the forward: clips are independent units).  `python bench.py --gpus N` spawns the N
+ranks itself (re-exec under torch.distributed.run on 127.0.0.1) when it is not already running under a launcher.
+
+The same line also carries `train_step`: BASELINE.json configs[2], the full train.py iteration (discriminator
+step + generator step, 16 clips per GPU) with the RCCL gradient all-reduce of every model key INSIDE the timed
+region, and `codes_match`: the bench model's code indices on the golden clips against the real reference's
+(tests/golden/codec_e2e.npz), checked before anything is timed.
 
 Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement" for how each field is computed).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -30,6 +38,10 @@ SAMPLE_RATE = 24000
 # Algorithmic work of the forward path per 2 s clip (SURVEY.md 8d / BASELINE.md 2, hook-counted on
 # the reference): 118.44 GMAC = 236.88 GFLOP, i.e. 118.44 GFLOP per audio-second.
 FLOP_PER_AUDIO_S = 118.44e9
+# Train step (configs[2]), SURVEY.md 8d estimate: 3 x (118.44 + 20.51 predictors) + ~10 x 34.8 discriminator GMAC per clip
+# = 0.77 TFLOP per audio-second (the predictor heads are not part of the timed step: their targets come from external models).
+TRAIN_FLOP_PER_AUDIO_S = 0.77e12
+TRAIN_BATCH = 16
 FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 BF16_MFMA_PEAK_TFLOPS = 2516.6  # MI355X_MICROARCH.md: dense bf16 MFMA peak
 # conv1d_bsplit.hip computes every fp32 product as six exact bf16 products (fp32 accumulate): its roofline is the
@@ -53,6 +65,80 @@ def make_step(model, wave):
             y = model.decoder(outs)
         return y, codes
     return step
+
+
+def check_codes(model, device):
+    """Correctness gate of the metric ("...; code-index match"): the six code streams of the golden clips must equal the
+    REAL reference's (tests/golden/codec_e2e.npz was produced by importing /root/reference).  Raises on any mismatch."""
+    import numpy as np
+    gold = np.load(os.path.join(REPO, "tests", "golden", "codec_e2e.npz"))
+    wave = synth.synth_clips(2, int(CLIP_SECONDS * SAMPLE_RATE), seed=0).to(device)
+    _, codes = make_step(model, wave)()
+    mism = sum(int((c.cpu().numpy().astype(np.int64) != gold[k].astype(np.int64)).sum())
+               for c, k in zip(codes, ("codes_p", "codes_c", "codes_r")))
+    if mism:
+        raise SystemExit(f"[bench] code-index mismatch against the reference golden vectors: {mism} of {6 * 2 * 160}")
+    return True
+
+
+def train_leg(model, device, rank, world, steps, warmup):
+    """configs[2]: discriminator step + generator step on 16 clips per GPU, gradient all-reduce (RCCL) inside the timing."""
+    import torch.distributed as dist
+    from facodec_amd.train import TrainStep
+    synth.load_synthetic(model.discriminator, seed=0, prefix="discriminator.")
+    model.discriminator.to(device)
+    step = TrainStep(model)
+    wave = synth.synth_clips(TRAIN_BATCH, int(CLIP_SECONDS * SAMPLE_RATE), seed=1, rank=rank).to(device)
+    last = {}
+
+    def fn():
+        last.update(step(wave))
+
+    torch.cuda.reset_peak_memory_stats()
+    elapsed = benchutil.timed_steps(fn, steps, warmup, torch.cuda.synchronize, device)
+    units = benchutil.aggregate_units(TRAIN_BATCH * CLIP_SECONDS * steps, device)
+    finite = all(bool(torch.isfinite(last[k]).all()) for k in ("loss", "loss_d", "mel", "feature"))
+    ar_ms, ar_bytes = None, sum(o.g.numel() * 4 for o in step.opt.values())
+    if world > 1:   # the exchange alone (all four arenas back to back, blocking): what the overlap has to hide
+        torch.cuda.synchronize()
+        dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            for o in step.opt.values():
+                dist.all_reduce(o.g, op=dist.ReduceOp.AVG)
+        torch.cuda.synchronize()
+        ar_ms = 1e3 * (time.perf_counter() - t0) / 3
+    value = units / elapsed
+    per_gpu_tflops = value / world * TRAIN_FLOP_PER_AUDIO_S / 1e12
+    return {
+        "value": round(value, 2), "unit": "audio-s/s", "ms_per_step": round(1e3 * elapsed / steps, 2), "steps": steps, "warmup": warmup,
+        "workload": f"configs[2]: train.py iteration, {TRAIN_BATCH} clips/GPU x 2 s: encoder -> FA-quantizer -> decoder forward + backward, "
+                    "5 MPD + 3 MRD discriminators (discriminator step, then generator step with adversarial + feature-matching), "
+                    "7-scale mel loss, commitment + codebook losses, 4 x (clip + AdamW + ExponentialLR); predictor heads excluded "
+                    "(their targets come from external networks)",
+        "parallelism": f"dp{world}: one all-reduce(mean) per model key over RCCL, launched asynchronously under backward",
+        "allreduce_bytes_per_step": ar_bytes, "allreduce_ms_standalone": None if ar_ms is None else round(ar_ms, 2),
+        "losses_finite": finite, "loss": round(float(last["loss"]), 4), "mel": round(float(last["mel"]), 4),
+        "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
+        "roofline": {"bound": "mfma", "achieved": round(per_gpu_tflops, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": round(per_gpu_tflops / FP32_MFMA_PEAK_TFLOPS, 4),
+                     "basis": "whole step, per GPU: audio-s/s x 0.77 TFLOP per audio-second (SURVEY.md 8d estimate) against the fp32 "
+                              "MFMA peak; per-kernel numbers in profiles/"},
+    }
+
+
+def respawn_under_launcher(n):
+    """`python bench.py --gpus N` without a launcher: re-exec as N ranks (one per GPU) under torch.distributed.run."""
+    if torch.cuda.device_count() < n:
+        raise SystemExit(f"[bench] --gpus {n} but only {torch.cuda.device_count()} GPU(s) visible: refusing to measure fewer")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.run(cmd, env=env).returncode)
 
 
 def cpu_baseline(batch=4, passes=5):
@@ -88,18 +174,24 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="clips per GPU per step (configs[1]: 32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true", help="skip per-launch HIP-event timing of the conv kernel")
+    ap.add_argument("--no-train", action="store_true", help="skip the configs[2] train-step leg")
+    ap.add_argument("--train-steps", type=int, default=4)
+    ap.add_argument("--train-warmup", type=int, default=2)
     args = ap.parse_args()
 
-    rank, local_rank, world = benchutil.init_distributed()
-    if world != args.gpus and rank == 0:
-        print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        respawn_under_launcher(args.gpus)
+    rank, local_rank, world = benchutil.init_distributed()
+    if world != args.gpus:
+        raise SystemExit(f"[bench] --gpus {args.gpus} but WORLD_SIZE={world}")
     device = torch.device(f"cuda:{local_rank % torch.cuda.device_count()}")
     torch.cuda.set_device(device)
 
     model = build(device)
     n_samples = int(CLIP_SECONDS * SAMPLE_RATE)
+    codes_match = check_codes(model, device)
     wave = synth.synth_clips(args.batch, n_samples, seed=0, rank=rank).to(device)   # resident in HBM
     step = make_step(model, wave)
     sync = torch.cuda.synchronize
@@ -133,6 +225,11 @@ def main():
         finally:
             ops.BF16_SPLIT = True
 
+    train = None
+    if not args.no_train:
+        del step
+        train = train_leg(model, device, rank, world, args.train_steps, args.train_warmup)
+
     if rank != 0:
         if torch.distributed.is_initialized():
             torch.distributed.destroy_process_group()
@@ -142,7 +239,7 @@ def main():
         "metric": "24kHz audio sec encoded+decoded per wall-sec",
         "value": round(value, 2), "unit": "audio-s/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic", "codes_match": codes_match,
         "arithmetic": ("fp32 tensors and fp32 accumulation everywhere; the k=7 ResidualUnit convs form each fp32 product from "
                        "three-way exact bf16 splits of both operands on the bf16 matrix pipe (error vs fp64 <= the fp32 MFMA's, "
                        "tests/test_gpu_parity.py::test_split_bf16_conv_matches_fp32_grade)" if ops.BF16_SPLIT else "fp32 MFMA"),
@@ -176,7 +273,13 @@ def main():
                                       "ms_per_step": round(v["ms"] / args.steps, 3)} for k, v in summ.items()},
             "conv_ms_per_step": round(tot_ms / args.steps, 3),
             "whole_step_tflops": round(value / world * FLOP_PER_AUDIO_S / 1e12, 2),
+            "whole_step_frac_of_fp32_mfma_peak": round(value / world * FLOP_PER_AUDIO_S / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
+            "note": "SURVEY.md 8d prices the whole forward against the fp32 MFMA peak (157.3): that fraction is "
+                    "whole_step_frac_of_fp32_mfma_peak.  The bf16 pipe sustains 1913 TFLOP/s on random operands on this part "
+                    "(tools/microbench), so the practical ceiling of the split kernel is ~319 fp32-equivalent TFLOP/s, not 419.",
         }
+    if train is not None:
+        out["train_step"] = train
     if fp32_ref is not None:
         out["fp32_mfma_only"] = fp32_ref
     if world == 1 and not args.no_cpu_baseline:

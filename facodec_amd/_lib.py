@@ -95,6 +95,8 @@ SIGNATURES = {
     "fac_pad_reflect": (_i, [_p, _p, _i, _i, _i, _i, _p]),
     "fac_disc_preprocess": (_i, [_p, _p, _p, _p, _i, _i, _p]),
     "fac_cross_entropy": (_i, [_p, _p, _p, _p, _p, _i64, _i, _f, _p]),
+    "fac_focal_scalar": (_i, [_p, _p, _f, _p]),
+    "fac_crop_rows": (_i, [_p, _p, _p, _i, _i, _i64, _i, _i, _p]),
     "fac_stream_push": (_i, [_p, _p, _i64, _i64, _i, _i, _i, _p]),
     "fac_vq_fwd": (_i, [C.POINTER(VqDesc), _p]),
     "fac_vq_search": (_i, [_p, _p, _p, _i64, _i, _p]),

@@ -250,3 +250,39 @@ class CrossEntropy(Function):
         scratch = torch.empty(N, device=ld.device)
         _call("fac_cross_entropy", _p(ld), C.c_void_p(labels.data_ptr()), _p(None), _p(dl), _p(scratch), N, Cn, C.c_float(1.0 / N))
         return ops.rows_fma(dl.reshape(1, -1), g.reshape(1).to(dl.dtype)).reshape(ld.shape), None
+
+
+class Focal(Function):
+    """FocalLoss on a mean cross entropy (losses.py:264-276; train.py:153 gamma = 2): (1 - exp(-ce))**gamma * ce."""
+
+    @staticmethod
+    def forward(ctx, ce, gamma):
+        out = torch.empty(2, device=ce.device)
+        _call("fac_focal_scalar", _p(ce.detach().reshape(1).contiguous()), _p(out), C.c_float(gamma))
+        ctx.save_for_backward(out)
+        return out[0].clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        (out,) = ctx.saved_tensors
+        return ops.rows_fma(out[1:2].reshape(1, 1), g.reshape(1).to(out.dtype)).reshape(()), None
+
+
+def focal_cross_entropy(logits, labels, gamma=2.0):
+    """content_criterion of train.py:153,334-336."""
+    return Focal.apply(CrossEntropy.apply(logits, labels), gamma)
+
+
+class CropRows(Function):
+    """dst[b, c, t] = src[b, c, start[b] * scale + t]: the random-crop batching of train.py:188-212 without host loops."""
+
+    @staticmethod
+    def forward(ctx, src, start, t_dst, scale):
+        B, Cn, T = src.shape
+        out = torch.empty(B, Cn, t_dst, device=src.device)
+        _call("fac_crop_rows", _p(src.detach().contiguous()), _p(out), C.c_void_p(start.data_ptr()), B, Cn, T, t_dst, scale)
+        return out
+
+    @staticmethod
+    def backward(ctx, d):
+        raise NotImplementedError("crop_rows feeds constant inputs (waves / mel targets): no gradient path")

@@ -7,9 +7,11 @@ State-dict keys equal the reference's (`discriminators.N.convs.i.0.{weight_g,wei
 Execution: every Conv2d here has one trivial kernel dimension, so it runs on the 1-D conv kernels --
   MPD  (k,1) convs: 1-D along the folded time axis, the period folded into the batch: tensors (B*period, C, L);
   MRD  (3,k) convs: 1-D along frequency over the three neighbouring time rows stacked into channels: tensors (B*T, C, F).
-Feature maps are returned in these internal layouts: the losses that consume them (LSGAN on the logits, L1 feature
-matching: train.py:282-312) are means over all elements, hence layout-independent; `reference_layout()` converts a map
-for callers that want the reference's (B, C, L, period) / (B, C, T, F)."""
+`Discriminator.forward` returns the reference's structure (dac/model/discriminator.py:214-217): a list of 8 lists of
+feature maps shaped (B, C, L, period) for MPD and (B, C, T, F) for MRD, so train.py:280-312 (`torch.mean`,
+`F.l1_loss` over them) runs unchanged.  Each returned tensor is a zero-copy strided VIEW of the internal map (autograd
+flows through it) and carries the internal tensor as `._fac_internal`; `gan_losses()` -- the fused path TrainStep uses --
+reads that attribute and never touches the views."""
 import torch
 from torch import nn
 
@@ -137,13 +139,33 @@ class Discriminator(nn.Module):
     def preprocess(self, y):
         return AD.Preprocess.apply(y)
 
-    def forward(self, x):
+    def forward_internal(self, x):
+        """The 8 lists of internal-layout maps (row-concatenated MPD signals, (B*T, C, F) MRD rows)."""
         x = self.preprocess(x)
         return [d(x) for d in self.discriminators]
 
+    def forward(self, x):
+        B = x.shape[0]
+        x = self.preprocess(x)
+        return [[_reference_view(d, m, B) for m in d(x)] for d in self.discriminators]
+
+
+def _reference_view(d, m, batch):
+    """Zero-copy view of an internal map in the reference's layout: MPD (1, C, B*period*pitch) -> (B, C, L, period)
+    (element [b, c, l, p] = row b*period + p, column l), MRD (B*T, C, F) -> (B, C, T, F)."""
+    if isinstance(d, MPD):
+        pitch, valid, rows = m.rows
+        c = m.shape[1]
+        v = m.as_strided((batch, c, valid, d.period), (d.period * pitch, rows * pitch, 1, pitch))
+    else:
+        rows, c, f = m.shape
+        v = m.view(batch, rows // batch, c, f).permute(0, 2, 1, 3)
+    v._fac_internal = m
+    return v
+
 
 def reference_layout(disc, fmaps, batch):
-    """Internal feature maps -> the reference's (B, C, L, period) / (B, C, T, F) tensors."""
+    """Internal feature maps (`forward_internal`) -> contiguous copies in the reference's (B, C, L, period) / (B, C, T, F)."""
     out = []
     for d, maps in zip(disc.discriminators, fmaps):
         conv = []
@@ -176,12 +198,18 @@ def _row_mask(t):
     return _MASKS[key], t.shape[1] * n_rows * valid
 
 
+def _internal(t):
+    return getattr(t, "_fac_internal", t)
+
+
 def gan_losses(d_fake, d_real):
-    """train.py:282-285 and :304-312 -> (loss_d, loss_g, loss_feature) as autograd scalars.  Means run over the data
-    elements only (gap columns of the row-concatenated MPD maps are zero in both operands)."""
+    """train.py:282-285 and :304-312 -> (loss_d, loss_g, loss_feature) as autograd scalars, on the internal maps behind
+    the views `Discriminator.forward` returns (plain tensors work too).  Means run over the data elements only (gap
+    columns of the row-concatenated MPD maps are zero in both operands)."""
     loss_d = loss_g = loss_f = None
     acc = lambda a, b: b if a is None else a + b     # noqa: E731  (scalar adds: bookkeeping)
     for xf, xr in zip(d_fake, d_real):
+        xf, xr = [_internal(t) for t in xf], [_internal(t) for t in xr]
         mask, cnt = _row_mask(xf[-1])
         one = mask if mask is not None else torch.ones_like(xf[-1])
         zero = torch.zeros_like(xf[-1])

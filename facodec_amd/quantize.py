@@ -227,6 +227,12 @@ class LogMelFrontend(nn.Module):
         self._basis = None
         return super()._apply(fn, *a, **kw)
 
+    def _load_from_state_dict(self, *a, **kw):
+        """The packed DFT basis / filterbank are derived from the `to_mel.*` buffers: a checkpoint loaded after a forward
+        must not keep the tables of the old buffers (hooked on the children too: the buffers live one level down)."""
+        self._basis = None
+        return super()._load_from_state_dict(*a, **kw)
+
     def forward(self, wave, all_frames=False):
         """wave (B, 1, T) or (B, T) -> normalised log-mel (B, n_mels, T // hop) (the quantizer's crop,
         modules/quantize.py:242) or, with all_frames, all 1 + T // hop centred frames (meldataset.py:45)."""
@@ -317,7 +323,7 @@ class FAquantizer(nn.Module):
             timbre = AQ.style_encoder(self.timbre_encoder, mel, None, use_dropout=use_drop)
         else:
             mel_full = self.to_mel(full_waves)
-            m = sequence_mask(wave_lens // self.hop_length, mel_full.shape[-1]).to(torch.float32).contiguous()
+            m = sequence_mask(wave_lens.to(dev) // self.hop_length, mel_full.shape[-1]).to(torch.float32).contiguous()
             timbre = AQ.style_encoder(self.timbre_encoder, mel_full, m, use_dropout=use_drop)
         f0 = A.conv(self.melspec_linear, mel[:, :20].contiguous())
         f0 = A.conv(self.melspec_linear2, AQ.wavenet(self.melspec_encoder, f0, use_dropout=use_drop))
@@ -358,7 +364,7 @@ class FAquantizer(nn.Module):
             timbre = self.timbre_encoder(mel, None)
         else:
             mel_full = self.to_mel(full_waves)
-            m = sequence_mask(wave_lens // self.hop_length, mel_full.shape[-1]).to(torch.float32).contiguous()
+            m = sequence_mask(wave_lens.to(mel_full.device) // self.hop_length, mel_full.shape[-1]).to(torch.float32).contiguous()
             timbre = self.timbre_encoder(mel_full, m)
 
         f0 = ops.conv1d(mel[:, :20], self.melspec_linear.w.packed(), 256, 1, bias=self.melspec_linear.w.bias,

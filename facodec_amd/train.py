@@ -1,18 +1,45 @@
-"""Generator half of the training step (reference: train.py:265-272, 295-299, 357-374) on the HIP path:
+"""The training iteration of the reference (train.py:188-374) on the HIP path.
 
-    z = encoder(wave);  outs, _, commitment, codebook, _ = quantizer(z, wave);  wave_hat = decoder(outs)
-    loss = 15 * mel_loss(wave_hat, wave) + 0.25 * commitment + 1.0 * codebook
-    backward;  per model key: average gradients across ranks (one all-reduce), clip at 1000, AdamW, ExponentialLR
+    wav_seg, ... = crop_segments(waves, mel_lengths, ...)                                         train.py:188-212
+    z = encoder(wav_seg);  outs, quantized, commitment, codebook, timbre = quantizer(z, wav_seg, n_c=2,
+                                                                   full_waves=waves, wave_lens=wave_lengths)  :265-269
+    preds, rev_preds = fa_predictors(quantized, timbre);  pred = decoder(outs)                    :270-277
+    discriminator:  loss_d = sum_k mean(D_k(pred.detach())^2) + mean((1 - D_k(target))^2); clip 10; AdamW    :279-292
+    generator:      15 mel + feature matching + adversarial + 0.25 commitment + codebook
+                    + f0 + uv + 5 focal(content) + speaker;  clip 1000;  AdamW x4                 :294-374
 
-Not in this round: the discriminator terms (feature matching + adversarial) and the predictor heads'
-losses (they need external phoneme / F0 / speaker targets).  Every parameter of encoder, quantizer and decoder that
-the remaining loss reaches is trained."""
+Data parallel: one asynchronous all-reduce(mean) of each key's gradient arena, launched as soon as that key's
+gradients are final (decoder: from a hook on the decoder input's gradient, i.e. under the quantizer / encoder
+backward; discriminator: under the mel-loss forward of the generator half), waited for in the key's optimiser step.
+"""
 import torch
 
 from . import losses, optim
 
 
+def crop_segments(waves, mel_input_length, max_frame_len=80, hop=300, starts=None, generator=None, extra=()):
+    """train.py:188-212 on the device.  waves (B, T_full) padded batch (device); mel_input_length: per-clip frame counts as a
+    HOST sequence (the dataloader hands them over on the CPU, train.py:176 -- reading them costs no device sync);
+    starts: optional (B,) int64 frame offsets (the reference draws np.random.randint(0, mel_length - seg_len) per clip,
+    :195); extra: further (B, C, F) frame-rate tensors (mel targets, phone ids as float) cropped with the same offsets.
+    Returns wav_seg (B, 1, seg_len * hop), starts (device int64), [cropped extras]."""
+    from . import autograd_disc as AD
+    lens = [int(v) for v in mel_input_length]
+    seg = min(min(lens), int(max_frame_len))
+    B = waves.shape[0]
+    if starts is None:
+        span = torch.tensor([max(n - seg, 0) for n in lens], dtype=torch.float64)
+        u = torch.rand(B, generator=generator, dtype=torch.float64)
+        starts = torch.minimum((u * span).floor(), (span - 1).clamp_min(0)).to(torch.int64)   # randint(0, len - seg); 0 when equal
+    starts = torch.as_tensor(starts, dtype=torch.int64).to(waves.device)
+    wav_seg = AD.CropRows.apply(waves.reshape(B, 1, -1), starts, seg * hop, hop)
+    out_extra = [AD.CropRows.apply(e if e.dim() == 3 else e.reshape(B, 1, -1), starts, seg, 1).reshape(*e.shape[:-1], seg) for e in extra]
+    return wav_seg, starts, out_extra
+
+
 class GeneratorStep:
+    """Generator half without the GAN / predictor terms: 15 mel + 0.25 commitment + codebook (train.py:357-358 subset)."""
+
     def __init__(self, model, lr=1e-4, sample_rate=24000):
         self.model = model
         for k in ("encoder", "quantizer", "decoder"):
@@ -24,20 +51,28 @@ class GeneratorStep:
                     "quantizer": optim.FlatAdamW(model.quantizer.parameters(), lr=lr),
                     "decoder": optim.FlatAdamW(model.decoder.parameters(), lr=lr)}
 
-    def forward_backward(self, wave, masks=None):
+    def _zero(self, keys):
+        for k in keys:
+            self.opt[k].zero_grad()
+
+    def forward_backward(self, wave, masks=None, full_waves=None, wave_lens=None):
         m = self.model
+        self._zero(("encoder", "quantizer", "decoder"))
         z = m.encoder(wave)
-        outs, _, commitment, codebook, _ = m.quantizer(z, wave, n_c=2, masks=masks)
+        outs, _, commitment, codebook, _ = m.quantizer(z, wave, n_c=2, masks=masks, full_waves=full_waves, wave_lens=wave_lens)
         wave_hat = m.decoder(outs)
         mel = self.mel(wave_hat, wave)
-        loss = 15.0 * mel + 0.25 * commitment + 1.0 * codebook          # train.py:357-358 without the GAN / predictor terms
+        loss = 15.0 * mel + 0.25 * commitment + 1.0 * codebook
+        outs.register_hook(lambda g: self.opt["decoder"].launch_all_reduce(only_if_complete=True))
         loss.backward()
         return dict(loss=loss.detach(), mel=mel.detach(), commitment=commitment.detach(), codebook=codebook.detach())
 
-    def __call__(self, wave, masks=None):
-        out = self.forward_backward(wave, masks)
+    def __call__(self, wave, masks=None, full_waves=None, wave_lens=None):
+        out = self.forward_backward(wave, masks, full_waves, wave_lens)
+        for k in ("decoder", "quantizer", "encoder"):
+            self.opt[k].launch_all_reduce()
         for k in ("encoder", "decoder", "quantizer"):                    # train.py:362-374
-            self.opt[k].step()
+            self.opt[k].step(zero_grad=False)
         out["grad_norm"] = {k: self.opt[k].grad_norm() for k in self.opt}
         return out
 
@@ -45,12 +80,8 @@ class GeneratorStep:
 class TrainStep(GeneratorStep):
     """Both halves of train.py's iteration (:265-374).  The predictor-head losses (:314-356) are included when
     `with_predictors=True` and the caller supplies their targets (the reference obtains them from a pitch extractor, a
-    CTC phoneme model and a speaker model, none of which is part of this build):
-
-        pred = decoder(quantizer(encoder(wave)))
-        discriminator:  loss_d = sum_k mean(D_k(pred.detach())^2) + mean((1 - D_k(wave))^2);  clip 10;  AdamW
-        generator:      15 mel + feature matching + adversarial + 0.25 commitment + codebook;  clip 1000;  AdamW x3
-    """
+    CTC phoneme model and a speaker model, none of which is part of this build).  After a call every `p.grad` still holds
+    the (rank-averaged, unclipped) gradient of the step; the arenas are cleared at the start of the next call."""
 
     def __init__(self, model, lr=1e-4, sample_rate=24000, with_predictors=False):
         super().__init__(model, lr, sample_rate)
@@ -60,13 +91,14 @@ class TrainStep(GeneratorStep):
         if with_predictors:
             model.fa_predictors.train()
             self.opt["fa_predictors"] = optim.FlatAdamW(model.fa_predictors.parameters(), lr=lr)
+        self.stft = losses.MultiScaleSTFTLoss()
+        self.l1 = losses.L1Loss()
 
-    def predictor_losses(self, quantized, timbre, targets):
+    def predictor_losses(self, preds, rev, targets):
         """train.py:314-356 given the targets the reference takes from external models: f0 (B, F) normalised log-F0
         (-10 = unvoiced), uv (B, F) the log-normalised mel energy `real_norm`, phones (B, F) int64 in [0, 1024),
-        speaker (B,) int64 in [0, 20000).  Returns 1*f0 + 1*uv + 5*content + 1*speaker (:357-358)."""
+        speaker (B,) int64 in [0, 20000).  Returns (1*f0 + 1*uv + 5*content + 1*speaker (:357-358), the eight terms)."""
         from . import autograd_disc as AD
-        preds, rev = self.model.fa_predictors(quantized, timbre)
         n = min(preds["f0"].shape[-2], targets["f0"].shape[-1])
         f0_t, uv_t = targets["f0"][..., :n].contiguous(), targets["uv"][..., :n].contiguous()
         ph_t = targets["phones"][..., :n].contiguous().reshape(-1)
@@ -74,49 +106,80 @@ class TrainStep(GeneratorStep):
         def sl1(p, t):        # F.smooth_l1_loss(target, pred.squeeze(-1)[..., :n])
             return AD.PairMean.apply(p.squeeze(-1)[..., :n].contiguous(), t, 3)
 
-        def ce(logits_btc):   # criterion(pred.transpose(1, 2)[..., :n], target): rows (b, t), classes contiguous
+        def focal(logits_btc):   # FocalLoss(gamma=2)(pred.transpose(1, 2)[..., :n], target) (:153, :334-336): rows (b, t)
             lg = logits_btc[:, :n].contiguous()
-            return AD.CrossEntropy.apply(lg.reshape(-1, lg.shape[-1]), ph_t)
+            return AD.focal_cross_entropy(lg.reshape(-1, lg.shape[-1]), ph_t, 2.0)
 
-        tot_f0 = sl1(preds["f0"], f0_t) + (sl1(rev["rev_f0"], f0_t) if rev["rev_f0"] is not None else 0.0)
-        tot_uv = sl1(preds["uv"], uv_t) + (sl1(rev["rev_uv"], uv_t) if rev["rev_uv"] is not None else 0.0)
-        tot_content = ce(preds["content"]) + (ce(rev["rev_content"]) if rev["rev_content"] is not None else 0.0)
-        tot_spk = AD.CrossEntropy.apply(preds["timbre"], targets["speaker"])
+        t = dict(f0_loss=sl1(preds["f0"], f0_t), uv_loss=sl1(preds["uv"], uv_t), content_loss=focal(preds["content"]),
+                 spk_loss=AD.CrossEntropy.apply(preds["timbre"], targets["speaker"]))
+        if rev["rev_f0"] is not None:
+            t["rev_f0_loss"] = sl1(rev["rev_f0"], f0_t)
+        if rev["rev_uv"] is not None:
+            t["rev_uv_loss"] = sl1(rev["rev_uv"], uv_t)
+        if rev["rev_content"] is not None:
+            t["rev_content_loss"] = focal(rev["rev_content"])
         if rev["x_timbre"] is not None:
-            tot_spk = tot_spk + AD.CrossEntropy.apply(rev["x_timbre"], targets["speaker"])
-        return 1.0 * tot_f0 + 1.0 * tot_uv + 5.0 * tot_content + 1.0 * tot_spk
+            t["x_spk_loss"] = AD.CrossEntropy.apply(rev["x_timbre"], targets["speaker"])
+        z = lambda k: t.get(k, 0.0)    # noqa: E731
+        total = 1.0 * (t["f0_loss"] + z("rev_f0_loss")) + 1.0 * (t["uv_loss"] + z("rev_uv_loss")) \
+            + 5.0 * (t["content_loss"] + z("rev_content_loss")) + 1.0 * (t["spk_loss"] + z("x_spk_loss"))
+        return total, t
 
-    def __call__(self, wave, masks=None, targets=None):
+    def __call__(self, wave, masks=None, targets=None, full_waves=None, wave_lens=None, log_losses=False):
+        """wave (B, 1, T) the cropped segments; full_waves (B, T_full) / wave_lens (B,) the whole utterances for the timbre
+        encoder (train.py:266-269); targets: predictor targets (with_predictors); log_losses: also evaluate the two
+        logged-only criteria of train.py:296,298 (multi-scale STFT, waveform L1)."""
         from .discriminator import gan_losses
-        m = self.model
+        m, opt = self.model, self.opt
+        self._zero(opt.keys())
         z = m.encoder(wave)
-        outs, quantized, commitment, codebook, timbre = m.quantizer(z, wave, n_c=2, masks=masks)
+        outs, quantized, commitment, codebook, timbre = m.quantizer(z, wave, n_c=2, masks=masks, full_waves=full_waves,
+                                                                    wave_lens=wave_lens)
+        if self.with_predictors:
+            if targets is None:
+                raise ValueError("with_predictors=True needs targets (f0, uv, phones, speaker)")
+            preds, rev = m.fa_predictors(quantized, timbre)
         pred = m.decoder(outs)
+        target = wave
+        len_diff = target.size(-1) - pred.size(-1)                       # train.py:274-276
+        if len_diff > 0:
+            target = target[..., len_diff // 2:-len_diff // 2].contiguous()
         # ---- discriminator step (train.py:279-292)
-        d_fake, d_real = m.discriminator(pred.detach()), m.discriminator(wave)
+        disc = m.discriminator
+        d_fake, d_real = disc.forward_internal(pred.detach()), disc.forward_internal(target)
         loss_d, _, _ = gan_losses(d_fake, d_real)
         loss_d.backward()
-        self.opt["discriminator"].step()
+        opt["discriminator"].launch_all_reduce()                         # rides under the loss forwards below
+        mel = self.mel(pred, target)
+        extra = {}
+        if log_losses:
+            with torch.no_grad():
+                extra = dict(stft=self.stft(pred, target), waveform=self.l1(pred, target))
+        if self.with_predictors:
+            pred_total, terms = self.predictor_losses(preds, rev, targets)
+            extra.update({k: v.detach() for k, v in terms.items()})
+        opt["discriminator"].step(zero_grad=False)
         # ---- generator step (:295-374): the discriminator is only differentiated w.r.t. its input
-        for p in self.opt["discriminator"].params:
+        for p in opt["discriminator"].params:
             p.requires_grad_(False)
         try:
-            d_fake = m.discriminator(pred)
+            d_fake = disc.forward_internal(pred)
             with torch.no_grad():
-                d_real = m.discriminator(wave)
+                d_real = disc.forward_internal(target)
             _, loss_g, loss_feat = gan_losses(d_fake, d_real)
-            mel = self.mel(pred, wave)
             loss = 15.0 * mel + 1.0 * loss_feat + 1.0 * loss_g + 0.25 * commitment + 1.0 * codebook
             if self.with_predictors:
-                if targets is None:
-                    raise ValueError("with_predictors=True needs targets (f0, uv, phones, speaker)")
-                loss = loss + self.predictor_losses(quantized, timbre, targets)
+                loss = loss + pred_total
+            outs.register_hook(lambda g: opt["decoder"].launch_all_reduce(only_if_complete=True))
             loss.backward()
         finally:
-            for p in self.opt["discriminator"].params:
+            for p in opt["discriminator"].params:
                 p.requires_grad_(True)
+        gen_keys = ("decoder", "quantizer", "encoder") + (("fa_predictors",) if self.with_predictors else ())
+        for k in gen_keys:
+            opt[k].launch_all_reduce()
         for k in ("encoder", "decoder", "quantizer") + (("fa_predictors",) if self.with_predictors else ()):
-            self.opt[k].step()
+            opt[k].step(zero_grad=False)
         return dict(loss=loss.detach(), loss_d=loss_d.detach(), loss_g=loss_g.detach(), feature=loss_feat.detach(),
                     mel=mel.detach(), commitment=commitment.detach(), codebook=codebook.detach(),
-                    grad_norm={k: self.opt[k].grad_norm() for k in self.opt})
+                    grad_norm={k: opt[k].grad_norm() for k in opt}, **extra)

@@ -255,6 +255,13 @@ int fac_disc_preprocess(const float* x, const float* dz, float* out, float* stat
  * onehot) * grad_scale; scratch: N floats. */
 int fac_cross_entropy(const float* logits, const int64_t* labels, float* loss, float* dlogits, float* scratch, int64_t N,
                       int C, float grad_scale, fac_stream_t stream);
+/* FocalLoss on the mean cross entropy (losses.py:264-276; train.py:153 gamma = 2): out2[0] = (1 - exp(-ce))^gamma * ce,
+ * out2[1] = d out2[0] / d ce.  ce, out2: device scalars. */
+int fac_focal_scalar(const float* ce, float* out2, float gamma, fac_stream_t stream);
+/* Random-crop batching of train.py:188-212 on the device: dst[b][c][t] = src[b][c][start[b] * scale + t] (0 outside);
+ * src (B, C, T_src), dst (B, C, T_dst), start (B) int64 device values in units of `scale` samples. */
+int fac_crop_rows(const float* src, float* dst, const int64_t* start, int B, int C, int64_t T_src, int T_dst, int scale,
+                  fac_stream_t stream);
 /* Left-context buffer of a streaming causal conv: every row of buf (rows x cap) holds
  * [hist columns of history | n_prev columns appended last time]; moves the last `hist` columns to the
  * front (skipped when n_prev == 0) and appends src (rows x n_new, dense) behind them.  hist <= 2048. */

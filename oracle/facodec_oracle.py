@@ -471,15 +471,22 @@ def quantizer_forward(sd, z, wave, n_c=2, full_waves=None, wave_lens=None, hop=3
     return outs, [z_p, z_c, z_r], cm_p + cm_c + cm_r, cb_p + cb_c + cb_r, timbre, [codes_p, codes_c, codes_r]
 
 
-def quantizer_forward_train(sd, z, wave, masks, side_branches_no_grad=True):
+def quantizer_forward_train(sd, z, wave, masks, side_branches_no_grad=True, full_waves=None, wave_lens=None, hop=300):
     """FAquantizer.forward_v2 in training mode (modules/quantize.py:375-454) with its detach placements (:402-411),
     the quantizer-dropout masks (dac/nn/quantize.py:163-183) and the residual mask (:419-435) given explicitly.
-    side_branches_no_grad mirrors the product's current gradient coverage (timbre encoder and prosody WaveNet run
-    forward-only); WaveNet dropout is not applied on either side."""
+    side_branches_no_grad=True runs the timbre encoder and prosody WaveNet forward-only; dropouts (WaveNet 0.2,
+    StyleEncoder 0.1) are not applied.  full_waves / wave_lens: the timbre encoder sees the whole utterance under
+    a sequence mask (:378-383, train.py:266-269).
+    Pinned to the real reference's .train() run by tests/golden/make_golden_train.py (train_step.npz)."""
     ctx = torch.no_grad() if side_branches_no_grad else torch.enable_grad()
     with ctx:
-        mel = logmel_frontend(wave, 80)
-        timbre = style_encoder_forward(mel, sd, "timbre_encoder.")
+        if full_waves is None:
+            mel = logmel_frontend(wave, 80)
+            timbre = style_encoder_forward(mel, sd, "timbre_encoder.")
+        else:
+            mel_full = logmel_frontend(full_waves.unsqueeze(1), 80)
+            m = sequence_mask(wave_lens // hop, mel_full.shape[-1]).unsqueeze(1)
+            timbre = style_encoder_forward(mel_full, sd, "timbre_encoder.", m)
         f0 = logmel_frontend(wave, 20)
         f0 = sconv1d(f0, sd["melspec_linear.conv.conv.weight"], sd["melspec_linear.conv.conv.bias"])
         f0 = wavenet_forward(f0, sd, "melspec_encoder.", hidden=256, n_layers=8)
@@ -572,14 +579,18 @@ def predictors_forward(sd, quantized, timbre):
     """FApredictors.forward_v2 modules/quantize.py:564-606 with build_model's flags
     (modules/commons.py:311-322: use_gr_content_f0=False, use_gr_prosody_phone=False,
     use_gr_residual_f0=True, use_gr_residual_phone=True, use_gr_x_timbre=True); GradientReversal
-    (gradient_reversal.py:11-23) is the identity in the forward pass."""
+    (gradient_reversal.py:11-23, alpha = 1) is the identity in the forward pass and negates the gradient: written
+    here as 2 * x.detach() - x (same value bit for bit, derivative -1) so autograd through the oracle reproduces it."""
+    def gr(x):
+        return 2.0 * x.detach() - x
+
     z_p, z_c, z_r = quantized
     content = cnnlstm_forward(z_c, sd, "phone_predictor.", 1)[0]
     spk = F.linear(timbre, sd["timbre_predictor.weight"], sd["timbre_predictor.bias"])
     f0, uv = cnnlstm_forward(z_p, sd, "f0_predictor.", 2)
-    rev_f0, rev_uv = cnnlstm_forward(z_r, sd, "rev_f0_predictor.1.", 2)
-    rev_content = cnnlstm_forward(z_r, sd, "rev_content_predictor.1.", 1)[0]
-    x_spk = cnnlstm_forward(z_p + z_c + z_r, sd, "rev_timbre_predictor.1.", 1, global_pred=True)[0]
+    rev_f0, rev_uv = cnnlstm_forward(gr(z_r), sd, "rev_f0_predictor.1.", 2)
+    rev_content = cnnlstm_forward(gr(z_r), sd, "rev_content_predictor.1.", 1)[0]
+    x_spk = cnnlstm_forward(gr(z_p + z_c + z_r), sd, "rev_timbre_predictor.1.", 1, global_pred=True)[0]
     return (dict(f0=f0, uv=uv, content=content, timbre=spk),
             dict(rev_f0=rev_f0, rev_uv=rev_uv, rev_content=rev_content, x_timbre=x_spk))
 
@@ -621,6 +632,21 @@ def multiscale_stft_loss(x, y, window_lengths=(2048, 512), clamp_eps=1e-5, mag_w
 def waveform_l1_loss(x, y):
     """L1Loss.forward dac/nn/loss.py:31-48."""
     return (x - y).abs().mean()
+
+
+def focal_loss(logits, target, gamma=2.0):
+    """FocalLoss.forward losses.py:264-276 (train.py:153 gamma=2): the modulation acts on the MEAN cross entropy,
+    (1 - exp(-ce))**gamma * ce.  logits (B, C, T) / (N, C), target (B, T) / (N,)."""
+    ce = F.cross_entropy(logits, target)
+    return (1.0 - torch.exp(-ce)) ** gamma * ce
+
+
+def meldataset_preprocess(wave):
+    """meldataset.py:37-47: torchaudio MelSpectrogram(n_mels=80, n_fft=2048, win 1200, hop 300) with the DEFAULT
+    sample rate 16000 (filterbank quirk), all centred frames, (log(1e-5 + mel) + 4) / 4 -> (1, 80, 1 + T // 300)."""
+    spec = stft_complex(wave.reshape(1, -1), 2048, 300, 1200).abs().pow(2)
+    fb = mel_filterbank_htk(1025, 80, 16000)
+    return (torch.log(1e-5 + torch.matmul(spec.transpose(-1, -2), fb).transpose(-1, -2)) + 4) / 4
 
 
 def reconstruction_loss(x, g_x, eps=1e-7):

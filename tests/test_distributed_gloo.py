@@ -106,3 +106,68 @@ def test_two_rank_gradient_arena_all_reduce():
     assert torch.allclose(g0[:15], torch.full((15,), 1.5))
     assert torch.allclose(g0[15:22], torch.arange(7, dtype=torch.float32) * 1.5)
     assert torch.equal(g0[22:], torch.zeros(4))
+
+
+def _overlap_worker(rank, world, port, q):
+    sys.path.insert(0, REPO)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from facodec_amd import benchutil
+    from facodec_amd.optim import FlatAdamW
+    benchutil.init_distributed("gloo")
+    torch.manual_seed(0)
+    keys = {}
+    for name, shapes in (("decoder", [(4, 3), (5,)]), ("unused", [(6,)]), ("encoder", [(2, 2)])):
+        keys[name] = FlatAdamW([torch.nn.Parameter(torch.randn(*s)) for s in shapes])
+    # backward: autograd accumulates straight into the arenas through the .grad views
+    for i, p in enumerate(keys["decoder"].params):
+        (p * float(rank + 1) * (i + 1)).sum().backward()
+    assert keys["decoder"].params[0].grad.data_ptr() == keys["decoder"].g.data_ptr()      # views, no gather copy
+    assert keys["decoder"].params_without_grad() == [] and keys["unused"].params_without_grad() == [0]
+    # first step: nothing is known about the usage pattern yet -> a hook-time launch must decline
+    keys["decoder"].launch_all_reduce(only_if_complete=True)
+    assert keys["decoder"]._work is None
+    (keys["encoder"].params[0] * float(rank + 1)).sum().backward()
+    # end of backward: every key launches in the same fixed order on every rank, including the key without any gradient
+    for k in ("decoder", "unused", "encoder"):
+        keys[k].launch_all_reduce()
+    for k in ("encoder", "decoder", "unused"):          # waited for in a different order (the optimiser-step order)
+        keys[k].wait_all_reduce()
+    res = {k: o.g.clone() for k, o in keys.items()}
+    # second iteration with the usage pattern known: the decoder's exchange may start from inside backward
+    for o in keys.values():
+        o._expected = tuple(o._touched)
+        o.zero_grad()
+    (keys["decoder"].params[0] * 2.0).sum().backward()
+    keys["decoder"].launch_all_reduce(only_if_complete=True)
+    early = keys["decoder"]._work is not None           # still incomplete: parameter 1 not reached yet
+    (keys["decoder"].params[1] * 2.0).sum().backward()
+    keys["decoder"].launch_all_reduce(only_if_complete=True)
+    late = keys["decoder"]._work is not None
+    keys["decoder"].wait_all_reduce()
+    q.put((rank, res, early, late, keys["decoder"].g.clone()))
+    torch.distributed.destroy_process_group()
+
+
+def test_two_rank_async_exchange_order_and_empty_key():
+    """One asynchronous all-reduce per model key: gradients live in the arena (views), keys launch in a fixed order and are
+    waited for in another, a key whose parameters get no gradient still takes part (zeros) so the collectives stay matched,
+    and a launch from inside backward only happens once the key's gradients are complete."""
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_overlap_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=120) for _ in range(world)), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, g0, e0, l0, d0), (_, g1, e1, l1, d1) = res
+    for k in g0:
+        assert torch.equal(g0[k], g1[k])
+    assert torch.allclose(g0["decoder"][:12], torch.full((12,), 1.5)) and torch.allclose(g0["decoder"][12:], torch.full((5,), 3.0))
+    assert torch.equal(g0["unused"], torch.zeros(6)) and torch.allclose(g0["encoder"], torch.full((4,), 1.5))
+    assert (e0, l0, e1, l1) == (False, True, False, True)
+    assert torch.allclose(d0, torch.full((17,), 2.0)) and torch.equal(d0, d1)

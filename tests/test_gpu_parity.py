@@ -1018,8 +1018,12 @@ def test_discriminator_forward_backward(O, cuda, golden_dir):
     x = synth.synth_clips(2, 24000, seed=5)
     disc.to(cuda)
     with torch.no_grad():
-        fm = disc(x.to(cuda))
+        fm = disc.forward_internal(x.to(cuda))
         ref_l = D.reference_layout(disc, fm, 2)
+        views = disc(x.to(cuda))                         # the drop-in structure: zero-copy views of the same maps
+    for a, v in zip(ref_l, views):
+        for u, w in zip(a, v):
+            assert u.shape == w.shape and torch.equal(u, w.contiguous())
     fm_or = O.discriminator_forward(sd, x)
     for i, (a, b) in enumerate(zip(ref_l, fm_or)):
         assert rel(a[-1], gold[f"logit{i}"]) < E2E_TOL, i

@@ -171,3 +171,80 @@ def test_gan_and_train_losses_restated_like_train_py():
     real = [[torch.full((2, 3), 1.5), torch.full((2, 1), 0.75)]]
     ld, lg, lf = O.gan_losses(fake, real)
     assert abs(float(ld) - (0.25 ** 2 + 0.25 ** 2)) < 1e-7 and abs(float(lg) - 0.75 ** 2) < 1e-7 and abs(float(lf) - 1.0) < 1e-7
+
+
+# ------------------------------------------------------------------------------------------------ training iteration
+def test_train_pinning_report_is_green(golden_dir):
+    """tests/golden/make_golden_train.py: the oracle's train-mode restatements against the real reference in .train()."""
+    r = json.load(open(os.path.join(golden_dir, "oracle_pinning_report_train.json")))
+    assert r["fvq_eval_oracle_code_mismatch"] == 0 and r["fvq_train_oracle_code_mismatch"] == 0
+    for k in ("train_quantizer_outs_oracle_rel", "train_commitment_oracle_rel", "train_codebook_oracle_rel", "train_timbre_oracle_rel",
+              "train_encoder_oracle_rel", "focal_oracle_rel", "fvq_eval_oracle_rel", "fvq_train_oracle_rel",
+              "reconstruction_loss_oracle_rel", "meldataset_oracle_rel"):
+        assert r[k] < 1e-5, (k, r[k])
+
+
+def test_fvq_and_rvq_against_reference(golden_dir):
+    """quantize/fvq.py:36-116 and quantize/rvq.py:32-73 (row a11): outputs of the real classes, eval and train mode."""
+    d = np.load(os.path.join(golden_dir, "fvq.npz"))
+    from facodec_amd.fvq import FactorizedVectorQuantize, ResidualVQ   # parameter shapes only (CPU, no forward)
+    vq = FactorizedVectorQuantize(dim=64, codebook_size=1024, codebook_dim=8, commitment=0.15)
+    sd = synth.synth_state_dict(synth.param_shapes(vq), 4, "fvq.")
+    z = torch.from_numpy(d["z"])
+    for mode in ("eval", "train"):
+        zq, idx, loss = O.fvq_forward(z, sd, "", training=(mode == "train"))
+        assert torch.equal(idx, torch.from_numpy(d[f"{mode}_idx"].astype(np.int64)))
+        assert rel(zq, d[f"{mode}_zq"]) < 1e-5
+        assert float((loss - torch.from_numpy(d[f"{mode}_loss"])).abs().max()) < 1e-6
+    rv = ResidualVQ(num_quantizers=3, codebook_size=10, dim=64, codebook_dim=8, commitment=0.15)
+    sdr = synth.synth_state_dict(synth.param_shapes(rv), 6, "rvq.")
+    residual, total = z, 0.0
+    for i in range(3):
+        q, idx, _ = O.fvq_forward(residual, sdr, f"layers.{i}.")
+        assert torch.equal(idx, torch.from_numpy(d["rvq_idx"][i].astype(np.int64)))
+        assert rel(q[:, ::4, ::5], d["rvq_quantized_probe"][i]) < 1e-5
+        residual, total = residual - q, total + q
+    assert rel(total, d["rvq_out"]) < 1e-5
+
+
+def test_focal_recon_meldataset_against_reference(golden_dir):
+    """losses.py:264-276 FocalLoss (pure torch: pinned), losses.py:65-89 and meldataset.py:42-47 (over the torchaudio
+    shim: composition pinned, STFT unpinned)."""
+    d = np.load(os.path.join(golden_dir, "recon_misc.npz"))
+    lg, lb = torch.from_numpy(d["focal_logits"]), torch.from_numpy(d["focal_labels"])
+    assert abs(float(O.focal_loss(lg, lb, 2.0)) - float(d["focal_gamma2"])) / float(d["focal_gamma2"]) < 1e-6
+    assert abs(float(O.focal_loss(lg, lb, 0.0)) - float(d["focal_gamma0"])) / float(d["focal_gamma0"]) < 1e-6
+    rl = O.reconstruction_loss(torch.from_numpy(d["recon_x"]), torch.from_numpy(d["recon_gx"]))
+    assert abs(float(rl) - float(d["recon_loss"])) / float(d["recon_loss"]) < 1e-5
+    mm = O.meldataset_preprocess(torch.from_numpy(d["meldataset_wave"]))
+    assert tuple(mm.shape) == tuple(d["meldataset_shape"]) and rel(mm[0, ::4, :], d["meldataset_mel_probe"]) < 1e-5
+
+
+def test_train_iteration_oracle_against_reference(golden_dir):
+    """The whole iteration of train.py:265-374 replayed through the oracle + torch autograd against the real reference's
+    .train() run (tests/golden/train_step.npz): 17 loss scalars, 5 gradient norms, gradient probes of ~60 tensors,
+    the set of parameters that receive no gradient, and the discriminator's weights after its AdamW step."""
+    from facodec_amd.commons import build_model, default_model_params
+    import train_replay as TR
+    fx = TR.load_fixture(golden_dir)
+    model = build_model(default_model_params())            # parameter / buffer holders on the CPU (no forward here)
+    for k in TR.KEYS:
+        synth.load_synthetic(model[k], seed=0, prefix=k + ".")
+    sds, names = TR.product_state(model)
+    sc, grads, norms, d_after = TR.oracle_iteration(O, sds, names, fx)
+    for k in TR.SCALARS:
+        assert abs(sc[k] - float(fx[k])) / abs(float(fx[k])) < 2e-5, (k, sc[k], float(fx[k]))
+    for k in TR.KEYS:
+        # fp64 norm over the key; the reference's own clip_grad_norm_ value (fp32 accumulation over ~1e8 elements) is kept
+        # in the fixture too and sits up to 4.5e-4 away from it
+        assert abs(norms[k] - float(fx[f"grad_norm64_{k}"])) / float(fx[f"grad_norm64_{k}"]) < 1e-5, k
+        assert abs(norms[k] - float(fx[f"grad_norm_{k}"])) / float(fx[f"grad_norm_{k}"]) < 1e-3, k
+        worst = TR.compare_grads(fx, k, grads[k], 1e-4, 1e-4)
+        assert worst[1] < 1e-4 and worst[2] < 1e-4, worst
+    for k, missing in fx["no_grad"].items():
+        assert sorted(n for n in names[k] if n not in grads[k]) == sorted(missing), k
+    for key in fx:
+        if key.startswith("param_after.discriminator."):
+            n = key[len("param_after.discriminator."):-len(".probe")]
+            flat = d_after[n].reshape(-1)
+            assert np.abs(flat[TR.probe_index(flat.numel())].numpy() - fx[key]).max() < 1e-6, n
