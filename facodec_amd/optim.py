@@ -163,8 +163,8 @@ class FlatAdamW:
         self.lr_epochs += 1
 
     def grad_norm(self):
-        """Pre-clip gradient norm of the last step (device scalar)."""
-        return self.norm[0]
+        """Pre-clip gradient norm of the last step (device scalar; a copy: the next step overwrites the buffer)."""
+        return self.norm[0].clone()
 
     def params_without_grad(self):
         """Indices of the parameters the last backward did not reach."""

@@ -13,7 +13,7 @@ from facodec_amd import synth
 
 pytestmark = pytest.mark.gpu
 
-LOSS_TOL = 1e-4          # north_star: losses within 1e-4 relative of the reference
+LOSS_TOL = 1e-5          # north_star asks for 1e-4 relative; measured <= 2.2e-7
 
 
 def _model(cuda, keys=TR.KEYS):
@@ -55,19 +55,20 @@ def test_train_step_against_reference_golden(cuda, golden_dir):
     for k in TR.KEYS:
         report["grad_norm_rel"][k] = abs(float(out["grad_norm"][k]) - float(fx[f"grad_norm64_{k}"])) / float(fx[f"grad_norm64_{k}"])
         grads = {n: p.grad for n, p in model[k].named_parameters()}
-        report["worst_grad"][k] = TR.compare_grads(fx, k, grads, 1e-3, 2e-3)
+        report["worst_grad"][k] = TR.compare_grads(fx, k, grads, 1e-4, 2e-4)
     os.makedirs("gpurun_out", exist_ok=True)
     json.dump(report, open("gpurun_out/train_golden_report.json", "w"), indent=1)
     for k, e in report["loss_rel"].items():
         assert e < LOSS_TOL, (k, e)
     # Gradient bars.  Two fp32 CPU implementations of the same iteration (the reference vs. the oracle, both torch autograd)
     # already differ by up to 7.4e-5 on these probes (tests/test_oracle_golden.py): the mel loss is an L1 of log-magnitudes,
-    # its gradient is a sum of sign() terms and a sign flips when a rounding difference crosses a kink.  Bars: 1e-3 on norms,
-    # 2e-3 (relative to the probe's max) on probe values.
+    # its gradient is a sum of sign() terms and a sign flips when a rounding difference crosses a kink.  Measured on MI355X
+    # (profiles/r02_train_golden_report.json): losses <= 2.2e-7, key norms <= 7.6e-6, per-tensor norms <= 1.2e-5, probes
+    # <= 6.3e-5 (relative to the probe's max).  Bars: 1e-4 on norms, 2e-4 on probe values.
     for k, e in report["grad_norm_rel"].items():
-        assert e < 1e-3, (k, e)
+        assert e < 1e-4, (k, e)
     for k, w in report["worst_grad"].items():
-        assert w[1] < 1e-3 and w[2] < 2e-3, w
+        assert w[1] < 1e-4 and w[2] < 2e-4, w
     for k, missing in fx["no_grad"].items():
         names = [n for n, _ in model[k].named_parameters()]
         idx = step.opt[k].params_without_grad()
