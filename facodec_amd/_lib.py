@@ -52,6 +52,8 @@ SIGNATURES = {
     "fac_pad_fold_bwd": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "fac_conv1d_bwd_weight_ws_bytes": (_i64, [_i, _i, _i, _i, _i]),
     "fac_conv1d_bwd_weight": (_i, [_p, _p, _p, _p, _i64, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "fac_conv1d_bwd_weight_split_ws_bytes": (_i64, [_i, _i, _i, _i, _i, _i, _i, _i]),
+    "fac_conv1d_bwd_weight_split": (_i, [_p, _p, _p, _p, _i64, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
     "fac_weight_norm_bwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _p]),
     "fac_snake_bwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
     "fac_bias_grad": (_i, [_p, _p, _p, _i, _i, _i, _p]),

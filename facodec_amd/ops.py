@@ -523,13 +523,25 @@ def conv1d_bwd_weight(x, dy, k, stride=1, dilation=1, pad_mode=PAD_REFLECT, caus
     if pad_left is None:
         _, padding_total, _ = conv_out_len(t_in, k, stride, dilation)
         pad_left = padding_total if causal else padding_total - padding_total // 2
+    dw = torch.empty(c_out, c_in, k, device=x.device, dtype=torch.float32)
+    _bwd_weight_launch(x, dy, dw, B, c_in, t_in, c_out, t_out, k, stride, dilation, pad_left, pad_mode)
+    return dw
+
+
+def _bwd_weight_launch(x, dy, dw, B, c_in, t_in, c_out, t_out, k, stride, dilation, pad_left, pad_mode):
+    """dW on the bf16 matrix pipe with fp32-exact splitting (conv1d_wgrad_split.hip) when the shape qualifies and
+    FAC_BF16_SPLIT is on, else on the fp32 MFMA kernel."""
     lib = _lib.load()
+    nbytes = lib.fac_conv1d_bwd_weight_split_ws_bytes(B, c_in, t_in, c_out, t_out, k, stride, dilation) if BF16_SPLIT else -1
+    if nbytes > 0:
+        ws = torch.empty(nbytes // 4, device=x.device, dtype=torch.float32)
+        _lib.check(lib.fac_conv1d_bwd_weight_split(_ptr(x), _ptr(dy), _ptr(dw), _ptr(ws), nbytes, B, c_in, t_in, c_out, t_out, k,
+                                                   stride, dilation, pad_left, pad_mode, _stream()), "fac_conv1d_bwd_weight_split")
+        return
     nbytes = lib.fac_conv1d_bwd_weight_ws_bytes(B, c_in, c_out, t_out, k)
     ws = torch.empty(nbytes // 4, device=x.device, dtype=torch.float32)
-    dw = torch.empty(c_out, c_in, k, device=x.device, dtype=torch.float32)
     _lib.check(lib.fac_conv1d_bwd_weight(_ptr(x), _ptr(dy), _ptr(dw), _ptr(ws), nbytes, B, c_in, t_in, c_out, t_out, k,
                                          stride, dilation, pad_left, pad_mode, _stream()), "fac_conv1d_bwd_weight")
-    return dw
 
 
 def weight_norm_bwd(v, g, dw):
@@ -568,12 +580,8 @@ def conv_transpose1d_bwd(x, dy, v, g, stride):
     c_out, k = v.shape[1], v.shape[2]
     assert k == 2 * stride and dy.shape == (B, c_out, t_in * stride)
     dx = conv1d(dy, pack_conv_weight(v, g), c_in, k, stride=stride, pad_left=0, pad_mode=PAD_ZERO, t_out=t_in)
-    lib = _lib.load()
-    nbytes = lib.fac_conv1d_bwd_weight_ws_bytes(B, c_out, c_in, t_in, k)
-    ws = torch.empty(nbytes // 4, device=x.device, dtype=torch.float32)
     dw = torch.empty(c_in, c_out, k, device=x.device, dtype=torch.float32)
-    _lib.check(lib.fac_conv1d_bwd_weight(_ptr(dy), _ptr(x), _ptr(dw), _ptr(ws), nbytes, B, c_out, t_in * stride, c_in, t_in,
-                                         k, stride, 1, 0, PAD_ZERO, _stream()), "fac_conv1d_bwd_weight(convtr)")
+    _bwd_weight_launch(dy, x, dw, B, c_out, t_in * stride, c_in, t_in, k, stride, 1, 0, PAD_ZERO)
     return dx, dw
 
 

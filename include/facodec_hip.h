@@ -289,6 +289,13 @@ int64_t fac_conv1d_bwd_weight_ws_bytes(int B, int C_in, int C_out, int T_out, in
 int fac_conv1d_bwd_weight(const float* x, const float* dy, float* dw, void* ws, int64_t ws_bytes, int B, int C_in,
                           int T_in, int C_out, int T_out, int K, int stride, int dilation, int pad_left, int pad_mode,
                           fac_stream_t stream);
+/* The same gradient on the bf16 matrix pipe with fp32-exact operand splitting (conv1d_wgrad_split.hip; same arguments
+ * and result layout as fac_conv1d_bwd_weight, error vs fp64 no larger than the fp32 MFMA's).  The workspace query
+ * returns -1 for a (K, stride, dilation) the kernel does not cover: use fac_conv1d_bwd_weight then. */
+int64_t fac_conv1d_bwd_weight_split_ws_bytes(int B, int C_in, int T_in, int C_out, int T_out, int K, int stride, int dilation);
+int fac_conv1d_bwd_weight_split(const float* x, const float* dy, float* dw, void* ws, int64_t ws_bytes, int B, int C_in, int T_in,
+                                int C_out, int T_out, int K, int stride, int dilation, int pad_left, int pad_mode,
+                                fac_stream_t stream);
 /* w = g*v/||v|| per row (n_rows x row_len): dv, dg from dW. */
 int fac_weight_norm_bwd(const float* v, const float* g, const float* dw, float* dv, float* dg, int n_rows, int row_len,
                         fac_stream_t stream);

@@ -1,0 +1,112 @@
+"""Weight-gradient GEMM on the bf16 matrix pipe with fp32-exact operand splitting (facodec_amd/csrc/conv1d_wgrad_split.hip)
+against an fp64 restatement of torch's conv1d weight gradient, next to the fp32-MFMA kernel it replaces."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from facodec_amd import ops
+
+pytestmark = pytest.mark.gpu
+
+
+def _pad(x, left, right, mode):
+    if mode == ops.PAD_ZERO:
+        return F.pad(x, (left, right))
+    # pad1d of dac/model/encodec.py:96-113 (reflect; signals shorter than the pad are zero-extended first)
+    length = x.shape[-1]
+    max_pad = max(left, right)
+    extra = 0
+    if length <= max_pad:
+        extra = max_pad - length + 1
+        x = F.pad(x, (0, extra))
+    y = F.pad(x, (left, right), mode="reflect")
+    return y[..., : y.shape[-1] - extra] if extra else y
+
+
+def _ref_dw(x, dy, k, stride, dil, pad_left, mode):
+    """fp64 dW of y = conv1d(pad(x), w, stride, dilation) for the given upstream gradient."""
+    xd = x.double()
+    t_out = dy.shape[-1]
+    need = (t_out - 1) * stride + (k - 1) * dil + 1
+    right = max(0, need - pad_left - x.shape[-1])
+    xp = _pad(xd, pad_left, right, mode)
+    w = torch.zeros(dy.shape[1], x.shape[1], k, dtype=torch.float64, requires_grad=True)
+    y = F.conv1d(xp, w, stride=stride, dilation=dil)[..., :t_out]
+    (y * dy.double()).sum().backward()
+    return w.grad
+
+
+CASES = [
+    # B, C_in, C_out, T_in, K, stride, dil, pad_left, mode
+    (2, 64, 64, 700, 7, 1, 1, 6, ops.PAD_REFLECT),
+    (2, 96, 96, 1000, 7, 1, 3, 18, ops.PAD_REFLECT),
+    (1, 128, 160, 517, 7, 1, 9, 54, ops.PAD_REFLECT),
+    (2, 24, 200, 333, 1, 1, 1, 0, ops.PAD_ZERO),
+    (3, 300, 40, 97, 1, 1, 1, 0, ops.PAD_ZERO),
+    (2, 64, 128, 640, 4, 2, 1, 2, ops.PAD_REFLECT),
+    (2, 128, 256, 650, 10, 5, 1, 5, ops.PAD_REFLECT),
+    (2, 96, 192, 612, 12, 6, 1, 6, ops.PAD_REFLECT),
+    (1, 32, 128, 3001, 5, 3, 1, 2, ops.PAD_ZERO),
+    (1, 128, 96, 900, 5, 1, 1, 2, ops.PAD_ZERO),
+    (40, 96, 32, 65, 9, 2, 1, 4, ops.PAD_ZERO),
+    (40, 6, 32, 129, 9, 1, 1, 4, ops.PAD_ZERO),
+    (8, 96, 32, 33, 3, 1, 1, 1, ops.PAD_ZERO),
+    (2, 1, 64, 2400, 7, 1, 1, 6, ops.PAD_REFLECT),
+    (2, 96, 1, 2400, 7, 1, 1, 6, ops.PAD_REFLECT),
+    (2, 64, 64, 5, 7, 1, 1, 6, ops.PAD_REFLECT),          # signal shorter than the pad
+    (2, 20, 256, 40, 1, 1, 1, 0, ops.PAD_ZERO),
+    (1, 1536, 1536, 160, 7, 1, 1, 6, ops.PAD_REFLECT),    # largest layer shape (decoder input conv)
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=lambda c: "B%d_%dto%d_T%d_k%d_s%d_d%d" % c[:7])
+def test_wgrad_split_against_fp64(case, cuda):
+    B, c_in, c_out, t_in, k, stride, dil, pad_left, mode = case
+    g = torch.Generator().manual_seed(hash(case[:7]) % (1 << 31))
+    x = torch.randn(B, c_in, t_in, generator=g)
+    t_out = (t_in + pad_left - (k - 1) * dil - 1) // stride + 1 if mode == ops.PAD_ZERO else -(-t_in // stride)
+    if mode == ops.PAD_ZERO:
+        t_out = (t_in + 2 * pad_left - (k - 1) * dil - 1) // stride + 1
+    dy = torch.randn(B, c_out, t_out, generator=g)
+    ref = _ref_dw(x, dy, k, stride, dil, pad_left, mode)
+    scale = float(ref.abs().max())
+    lib_bytes = ops._lib.load().fac_conv1d_bwd_weight_split_ws_bytes(B, c_in, t_in, c_out, t_out, k, stride, dil)
+    assert lib_bytes > 0, "shape must qualify for the split kernel"
+    prev = ops.BF16_SPLIT
+    try:
+        ops.BF16_SPLIT = True
+        got = ops.conv1d_bwd_weight(x.to(cuda), dy.to(cuda), k, stride=stride, dilation=dil, pad_mode=mode, pad_left=pad_left)
+        ops.BF16_SPLIT = False
+        base = ops.conv1d_bwd_weight(x.to(cuda), dy.to(cuda), k, stride=stride, dilation=dil, pad_mode=mode, pad_left=pad_left)
+    finally:
+        ops.BF16_SPLIT = prev
+    e_split = float((got.cpu().double() - ref).abs().max()) / scale
+    e_fp32 = float((base.cpu().double() - ref).abs().max()) / scale
+    assert e_split < 1e-5, (e_split, e_fp32)
+    assert e_split <= 2.0 * e_fp32 + 2e-7, (e_split, e_fp32)
+    # deterministic (fixed slice order)
+    ops.BF16_SPLIT = True
+    try:
+        again = ops.conv1d_bwd_weight(x.to(cuda), dy.to(cuda), k, stride=stride, dilation=dil, pad_mode=mode, pad_left=pad_left)
+    finally:
+        ops.BF16_SPLIT = prev
+    assert torch.equal(again, got)
+
+
+def test_convtr_wgrad_on_split_kernel(cuda):
+    """SConvTranspose1d weight gradient (roles of input and output swapped, stride = K / 2) through the split kernel."""
+    g = torch.Generator().manual_seed(3)
+    B, c_in, c_out, t_in, s = 2, 96, 48, 300, 5
+    x = torch.randn(B, c_in, t_in, generator=g)
+    v = torch.randn(c_in, c_out, 2 * s, generator=g) * 0.1
+    dy = torch.randn(B, c_out, t_in * s, generator=g)
+    w = v.double().clone().requires_grad_()
+    y = F.conv_transpose1d(x.double(), w, stride=s)[..., : t_in * s]
+    (y * dy.double()).sum().backward()
+    prev = ops.BF16_SPLIT
+    try:
+        ops.BF16_SPLIT = True
+        _, dw = ops.conv_transpose1d_bwd(x.to(cuda), dy.to(cuda), v.to(cuda), None, s)
+    finally:
+        ops.BF16_SPLIT = prev
+    assert float((dw.cpu().double() - w.grad).abs().max() / w.grad.abs().max()) < 1e-5
