@@ -7,7 +7,11 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-LIB = os.path.join(HERE, "libfacodec_hip.so")
+# FAC_BUILD_TAG=<tag> builds a tuning variant (e.g. with FAC_EXTRA_FLAGS=-DFAC_ABL_...) next to the product library:
+# libfacodec_hip_<tag>.so, objects under csrc/build_<tag>/; select it at run time with FAC_LIB_PATH.
+TAG = os.environ.get("FAC_BUILD_TAG", "")
+LIB = os.path.join(HERE, "libfacodec_hip%s.so" % ("_" + TAG if TAG else ""))
+OBJDIR = "build" + ("_" + TAG if TAG else "")
 SOURCES = ["conv1d_api.hip", "conv1d_tile_128x128.hip", "conv1d_tile_96x128.hip", "conv1d_tile_64x128.hip",
            "conv1d_tile_32x256.hip", "conv1d_tile_128x32.hip", "conv1d_tile_128x256.hip", "conv1d_fused_ru.hip", "conv1d_narrow.hip", "conv1d_skinny.hip", "conv1d_bsplit.hip", "conv1d_bwd.hip", "conv1d_wgrad_split.hip", "train_misc.hip", "optim.hip", "train_quant.hip", "train_pred.hip", "train_disc.hip", "pack.hip", "lstm.hip", "vq.hip", "misc.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
@@ -32,10 +36,10 @@ def build_lib(force=False, verbose=True):
     hipcc = _hipcc()
     headers = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "conv1d_mfma.h"), os.path.join(HERE, "..", "include", "facodec_hip.h")]
     objs, jobs = [], []
-    os.makedirs(os.path.join(CSRC, "build"), exist_ok=True)
+    os.makedirs(os.path.join(CSRC, OBJDIR), exist_ok=True)
     for src in SOURCES:
         s = os.path.join(CSRC, src)
-        o = os.path.join(CSRC, "build", src.replace(".hip", ".o"))
+        o = os.path.join(CSRC, OBJDIR, src.replace(".hip", ".o"))
         objs.append(o)
         if force or _stale(o, [s] + headers):
             jobs.append([hipcc, *FLAGS, "-c", s, "-o", o])

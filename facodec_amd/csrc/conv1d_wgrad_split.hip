@@ -3,25 +3,35 @@
 //
 //   dW[co][ci][k] = sum_{b,t} dy[b][co][t] * xpad[b][ci][t*stride + k*dil]        (torch autograd of F.conv1d behind
 //                                                                                  dac/model/encodec.py:212-228)
-// GEMM view: M = C_out (A = dy), N = (ci, k) columns (B = shifted x), contraction over time.  The MFMA contracts 16
-// consecutive time steps, so a B fragment is 8 consecutive bf16 of one input row starting at element t + k*dil -- an
-// arbitrary, mostly unaligned offset.  Measured on MI355X (tools/microbench/lds_unaligned_probe.hip): ds_read_b128 at
-// any address that is not 16-byte aligned costs 8x; so the staged input rows are kept in up to FOUR copies shifted by
-// 0..3 elements and a fragment is read as two 8-byte-aligned ds_read_b64 from the copy (shift mod 4) -- the LDS cycles
-// of one b128, no VALU work in the MFMA waves, any (K, dilation, stride) through per-lane base offsets computed once.
-// Strided convs (K = 2*stride and the discriminators' k = 5 / stride 3) stage the input phase-major
-// (row (ci, phase)[u] = x[ci][u*stride + phase]) so that consecutive output steps are consecutive elements again.
+// GEMM view: M = C_out (A = dy), N = (ci, k) columns (B = shifted x), contraction over time.
 //
-// Workgroup = 8 waves on a 128 (co) x 128 (ci,k columns) tile of dW for one slice of the (b, t) range:
-//   waves 4-7 stage 32 time steps per stage: fp32 loads -> split3 -> A [plane][128 co][32 t], B [copy][plane][row][..];
-//   waves 0-3 each own 64 x 64 (2 x 2 MFMA blocks), two K = 16 steps per stage; LDS double-buffered.
-// Partial tiles of the S slices are added in slice order by wgrad_reduce_kernel (deterministic, as before).
+// Two launches (+ the deterministic slice reduction):
+//  1. split_planes_kernel, once per operand: fp32 -> three bf16 planes in HBM (hi, mid, lo; x = hi + mid + lo exactly), with
+//     the conv's padding MATERIALISED (reflect / zero, dac/model/encodec.py:96-113) and, for strided convs, the time axis
+//     de-interleaved phase-major (row (ci, phase)[u] = xpad[ci][u*stride + phase]) so that consecutive output steps are
+//     consecutive elements.  dy gets a zero tail up to a multiple of 32 steps.  HBM-bound: 4 B read + 6 B written per
+//     element.  (Measured before this split existed: with the fp32 -> bf16 splitting done by the GEMM's own staging waves,
+//     ~6 VALU instructions per MFMA shared each SIMD's issue port with the matrix pipe and held the kernel at 100-110
+//     TFLOP/s-equivalent -- 137 with the arithmetic removed, 147 with no staging at all; every dy tile was also re-split by
+//     every column tile, 43 times at C = 768.)
+//  2. conv1d_wgrad_planes_kernel: workgroup = 8 waves on a 128 (co) x 128 ((ci,k) columns) tile of dW for one slice of the
+//     (b, t) range.  Waves 4-7 only COPY 32 time steps per stage from the planes into LDS (inline-asm loads in a register
+//     ring D tiles deep with explicit s_waitcnt -- hipcc's own placement waited for the youngest loads); waves 0-3 each own
+//     64 x 64 (2 x 2 MFMA blocks), two K = 16 steps per stage; LDS double-buffered.
+//     The MFMA contracts 16 consecutive time steps, so a B fragment is 8 consecutive bf16 of one staged row starting at
+//     element t + (k*dil)/stride -- mostly unaligned, and ds_read_b128 at an address that is not 16-byte aligned costs 8x
+//     on this part (tools/microbench/lds_unaligned_probe.hip).  Hence up to FOUR copies of the staged rows shifted by 0..3
+//     elements: a fragment is two 8-byte-aligned ds_read_b64 from copy (shift mod 4) -- the LDS cycles of one b128, no
+//     VALU in the MFMA waves, any (K, dilation, stride) through per-lane base offsets computed once.
+// Partial tiles of the S slices are added in slice order by wgrad_split_reduce_kernel (deterministic).
 #include "conv1d_mfma.h"
 
 namespace fac {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int WS_CO = 128;          // output channels per tile (A rows)
 constexpr int WS_NC = 128;          // (ci, k) columns per tile
@@ -29,15 +39,15 @@ constexpr int WS_TT = 32;           // time steps per stage
 constexpr int WS_APB = 80;          // A row pitch in bytes: 32 bf16 + 16 B pad -> conflict-free 16-lane b128 groups
 constexpr int WS_A_PLANE = WS_CO * WS_APB;
 constexpr int WS_A_STAGE = 3 * WS_A_PLANE;
-constexpr int WS_ITEMS = 4;         // staging work items per lane and operand (256 staging lanes)
+constexpr int WS_APIECES = 6;       // 16-byte A pieces per staging lane and stage (3 planes x 128 rows x 4 / 256)
 
 struct WsArgs {
-  const float* x;      // (B, C_in, T_in)
-  const float* dy;     // (B, C_out, T_out)
-  float* part;         // [S][C_out][C_in][K]
-  long long x_bs, dy_bs;
-  int x_cs, dy_cs;
-  int B, C_in, T_in, T_ext, C_out, T_out, K, stride, dil, pad_left, pad_mode;
+  const unsigned char* ap;   // dy planes  [3][B*C_out][UA] bf16
+  const unsigned char* bp;   // x planes   [3][B*C_in*stride][UB] bf16 (padded, phase-major)
+  float* part;               // [S][C_out][C_in][K]
+  long long a_plane_bytes, b_plane_bytes;
+  int UA, UB;                // row lengths (elements) of the plane tensors
+  int B, C_in, C_out, K, stride, dil;
   int cit;             // input channels per column tile (cit * K <= 128)
   int R;               // staged input rows per stage = cit * stride (row = (channel, phase))
   int NCP;             // shifted copies of the staged rows (1..4)
@@ -47,8 +57,6 @@ struct WsArgs {
   int tiles_per_split;
 };
 
-struct __attribute__((packed, aligned(4))) F4u { float v[4]; };   // 4-byte-aligned 16-byte global load
-
 __device__ __forceinline__ void split3w(float x, __bf16& h, __bf16& m, __bf16& l) {
   h = (__bf16)x;
   const float r1 = x - (float)h;
@@ -56,7 +64,53 @@ __device__ __forceinline__ void split3w(float x, __bf16& h, __bf16& m, __bf16& l
   l = (__bf16)(r1 - (float)m);
 }
 
-__global__ __launch_bounds__(512, 2) void conv1d_wgrad_split_kernel(WsArgs a) {
+// dst[p][row * s + ph][u] = plane p of pad(src[row])[u * s + ph - pad_left]  (0 beyond the padded signal), u < U (U % 8 == 0).
+// One thread = 8 consecutive u of one destination row: three 16-byte stores.
+__global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ src, unsigned char* __restrict__ dst, long long rows,
+                                                           int T, int T_ext, int T_pad, int s, int U, int pad_left, int pad_mode,
+                                                           long long plane_bytes) {
+  const int u8 = U >> 3;
+  const long long n = rows * s * u8;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const int uq = (int)(i % u8);
+    const long long drow = i / u8;
+    const long long row = drow / s;
+    const int ph = (int)(drow - row * s);
+    const float* xr = src + row * T;
+    const int p0 = (uq * 8) * s + ph - pad_left;
+    float v[8];
+    if (s == 1 && p0 >= 0 && p0 + 7 < T) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = xr[p0 + j];
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int pos = p0 + j * s;
+        int idx = -1;
+        if (pos + pad_left < T_pad) {                 // inside the padded signal (the tail beyond it is zero fill)
+          if (pad_mode == FAC_PAD_REFLECT) idx = reflect_index(pos, T, T_ext);
+          else idx = (pos >= 0 && pos < T) ? pos : -1;
+        }
+        v[j] = idx >= 0 ? xr[idx] : 0.f;
+      }
+    }
+    bf16x8 h, m, l;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      __bf16 a, b, c;
+      split3w(v[j], a, b, c);
+      h[j] = a; m[j] = b; l[j] = c;
+    }
+    unsigned char* d = dst + (drow * U + uq * 8) * 2;
+    *reinterpret_cast<bf16x8*>(d) = h;
+    *reinterpret_cast<bf16x8*>(d + plane_bytes) = m;
+    *reinterpret_cast<bf16x8*>(d + 2 * plane_bytes) = l;
+  }
+}
+
+// NB: 8-byte B pieces per staging lane and stage (ceil(NCP * 3 * R * nq / 256));  D: depth of the register ring.
+template <int NB, int D>
+__global__ __launch_bounds__(512, 2) void conv1d_wgrad_planes_kernel(WsArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -73,138 +127,101 @@ __global__ __launch_bounds__(512, 2) void conv1d_wgrad_split_kernel(WsArgs a) {
   const int s = a.stride;
 
   if (wave >= 4) {
-    // ======================================================================= staging waves
+    // ======================================================================= staging waves: planes -> LDS, copies only
     const int sl = tid - 256;
     __builtin_amdgcn_s_setprio(3);
-    // B work items (row, quad): constant over the stages
-    int b_xoff[WS_ITEMS], b_u0[WS_ITEMS], b_lds[WS_ITEMS], b_ph[WS_ITEMS];
-    const int n_items = a.R * a.nq;
+    // Per-lane constants: byte offset of each piece relative to the tile's uniform base pointer, and its LDS address.
+    unsigned a_off[WS_APIECES];
+    int a_lds[WS_APIECES];
 #pragma unroll
-    for (int j = 0; j < WS_ITEMS; ++j) {
+    for (int j = 0; j < WS_APIECES; ++j) {
       const int id = sl + 256 * j;
-      const bool ok = id < n_items;
-      const int row = ok ? id / a.nq : 0;
-      const int q = id - row * a.nq;
-      const int cl = row / s, ph = row - cl * s;
-      const int ci = ci0 + cl;
-      b_xoff[j] = (ok && ci < a.C_in) ? ci * a.x_cs : -1;
-      b_ph[j] = ph;
-      b_u0[j] = 4 * q;
-      b_lds[j] = row * a.XPB + q * 8;
+      const int plane = id >> 9, rem = id & 511;
+      const int row = rem >> 2, pc = rem & 3;
+      const int co = co0 + row < a.C_out ? co0 + row : a.C_out - 1;     // rows past C_out are computed but never stored
+      a_off[j] = (unsigned)(plane * a.a_plane_bytes + ((long long)co * a.UA + 8 * pc) * 2);
+      a_lds[j] = plane * WS_A_PLANE + row * WS_APB + pc * 16;
     }
-    const int n_need = 3 + a.NCP;          // consecutive staged elements one item touches (4 + NCP - 1)
+    unsigned b_off[NB];
+    int b_lds[NB];
+    const int n_b = a.NCP * 3 * a.R * a.nq;
+    const int rows_valid = min(a.cit, a.C_in - ci0) * s;
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      int id = sl + 256 * j;
+      const bool ok = id < n_b;
+      if (!ok) id = 0;
+      const int q = id % a.nq;
+      int t = id / a.nq;
+      int row = t % a.R;
+      t /= a.R;
+      const int p = t % 3, r = t / 3;
+      const int srow = row < rows_valid ? row : 0;                       // rows of channels past C_in: never stored columns
+      b_off[j] = (unsigned)(p * a.b_plane_bytes + ((long long)(ci0 * s + srow) * a.UB + 4 * q + r) * 2);
+      b_lds[j] = ok ? WS_A_STAGE + (r * 3 + p) * PSB + row * a.XPB + q * 8 : -1;
+    }
 
-    auto load_tile = [&](int chunk, float (&ra)[WS_ITEMS][4], float (&rb)[WS_ITEMS][8]) {
-      const int tile = tile_lo + chunk;
+    // Exactly LPT loads per tile, all inline asm (invisible to hipcc's s_waitcnt pass, which otherwise waits for the
+    // YOUNGEST loads at the tile-dependent joins); after `s_waitcnt vmcnt((D - 1) * LPT)` the tile issued D - 1 tiles ago
+    // has landed (loads return in order).  No copies between a load and its wait: the asm writes the ring registers.
+    constexpr int LPT = WS_APIECES + NB;
+    constexpr int WAITN = (D - 1) * LPT < 63 ? (D - 1) * LPT : 63;
+    auto load_tile = [&](int chunk, f32x4 (&ra)[WS_APIECES], f32x2 (&rb)[NB]) {
+      const int tile = tile_lo + (chunk < n_chunks ? chunk : n_chunks - 1);     // past the end: reload the last tile (keeps LPT)
       const int b = tile / a.n_tt;
       const int t0 = (tile - b * a.n_tt) * WS_TT;
-      const float* dyb = a.dy + (long long)b * a.dy_bs;
-      const float* xb = a.x + (long long)b * a.x_bs;
+      const unsigned char* ab = a.ap + ((long long)b * a.C_out * a.UA + t0) * 2;            // uniform
+      const unsigned char* bb = a.bp + ((long long)b * a.C_in * s * a.UB + t0) * 2;         // uniform
 #pragma unroll
-      for (int j = 0; j < WS_ITEMS; ++j) {          // A: dy[co0 + row][t0 + 4q .. +3]
-        const int id = sl + 256 * j;
-        const int row = id >> 3, q = id & 7;
-        const int co = co0 + row, t = t0 + 4 * q;
-        if (co < a.C_out && t + 3 < a.T_out) {
-          const F4u v = *reinterpret_cast<const F4u*>(dyb + co * a.dy_cs + t);
+      for (int j = 0; j < WS_APIECES; ++j)
+        asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(ra[j]) : "v"(a_off[j]), "s"(ab) : "memory");
 #pragma unroll
-          for (int i = 0; i < 4; ++i) ra[j][i] = v.v[i];
-        } else {
+      for (int j = 0; j < NB; ++j)
+        asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(rb[j]) : "v"(b_off[j]), "s"(bb) : "memory");
+    };
+    auto wait_tile = [&](f32x4 (&ra)[WS_APIECES], f32x2 (&rb)[NB]) {
+      asm volatile("s_waitcnt vmcnt(%6)" : "+v"(ra[0]), "+v"(ra[1]), "+v"(ra[2]), "+v"(ra[3]), "+v"(ra[4]), "+v"(ra[5])
+                   : "n"(WAITN) : "memory");
 #pragma unroll
-          for (int i = 0; i < 4; ++i) ra[j][i] = (co < a.C_out && t + i < a.T_out) ? dyb[co * a.dy_cs + t + i] : 0.f;
-        }
-      }
-      const int tb = t0 * s - a.pad_left;            // input position of staged element u = 0, phase 0
+      for (int j = 0; j < NB; ++j) asm volatile("" : "+v"(rb[j]) : : "memory");
+    };
+    auto write_tile = [&](int buf, const f32x4 (&ra)[WS_APIECES], const f32x2 (&rb)[NB]) {
+      unsigned char* st = sm + buf * STAGE;
 #pragma unroll
-      for (int j = 0; j < WS_ITEMS; ++j) {          // B: row (ci, phase), elements u0 .. u0 + n_need - 1
-        if (b_xoff[j] < 0) {
+      for (int j = 0; j < WS_APIECES; ++j) *reinterpret_cast<f32x4*>(st + a_lds[j]) = ra[j];
 #pragma unroll
-          for (int i = 0; i < 8; ++i) rb[j][i] = 0.f;
-          continue;
-        }
-        const float* xr = xb + b_xoff[j];
-        const int p0 = tb + b_u0[j] * s + b_ph[j];
-        if (s == 1 && p0 >= 0 && p0 + 7 < a.T_in) {
-          const F4u v0 = *reinterpret_cast<const F4u*>(xr + p0);
-          const F4u v1 = *reinterpret_cast<const F4u*>(xr + p0 + 4);
-#pragma unroll
-          for (int i = 0; i < 4; ++i) { rb[j][i] = v0.v[i]; rb[j][4 + i] = v1.v[i]; }
-        } else {
-#pragma unroll
-          for (int i = 0; i < 8; ++i) {
-            float v = 0.f;
-            if (i < n_need) {
-              const int tin = p0 + i * s;
-              int idx;
-              if (a.pad_mode == FAC_PAD_REFLECT) idx = reflect_index(tin, a.T_in, a.T_ext);
-              else idx = (tin >= 0 && tin < a.T_in) ? tin : -1;
-              if (idx >= 0) v = xr[idx];
-            }
-            rb[j][i] = v;
-          }
-        }
-      }
+      for (int j = 0; j < NB; ++j)
+        if (b_lds[j] >= 0) *reinterpret_cast<f32x2*>(st + b_lds[j]) = rb[j];
     };
 
-    auto write_tile = [&](int buf, const float (&ra)[WS_ITEMS][4], const float (&rb)[WS_ITEMS][8]) {
-      unsigned char* Ab = sm + buf * STAGE;
-      unsigned char* Bb = Ab + WS_A_STAGE;
+    // Ring of D tiles in registers: tile t lives in slot t % D.  Slot c (the MFMA waves multiply tile c): wait for and write
+    // tile c + 1 into the other LDS stage, then reuse its registers for the loads of tile c + 1 + D.  Exactly one load_tile
+    // per slot (clamped past the end), so the in-flight count behind any tile is always D - 1 tiles.
+    f32x4 ra[D][WS_APIECES];
+    f32x2 rb[D][NB];
 #pragma unroll
-      for (int j = 0; j < WS_ITEMS; ++j) {
-        const int id = sl + 256 * j;
-        const int row = id >> 3, q = id & 7;
-        bf16x4 h, m, l;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          __bf16 p0, p1, p2;
-          split3w(ra[j][i], p0, p1, p2);
-          h[i] = p0; m[i] = p1; l[i] = p2;
-        }
-        unsigned char* d = Ab + row * WS_APB + q * 8;
-        *reinterpret_cast<bf16x4*>(d) = h;
-        *reinterpret_cast<bf16x4*>(d + WS_A_PLANE) = m;
-        *reinterpret_cast<bf16x4*>(d + 2 * WS_A_PLANE) = l;
-      }
-#pragma unroll
-      for (int j = 0; j < WS_ITEMS; ++j) {
-        if (sl + 256 * j >= n_items) continue;
-        __bf16 ph_[7], pm_[7], pl_[7];
-#pragma unroll
-        for (int i = 0; i < 7; ++i) split3w(rb[j][i], ph_[i], pm_[i], pl_[i]);
-        unsigned char* d = Bb + b_lds[j];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          if (r >= a.NCP) break;
-          bf16x4 h, m, l;
-#pragma unroll
-          for (int i = 0; i < 4; ++i) { h[i] = ph_[r + i]; m[i] = pm_[r + i]; l[i] = pl_[r + i]; }
-          unsigned char* dr = d + (r * 3) * PSB;
-          *reinterpret_cast<bf16x4*>(dr) = h;
-          *reinterpret_cast<bf16x4*>(dr + PSB) = m;
-          *reinterpret_cast<bf16x4*>(dr + 2 * PSB) = l;
-        }
-      }
-    };
-
-    // loads of tile c+2 are issued one stage before they are split and written (register double buffer)
-    float a0[WS_ITEMS][4], b0[WS_ITEMS][8], a1[WS_ITEMS][4], b1[WS_ITEMS][8];
-    load_tile(0, a0, b0);
-    if (n_chunks > 1) load_tile(1, a1, b1);
-    write_tile(0, a0, b0);
+    for (int i = 0; i < D; ++i) load_tile(i, ra[i], rb[i]);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    wait_tile(ra[0], rb[0]);
+    write_tile(0, ra[0], rb[0]);
+    load_tile(D, ra[0], rb[0]);
     __syncthreads();
-    for (int chunk = 0; chunk < n_chunks; chunk += 2) {
-      if (chunk + 1 < n_chunks) {
-        if (chunk + 2 < n_chunks) load_tile(chunk + 2, a0, b0);
-        write_tile(1, a1, b1);
+    constexpr int U = (D % 2 == 0) ? D : 2 * D;      // unroll: static ring slot and LDS stage per position
+    for (int base = 0; base < n_chunks; base += U) {
+#pragma unroll
+      for (int i = 0; i < U; ++i) {
+        const int c = base + i;
+        if (c < n_chunks) {
+          if (c + 1 < n_chunks) {
+            wait_tile(ra[(i + 1) % D], rb[(i + 1) % D]);
+            write_tile((i + 1) & 1, ra[(i + 1) % D], rb[(i + 1) % D]);
+            load_tile(c + 1 + D, ra[(i + 1) % D], rb[(i + 1) % D]);
+          }
+          __syncthreads();
+        }
       }
-      __syncthreads();
-      if (chunk + 1 >= n_chunks) break;
-      if (chunk + 2 < n_chunks) {
-        if (chunk + 3 < n_chunks) load_tile(chunk + 3, a1, b1);
-        write_tile(0, a0, b0);
-      }
-      __syncthreads();
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     return;
   }
 
@@ -233,26 +250,31 @@ __global__ __launch_bounds__(512, 2) void conv1d_wgrad_split_kernel(WsArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
 
+  auto ld_frags = [&](const unsigned char* st, int ks, bf16x8 (&A)[2][3], bf16x8 (&Bf)[2][3]) {
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+        A[m][p] = *reinterpret_cast<const bf16x8*>(st + aoff + p * WS_A_PLANE + m * 32 * WS_APB + ks * 32);
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+      for (int n = 0; n < 2; ++n) {
+        const unsigned char* bp = st + boff[n] + p * PSB + ks * 32;
+        const bf16x4 lo = *reinterpret_cast<const bf16x4*>(bp);
+        const bf16x4 hi = *reinterpret_cast<const bf16x4*>(bp + 8);
+        Bf[n][p] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+      }
+  };
+
   __syncthreads();   // tile 0 staged
+  bf16x8 A[2][2][3], Bf[2][2][3];                // fragments of step ks + 1 are requested before the MFMAs of step ks
   for (int chunk = 0; chunk < n_chunks; ++chunk) {
     const unsigned char* st = sm + (chunk & 1) * STAGE;
+    ld_frags(st, 0, A[0], Bf[0]);
 #pragma unroll
     for (int ks = 0; ks < WS_TT / 16; ++ks) {
-      bf16x8 A[2][3], Bf[2][3];
-#pragma unroll
-      for (int p = 0; p < 3; ++p)
-#pragma unroll
-        for (int m = 0; m < 2; ++m)
-          A[m][p] = *reinterpret_cast<const bf16x8*>(st + aoff + p * WS_A_PLANE + m * 32 * WS_APB + ks * 32);
-#pragma unroll
-      for (int p = 0; p < 3; ++p)
-#pragma unroll
-        for (int n = 0; n < 2; ++n) {
-          const unsigned char* bp = st + boff[n] + p * PSB + ks * 32;
-          const bf16x4 lo = *reinterpret_cast<const bf16x4*>(bp);
-          const bf16x4 hi = *reinterpret_cast<const bf16x4*>(bp + 8);
-          Bf[n][p] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-        }
+      if (ks + 1 < WS_TT / 16) ld_frags(st, ks + 1, A[(ks + 1) & 1], Bf[(ks + 1) & 1]);
       __builtin_amdgcn_sched_barrier(0);
       // smallest terms first: mid*mid, lo*hi, hi*lo, mid*hi, hi*mid, hi*hi (planes 0 = hi, 1 = mid, 2 = lo); the term
       // loop is outside the block loops so that consecutive MFMAs write different accumulators
@@ -263,7 +285,7 @@ __global__ __launch_bounds__(512, 2) void conv1d_wgrad_split_kernel(WsArgs a) {
         for (int m = 0; m < 2; ++m)
 #pragma unroll
           for (int n = 0; n < 2; ++n)
-            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[m][TA[q]], Bf[n][TB[q]], acc[m][n], 0, 0, 0);
+            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[ks & 1][m][TA[q]], Bf[ks & 1][n][TB[q]], acc[m][n], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
     __syncthreads();
@@ -303,36 +325,94 @@ static int ws_geometry(int B, int C_in, int T_in, int C_out, int T_out, int K, i
   a->NCP = max_shift + 1 < 4 ? max_shift + 1 : 4;
   const int XW = WS_TT + max_shift;
   a->nq = (XW + 3) / 4;
-  a->XPB = 8 * a->nq + 8;
-  if ((long long)a->R * a->nq > 256 * WS_ITEMS) return -1;                       // staging items per stage
+  if ((long long)a->NCP * 3 * a->R * a->nq > 256 * 19) return -1;               // 8-byte B pieces per stage (NB <= 19)
+  // Row pitch: 8 * nq bytes of data + 8..64 bytes of padding, chosen to minimise LDS bank conflicts of the B fragment
+  // reads (ds_read_b64: 32 lanes per cycle over 64 dword banks; lane J reads row (J / K, phase) of copy shift % 4).
+  int best_pitch = -1;
+  long best_score = -1;
+  for (int p = 1; p <= 8; ++p) {
+    const int pitch = 8 * a->nq + 8 * p;
+    const size_t st = ((size_t)WS_A_STAGE + (size_t)a->NCP * 3 * a->R * pitch + 15) & ~(size_t)15;
+    if (2 * st > 160 * 1024) break;
+    long score = 0;
+    for (int blk = 0; blk < 4; ++blk) {               // the four 32-column blocks of the tile
+      int cnt[64] = {0};
+      for (int l = 0; l < 32; ++l) {
+        int J = blk * 32 + l;
+        if (J >= a->cit * K) J = 0;
+        const int cl = J / K, k = J - cl * K, kd = k * dil, shift = kd / stride, ph = kd - shift * stride, r = shift & 3;
+        const long addr = (long)(r * 3) * a->R * pitch + (long)(cl * stride + ph) * pitch + (shift - r) * 2;
+        cnt[(addr / 4) & 63]++;
+        cnt[(addr / 4 + 1) & 63]++;
+      }
+      int mx = 0;
+      for (int i = 0; i < 64; ++i) mx = cnt[i] > mx ? cnt[i] : mx;
+      score += mx;
+    }
+    if (best_score < 0 || score < best_score) { best_score = score; best_pitch = pitch; }
+  }
+  if (best_pitch < 0) return -1;
+  a->XPB = best_pitch;
   const size_t stage = ((size_t)WS_A_STAGE + (size_t)a->NCP * 3 * a->R * a->XPB + 15) & ~(size_t)15;
   *lds = 2 * stage;
-  if (*lds > 160 * 1024) return -1;
-  if ((long long)C_in * T_in >= (1ll << 31) || (long long)C_out * T_out >= (1ll << 31)) return -1;
   a->n_tt = (T_out + WS_TT - 1) / WS_TT;
+  a->UA = a->n_tt * WS_TT;
+  a->UB = (a->n_tt * WS_TT + max_shift + 8 + 7) & ~7;
+  a->a_plane_bytes = (long long)B * C_out * a->UA * 2;
+  a->b_plane_bytes = (long long)B * C_in * stride * a->UB * 2;
+  // per-lane plane offsets are 32-bit; per-clip bases are 64-bit
+  if (3 * a->a_plane_bytes >= (1ll << 32) || 3 * a->b_plane_bytes >= (1ll << 32)) return -1;
   const long long tiles = (long long)B * a->n_tt;
   const long long wgs = (long long)((C_out + WS_CO - 1) / WS_CO) * ((C_in + a->cit - 1) / a->cit);
-  // one workgroup per CU (LDS): aim at ~4 waves of workgroups over the 256 CUs; bounded by 512 MB of partials
-  long long S = (1024 + wgs - 1) / wgs;
-  if (S > tiles) S = tiles;
-  if (S > 2048) S = 2048;
+  // One workgroup per CU (LDS) and equal-length workgroups: the launch runs in ceil(wgs * S / 256) rounds.  Pick the slice
+  // count (around 4 rounds; more slices = more partial-sum traffic) that wastes the least of the last round; bounded by
+  // 512 MB of partials.
   const long long per_split_bytes = (long long)C_out * C_in * K * 4;
-  if (S * per_split_bytes > (512ll << 20)) S = (512ll << 20) / per_split_bytes;
-  if (S < 1) S = 1;
+  long long s_max = (2048 + wgs - 1) / wgs;
+  if (s_max > tiles) s_max = tiles;
+  if (s_max > 2048) s_max = 2048;
+  if (s_max * per_split_bytes > (512ll << 20)) s_max = (512ll << 20) / per_split_bytes;
+  if (s_max < 1) s_max = 1;
+  long long s_min = (768 + wgs - 1) / wgs;
+  if (s_min > s_max) s_min = s_max;
+  long long S = s_min;
+  double best = -1.0;
+  for (long long c = s_min; c <= s_max; ++c) {
+    const long long per = (tiles + c - 1) / c, real = (tiles + per - 1) / per;     // slices that actually get tiles
+    const long long total = wgs * real, rounds = (total + 255) / 256;
+    // time ~ rounds * tiles per slice (+ ~3 tiles of fixed cost per workgroup)
+    const double cost = (double)rounds * (double)(per + 3);
+    const double eff = (double)(wgs * tiles) / (256.0 * cost);
+    if (eff > best + 1e-9) { best = eff; S = c; }
+  }
   a->tiles_per_split = (int)((tiles + S - 1) / S);
   *splits = (int)((tiles + a->tiles_per_split - 1) / a->tiles_per_split);
   return 0;
 }
 
+template <int NB, int D>
+static void ws_launch(const WsArgs& a, dim3 grid, size_t lds, hipStream_t stream) {
+  auto kern = conv1d_wgrad_planes_kernel<NB, D>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, grid, dim3(512), lds, stream, a);
+}
+
+static long long ws_align(long long v) { return (v + 255) & ~255ll; }
+
 }  // namespace fac
 
+// workspace = [partials | dy planes | x planes]
 extern "C" int64_t fac_conv1d_bwd_weight_split_ws_bytes(int B, int C_in, int T_in, int C_out, int T_out, int K, int stride,
                                                         int dilation) {
   fac::WsArgs a;
   int S;
   size_t lds;
   if (fac::ws_geometry(B, C_in, T_in, C_out, T_out, K, stride, dilation, &a, &S, &lds)) return -1;
-  return (int64_t)S * C_out * C_in * K * 4;
+  return fac::ws_align((int64_t)S * C_out * C_in * K * 4) + fac::ws_align(3 * a.a_plane_bytes) + fac::ws_align(3 * a.b_plane_bytes);
 }
 
 extern "C" int fac_conv1d_bwd_weight_split(const float* x, const float* dy, float* dw, void* ws, int64_t ws_bytes, int B,
@@ -347,27 +427,40 @@ extern "C" int fac_conv1d_bwd_weight_split(const float* x, const float* dy, floa
   size_t lds;
   FAC_REQUIRE(ws_geometry(B, C_in, T_in, C_out, T_out, K, stride, dilation, &a, &S, &lds) == 0,
               "conv1d_bwd_weight_split: shape not supported (K=%d stride=%d dilation=%d)", K, stride, dilation);
-  FAC_REQUIRE(ws_bytes >= (int64_t)S * C_out * C_in * K * 4, "conv1d_bwd_weight_split: workspace too small");
-  a.x = x; a.dy = dy; a.part = reinterpret_cast<float*>(ws);
-  a.x_bs = (long long)C_in * T_in; a.x_cs = T_in; a.dy_bs = (long long)C_out * T_out; a.dy_cs = T_out;
-  a.B = B; a.C_in = C_in; a.T_in = T_in; a.C_out = C_out; a.T_out = T_out; a.K = K; a.stride = stride; a.dil = dilation;
-  a.pad_left = pad_left; a.pad_mode = pad_mode;
+  const long long part_bytes = ws_align((long long)S * C_out * C_in * K * 4);
+  FAC_REQUIRE(ws_bytes >= part_bytes + ws_align(3 * a.a_plane_bytes) + ws_align(3 * a.b_plane_bytes),
+              "conv1d_bwd_weight_split: workspace too small");
+  unsigned char* wsb = reinterpret_cast<unsigned char*>(ws);
+  a.part = reinterpret_cast<float*>(ws);
+  unsigned char* ap = wsb + part_bytes;
+  unsigned char* bp = ap + ws_align(3 * a.a_plane_bytes);
+  a.ap = ap; a.bp = bp;
+  a.B = B; a.C_in = C_in; a.C_out = C_out; a.K = K; a.stride = stride; a.dil = dilation;
+  const hipStream_t st = (hipStream_t)stream;
+  int T_ext;
+  long long last = (long long)(T_out - 1) * stride + (long long)(K - 1) * dilation - pad_left;
   {
-    long long last = (long long)(T_out - 1) * stride + (long long)(K - 1) * dilation - pad_left;
     int pad_right = last >= T_in ? (int)(last - T_in + 1) : 0;
     int max_pad = pad_left > pad_right ? pad_left : pad_right;
-    a.T_ext = T_in > max_pad ? T_in : max_pad + 1;
+    T_ext = T_in > max_pad ? T_in : max_pad + 1;
   }
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv1d_wgrad_split_kernel),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
+  const int T_pad = (int)(pad_left + (last + 1 > T_in ? last + 1 : T_in));       // padded positions that hold (mapped) samples
+  {  // dy -> planes with a zero tail;  x -> padded, phase-major planes
+    const long long na = (long long)B * C_out * (a.UA / 8), nb = (long long)B * C_in * stride * (a.UB / 8);
+    const int ga = (int)((na + 255) / 256 < 65535 * 16 ? (na + 255) / 256 : 65535 * 16);
+    const int gb = (int)((nb + 255) / 256 < 65535 * 16 ? (nb + 255) / 256 : 65535 * 16);
+    hipLaunchKernelGGL(split_planes_kernel, dim3(ga), dim3(256), 0, st, dy, ap, (long long)B * C_out, T_out, T_out, T_out, 1, a.UA, 0,
+                       FAC_PAD_ZERO, a.a_plane_bytes);
+    hipLaunchKernelGGL(split_planes_kernel, dim3(gb), dim3(256), 0, st, x, bp, (long long)B * C_in, T_in, T_ext, T_pad, stride, a.UB,
+                       pad_left, pad_mode, a.b_plane_bytes);
   }
   dim3 grid((C_out + WS_CO - 1) / WS_CO, (C_in + a.cit - 1) / a.cit, S);
-  hipLaunchKernelGGL(conv1d_wgrad_split_kernel, grid, dim3(512), lds, (hipStream_t)stream, a);
+  const int nb8 = (a.NCP * 3 * a.R * a.nq + 255) / 256;
+  if (nb8 <= 10) ws_launch<10, 3>(a, grid, lds, st);
+  else if (nb8 <= 14) ws_launch<14, 3>(a, grid, lds, st);
+  else ws_launch<19, 2>(a, grid, lds, st);
   const long long n = (long long)C_out * C_in * K;
   const int blocks = (int)((n + 255) / 256 < 65535 ? (n + 255) / 256 : 65535);
-  hipLaunchKernelGGL(wgrad_split_reduce_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a.part, dw, S, n);
+  hipLaunchKernelGGL(wgrad_split_reduce_kernel, dim3(blocks), dim3(256), 0, st, a.part, dw, S, n);
   return check_launch("conv1d_bwd_weight_split");
 }
