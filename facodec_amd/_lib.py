@@ -28,6 +28,7 @@ class ConvDesc(C.Structure):
         ("pad_mode", C.c_int32), ("n_phase", C.c_int32), ("y_tstride", C.c_int32), ("phase_shift", C.c_int32),
         ("act", C.c_int32),
         ("w_batched", C.c_int32), ("w_bs", _i64), ("ws", _p), ("ws_bytes", _i64), ("w_split", _p),
+        ("K1", C.c_int32), ("dilation2", C.c_int32),
     ]
 
 
@@ -51,9 +52,9 @@ SIGNATURES = {
     "fac_pack_conv_w_bwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
     "fac_pad_fold_bwd": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "fac_conv1d_bwd_weight_ws_bytes": (_i64, [_i, _i, _i, _i, _i]),
-    "fac_conv1d_bwd_weight": (_i, [_p, _p, _p, _p, _i64, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
-    "fac_conv1d_bwd_weight_split_ws_bytes": (_i64, [_i, _i, _i, _i, _i, _i, _i, _i]),
-    "fac_conv1d_bwd_weight_split": (_i, [_p, _p, _p, _p, _i64, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "fac_conv1d_bwd_weight": (_i, [_p, _p, _p, _p, _i64, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "fac_conv1d_bwd_weight_split_ws_bytes": (_i64, [_i, _i, _i, _i, _i, _i, _i, _i, _i, _i]),
+    "fac_conv1d_bwd_weight_split": (_i, [_p, _p, _p, _p, _i64, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
     "fac_weight_norm_bwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _p]),
     "fac_snake_bwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
     "fac_bias_grad": (_i, [_p, _p, _p, _i, _i, _i, _p]),
@@ -89,7 +90,8 @@ SIGNATURES = {
     "fac_attention_bwd_pv": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "fac_attention_bwd_qk": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "fac_aa_snakebeta_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
-    "fac_leaky_relu": (_i, [_p, _p, _p, _i64, _f, _i, _i, _i, _p]),
+    "fac_leaky_relu": (_i, [_p, _p, _p, _i64, _f, _i, _i, _i, _i, _i, _p]),
+    "fac_spec_to_cat": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     "fac_period_fold": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "fac_zero_insert": (_i, [_p, _p, _i64, _i, _i, _p]),
     "fac_row_stack3": (_i, [_p, _p, _i64, _i, _i, _i, _i, _p]),

@@ -20,27 +20,31 @@ def _split_ok(k, stride, c_in, c_out, ncol):
 
 
 class PlainConv(Function):
-    """torch-semantics Conv1d (zero padding `pad` both sides, stride) with optional weight-norm gain g (C_out,1,1)."""
+    """torch-semantics Conv1d (zero padding `pad` both sides, stride) with optional weight-norm gain g (C_out,1,1).
+    taps = (k1, dilation2): two-level taps -- tap k = k2 * k1 + k1' reads offset k2 * dilation2 + k1' (a (K2, k1) Conv2d over
+    a row-concatenated signal of row pitch dilation2); `pad` is then the padding along the concatenated axis."""
 
     @staticmethod
-    def forward(ctx, x, v, g, bias, k, stride, pad):
+    def forward(ctx, x, v, g, bias, k, stride, pad, taps=None):
         B, c_in, t_in = x.shape
-        t_out = (t_in + 2 * pad - k) // stride + 1
+        k1, dil2 = taps if taps is not None else (0, 0)
+        max_off = (k // k1 - 1) * dil2 + (k1 - 1) if k1 else k - 1
+        t_out = (t_in + 2 * pad - max_off - 1) // stride + 1
         vd, gd = v.detach().contiguous(), (g.detach().contiguous() if g is not None else None)
-        if _split_ok(k, stride, c_in, v.shape[0], B * t_out):
+        if not k1 and _split_ok(k, stride, c_in, v.shape[0], B * t_out):
             wp, ws = None, ops.pack_conv_weight_split(vd, gd)
         else:
             wp, ws = ops.pack_conv_weight(vd, gd), None
         y = ops.conv1d(x.detach(), wp, v.shape[0], k, bias=bias.detach() if bias is not None else None,
-                       stride=stride, pad_left=pad, pad_mode=ops.PAD_ZERO, t_out=t_out, w_split=ws)
-        ctx.cfg = (k, stride, pad, t_in, t_out)
+                       stride=stride, pad_left=pad, pad_mode=ops.PAD_ZERO, t_out=t_out, w_split=ws, k1=k1, dilation2=dil2)
+        ctx.cfg = (k, stride, pad, t_in, t_out, k1, dil2, max_off)
         ctx.save_for_backward(x, v, g, bias)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, v, g, bias = ctx.saved_tensors
-        k, stride, pad, t_in, t_out = ctx.cfg
+        k, stride, pad, t_in, t_out, k1, dil2, max_off = ctx.cfg
         dy = dy.contiguous()
         B, c_out, _ = dy.shape
         c_in = v.shape[1]
@@ -52,46 +56,50 @@ class PlainConv(Function):
                 tu = (t_out - 1) * stride + 1
                 up = torch.empty(B, c_out, tu, device=dy.device)
                 _call("fac_zero_insert", _p(dy), _p(up), B * c_out, t_out, stride)
-            tp = up.shape[-1] + k - 1
-            if _split_ok(k, 1, c_out, c_in, B * tp):
+            tp = up.shape[-1] + max_off        # full correlation: dxpad[i] = sum_k wflip[k] up[i - max_off + off'_k]
+            if not k1 and _split_ok(k, 1, c_out, c_in, B * tp):
                 w = ops.rows_fma(vd, ops.wn_scale(vd, gd)) if gd is not None else vd
                 ws = ops.pack_conv_weight_split(w.permute(1, 0, 2).flip(2).contiguous())
                 dxp = ops.conv1d(up, None, c_in, k, pad_left=k - 1, pad_mode=ops.PAD_ZERO, t_out=tp, w_split=ws)
             else:
-                dxp = ops.conv1d(up, ops.pack_conv_weight_bwd(vd, gd), c_in, k, pad_left=k - 1, pad_mode=ops.PAD_ZERO, t_out=tp)
+                dxp = ops.conv1d(up, ops.pack_conv_weight_bwd(vd, gd), c_in, k, pad_left=max_off, pad_mode=ops.PAD_ZERO, t_out=tp,
+                                 k1=k1, dilation2=dil2)
             if tp < pad + t_in:       # trailing inputs no window reads
                 dxp = torch.cat([dxp, torch.zeros(B, c_in, pad + t_in - tp, device=dy.device)], dim=2)
             dx = dxp[:, :, pad:pad + t_in].contiguous()
         dv = dg = db = None
         if ctx.needs_input_grad[1]:       # frozen discriminator (generator step): no weight gradients
-            dw = ops.conv1d_bwd_weight(x.detach(), dy, k, stride=stride, pad_mode=ops.PAD_ZERO, pad_left=pad)
+            dw = ops.conv1d_bwd_weight(x.detach(), dy, k, stride=stride, pad_mode=ops.PAD_ZERO, pad_left=pad, k1=k1, dilation2=dil2)
             if g is not None:
                 dv, dg = ops.weight_norm_bwd(vd, gd, dw)
             else:
                 dv = dw
         if bias is not None and ctx.needs_input_grad[3]:
             db = ops.bias_grad(dy)
-        return dx, dv, dg, db, None, None, None
+        return dx, dv, dg, db, None, None, None, None
 
 
 class LeakyReLU(Function):
-    """LeakyReLU; with rows = (pitch, valid) also zeroes the gap columns of a row-concatenated signal."""
+    """LeakyReLU; with rows = (pitch, valid[, rows_per_group, valid_rows]) also zeroes the gap columns (and the separator rows)
+    of a row-concatenated signal."""
 
     @staticmethod
     def forward(ctx, x, slope, rows=None):
         ctx.save_for_backward(x)
-        pitch, valid = rows if rows is not None else (0, 0)
-        ctx.cfg = (slope, x.shape[-1], pitch, valid)
+        pitch, valid, rpg, vrows = (tuple(rows) + (0, 0))[:4] if rows is not None else (0, 0, 0, 0)
+        ctx.cfg = (slope, x.shape[-1], pitch, valid, rpg, vrows)
         y = torch.empty_like(x)
-        _call("fac_leaky_relu", _p(x.detach().contiguous()), _p(None), _p(y), x.numel(), C.c_float(slope), x.shape[-1], pitch, valid)
+        _call("fac_leaky_relu", _p(x.detach().contiguous()), _p(None), _p(y), x.numel(), C.c_float(slope), x.shape[-1], pitch, valid,
+              rpg, vrows)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         (x,) = ctx.saved_tensors
-        slope, T, pitch, valid = ctx.cfg
+        slope, T, pitch, valid, rpg, vrows = ctx.cfg
         dx = torch.empty_like(x)
-        _call("fac_leaky_relu", _p(x.detach().contiguous()), _p(dy.contiguous()), _p(dx), x.numel(), C.c_float(slope), T, pitch, valid)
+        _call("fac_leaky_relu", _p(x.detach().contiguous()), _p(dy.contiguous()), _p(dx), x.numel(), C.c_float(slope), T, pitch, valid,
+              rpg, vrows)
         return dx, None, None
 
 
@@ -182,6 +190,26 @@ class SpecBand(Function):
         dspec = torch.zeros(B, 2 * Ft, T, device=d.device)
         _call("fac_spec_to_rows", _p(d.contiguous()), _p(dspec), B, Ft, T, f0, fb, 1)
         return dspec, None, None
+
+
+class SpecCat(Function):
+    """One frequency band of the spectrogram in the row-concatenated layout: (B, 2F, T) -> (1, 2, B*(T+1)*pitch); row
+    r = b*(T+1) + t holds the band's bins then zeros, row t = T of each clip is a zero separator."""
+
+    @staticmethod
+    def forward(ctx, spec, f0, fb, pitch):
+        B, f2, T = spec.shape
+        out = torch.empty(1, 2, B * (T + 1) * pitch, device=spec.device)
+        _call("fac_spec_to_cat", _p(spec.detach().contiguous()), _p(out), B, f2 // 2, T, f0, fb, pitch, 0)
+        ctx.cfg = (B, f2 // 2, T, f0, fb, pitch)
+        return out
+
+    @staticmethod
+    def backward(ctx, d):
+        B, Ft, T, f0, fb, pitch = ctx.cfg
+        dspec = torch.zeros(B, 2 * Ft, T, device=d.device)
+        _call("fac_spec_to_cat", _p(d.contiguous()), _p(dspec), B, Ft, T, f0, fb, pitch, 1)
+        return dspec, None, None, None
 
 
 class Preprocess(Function):

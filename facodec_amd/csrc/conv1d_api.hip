@@ -63,18 +63,22 @@ extern "C" int fac_conv1d_fwd(const fac_conv_desc* d, fac_stream_t stream) {
   a.pad_left = d->pad_left; a.pad_mode = d->pad_mode; a.n_phase = d->n_phase;
   a.y_tstride = d->y_tstride; a.act = d->act; a.w_batched = d->w_batched;
   a.phase_shift = d->phase_shift;
+  a.K1 = d->K1 > 0 ? d->K1 : d->K; a.dil2 = d->dilation2;
+  FAC_REQUIRE(a.K1 <= d->K && d->K % a.K1 == 0 && (a.K1 == d->K || d->dilation2 > 0), "conv1d: bad two-level taps (K=%d K1=%d)", d->K, d->K1);
+  FAC_REQUIRE(!conv_two_level(a) || (!d->w_k1 && d->n_phase == 1 && !d->w_split), "conv1d: two-level taps need a plain conv");
   FAC_REQUIRE(d->phase_shift >= 0 && d->phase_shift < d->n_phase + (d->n_phase == 1), "conv1d: bad phase_shift");
   // length of pad1d's temporary zero extension (only differs from T_in for inputs shorter than the pad)
   {
-    long long last = (long long)(d->T_out - 1) * d->stride + (long long)(d->K - 1) * d->dilation - d->pad_left;
+    long long last = (long long)(d->T_out - 1) * d->stride + (long long)conv_max_tap_offset(a) - d->pad_left;
     int pad_right = last >= d->T_in ? (int)(last - d->T_in + 1) : 0;
     int max_pad = d->pad_left > pad_right ? d->pad_left : pad_right;
     a.T_ext = d->T_in > max_pad ? d->T_in : max_pad + 1;
   }
   hipStream_t s = (hipStream_t)stream;
   if (d->w_k1) return conv_dispatch_fused_ru(a, s);
-  if (conv_skinny_ok(a, d->ws, d->ws_bytes)) return conv_dispatch_skinny(a, d->ws, d->ws_bytes, s);
-  if (narrow_ok(d)) return conv_dispatch_narrow(a, s);
+  const bool two_level = conv_two_level(a);
+  if (!two_level && conv_skinny_ok(a, d->ws, d->ws_bytes)) return conv_dispatch_skinny(a, d->ws, d->ws_bytes, s);
+  if (!two_level && narrow_ok(d)) return conv_dispatch_narrow(a, s);
   if (d->w_split) {
     if (conv_bsplit_ok(a)) {
       a.w = reinterpret_cast<const float*>(d->w_split);
@@ -110,12 +114,12 @@ extern "C" int fac_conv1d_variant(const fac_conv_desc* d, char* name, int name_l
     a.alpha_in = d->alpha_in; a.w1 = d->w_k1; a.w_batched = d->w_batched; a.phase_shift = d->phase_shift;
     a.pad_mode = d->pad_mode; a.pad_left = d->pad_left; a.B = d->B; a.T_out = d->T_out; a.C_in = d->C_in; a.C_out = d->C_out; a.K = d->K;
     a.n_phase = d->n_phase; a.x_cs = d->x_cs; a.x_bs = d->x_bs;
-    if (conv_skinny_ok(a, d->ws, d->ws_bytes)) {
+    if (!(d->K1 > 0 && d->K1 < d->K) && conv_skinny_ok(a, d->ws, d->ws_bytes)) {
       if (name && name_len > 0) snprintf(name, name_len, "conv1d_skinny_kernel (split reduction, <=640 columns)");
       return 10;
     }
   }
-  if (narrow_ok(d)) {
+  if (!(d->K1 > 0 && d->K1 < d->K) && narrow_ok(d)) {
     if (name && name_len > 0) snprintf(name, name_len, "conv1d_narrow_kernel (VALU, C_out<=2)");
     return 9;
   }

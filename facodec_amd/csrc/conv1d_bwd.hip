@@ -57,6 +57,7 @@ struct WgArgs {
   float* part;         // [S][C_out][C_in][K]
   long long x_bs, x_cs, dy_bs, dy_cs;
   int B, C_in, T_in, T_ext, C_out, T_out, K, stride, dil, pad_left, pad_mode;
+  int K2, dil2;        // two-level taps as K2 virtual channels per real one (C_in, K here are the virtual count and K1)
   int CIT;             // input channels per column tile (CIT*K <= 128)
   int XWl;             // staged input columns per time tile
   int n_tt;            // 64-step time tiles per clip
@@ -108,10 +109,11 @@ __global__ __launch_bounds__(256) void conv1d_wgrad_kernel(WgArgs a) {
     const int tin0 = t0 * a.stride - a.pad_left;
     for (int idx = tid; idx < a.CIT * a.XWl; idx += 256) {
       const int cl = idx / a.XWl, c = idx - cl * a.XWl;
-      const int ci = ci0 + cl;
-      int tin = tin0 + c;
+      const int v = ci0 + cl;
+      const int ci = v / a.K2, k2 = v - ci * a.K2;
+      int tin = tin0 + c + k2 * a.dil2;
       if (a.pad_mode == FAC_PAD_REFLECT) tin = reflect_index(tin, a.T_in, a.T_ext);
-      xl[idx] = (ci < a.C_in && tin >= 0 && tin < a.T_in) ? xb[(long long)ci * a.x_cs + tin] : 0.f;
+      xl[idx] = (v < a.C_in && tin >= 0 && tin < a.T_in) ? xb[(long long)ci * a.x_cs + tin] : 0.f;
     }
     __syncthreads();
     const float* ap = dyl + (cb * 32 + l31) * (WG_TT + 1) + kk;
@@ -291,8 +293,13 @@ extern "C" int64_t fac_conv1d_bwd_weight_ws_bytes(int B, int C_in, int C_out, in
 
 extern "C" int fac_conv1d_bwd_weight(const float* x, const float* dy, float* dw, void* ws, int64_t ws_bytes, int B,
                                      int C_in, int T_in, int C_out, int T_out, int K, int stride, int dilation,
-                                     int pad_left, int pad_mode, fac_stream_t stream) {
+                                     int pad_left, int pad_mode, int K1, int dilation2, fac_stream_t stream) {
   using namespace fac;
+  if (K1 <= 0 || K1 > K) K1 = K;
+  FAC_REQUIRE(K % K1 == 0 && (K1 == K || dilation2 > 0), "conv1d_bwd_weight: bad two-level taps");
+  const int K2 = K / K1, K_total = K, C_in_real = C_in;
+  K = K1;                  // the kernel sees K2 virtual input channels per real one, K1 taps each
+  C_in = C_in_real * K2;
   FAC_REQUIRE(x && dy && dw && ws && B > 0 && C_in > 0 && C_out > 0 && T_in > 0 && T_out > 0 && K > 0 && stride > 0 &&
                   dilation > 0 && pad_left >= 0,
               "conv1d_bwd_weight: bad arguments");
@@ -302,11 +309,12 @@ extern "C" int fac_conv1d_bwd_weight(const float* x, const float* dy, float* dw,
               "conv1d_bwd_weight: K=%d too large", K);
   FAC_REQUIRE(ws_bytes >= (int64_t)S * C_out * C_in * K * 4, "conv1d_bwd_weight: workspace too small");
   a.x = x; a.dy = dy; a.part = reinterpret_cast<float*>(ws);
-  a.x_bs = (long long)C_in * T_in; a.x_cs = T_in; a.dy_bs = (long long)C_out * T_out; a.dy_cs = T_out;
+  a.x_bs = (long long)C_in_real * T_in; a.x_cs = T_in; a.dy_bs = (long long)C_out * T_out; a.dy_cs = T_out;
   a.B = B; a.C_in = C_in; a.T_in = T_in; a.C_out = C_out; a.T_out = T_out; a.K = K; a.stride = stride; a.dil = dilation;
-  a.pad_left = pad_left; a.pad_mode = pad_mode;
+  a.pad_left = pad_left; a.pad_mode = pad_mode; a.K2 = K2; a.dil2 = K2 > 1 ? dilation2 : 0;
+  (void)K_total;
   {
-    long long last = (long long)(T_out - 1) * stride + (long long)(K - 1) * dilation - pad_left;
+    long long last = (long long)(T_out - 1) * stride + (long long)(K2 - 1) * a.dil2 + (long long)(K - 1) * dilation - pad_left;
     int pad_right = last >= T_in ? (int)(last - T_in + 1) : 0;
     int max_pad = pad_left > pad_right ? pad_left : pad_right;
     a.T_ext = T_in > max_pad ? T_in : max_pad + 1;

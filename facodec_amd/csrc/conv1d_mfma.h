@@ -49,6 +49,7 @@ struct ConvArgs {
   int K, stride, dil, pad_left, pad_mode;
   int n_phase, y_tstride, act, w_batched;
   int phase_shift;   // left trim of a non-causal transposed conv (0 = causal)
+  int K1, dil2;      // two-level taps: tap k = k2*K1 + k1 at offset k2*dil2 + k1*dil (K1 == K: plain conv)
   int cic;  // input channels per LDS stage (multiple of 2*UC)
   int XW;   // staged input width = (T_TILE-1)*stride + (K-1)*dil + 1
   int XB;   // 64-wide column blocks per staged row = ceil(XW/64)
@@ -59,6 +60,13 @@ struct ConvArgs {
 #endif
   int x_off;   // columns staged to the left of the receptive field so that the slab starts 16-B aligned
 };
+
+// largest tap offset of a (possibly two-level) conv
+__host__ __device__ inline int conv_max_tap_offset(const ConvArgs& a) {
+  const int K1 = (a.K1 > 0 && a.K1 < a.K) ? a.K1 : a.K;
+  return (a.K / K1 - 1) * a.dil2 + (K1 - 1) * a.dil;
+}
+__host__ __device__ inline bool conv_two_level(const ConvArgs& a) { return a.K1 > 0 && a.K1 < a.K; }
 
 template <int KT>
 struct ConvUnroll {
@@ -383,21 +391,27 @@ __global__ __launch_bounds__((WM * WN + 4) * 64, (WM * WN == 4 ? FAC_CONV_WPE : 
         __builtin_amdgcn_sched_barrier(0);
       }
     } else {
+      const int K1 = conv_two_level(a) ? a.K1 : K;      // tap k = k2*K1 + k1 at offset k2*dil2 + k1*dil
+      const int K2 = K / K1;
       for (int c2 = 0; c2 < cic; c2 += 2) {
         const float* wp = Wb + c2 * wrow_stride;
-        const float* xp = Xb + c2 * XW;
+        const float* xp0 = Xb + c2 * XW;
+        for (int k2 = 0; k2 < K2; ++k2) {
+          const float* wq = wp + k2 * K1 * CO_TILE;
+          const float* xp = xp0 + k2 * a.dil2;
 #pragma unroll 2
-        for (int kk = 0; kk < K; ++kk) {
-          float av[MB], bv[NB];
+          for (int kk = 0; kk < K1; ++kk) {
+            float av[MB], bv[NB];
 #pragma unroll
-          for (int m = 0; m < MB; ++m) av[m] = wp[kk * CO_TILE + m * 32];
+            for (int m = 0; m < MB; ++m) av[m] = wq[kk * CO_TILE + m * 32];
 #pragma unroll
-          for (int n = 0; n < NB; ++n) bv[n] = xp[kk * dil + n * nstride];
+            for (int n = 0; n < NB; ++n) bv[n] = xp[kk * dil + n * nstride];
 #pragma unroll
-          for (int m = 0; m < MB; ++m)
+            for (int m = 0; m < MB; ++m)
 #pragma unroll
-            for (int n = 0; n < NB; ++n)
-              acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m], bv[n], acc[m][n], 0, 0, 0);
+              for (int n = 0; n < NB; ++n)
+                acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m], bv[n], acc[m][n], 0, 0, 0);
+          }
         }
       }
     }
@@ -545,7 +559,10 @@ int launch_cfg(ConvArgs& a, hipStream_t s) {
   // staged slab = receptive field of the tile, extended on the left to a 16-byte boundary and on the
   // right to a multiple of 4 columns, so interior slabs move as float4
   a.x_off = ((-a.pad_left) % 4 + 4) % 4;
-  a.XW = (((T_TILE - 1) * a.stride + (a.K - 1) * a.dil + 1 + a.x_off + (a.phase_shift > 0 ? 1 : 0)) + 3) & ~3;
+  if constexpr (KT > 0) {
+    if (conv_two_level(a)) return launch_cfg<MB, NB, WM, WN, 0, FUSE>(a, s);     // two-level taps: run-time tap loop only
+  }
+  a.XW = (((T_TILE - 1) * a.stride + conv_max_tap_offset(a) + 1 + a.x_off + (a.phase_shift > 0 ? 1 : 0)) + 3) & ~3;
   a.XB = (a.XW / 4 + 63) / 64;   // 64-lane blocks of float4 columns per staged row
   a.XQ = 4 / a.XB;
   a.XR = 4 % a.XB;

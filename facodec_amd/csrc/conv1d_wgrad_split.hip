@@ -48,7 +48,11 @@ struct WsArgs {
   long long a_plane_bytes, b_plane_bytes;
   int UA, UB;                // row lengths (elements) of the plane tensors
   int B, C_in, C_out, K, stride, dil;
-  int cit;             // input channels per column tile (cit * K <= 128)
+  // Two-level taps (tap k = k2*K1 + k1 at offset k2*dil2 + k1*dil, dil2 % stride == 0) are handled as K2 "virtual input
+  // channels" per real one: virtual channel v = ci*K2 + k2 has K1 taps and reads row ci shifted by k2*dil2/stride staged
+  // elements; the dW column order (ci, k2, k1) is unchanged.  Here K = K1 and C_in = C_in_real * K2.
+  int K2, dil2s;
+  int cit;             // (virtual) input channels per column tile (cit * K <= 128)
   int R;               // staged input rows per stage = cit * stride (row = (channel, phase))
   int NCP;             // shifted copies of the staged rows (1..4)
   int nq;              // 4-element quads per staged row
@@ -157,7 +161,9 @@ __global__ __launch_bounds__(512, 2) void conv1d_wgrad_planes_kernel(WsArgs a) {
       t /= a.R;
       const int p = t % 3, r = t / 3;
       const int srow = row < rows_valid ? row : 0;                       // rows of channels past C_in: never stored columns
-      b_off[j] = (unsigned)(p * a.b_plane_bytes + ((long long)(ci0 * s + srow) * a.UB + 4 * q + r) * 2);
+      const int v = ci0 + srow / s, ph = srow % s;                       // virtual channel -> (real channel, k2)
+      const int ci_real = v / a.K2, k2 = v - ci_real * a.K2;
+      b_off[j] = (unsigned)(p * a.b_plane_bytes + ((long long)(ci_real * s + ph) * a.UB + k2 * a.dil2s + 4 * q + r) * 2);
       b_lds[j] = ok ? WS_A_STAGE + (r * 3 + p) * PSB + row * a.XPB + q * 8 : -1;
     }
 
@@ -171,7 +177,7 @@ __global__ __launch_bounds__(512, 2) void conv1d_wgrad_planes_kernel(WsArgs a) {
       const int b = tile / a.n_tt;
       const int t0 = (tile - b * a.n_tt) * WS_TT;
       const unsigned char* ab = a.ap + ((long long)b * a.C_out * a.UA + t0) * 2;            // uniform
-      const unsigned char* bb = a.bp + ((long long)b * a.C_in * s * a.UB + t0) * 2;         // uniform
+      const unsigned char* bb = a.bp + ((long long)b * (a.C_in / a.K2) * s * a.UB + t0) * 2;   // uniform
 #pragma unroll
       for (int j = 0; j < WS_APIECES; ++j)
         asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(ra[j]) : "v"(a_off[j]), "s"(ab) : "memory");
@@ -316,8 +322,14 @@ __global__ void wgrad_split_reduce_kernel(const float* __restrict__ part, float*
 }
 
 // Geometry shared by the workspace query and the launch.  Returns 0 when the shape runs on the split kernel.
-static int ws_geometry(int B, int C_in, int T_in, int C_out, int T_out, int K, int stride, int dil, WsArgs* a, int* splits,
-                       size_t* lds) {
+static int ws_geometry(int B, int C_in_real, int T_in, int C_out, int T_out, int K_total, int stride, int dil, int K1, int dil2,
+                       WsArgs* a, int* splits, size_t* lds) {
+  if (K1 <= 0 || K1 > K_total) K1 = K_total;
+  if (K_total % K1 != 0) return -1;
+  const int K2 = K_total / K1, K = K1, C_in = C_in_real * K2;       // virtual channels (see WsArgs)
+  if (K2 > 1 && (dil2 <= 0 || dil2 % stride != 0)) return -1;
+  a->K2 = K2;
+  a->dil2s = K2 > 1 ? dil2 / stride : 0;
   if (K < 1 || K > WS_NC || stride < 1 || dil < 1) return -1;
   a->cit = WS_NC / K;
   a->R = a->cit * stride;
@@ -357,9 +369,9 @@ static int ws_geometry(int B, int C_in, int T_in, int C_out, int T_out, int K, i
   *lds = 2 * stage;
   a->n_tt = (T_out + WS_TT - 1) / WS_TT;
   a->UA = a->n_tt * WS_TT;
-  a->UB = (a->n_tt * WS_TT + max_shift + 8 + 7) & ~7;
+  a->UB = (a->n_tt * WS_TT + max_shift + (K2 - 1) * a->dil2s + 8 + 7) & ~7;
   a->a_plane_bytes = (long long)B * C_out * a->UA * 2;
-  a->b_plane_bytes = (long long)B * C_in * stride * a->UB * 2;
+  a->b_plane_bytes = (long long)B * C_in_real * stride * a->UB * 2;
   // per-lane plane offsets are 32-bit; per-clip bases are 64-bit
   if (3 * a->a_plane_bytes >= (1ll << 32) || 3 * a->b_plane_bytes >= (1ll << 32)) return -1;
   const long long tiles = (long long)B * a->n_tt;
@@ -407,17 +419,17 @@ static long long ws_align(long long v) { return (v + 255) & ~255ll; }
 
 // workspace = [partials | dy planes | x planes]
 extern "C" int64_t fac_conv1d_bwd_weight_split_ws_bytes(int B, int C_in, int T_in, int C_out, int T_out, int K, int stride,
-                                                        int dilation) {
+                                                        int dilation, int K1, int dilation2) {
   fac::WsArgs a;
   int S;
   size_t lds;
-  if (fac::ws_geometry(B, C_in, T_in, C_out, T_out, K, stride, dilation, &a, &S, &lds)) return -1;
+  if (fac::ws_geometry(B, C_in, T_in, C_out, T_out, K, stride, dilation, K1, dilation2, &a, &S, &lds)) return -1;
   return fac::ws_align((int64_t)S * C_out * C_in * K * 4) + fac::ws_align(3 * a.a_plane_bytes) + fac::ws_align(3 * a.b_plane_bytes);
 }
 
 extern "C" int fac_conv1d_bwd_weight_split(const float* x, const float* dy, float* dw, void* ws, int64_t ws_bytes, int B,
                                            int C_in, int T_in, int C_out, int T_out, int K, int stride, int dilation,
-                                           int pad_left, int pad_mode, fac_stream_t stream) {
+                                           int pad_left, int pad_mode, int K1, int dilation2, fac_stream_t stream) {
   using namespace fac;
   FAC_REQUIRE(x && dy && dw && ws && B > 0 && C_in > 0 && C_out > 0 && T_in > 0 && T_out > 0 && K > 0 && stride > 0 &&
                   dilation > 0 && pad_left >= 0,
@@ -425,7 +437,7 @@ extern "C" int fac_conv1d_bwd_weight_split(const float* x, const float* dy, floa
   WsArgs a;
   int S;
   size_t lds;
-  FAC_REQUIRE(ws_geometry(B, C_in, T_in, C_out, T_out, K, stride, dilation, &a, &S, &lds) == 0,
+  FAC_REQUIRE(ws_geometry(B, C_in, T_in, C_out, T_out, K, stride, dilation, K1, dilation2, &a, &S, &lds) == 0,
               "conv1d_bwd_weight_split: shape not supported (K=%d stride=%d dilation=%d)", K, stride, dilation);
   const long long part_bytes = ws_align((long long)S * C_out * C_in * K * 4);
   FAC_REQUIRE(ws_bytes >= part_bytes + ws_align(3 * a.a_plane_bytes) + ws_align(3 * a.b_plane_bytes),
@@ -435,10 +447,10 @@ extern "C" int fac_conv1d_bwd_weight_split(const float* x, const float* dy, floa
   unsigned char* ap = wsb + part_bytes;
   unsigned char* bp = ap + ws_align(3 * a.a_plane_bytes);
   a.ap = ap; a.bp = bp;
-  a.B = B; a.C_in = C_in; a.C_out = C_out; a.K = K; a.stride = stride; a.dil = dilation;
+  a.B = B; a.C_in = C_in * a.K2; a.C_out = C_out; a.K = K / a.K2; a.stride = stride; a.dil = dilation;
   const hipStream_t st = (hipStream_t)stream;
   int T_ext;
-  long long last = (long long)(T_out - 1) * stride + (long long)(K - 1) * dilation - pad_left;
+  long long last = (long long)(T_out - 1) * stride + (long long)(a.K2 - 1) * (a.K2 > 1 ? dilation2 : 0) + (long long)(a.K - 1) * dilation - pad_left;
   {
     int pad_right = last >= T_in ? (int)(last - T_in + 1) : 0;
     int max_pad = pad_left > pad_right ? pad_left : pad_right;
@@ -454,7 +466,7 @@ extern "C" int fac_conv1d_bwd_weight_split(const float* x, const float* dy, floa
     hipLaunchKernelGGL(split_planes_kernel, dim3(gb), dim3(256), 0, st, x, bp, (long long)B * C_in, T_in, T_ext, T_pad, stride, a.UB,
                        pad_left, pad_mode, a.b_plane_bytes);
   }
-  dim3 grid((C_out + WS_CO - 1) / WS_CO, (C_in + a.cit - 1) / a.cit, S);
+  dim3 grid((C_out + WS_CO - 1) / WS_CO, (a.C_in + a.cit - 1) / a.cit, S);
   const int nb8 = (a.NCP * 3 * a.R * a.nq + 255) / 256;
   if (nb8 <= 10) ws_launch<10, 3>(a, grid, lds, st);
   else if (nb8 <= 14) ws_launch<14, 3>(a, grid, lds, st);

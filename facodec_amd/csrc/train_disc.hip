@@ -12,18 +12,26 @@ static inline int grid_for(long long n) { return (int)((n + 255) / 256 < 65535 ?
 
 // Optional position mask for row-concatenated signals (MPD): only positions t with t % pitch < valid inside each
 // channel row of length T carry data; the rest are the zero gaps that stand in for the convs' padding.
-__global__ void leaky_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, float slope, int T, int pitch, int valid, long long n) {
+// MRD (rows_per_group > 0): additionally the rows r = position / pitch with r % rows_per_group >= valid_rows are zero (the
+// separator row after each clip's frames).
+__device__ __forceinline__ bool leaky_pos_ok(long long i, int T, int pitch, int valid, int rpg, int vrows) {
+  if (pitch == 0) return true;
+  const int pos = (int)(i % T);
+  const int row = pos / pitch;
+  if (pos - row * pitch >= valid) return false;
+  return rpg == 0 || row % rpg < vrows;
+}
+__global__ void leaky_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, float slope, int T, int pitch, int valid, int rpg,
+                                 int vrows, long long n) {
   GRID_STRIDE(i, n) {
     const float v = x[i];
-    const bool ok = pitch == 0 || (int)((i % T) % pitch) < valid;
-    y[i] = ok ? (v > 0.f ? v : v * slope) : 0.f;
+    y[i] = leaky_pos_ok(i, T, pitch, valid, rpg, vrows) ? (v > 0.f ? v : v * slope) : 0.f;
   }
 }
 __global__ void leaky_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dx, float slope, int T, int pitch,
-                                 int valid, long long n) {
+                                 int valid, int rpg, int vrows, long long n) {
   GRID_STRIDE(i, n) {
-    const bool ok = pitch == 0 || (int)((i % T) % pitch) < valid;
-    dx[i] = ok ? (x[i] > 0.f ? dy[i] : dy[i] * slope) : 0.f;
+    dx[i] = leaky_pos_ok(i, T, pitch, valid, rpg, vrows) ? (x[i] > 0.f ? dy[i] : dy[i] * slope) : 0.f;
   }
 }
 
@@ -113,6 +121,34 @@ __global__ void spec_to_rows_bwd_kernel(const float* __restrict__ drows, float* 
   }
 }
 
+// Row-concatenated band of the spectrogram: cat[c][(b*(T+1) + t)*pitch + f] = spec[b][c*Ft + f0 + f][t] for t < T, f < Fb; zero in
+// the gap columns and in the separator row t = T of every clip.
+__global__ void spec_to_cat_kernel(const float* __restrict__ spec, float* __restrict__ cat, int Ft, int T, int f0, int Fb, int pitch,
+                                   long long per_c, long long n) {
+  GRID_STRIDE(i, n) {
+    const int c = (int)(i / per_c);
+    const long long o = i - c * per_c;
+    const int f = (int)(o % pitch);
+    const long long r = o / pitch;
+    const int t = (int)(r % (T + 1));
+    const long long b = r / (T + 1);
+    cat[i] = (f < Fb && t < T) ? spec[(b * 2 * Ft + (long long)c * Ft + f0 + f) * T + t] : 0.f;
+  }
+}
+// adjoint: one thread per (b, c, f, t) of the band
+__global__ void spec_to_cat_bwd_kernel(const float* __restrict__ dcat, float* __restrict__ dspec, int Ft, int T, int f0, int Fb, int pitch,
+                                       long long per_c, long long n) {
+  GRID_STRIDE(i, n) {
+    const int t = (int)(i % T);
+    long long r = i / T;
+    const int f = (int)(r % Fb);
+    r /= Fb;
+    const int c = (int)(r & 1);
+    const long long b = r >> 1;
+    dspec[(b * 2 * Ft + (long long)c * Ft + f0 + f) * T + t] = dcat[c * per_c + (b * (T + 1) + t) * pitch + f];
+  }
+}
+
 // out[b][i] = x[b][reflect(i - pad_l)], i < T + pad_l + pad_r
 __global__ void pad_reflect_kernel(const float* __restrict__ x, float* __restrict__ out, int T, int pad_l, int Tp, long long n) {
   GRID_STRIDE(i, n) {
@@ -181,10 +217,11 @@ __global__ __launch_bounds__(256) void disc_pre_bwd_kernel(const float* __restri
 #define L1(kern, n, ...) hipLaunchKernelGGL(fac::kern, dim3(fac::grid_for(n)), dim3(256), 0, (hipStream_t)stream, __VA_ARGS__)
 
 extern "C" int fac_leaky_relu(const float* x, const float* dy, float* out, int64_t n, float slope, int T, int pitch, int valid,
-                              fac_stream_t stream) {
+                              int rows_per_group, int valid_rows, fac_stream_t stream) {
   FAC_REQUIRE(x && out && n > 0 && (pitch == 0 || (T > 0 && valid > 0 && valid <= pitch)), "leaky_relu: bad arguments");
-  if (dy) L1(leaky_bwd_kernel, n, x, dy, out, slope, T > 0 ? T : 1, pitch, valid, (long long)n);
-  else L1(leaky_fwd_kernel, n, x, out, slope, T > 0 ? T : 1, pitch, valid, (long long)n);
+  FAC_REQUIRE(rows_per_group == 0 || (pitch > 0 && valid_rows > 0 && valid_rows <= rows_per_group), "leaky_relu: bad row groups");
+  if (dy) L1(leaky_bwd_kernel, n, x, dy, out, slope, T > 0 ? T : 1, pitch, valid, rows_per_group, valid_rows, (long long)n);
+  else L1(leaky_fwd_kernel, n, x, out, slope, T > 0 ? T : 1, pitch, valid, rows_per_group, valid_rows, (long long)n);
   return fac::check_launch("leaky_relu");
 }
 
@@ -219,6 +256,15 @@ extern "C" int fac_spec_to_rows(const float* src, float* dst, int B, int Ft, int
   if (backward) L1(spec_to_rows_bwd_kernel, n, src, dst, Ft, T, f0, Fb, n);
   else L1(spec_to_rows_kernel, n, src, dst, Ft, T, f0, Fb, n);
   return fac::check_launch("spec_to_rows");
+}
+
+extern "C" int fac_spec_to_cat(const float* src, float* dst, int B, int Ft, int T, int f0, int Fb, int pitch, int backward,
+                               fac_stream_t stream) {
+  FAC_REQUIRE(src && dst && B > 0 && Ft > 0 && T > 0 && f0 >= 0 && Fb > 0 && f0 + Fb <= Ft && pitch >= Fb, "spec_to_cat: bad arguments");
+  const long long per_c = (long long)B * (T + 1) * pitch;
+  if (backward) { const long long n = (long long)B * 2 * Fb * T; L1(spec_to_cat_bwd_kernel, n, src, dst, Ft, T, f0, Fb, pitch, per_c, n); }
+  else { const long long n = 2 * per_c; L1(spec_to_cat_kernel, n, src, dst, Ft, T, f0, Fb, pitch, per_c, n); }
+  return fac::check_launch("spec_to_cat");
 }
 
 extern "C" int fac_pad_reflect(const float* x, float* out, int B, int T, int pad_l, int pad_r, fac_stream_t stream) {

@@ -6,7 +6,7 @@ State-dict keys equal the reference's (`discriminators.N.convs.i.0.{weight_g,wei
 
 Execution: every Conv2d here has one trivial kernel dimension, so it runs on the 1-D conv kernels --
   MPD  (k,1) convs: 1-D along the folded time axis, the period folded into the batch: tensors (B*period, C, L);
-  MRD  (3,k) convs: 1-D along frequency over the three neighbouring time rows stacked into channels: tensors (B*T, C, F).
+  MRD  (3,k) convs: 1-D two-level-tap convs over the row-concatenated (frame, frequency) signal: tensors (1, C, B*(T+1)*P).
 `Discriminator.forward` returns the reference's structure (dac/model/discriminator.py:214-217): a list of 8 lists of
 feature maps shaped (B, C, L, period) for MPD and (B, C, T, F) for MRD, so train.py:280-312 (`torch.mean`,
 `F.l1_loss` over them) runs unchanged.  Each returned tensor is a zero-copy strided VIEW of the internal map (autograd
@@ -85,7 +85,14 @@ class MPD(nn.Module):
 
 
 class MRD(nn.Module):
-    """discriminator.py:101-170."""
+    """discriminator.py:101-170.
+
+    Every band runs in a row-concatenated layout (like MPD): one long signal per channel, row r = b*(T+1) + t holds the
+    band's F_i valid bins followed by zeros up to the row pitch P_i; the extra row t = T of every clip is all zero.  The
+    zeros are the convs' padding along frequency (gap columns) and along time (separator rows), so a (3, k) Conv2d with
+    stride (1, s) is ONE 1-D conv along the concatenated axis with two-level taps (k2 = time row at offset k2 * P_in,
+    k1 = frequency tap), stride s -- a long GEMM-shaped launch instead of B*T tiny per-frame ones.  P_i = s_i * P_{i+1}
+    keeps rows aligned through the strided layers."""
 
     def __init__(self, window_length, sample_rate=24000, bands=BANDS):
         super().__init__()
@@ -100,28 +107,51 @@ class MRD(nn.Module):
         self.fstrides = (1, 2, 2, 2, 1)
         self._scale = None
 
-    def _conv(self, c, rows, T, kf, sf):
-        co, ci = c.weight_v.shape[0], c.weight_v.shape[1]
-        v = c.weight_v.permute(0, 2, 1, 3).reshape(co, 3 * ci, kf)       # channel axis of the stacked rows: (dt, ci)
-        return AD.PlainConv.apply(AD.RowStack3.apply(rows, T), v, c.weight_g.reshape(co, 1, 1), c.bias, kf, sf, kf // 2)
+    @staticmethod
+    def geometry(F0):
+        """Valid widths F_i and row pitches P_i of the six tensors x0..x5 of one band (x0 = the spectrogram band)."""
+        F = [F0, F0]
+        for _ in range(3):
+            F.append((F[-1] + 8 - 9) // 2 + 1)
+        F.append(F[-1])
+        p8 = max(F[4] + 1, -(-(F[3] + 4) // 2), -(-(F[2] + 4) // 4), -(-(F[1] + 4) // 8))    # gaps >= 4 before every k = 9 conv
+        return F, [8 * p8, 8 * p8, 4 * p8, 2 * p8, p8, p8]
+
+    @staticmethod
+    def _conv(c, x, pitch_in, sf, pf):
+        """(3, kf) Conv2d with stride (1, sf), padding (1, pf) as a two-level-tap 1-D conv over the concatenated axis."""
+        co, ci, _, kf = c.weight_v.shape
+        return AD.PlainConv.apply(x, c.weight_v.reshape(co, ci, 3 * kf), c.weight_g.reshape(co, 1, 1), c.bias, 3 * kf, sf,
+                                  pitch_in + pf, (kf, pitch_in))
 
     def forward(self, x):
-        """x (B, 1, T) preprocessed -> 26 feature maps (B*T_frames, C, F)."""
+        """x (B, 1, T) preprocessed -> 26 feature maps (1, C, B*(T'+1)*P_i) with `.rows = (pitch, valid, n_rows, T'+1, T')`."""
         B = x.shape[0]
         dev = x.device
         if self._scale is None or self._scale.basis.device != dev:
             self._scale = losses._SpectralScale(dev, self.window_length, self.window_length, self.window_length // 4)
         spec = AD.Spectrogram.apply(x.reshape(B, x.shape[-1]), self._scale)     # (B, 2F, T')
         T = spec.shape[-1]
-        fmap, outs = [], []
+        R = B * (T + 1)
+        fmap, outs, widths = [], [], []
         for (lo, hi), stack in zip(self.bands, self.band_convs):
-            rows = AD.SpecBand.apply(spec, lo, hi - lo)
-            for seq, sf in zip(stack, self.fstrides):
+            F, P = self.geometry(hi - lo)
+            h = AD.SpecCat.apply(spec, lo, hi - lo, P[0])
+            for i, (seq, sf) in enumerate(zip(stack, self.fstrides)):
                 c = seq[0]
-                rows = AD.LeakyReLU.apply(self._conv(c, rows, T, c.weight_v.shape[-1], sf), 0.1)
-                fmap.append(rows)
-            outs.append(rows)
-        y = self._conv(self.conv_post, torch.cat(outs, dim=2), T, 3, 1)
+                kf = c.weight_v.shape[-1]
+                h = self._conv(c, h, P[i], sf, kf // 2)
+                h = AD.LeakyReLU.apply(h, 0.1, (P[i + 1], F[i + 1], T + 1, T))
+                h.rows = (P[i + 1], F[i + 1], R, T + 1, T)
+                fmap.append(h)
+            outs.append(h.reshape(32, R, P[5])[:, :, :F[5]])
+            widths.append(F[5])
+        Fp = sum(widths)
+        Pp = Fp + 2
+        cat = torch.nn.functional.pad(torch.cat(outs, dim=2), (0, Pp - Fp)).reshape(1, 32, R * Pp)   # bands side by side (layout copy)
+        y = self._conv(self.conv_post, cat, Pp, 1, 1)
+        y = AD.LeakyReLU.apply(y, 1.0, (Pp, Fp, T + 1, T))      # identity on the data, zero in gaps / separator rows
+        y.rows = (Pp, Fp, R, T + 1, T)
         fmap.append(y)
         self.last_frames = T
         return fmap
@@ -152,14 +182,15 @@ class Discriminator(nn.Module):
 
 def _reference_view(d, m, batch):
     """Zero-copy view of an internal map in the reference's layout: MPD (1, C, B*period*pitch) -> (B, C, L, period)
-    (element [b, c, l, p] = row b*period + p, column l), MRD (B*T, C, F) -> (B, C, T, F)."""
+    (element [b, c, l, p] = row b*period + p, column l), MRD (1, C, B*(T+1)*pitch) -> (B, C, T, F)."""
     if isinstance(d, MPD):
         pitch, valid, rows = m.rows
         c = m.shape[1]
         v = m.as_strided((batch, c, valid, d.period), (d.period * pitch, rows * pitch, 1, pitch))
     else:
-        rows, c, f = m.shape
-        v = m.view(batch, rows // batch, c, f).permute(0, 2, 1, 3)
+        pitch, valid, rows, rpg, vrows = m.rows
+        c = m.shape[1]
+        v = m.as_strided((batch, c, vrows, valid), (rpg * pitch, rows * pitch, pitch, 1))
     v._fac_internal = m
     return v
 
@@ -176,8 +207,10 @@ def reference_layout(disc, fmaps, batch):
                 v = m.reshape(c, rows, pitch)[:, :, :valid]                       # (C, B*period, L)
                 conv.append(v.reshape(c, batch, d.period, valid).permute(1, 0, 3, 2).contiguous())
             else:
-                rows, c, f = m.shape
-                conv.append(m.reshape(batch, rows // batch, c, f).permute(0, 2, 1, 3).contiguous())
+                pitch, valid, rows, rpg, vrows = m.rows
+                c = m.shape[1]
+                v = m.reshape(c, batch, rpg, pitch)[:, :, :vrows, :valid]          # (C, B, T, F)
+                conv.append(v.permute(1, 0, 2, 3).contiguous())
         out.append(conv)
     return out
 
@@ -190,12 +223,14 @@ def _row_mask(t):
     rows = getattr(t, "rows", None)
     if rows is None:
         return None, t.numel()
-    pitch, valid, n_rows = rows
-    key = (t.shape, pitch, valid, t.device)
+    pitch, valid, n_rows = rows[:3]
+    rpg, vrows = rows[3:] if len(rows) == 5 else (1, 1)        # MRD: rows_per_group = T + 1 with one zero separator row
+    key = (t.shape, pitch, valid, rpg, vrows, t.device)
     if key not in _MASKS:
-        m = (torch.arange(t.shape[-1], device=t.device) % pitch < valid).to(torch.float32)
+        pos = torch.arange(t.shape[-1], device=t.device)
+        m = ((pos % pitch < valid) & ((pos // pitch) % rpg < vrows)).to(torch.float32)
         _MASKS[key] = m.reshape(1, 1, -1).expand(t.shape).contiguous()
-    return _MASKS[key], t.shape[1] * n_rows * valid
+    return _MASKS[key], t.shape[1] * (n_rows // rpg) * vrows * valid
 
 
 def _internal(t):

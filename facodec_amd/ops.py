@@ -171,9 +171,10 @@ def conv_out_len(t_in, k, stride, dilation):
 
 def conv1d(x, w_packed, c_out, k, bias=None, stride=1, dilation=1, pad_left=None, pad_mode=PAD_REFLECT,
            t_out=None, alpha_in=None, alpha_out=None, res=None, act=ACT_NONE, out=None, causal=True,
-           alpha_y2=None, want_y=True, w_k1=None, bias_k1=None, w_split=None):
+           alpha_y2=None, want_y=True, w_k1=None, bias_k1=None, w_split=None, k1=0, dilation2=0):
     """Fused conv (see fac_conv1d_fwd).  x (B, C_in, T).  With pad_left=None the SConv1d padding
     rule is applied (causal: everything on the left; non-causal: asymmetric split).
+    k1 / dilation2: two-level taps (tap k = k2 * k1 + k1' reads offset k2 * dilation2 + k1' * dilation), see fac_conv_desc.
     alpha_y2: also produce y2 = snake(y, alpha_y2) (returned as (y, y2); y is None if not want_y).
     w_k1 / bias_k1: fused ResidualUnit tail -- y = w_k1 * snake(conv + bias, alpha_out) + bias_k1 + res."""
     if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 3 and x.stride(2) == 1):
@@ -208,6 +209,7 @@ def conv1d(x, w_packed, c_out, k, bias=None, stride=1, dilation=1, pad_left=None
     d.B, d.C_in, d.T_in, d.C_out, d.C_out_pad, d.T_out = B, c_in, t_in, c_out, cp, t_out
     d.K, d.stride, d.dilation, d.pad_left, d.pad_mode = k, stride, dilation, pad_left, pad_mode
     d.n_phase, d.y_tstride, d.act, d.w_batched, d.w_bs = 1, 1, act, 0, 0
+    d.K1, d.dilation2 = k1, dilation2
     _launch_conv(d, "fac_conv1d_fwd")
     return (out, y2) if alpha_y2 is not None else out
 
@@ -515,8 +517,8 @@ def conv1d_bwd_data(dy, v, g, t_in, stride=1, dilation=1, pad_mode=PAD_REFLECT, 
     return dx
 
 
-def conv1d_bwd_weight(x, dy, k, stride=1, dilation=1, pad_mode=PAD_REFLECT, causal=True, pad_left=None):
-    """dW (C_out, C_in, K) of SConv1d (or of a plain conv when pad_left is given explicitly)."""
+def conv1d_bwd_weight(x, dy, k, stride=1, dilation=1, pad_mode=PAD_REFLECT, causal=True, pad_left=None, k1=0, dilation2=0):
+    """dW (C_out, C_in, K) of SConv1d (or of a plain conv when pad_left is given explicitly; k1 / dilation2: two-level taps)."""
     x, dy = _dev(x, "x"), _dev(dy, "dy")
     B, c_in, t_in = x.shape
     _, c_out, t_out = dy.shape
@@ -524,24 +526,26 @@ def conv1d_bwd_weight(x, dy, k, stride=1, dilation=1, pad_mode=PAD_REFLECT, caus
         _, padding_total, _ = conv_out_len(t_in, k, stride, dilation)
         pad_left = padding_total if causal else padding_total - padding_total // 2
     dw = torch.empty(c_out, c_in, k, device=x.device, dtype=torch.float32)
-    _bwd_weight_launch(x, dy, dw, B, c_in, t_in, c_out, t_out, k, stride, dilation, pad_left, pad_mode)
+    _bwd_weight_launch(x, dy, dw, B, c_in, t_in, c_out, t_out, k, stride, dilation, pad_left, pad_mode, k1, dilation2)
     return dw
 
 
-def _bwd_weight_launch(x, dy, dw, B, c_in, t_in, c_out, t_out, k, stride, dilation, pad_left, pad_mode):
+def _bwd_weight_launch(x, dy, dw, B, c_in, t_in, c_out, t_out, k, stride, dilation, pad_left, pad_mode, k1=0, dilation2=0):
     """dW on the bf16 matrix pipe with fp32-exact splitting (conv1d_wgrad_split.hip) when the shape qualifies and
     FAC_BF16_SPLIT is on, else on the fp32 MFMA kernel."""
     lib = _lib.load()
-    nbytes = lib.fac_conv1d_bwd_weight_split_ws_bytes(B, c_in, t_in, c_out, t_out, k, stride, dilation) if BF16_SPLIT else -1
+    nbytes = lib.fac_conv1d_bwd_weight_split_ws_bytes(B, c_in, t_in, c_out, t_out, k, stride, dilation, k1, dilation2) if BF16_SPLIT else -1
     if nbytes > 0:
         ws = torch.empty(nbytes // 4, device=x.device, dtype=torch.float32)
         _lib.check(lib.fac_conv1d_bwd_weight_split(_ptr(x), _ptr(dy), _ptr(dw), _ptr(ws), nbytes, B, c_in, t_in, c_out, t_out, k,
-                                                   stride, dilation, pad_left, pad_mode, _stream()), "fac_conv1d_bwd_weight_split")
+                                                   stride, dilation, pad_left, pad_mode, k1, dilation2, _stream()),
+                   "fac_conv1d_bwd_weight_split")
         return
-    nbytes = lib.fac_conv1d_bwd_weight_ws_bytes(B, c_in, c_out, t_out, k)
+    kk1 = k1 if 0 < k1 < k else k                      # the fp32 kernel sees k / kk1 virtual channels per input channel
+    nbytes = lib.fac_conv1d_bwd_weight_ws_bytes(B, c_in * (k // kk1), c_out, t_out, kk1)
     ws = torch.empty(nbytes // 4, device=x.device, dtype=torch.float32)
     _lib.check(lib.fac_conv1d_bwd_weight(_ptr(x), _ptr(dy), _ptr(dw), _ptr(ws), nbytes, B, c_in, t_in, c_out, t_out, k,
-                                         stride, dilation, pad_left, pad_mode, _stream()), "fac_conv1d_bwd_weight")
+                                         stride, dilation, pad_left, pad_mode, k1, dilation2, _stream()), "fac_conv1d_bwd_weight")
 
 
 def weight_norm_bwd(v, g, dw):

@@ -125,6 +125,11 @@ typedef struct fac_conv_desc {
    * qualifies (K = 7, stride 1, C_in % 16 == 0, no Snake prologue), the conv runs on the bf16 matrix pipe
    * with fp32-exact operand splitting (conv1d_bsplit.hip); `w` is still required for every other shape. */
   const void* w_split;
+  /* Optional two-level taps (0 = plain): tap k = k2 * K1 + k1 reads the input at offset k2 * dilation2 + k1 * dilation
+   * (K % K1 == 0).  A (3, k) Conv2d over a row-concatenated (time, frequency) signal -- the multi-resolution
+   * discriminator, dac/model/discriminator.py:101-170 -- is such a conv along the concatenated axis: K1 = k taps along
+   * frequency, dilation2 = the row pitch.  Runs on the generic fp32-MFMA tile. */
+  int32_t K1, dilation2;
 } fac_conv_desc;
 
 int fac_conv1d_fwd(const fac_conv_desc* d, fac_stream_t stream);
@@ -243,11 +248,18 @@ int fac_aa_snakebeta_bwd(const float* x, const float* alpha_log, const float* be
  *   spec_to_rows: one frequency band [f0, f0+Fb) of spec (B, 2*Ft, T) = [re|im] -> (B*T, 2, Fb)
  *   pad_reflect: (B, T) -> (B, pad_l + T + pad_r)
  *   disc_preprocess: z = 0.8 (x - mean)/(max|x - mean| + 1e-9) per clip; stats: 4*B floats kept for the backward */
+/* rows_per_group > 0: besides the column mask, rows (position / pitch) with row % rows_per_group >= valid_rows are zero
+ * (the all-zero separator rows between clips of the row-concatenated spectrogram layout). */
 int fac_leaky_relu(const float* x, const float* dy, float* out, int64_t n, float slope, int T, int pitch, int valid,
-                   fac_stream_t stream);
+                   int rows_per_group, int valid_rows, fac_stream_t stream);
 int fac_period_fold(const float* x, float* out, int B, int T, int period, int L, int pitch, int backward, fac_stream_t stream);
 int fac_zero_insert(const float* dy, float* up, int64_t rows, int T, int stride, fac_stream_t stream);
 int fac_row_stack3(const float* x, float* out, int64_t rows, int T, int C, int F, int backward, fac_stream_t stream);
+/* Multi-resolution discriminator in the row-concatenated layout: spec (B, 2*Ft, T) [re | im] band [f0, f0 + Fb) ->
+ * cat (2, B*(T+1)*pitch): row r = b*(T+1) + t holds the band's Fb bins followed by zeros; row t = T of every clip is an
+ * all-zero separator (the time padding of the (3, k) convs).  backward: the adjoint, accumulating disjoint bands into a
+ * zero-initialised dspec. */
+int fac_spec_to_cat(const float* src, float* dst, int B, int Ft, int T, int f0, int Fb, int pitch, int backward, fac_stream_t stream);
 int fac_spec_to_rows(const float* src, float* dst, int B, int Ft, int T, int f0, int Fb, int backward, fac_stream_t stream);
 int fac_pad_reflect(const float* x, float* out, int B, int T, int pad_l, int pad_r, fac_stream_t stream);
 int fac_disc_preprocess(const float* x, const float* dz, float* out, float* stats, int B, int T, fac_stream_t stream);
@@ -288,14 +300,17 @@ int fac_pad_fold_bwd(const float* dxpad, float* dx, int B, int C, int T, int Tp,
 int64_t fac_conv1d_bwd_weight_ws_bytes(int B, int C_in, int C_out, int T_out, int K);
 int fac_conv1d_bwd_weight(const float* x, const float* dy, float* dw, void* ws, int64_t ws_bytes, int B, int C_in,
                           int T_in, int C_out, int T_out, int K, int stride, int dilation, int pad_left, int pad_mode,
-                          fac_stream_t stream);
+                          int K1, int dilation2, fac_stream_t stream);
 /* The same gradient on the bf16 matrix pipe with fp32-exact operand splitting (conv1d_wgrad_split.hip; same arguments
  * and result layout as fac_conv1d_bwd_weight, error vs fp64 no larger than the fp32 MFMA's).  The workspace query
- * returns -1 for a (K, stride, dilation) the kernel does not cover: use fac_conv1d_bwd_weight then. */
-int64_t fac_conv1d_bwd_weight_split_ws_bytes(int B, int C_in, int T_in, int C_out, int T_out, int K, int stride, int dilation);
+ * returns -1 for a (K, stride, dilation) the kernel does not cover: use fac_conv1d_bwd_weight then.  K1 / dilation2:
+ * two-level taps as in fac_conv_desc (0 = plain); dW stays (C_out, C_in, K) with k = k2 * K1 + k1.  The workspace also
+ * holds the pre-split bf16 planes of both operands. */
+int64_t fac_conv1d_bwd_weight_split_ws_bytes(int B, int C_in, int T_in, int C_out, int T_out, int K, int stride, int dilation,
+                                             int K1, int dilation2);
 int fac_conv1d_bwd_weight_split(const float* x, const float* dy, float* dw, void* ws, int64_t ws_bytes, int B, int C_in, int T_in,
-                                int C_out, int T_out, int K, int stride, int dilation, int pad_left, int pad_mode,
-                                fac_stream_t stream);
+                                int C_out, int T_out, int K, int stride, int dilation, int pad_left, int pad_mode, int K1,
+                                int dilation2, fac_stream_t stream);
 /* w = g*v/||v|| per row (n_rows x row_len): dv, dg from dW. */
 int fac_weight_norm_bwd(const float* v, const float* g, const float* dw, float* dv, float* dg, int n_rows, int row_len,
                         fac_stream_t stream);

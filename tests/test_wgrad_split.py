@@ -70,7 +70,7 @@ def test_wgrad_split_against_fp64(case, cuda):
     dy = torch.randn(B, c_out, t_out, generator=g)
     ref = _ref_dw(x, dy, k, stride, dil, pad_left, mode)
     scale = float(ref.abs().max())
-    lib_bytes = ops._lib.load().fac_conv1d_bwd_weight_split_ws_bytes(B, c_in, t_in, c_out, t_out, k, stride, dil)
+    lib_bytes = ops._lib.load().fac_conv1d_bwd_weight_split_ws_bytes(B, c_in, t_in, c_out, t_out, k, stride, dil, 0, 0)
     assert lib_bytes > 0, "shape must qualify for the split kernel"
     prev = ops.BF16_SPLIT
     try:
@@ -110,3 +110,49 @@ def test_convtr_wgrad_on_split_kernel(cuda):
     finally:
         ops.BF16_SPLIT = prev
     assert float((dw.cpu().double() - w.grad).abs().max() / w.grad.abs().max()) < 1e-5
+
+
+@pytest.mark.parametrize("sf,kf,F0,P", [(1, 9, 25, 32), (2, 9, 51, 64), (2, 9, 26, 32), (1, 3, 13, 16)])
+def test_two_level_conv_is_conv2d(sf, kf, F0, P, cuda):
+    """(3, kf) Conv2d with stride (1, sf), padding (1, kf // 2) (dac/model/discriminator.py:110-120) as ONE 1-D conv with
+    two-level taps over the row-concatenated (frame, frequency) signal: forward, data gradient and weight gradient (split
+    kernel and fp32 kernel) against torch's conv2d in fp64."""
+    from facodec_amd import autograd_disc as AD
+    g = torch.Generator().manual_seed(11 + kf + sf)
+    B, T, ci, co = 2, 7, 6, 32
+    pf = kf // 2
+    x4 = torch.randn(B, ci, T, F0, generator=g)
+    w = torch.randn(co, ci, 3, kf, generator=g) * 0.2
+    bias = torch.randn(co, generator=g)
+    xr = x4.double().requires_grad_()
+    wr = w.double().requires_grad_()
+    y_ref = F.conv2d(xr, wr, bias.double(), stride=(1, sf), padding=(1, pf))
+    F1 = y_ref.shape[-1]
+    r = torch.randn(*y_ref.shape, generator=g).double()
+    (y_ref * r).sum().backward()
+    P_out = P // sf
+    assert P - F0 >= pf and P_out >= F1
+    # row-concatenated layouts: (1, C, B*(T+1)*P), zero gaps and one zero separator row per clip
+    cat = torch.zeros(ci, B, T + 1, P)
+    cat[:, :, :T, :F0] = x4.permute(1, 0, 2, 3)
+    rc = torch.zeros(co, B, T + 1, P_out)
+    rc[:, :, :T, :F1] = r.permute(1, 0, 2, 3).float()
+    for split in (True, False):
+        prev = ops.BF16_SPLIT
+        ops.BF16_SPLIT = split
+        try:
+            xc = cat.reshape(1, ci, -1).to(cuda).requires_grad_()
+            wc = w.reshape(co, ci, 3 * kf).to(cuda).requires_grad_()
+            bc = bias.to(cuda).requires_grad_()
+            y = AD.PlainConv.apply(xc, wc, None, bc, 3 * kf, sf, P + pf, (kf, P))
+            assert y.shape[-1] == B * (T + 1) * P_out
+            yv = y.detach().cpu().reshape(co, B, T + 1, P_out)[:, :, :T, :F1].permute(1, 0, 2, 3)
+            assert float((yv.double() - y_ref.detach()).abs().max() / y_ref.detach().abs().max()) < 1e-5
+            (y * rc.reshape(1, co, -1).to(cuda)).sum().backward()
+        finally:
+            ops.BF16_SPLIT = prev
+        dx = xc.grad.cpu().reshape(ci, B, T + 1, P)[:, :, :T, :F0].permute(1, 0, 2, 3)
+        assert float((dx.double() - xr.grad).abs().max() / xr.grad.abs().max()) < 1e-5, split
+        dw = wc.grad.cpu().reshape(co, ci, 3, kf)
+        assert float((dw.double() - wr.grad).abs().max() / wr.grad.abs().max()) < 1e-5, split
+        assert float((bc.grad.cpu().double() - r.sum((0, 2, 3))).abs().max()) < 1e-3
