@@ -832,7 +832,7 @@ def test_mel_loss_backward_against_autograd(O, cuda):
     assert abs(float(got) - float(ref)) / float(ref) < E2E_TOL
     (3.0 * got).backward()
     _record("mel_loss_input_gradient", rel(xg.grad, 3.0 * x.grad))
-    assert rel(xg.grad, 3.0 * x.grad) < 5e-4
+    assert rel(xg.grad, 3.0 * x.grad) < 5e-5          # measured on MI355X: 3.1e-6 (profiles/r02_tolerance_report.json)
 
 
 def test_rvq_backward_against_autograd(O, cuda):
@@ -944,7 +944,9 @@ def test_generator_step_gradients_against_autograd(O, cuda):
             if e > worst[1]:
                 worst = (k + "." + n, e)
     _record("generator_step_worst_parameter_gradient", list(worst))
-    assert n_checked > 250 and worst[1] < 2e-3, (n_checked, worst)
+    # measured worst of the 361 tensors: 2.1e-4 (residual_quantizer.quantizers.0.in_proj.weight_g, a 1024-term weight-norm
+    # reduction of a gradient that is itself a sum over all frames); every other tensor is below 1e-4
+    assert n_checked > 250 and worst[1] < 5e-4, (n_checked, worst)
     for k in ("encoder", "decoder", "quantizer"):
         step.opt[k].step()
     assert all(torch.isfinite(step.opt[k].p).all() for k in step.opt)
@@ -1056,13 +1058,17 @@ def test_discriminator_forward_backward(O, cuda, golden_dir):
     assert abs(float(loss_d) - float(ld)) / float(ld) < 2e-4 and abs(float(loss_f) - float(lf)) / float(lf) < 2e-4
     (loss_d + 0.5 * loss_g + 0.25 * loss_f).backward()
     _record("discriminator_input_gradient", rel(xf.grad, xf_ref.grad))
-    assert rel(xf.grad, xf_ref.grad) < 2e-3
+    assert rel(xf.grad, xf_ref.grad) < 1e-4            # measured: 1.2e-6
     worst = ("", 0.0)
     for n, p in disc.named_parameters():
         e = rel(p.grad, leaves[n].grad)
         if e > worst[1]:
             worst = (n, e)
     _record("discriminator_worst_parameter_gradient", list(worst))
+    # measured worst: 1.4e-3 on discriminators.2.convs.0.0.weight_v -- the 1 -> 32 channel first conv of a period
+    # discriminator: each of its 160 weights is ONE fp32 sum over ~48 000 (clip, position) products with heavy cancellation,
+    # and the reference side here is the oracle's fp32 autograd on the CPU with a different summation order.  The same
+    # tensor family agrees with the real reference to 6e-6 in tests/test_train_golden.py (4 x 6000-sample clips).
     assert worst[1] < 2e-3, worst
 
 
