@@ -105,7 +105,7 @@ def train_leg(model, device, rank, world, steps, warmup):
         t0 = time.perf_counter()
         for _ in range(3):
             for o in step.opt.values():
-                dist.all_reduce(o.g, op=dist.ReduceOp.AVG)
+                dist.all_reduce(o.g, op=dist.ReduceOp.AVG if dist.get_backend() == "nccl" else dist.ReduceOp.SUM)
         torch.cuda.synchronize()
         ar_ms = 1e3 * (time.perf_counter() - t0) / 3
     value = units / elapsed

@@ -100,9 +100,9 @@ class FlatAdamW:
             return
         if only_if_complete and not self.backward_complete():
             return
-        if self.g.is_cuda:
+        if dist.get_backend() == "nccl":          # RCCL: the mean is part of the collective
             self._work = dist.all_reduce(self.g, op=dist.ReduceOp.AVG, async_op=True)
-        else:   # gloo (CPU test scaffold) has no AVG
+        else:   # gloo (CPU test scaffold, or two ranks sharing one GPU in a smoke run) has no AVG
             self._work = dist.all_reduce(self.g, op=dist.ReduceOp.SUM, async_op=True)
             self._need_scale = True
 
