@@ -208,9 +208,8 @@ __global__ __launch_bounds__((NMW + NSW) * 64, (NMW + NSW) / 4) void conv1d_bspl
       }
       __syncthreads();
     }
-    return;
-  }
-
+    __builtin_amdgcn_s_setprio(0);
+  } else {
   // ========================= MFMA waves
 #ifdef FAC_PROF
   const unsigned long long tp0 = wall_clock64();
@@ -305,78 +304,85 @@ __global__ __launch_bounds__((NMW + NSW) * 64, (NMW + NSW) / 4) void conv1d_bspl
 #ifdef FAC_PROF
   const unsigned long long tp2 = wall_clock64();
 #endif
-#ifdef FAC_ABL_NOEPI
+  // ---- accumulators -> LDS (both stage buffers are free now): tile[co][t] fp32, row pitch BS_TT + 4 floats.
+  // C/D layout of the 32x32 block: register r <-> row (r & 3) + 8 (r >> 2) + 4 kq, column l31.
   {
-    float sacc = 0.f;
+    float* tile = reinterpret_cast<float*>(sm);
+    constexpr int EP = BS_TT + 4;
 #pragma unroll
     for (int m = 0; m < MB; ++m)
 #pragma unroll
       for (int n = 0; n < NB; ++n)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) sacc += acc[m][n][r];
-    if (sacc == 123.456f) a.y[0] = sacc;
-    return;
+        for (int r = 0; r < 16; ++r)
+          tile[(m * 32 + (r & 3) + 8 * (r >> 2) + 4 * kq) * EP + n0 + n * 32 + l31] = acc[m][n][r];
   }
-#endif
-  // ---- epilogue (C/D layout of the 32x32 tile is the fp32 MFMA's): bias, Snake, activation, residual, y / y2
-  float* yg = a.y ? a.y + (long long)b * a.y_bs : nullptr;
-  float* y2g = a.y2 ? a.y2 + (long long)b * a.y_bs : nullptr;
-  const float* rg = a.res ? a.res + (long long)b * a.y_bs : nullptr;
+  }   // MFMA waves
+  __syncthreads();
+
+  // ---- epilogue by ALL waves (the staging waves are idle by now): bias, Snake, activation, residual, y / y2.
+  // One lane = 4 consecutive time steps of one output channel; consecutive lanes = consecutive quads of a row, so residual
+  // loads and the stores are 16-byte pieces of contiguous 1 KiB runs.  (With the MFMA waves alone -- 64 outputs per lane,
+  // scalar 4-byte accesses in C/D order, one workgroup per CU so nothing else to overlap with -- the epilogue cost the
+  // C <= 192 layers a third of their time.)
+  {
+    const float* tile = reinterpret_cast<const float*>(sm);
+    constexpr int EP = BS_TT + 4;
+    constexpr int NTH = (NMW + NSW) * 64;
+    constexpr int QPR = BS_TT / 4;                       // quads per row
+    float* yg = a.y ? a.y + (long long)b * a.y_bs : nullptr;
+    float* y2g = a.y2 ? a.y2 + (long long)b * a.y_bs : nullptr;
+    const float* rg = a.res ? a.res + (long long)b * a.y_bs : nullptr;
+    const bool vec_ok = (a.y_cs & 3) == 0 && (a.y_bs & 3) == 0 && (!yg || (reinterpret_cast<unsigned long long>(a.y) & 15) == 0) &&
+                        (!y2g || (reinterpret_cast<unsigned long long>(a.y2) & 15) == 0) &&
+                        (!rg || (reinterpret_cast<unsigned long long>(a.res) & 15) == 0);
+    for (int q = tid; q < BS_CO * QPR; q += NTH) {
+      const int row = q / QPR, tq = q - row * QPR;
+      const int co = co0 + row, t = t0 + 4 * tq;
+      if (co >= a.C_out || t >= a.T_out) continue;
+      const float4 av = *reinterpret_cast<const float4*>(tile + row * EP + 4 * tq);
+      float v[4] = {av.x, av.y, av.z, av.w};
+      const float bs = a.bias ? a.bias[co] : 0.f;
+      const float al = a.alpha_out ? a.alpha_out[co] : 0.f;
+      const float inv = a.alpha_out ? snake_inv(al) : 0.f;
+      const long long o = (long long)co * a.y_cs + t;
+      const bool full = vec_ok && t + 3 < a.T_out;
+      float rv[4] = {0.f, 0.f, 0.f, 0.f};
+      if (rg) {
+        if (full) {
+          const float4 r4 = *reinterpret_cast<const float4*>(rg + o);
+          rv[0] = r4.x; rv[1] = r4.y; rv[2] = r4.z; rv[3] = r4.w;
+        } else {
 #pragma unroll
-  for (int m = 0; m < MB; ++m) {
-    float bsv[2][4], alv[2][4], al2[2][4], rv[2][4][NB];
-    auto ld_group = [&](int g, int slot) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int co = co0 + m * 32 + i + 8 * g + 4 * kq;
-        const int cc = co < a.C_out ? co : a.C_out - 1;
-        bsv[slot][i] = a.bias ? a.bias[cc] : 0.f;
-        alv[slot][i] = a.alpha_out ? a.alpha_out[cc] : 0.f;
-        al2[slot][i] = y2g ? a.alpha2[cc] : 0.f;
-#pragma unroll
-        for (int n = 0; n < NB; ++n) {
-          const int t = t0 + n0 + n * 32 + l31;
-          rv[slot][i][n] = (rg && co < a.C_out && t < a.T_out) ? rg[(long long)co * a.y_cs + t] : 0.f;
+          for (int i = 0; i < 4; ++i) rv[i] = t + i < a.T_out ? rg[o + i] : 0.f;
         }
       }
-    };
-    ld_group(0, 0);
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const int slot = g & 1;
-      if (g + 1 < 4) ld_group(g + 1, slot ^ 1);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const int r = 4 * g + i;
-        const int co = co0 + m * 32 + i + 8 * g + 4 * kq;
-        if (co >= a.C_out) continue;
-        const float al = alv[slot][i];
-        const float inv = a.alpha_out ? snake_inv(al) : 0.f;
+        float x = v[i] + bs;
+        if (a.alpha_out) x = snake_apply(x, al, inv);
+        if (a.act != FAC_ACT_NONE) x = apply_act_slow(x, a.act);
+        v[i] = x + rv[i];
+      }
+      float w[4];
+      if (y2g) {
+        const float a2 = a.alpha2[co], i2 = snake_inv(a2);
 #pragma unroll
-        for (int n = 0; n < NB; ++n) {
-          const int t = t0 + n0 + n * 32 + l31;
-          if (t >= a.T_out) continue;
-          float v = acc[m][n][r] + bsv[slot][i];
-          if (a.alpha_out) v = snake_apply(v, al, inv);
-          if (a.act != FAC_ACT_NONE) v = apply_act_slow(v, a.act);
-          v += rv[slot][i][n];
-          const long long o = (long long)co * a.y_cs + t;
-          if (yg) yg[o] = v;
-          if (y2g) y2g[o] = snake_apply(v, al2[slot][i], snake_inv(al2[slot][i]));
+        for (int i = 0; i < 4; ++i) w[i] = snake_apply(v[i], a2, i2);
+      }
+      if (full) {
+        if (yg) *reinterpret_cast<float4*>(yg + o) = make_float4(v[0], v[1], v[2], v[3]);
+        if (y2g) *reinterpret_cast<float4*>(y2g + o) = make_float4(w[0], w[1], w[2], w[3]);
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          if (t + i >= a.T_out) continue;
+          if (yg) yg[o + i] = v[i];
+          if (y2g) y2g[o + i] = w[i];
         }
       }
     }
   }
-#ifdef FAC_PROF
-  if (a.dbg && wave == 0 && lane == 0) {
-    unsigned hw;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-    unsigned xcc;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-    unsigned long long* d = a.dbg + (long long)blockIdx.x * 8;
-    d[0] = tp0; d[1] = tp1; d[2] = tp2; d[3] = wall_clock64(); d[4] = hw; d[5] = xcc;
-  }
-#endif
 }
 
 bool conv_bsplit_ok(const ConvArgs& a) {
@@ -393,7 +399,9 @@ template <int KT, int G, int NMW, int NSW>
 static int bsplit_launch(ConvArgs& a, hipStream_t s) {
   constexpr int H = bs_slots(KT, G), TT = 64 * NMW;
   a.XW = TT + (H / G - 1) * a.dil;       // G = 1: the padded zero tap still reads (finite) staged columns
-  const size_t lds = 2 * ((size_t)3 * H * BS_CO * 16 + (size_t)48 * G * a.XW);
+  size_t lds = 2 * ((size_t)3 * H * BS_CO * 16 + (size_t)48 * G * a.XW);
+  const size_t epi = (size_t)BS_CO * (TT + 4) * sizeof(float);      // the accumulator tile of the all-waves epilogue
+  if (lds < epi) lds = epi;
   if (lds > 160 * 1024) {
     set_error("conv1d(bf16 split): tile needs %zu B of LDS (dil=%d)", lds, a.dil);
     return FAC_ERR_ARG;
