@@ -84,6 +84,9 @@ __global__ __launch_bounds__((WM * WN + 4) * 64, (WM * WN == 4 ? FAC_CONV_WPE : 
   constexpr int CO_TILE = 32 * MB * WM;
   constexpr int T_TILE = 32 * NB * WN;
   constexpr int CO4 = CO_TILE / 4;
+  // 8-MFMA-wave tiles keep one workgroup per CU, so nothing overlaps their epilogue: all 12 waves run it, from an
+  // accumulator tile in LDS, 16 bytes per lane along time (see the split kernel, conv1d_bsplit.hip).
+  constexpr bool ALLW = (WM * WN == 8) && !FUSE;
   extern __shared__ __attribute__((aligned(16))) float smem[];
 
   const int tid = threadIdx.x;
@@ -318,9 +321,11 @@ __global__ __launch_bounds__((WM * WN + 4) * 64, (WM * WN == 4 ? FAC_CONV_WPE : 
       d[0] = lt_issue; d[1] = lt_wait; d[2] = lt_store; d[3] = lt_bar;
     }
 #endif
-    return;
+    if constexpr (!ALLW) return;
+    __builtin_amdgcn_s_setprio(0);
   }
 
+  if (wave < NMW) {
   // ========================= MFMA waves
   const int l31 = lane & 31;
   const int kq = lane >> 5;
@@ -429,6 +434,16 @@ __global__ __launch_bounds__((WM * WN + 4) * 64, (WM * WN == 4 ? FAC_CONV_WPE : 
   const unsigned long long t_loop = __builtin_readcyclecounter() - t_start;
 #endif
 
+  if constexpr (ALLW) {
+    constexpr int EP = T_TILE + 4;
+#pragma unroll
+    for (int m = 0; m < MB; ++m)
+#pragma unroll
+      for (int n = 0; n < NB; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          smem[(wm * (MB * 32) + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * kq) * EP + wn * (NB * 32) + n * 32 + l31] = acc[m][n][r];
+  } else {
   // ---- epilogue: C/D layout col = lane&31 (time), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (co)
   float* yg = a.y ? a.y + (long long)b * a.y_bs : nullptr;
   float* y2g = a.y2 ? a.y2 + (long long)b * a.y_bs : nullptr;
@@ -543,6 +558,68 @@ __global__ __launch_bounds__((WM * WN + 4) * 64, (WM * WN == 4 ? FAC_CONV_WPE : 
     d[0] = t_first; d[1] = t_bar; d[2] = t_loop; d[3] = __builtin_readcyclecounter() - t_start;
   }
 #endif
+  }   // !ALLW epilogue
+  }   // MFMA waves
+
+  if constexpr (ALLW) {
+    __syncthreads();
+    constexpr int EP = T_TILE + 4;
+    constexpr int NTH = (NMW + 4) * 64;
+    constexpr int QPR = T_TILE / 4;
+    float* yg = a.y ? a.y + (long long)b * a.y_bs : nullptr;
+    float* y2g = a.y2 ? a.y2 + (long long)b * a.y_bs : nullptr;
+    const float* rg = a.res ? a.res + (long long)b * a.y_bs : nullptr;
+    const bool vec_ok = a.y_tstride == 1 && (a.y_cs & 3) == 0 && (a.y_bs & 3) == 0 &&
+                        (!yg || (reinterpret_cast<unsigned long long>(a.y) & 15) == 0) &&
+                        (!y2g || (reinterpret_cast<unsigned long long>(a.y2) & 15) == 0) &&
+                        (!rg || (reinterpret_cast<unsigned long long>(a.res) & 15) == 0);
+    for (int q = tid; q < CO_TILE * QPR; q += NTH) {
+      const int row = q / QPR, tq = q - row * QPR;
+      const int co = co0 + row, t = t0 + 4 * tq;
+      if (co >= a.C_out || t >= a.T_out) continue;
+      const float4 av = *reinterpret_cast<const float4*>(smem + row * EP + 4 * tq);
+      float v[4] = {av.x, av.y, av.z, av.w};
+      const float bs = a.bias ? a.bias[co] : 0.f;
+      const float al = a.alpha_out ? a.alpha_out[co] : 0.f;
+      const float inv = a.alpha_out ? snake_inv(al) : 0.f;
+      const long long o = (long long)co * a.y_cs + (long long)t * a.y_tstride + y_off;
+      const bool full = vec_ok && t + 3 < a.T_out;
+      float rv[4] = {0.f, 0.f, 0.f, 0.f};
+      if (rg) {
+        if (full) {
+          const float4 r4 = *reinterpret_cast<const float4*>(rg + o);
+          rv[0] = r4.x; rv[1] = r4.y; rv[2] = r4.z; rv[3] = r4.w;
+        } else {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) rv[i] = t + i < a.T_out ? rg[o + (long long)i * a.y_tstride] : 0.f;
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float x = v[i] + bs;
+        if (a.alpha_out) x = snake_apply(x, al, inv);
+        if (a.act != FAC_ACT_NONE) x = apply_act_slow(x, a.act);
+        v[i] = x + rv[i];
+      }
+      float w[4] = {0.f, 0.f, 0.f, 0.f};
+      if (y2g) {
+        const float a2 = a.alpha2[co], i2 = snake_inv(a2);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) w[i] = snake_apply(v[i], a2, i2);
+      }
+      if (full) {
+        if (yg) *reinterpret_cast<float4*>(yg + o) = make_float4(v[0], v[1], v[2], v[3]);
+        if (y2g) *reinterpret_cast<float4*>(y2g + o) = make_float4(w[0], w[1], w[2], w[3]);
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          if (t + i >= a.T_out) continue;
+          if (yg) yg[o + (long long)i * a.y_tstride] = v[i];
+          if (y2g) y2g[o + (long long)i * a.y_tstride] = w[i];
+        }
+      }
+    }
+  }
 }
 
 #ifdef FAC_PROF
@@ -592,7 +669,11 @@ int launch_cfg(ConvArgs& a, hipStream_t s) {
     }
   }
   a.cic = cic;
-  const size_t lds = (size_t)2 * cic * per_ci * sizeof(float);
+  size_t lds = (size_t)2 * cic * per_ci * sizeof(float);
+  if constexpr ((WM * WN == 8) && !FUSE) {   // accumulator tile of the all-waves epilogue
+    const size_t epi = (size_t)CO_TILE * (T_TILE + 4) * sizeof(float);
+    if (lds < epi) lds = epi;
+  }
   if (lds > 160 * 1024) {
     set_error("conv1d: tile needs %zu B of LDS (K=%d stride=%d dil=%d)", lds, a.K, a.stride, a.dil);
     return FAC_ERR_ARG;
