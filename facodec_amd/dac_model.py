@@ -23,7 +23,9 @@ from . import ops
 from .layers import SConv1d, SConvTranspose1d, SLSTM, Snake1d
 
 
-FUSED_RU_CHANNELS = (64, 96)   # channel counts that gain from the single-launch ResidualUnit kernel
+import os as _os
+# channel counts that take the single-launch fp32 ResidualUnit kernel (FAC_FUSED_RU="" / "64" / "64,96": tuning switch)
+FUSED_RU_CHANNELS = tuple(int(c) for c in _os.environ.get("FAC_FUSED_RU", "64").split(",") if c)
 # (C = 128 is instantiated too but measured slower than k7 + wide-tile k1: 2.56 vs 2.38 ms at T = 24000)
 
 
