@@ -41,7 +41,13 @@ constexpr int BS_XU = 3;    // (ci group, 64-column block) staging units per sta
 //   narrow  (C_in <  BS_WIDE_MIN): G = 1, tap PAIRS per MFMA (7 taps + one zero tap), 8 MFMA waves, tile 64 x 512:
 //           few-channel layers have few stages per tile, so a tile twice as long (and two MFMA waves per SIMD)
 //           amortises the per-tile prologue / epilogue that one resident workgroup per CU cannot hide.
-constexpr int BS_WIDE_MIN = 160;
+//   The boundary was 160 channels while the MFMA waves ran the epilogue alone; with the all-waves epilogue the wide shape
+//   wins from 64 channels up (C = 128: 140 -> 161, C = 96: 112 -> 126, C = 64: 110 -> 118 TFLOP/s-eq), so narrow is left for
+//   the 32- and 48-channel layers (MPD).
+#ifndef FAC_BS_WIDE_MIN
+#define FAC_BS_WIDE_MIN 64
+#endif
+constexpr int BS_WIDE_MIN = FAC_BS_WIDE_MIN;
 __host__ __device__ constexpr int bs_group(int C_in) { return C_in >= BS_WIDE_MIN ? 2 : 1; }
 
 __device__ __forceinline__ void split3(float x, __bf16& h, __bf16& m, __bf16& l) {

