@@ -25,9 +25,11 @@ unsigned long long* g_conv_dbg = nullptr;
 #endif
 
 // One or two output channels, plain stride-1 conv with nothing but bias / activation in the epilogue.
+// (it parallelises over (batch, 1024-step tile) only: with fewer than ~128 such tiles -- the period discriminators' 1024 -> 1
+// output conv over one row-concatenated signal -- the MFMA tile is 10x faster despite wasting 31 of its 32 rows)
 static bool narrow_ok(const fac_conv_desc* d) {
   return d->C_out <= 2 && d->stride == 1 && d->n_phase == 1 && d->phase_shift == 0 && d->y_tstride == 1 && !d->res && !d->y2 &&
-         !d->w_batched && d->y && (long long)d->B <= 65535;
+         !d->w_batched && d->y && (long long)d->B <= 65535 && (long long)d->B * ((d->T_out + 1023) / 1024) >= 128;
 }
 
 }  // namespace fac

@@ -313,11 +313,20 @@ __global__ __launch_bounds__(512, 2) void conv1d_wgrad_planes_kernel(WsArgs a) {
     }
 }
 
-__global__ void wgrad_split_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int S, long long n) {
+// dW[i] = sum over the S slices in a FIXED order: eight interleaved chains (slice z goes to chain z % 8, each chain in
+// increasing z), then the chains pairwise -- deterministic like a plain loop, but with eight loads in flight per lane
+// instead of one dependent add per HBM round trip (the plain loop cost 18 ms per training step over 324 launches).
+__global__ __launch_bounds__(256) void wgrad_split_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int S, long long n) {
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-    float acc = part[i];
-    for (int z = 1; z < S; ++z) acc += part[(long long)z * n + i];
-    dw[i] = acc;
+    float c[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const float* p = part + i;
+    int z = 0;
+    for (; z + 8 <= S; z += 8) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) c[j] += p[(long long)(z + j) * n];
+    }
+    for (int j = 0; z + j < S; ++j) c[j] += p[(long long)(z + j) * n];
+    dw[i] = ((c[0] + c[1]) + (c[2] + c[3])) + ((c[4] + c[5]) + (c[6] + c[7]));
   }
 }
 
