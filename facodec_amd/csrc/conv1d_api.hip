@@ -13,7 +13,8 @@ static int select_variant(const fac_conv_desc* d) {
   // k = 1 convs re-use nothing across taps: per staged byte they do 7x less MFMA work than k = 7 and are
   // LDS-DMA-bound on 128-wide time tiles; long sequences take 256-wide tiles with 8 MFMA waves
   // (measured +15..30 % on the k = 1 layers, neutral on k = 7).
-  const bool wide = d->K == 1 && d->n_phase == 1 && d->T_out >= 512;   // (wide tiles measured slower for K = 2)
+  static const bool k1_wide = !(getenv("FAC_K1_WIDE") && getenv("FAC_K1_WIDE")[0] == '0');
+  const bool wide = k1_wide && d->K == 1 && d->n_phase == 1 && d->T_out >= 512;   // (wide tiles measured slower for K = 2)
   // 2 s clips are 160 latent frames: a 160-wide tile wastes nothing where 128 + 32 would waste 37 %
   if (d->T_out > 128 && d->T_out <= 160 && co > 64) return 8;
   if (co % 128 != 0 && co % 96 == 0) return wide ? 6 : 3;

@@ -325,6 +325,10 @@ __global__ __launch_bounds__((WM * WN + 4) * 64, (WM * WN == 4 ? FAC_CONV_WPE : 
     __builtin_amdgcn_s_setprio(0);
   }
 
+#ifdef FAC_PROF
+  unsigned long long pf_first = 0, pf_bar = 0, pf_loop = 0;
+  const unsigned long long pf_start = __builtin_readcyclecounter();
+#endif
   if (wave < NMW) {
   // ========================= MFMA waves
   const int l31 = lane & 31;
@@ -432,6 +436,7 @@ __global__ __launch_bounds__((WM * WN + 4) * 64, (WM * WN == 4 ? FAC_CONV_WPE : 
   }
 #ifdef FAC_PROF
   const unsigned long long t_loop = __builtin_readcyclecounter() - t_start;
+  pf_first = t_first; pf_bar = t_bar; pf_loop = __builtin_readcyclecounter() - pf_start;
 #endif
 
   if constexpr (ALLW) {
@@ -619,6 +624,12 @@ __global__ __launch_bounds__((WM * WN + 4) * 64, (WM * WN == 4 ? FAC_CONV_WPE : 
         }
       }
     }
+#ifdef FAC_PROF
+    if (a.dbg && lane == 0 && wave < 4) {
+      unsigned long long* d = a.dbg + ((long long)blockIdx.x * 4 + wave) * 4;
+      d[0] = pf_first; d[1] = pf_bar; d[2] = pf_loop; d[3] = __builtin_readcyclecounter() - pf_start;
+    }
+#endif
   }
 }
 
