@@ -1,0 +1,61 @@
+"""Code-index mismatch triage (SURVEY.md 7 "hard parts"): codes are arg-max decisions, so two fp32-grade evaluations of the
+same network may legitimately differ where the best and second-best code of a latent are (nearly) tied, and every later
+stage of that residual chain then sees a different residual.  `classify_code_mismatches` separates those cases from real
+errors: per (stream, clip, frame) it looks at the FIRST residual stage that differs and measures, on this run's own
+projected latent, how much farther the expected code is than the chosen one (dac/nn/quantize.py:78-94 distance: squared
+distance between the L2-normalised latent and the L2-normalised code).  A gap below `tie_tol` is a near-tie flip, stages
+after it are its cascade; anything else is a genuine mismatch."""
+import torch
+
+from .quantize import ResidualVectorQuantize
+
+
+class LatentCapture:
+    """Context manager: records the projected latents (B, 8 n, T) every ResidualVectorQuantize under `module` returns."""
+
+    def __init__(self, module):
+        self.rvqs = [(n, m) for n, m in module.named_modules() if isinstance(m, ResidualVectorQuantize)]
+        self.latents = {}
+        self._handles = []
+
+    def __enter__(self):
+        for name, m in self.rvqs:
+            self._handles.append(m.register_forward_hook(lambda mod, args, out, name=name: self.latents.__setitem__(name, out[2].detach())))
+        return self
+
+    def __exit__(self, *exc):
+        for h in self._handles:
+            h.remove()
+        return False
+
+
+def _distances(lat, codebook):
+    """lat (N, 8), codebook (Kc, 8) -> (N, Kc) squared distances between the normalised vectors (fp64 on the host)."""
+    e = torch.nn.functional.normalize(lat.double(), dim=1)
+    c = torch.nn.functional.normalize(codebook.double(), dim=1)
+    return e.pow(2).sum(1, keepdim=True) - 2 * e @ c.t() + c.pow(2).sum(1, keepdim=True).t()
+
+
+def classify_code_mismatches(rvq, latents, got, expected, tie_tol=1e-5):
+    """rvq: the ResidualVectorQuantize that produced `got` (B, n, T) with projected latents (B, 8 n, T); expected: the
+    reference's codes, same shape.  -> dict(mismatches, near_tie, cascade, genuine, worst_gap)."""
+    got, expected = got.cpu().long(), torch.as_tensor(expected).long()
+    assert got.shape == expected.shape, (got.shape, expected.shape)
+    diff = got != expected
+    out = dict(mismatches=int(diff.sum()), near_tie=0, cascade=0, genuine=0, worst_gap=0.0)
+    if not out["mismatches"]:
+        return out
+    lat = latents.cpu()
+    B, n, T = got.shape
+    for b, t in diff.any(1).nonzero().tolist():
+        stages = diff[b, :, t].nonzero().flatten().tolist()
+        i = stages[0]
+        d = _distances(lat[b, 8 * i: 8 * i + 8, t][None], rvq.quantizers[i].codebook.weight.detach().cpu())[0]
+        gap = float(d[expected[b, i, t]] - d[got[b, i, t]])
+        out["worst_gap"] = max(out["worst_gap"], abs(gap))
+        if abs(gap) <= tie_tol:
+            out["near_tie"] += 1
+            out["cascade"] += len(stages) - 1
+        else:
+            out["genuine"] += len(stages)
+    return out
