@@ -720,6 +720,8 @@ int conv_dispatch_96x256(ConvArgs& a, hipStream_t s);
 int conv_dispatch_fused_ru(ConvArgs& a, hipStream_t s);
 int conv_dispatch_128x160(ConvArgs& a, hipStream_t s);
 int conv_dispatch_narrow(ConvArgs& a, hipStream_t s);
+bool conv_cin1_ok(const ConvArgs& a);
+int conv_dispatch_cin1(ConvArgs& a, hipStream_t s);
 bool conv_bsplit_ok(const ConvArgs& a);
 int conv_dispatch_bsplit(ConvArgs& a, hipStream_t s);
 bool conv_skinny_ok(const ConvArgs& a, const void* ws, long long ws_bytes);

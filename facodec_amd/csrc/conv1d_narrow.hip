@@ -2,6 +2,9 @@
 // An MFMA tile would waste 31/32 of its rows, and the layer is HBM-bound anyway (reads 590 MB at B = 32,
 // writes 6 MB): plain VALU kernel, one workgroup per (batch, 1024-step tile), input rows staged through LDS
 // eight channels at a time, four consecutive outputs per thread (a 10-value sliding window per channel).
+// Rows are padded to a multiple of 4 floats so that a thread's window starts 16-byte aligned: for dilation 1 and K <= 9 the
+// window is three ds_read_b128 (lanes 16 B apart: conflict-free); element-wise reads at a 16-byte lane stride are 4-way bank
+// conflicts, which made the 96 -> 1 layer LDS-bound at 1.6 TB/s of input.
 #include "conv1d_mfma.h"
 
 namespace fac {
@@ -14,7 +17,7 @@ __global__ __launch_bounds__(256) void conv1d_narrow_kernel(ConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int K = a.K, dil = a.dil;
   const int halo = (K - 1) * dil;
-  const int XW = NARROW_TT + halo;
+  const int XW = (NARROW_TT + halo + 3) & ~3;
   float* xs = sm;                                   // [CIC][XW]
   float* ws = sm + NARROW_CIC * XW;                 // [CIC][K][CO]
   const int b = blockIdx.y;
@@ -27,39 +30,47 @@ __global__ __launch_bounds__(256) void conv1d_narrow_kernel(ConvArgs a) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[c][j] = 0.f;
 
-  // The (row, column) -> input index map of this thread's staging slots is the same for every channel
-  // chunk: resolve padding / reflection once, then each chunk is NSLOT independent loads issued together.
-  constexpr int NSLOT = (NARROW_CIC * (NARROW_TT + 64) + 255) / 256;   // halo <= 64 columns
-  int s_row[NSLOT], s_idx[NSLOT];
+  // Staging slots: slot (r, s) of this thread is column s * 256 + tid of channel row r -- the column -> input index map
+  // (padding / reflection) is the same for every row and chunk and is resolved once.  The loads of chunk c + 1 are issued
+  // before chunk c is multiplied (register double buffer), so HBM latency hides behind the FMAs of the same workgroup.
+  constexpr int SPR = (NARROW_TT + 64 + 255) / 256;        // slots per row (halo <= 64 columns)
+  int s_idx[SPR];
 #pragma unroll
-  for (int j = 0; j < NSLOT; ++j) {
-    const int i = tid + 256 * j;
-    const int r = i / XW, c = i - r * XW;
+  for (int sl = 0; sl < SPR; ++sl) {
+    const int c = sl * 256 + tid;
     int idx = -1;
-    if (i < NARROW_CIC * XW) {
+    if (c < XW) {
       const int tin = t0 - a.pad_left + c;
       if (a.pad_mode == FAC_PAD_REFLECT) idx = reflect_index(tin, a.T_in, a.T_ext);
       else idx = (tin >= 0 && tin < a.T_in) ? tin : -1;
     }
-    s_row[j] = i < NARROW_CIC * XW ? r : -1;
-    s_idx[j] = idx;
+    s_idx[sl] = idx;
   }
+  float v[NARROW_CIC][SPR];
+  auto load_chunk = [&](int ci0) {
+#pragma unroll
+    for (int r = 0; r < NARROW_CIC; ++r) {
+      const int ci = ci0 + r;                      // uniform
+      const float* xrow = xg + (long long)ci * a.x_cs;
+#pragma unroll
+      for (int sl = 0; sl < SPR; ++sl) v[r][sl] = (ci < a.C_in && s_idx[sl] >= 0) ? xrow[s_idx[sl]] : 0.f;
+    }
+  };
+  load_chunk(0);
 
   for (int ci0 = 0; ci0 < a.C_in; ci0 += NARROW_CIC) {
     __syncthreads();
-    float v[NSLOT];
 #pragma unroll
-    for (int j = 0; j < NSLOT; ++j) {
-      const int ci = ci0 + s_row[j];
-      v[j] = (s_row[j] >= 0 && s_idx[j] >= 0 && ci < a.C_in) ? xg[(long long)ci * a.x_cs + s_idx[j]] : 0.f;
-    }
+    for (int r = 0; r < NARROW_CIC; ++r) {
+      const int ci = ci0 + r;
+      const bool sn = a.alpha_in != nullptr && ci < a.C_in;
+      const float al = sn ? a.alpha_in[ci] : 0.f;
+      const float inv = sn ? snake_inv(al) : 0.f;
 #pragma unroll
-    for (int j = 0; j < NSLOT; ++j) {
-      if (s_row[j] < 0) continue;
-      float x = v[j];
-      const int ci = ci0 + s_row[j];
-      if (a.alpha_in && ci < a.C_in) x = snake_apply(x, a.alpha_in[ci], snake_inv(a.alpha_in[ci]));
-      xs[tid + 256 * j] = x;
+      for (int sl = 0; sl < SPR; ++sl) {
+        const int c = sl * 256 + tid;
+        if (c < XW) xs[r * XW + c] = sn ? snake_apply(v[r][sl], al, inv) : v[r][sl];
+      }
     }
     for (int i = tid; i < NARROW_CIC * K * CO; i += 256) {
       const int r = i / (K * CO), rem = i - r * (K * CO);
@@ -68,6 +79,27 @@ __global__ __launch_bounds__(256) void conv1d_narrow_kernel(ConvArgs a) {
       ws[i] = ci < a.C_in ? a.w[((long long)ci * K + k) * a.C_out_pad + c] : 0.f;
     }
     __syncthreads();
+    if (ci0 + NARROW_CIC < a.C_in) load_chunk(ci0 + NARROW_CIC);
+    if (dil == 1 && K <= 9) {
+#pragma unroll 2
+      for (int r = 0; r < NARROW_CIC; ++r) {
+        const float4* xr = reinterpret_cast<const float4*>(xs + r * XW + tid * 4);
+        const float* wr = ws + r * K * CO;
+        const float4 q0 = xr[0], q1 = xr[1], q2 = xr[2];
+        const float win[12] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w};
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+          if (k >= K) break;
+#pragma unroll
+          for (int c = 0; c < CO; ++c) {
+            const float w = wr[k * CO + c];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[c][j] = fmaf(w, win[k + j], acc[c][j]);
+          }
+        }
+      }
+      continue;
+    }
 #pragma unroll 2
     for (int r = 0; r < NARROW_CIC; ++r) {
       const float* xr = xs + r * XW + tid * 4;
@@ -101,8 +133,90 @@ __global__ __launch_bounds__(256) void conv1d_narrow_kernel(ConvArgs a) {
   }
 }
 
+// One input channel, many output channels (the encoder's first conv, 1 -> 64, k = 7: dac/model/dac.py:84): 6 MB in, 2 x 393 MB
+// out at B = 32 -- a store stream.  One workgroup per (batch, 1024-step tile); the input window lives in registers (three
+// aligned ds_read_b128 per thread), the taps of one output channel come through the scalar cache (uniform addresses), and each
+// thread writes 16 bytes of y and of the pre-activated copy y2 per channel (consecutive threads: contiguous 4 KB rows).
+constexpr int CIN1_KMAX = 9;
+
+__global__ __launch_bounds__(256) void conv1d_cin1_kernel(ConvArgs a) {
+  __shared__ __attribute__((aligned(16))) float xs[NARROW_TT + 16];
+  const int b = blockIdx.y;
+  const int t0 = blockIdx.x * NARROW_TT;
+  const int tid = threadIdx.x;
+  const int K = a.K;
+  const float* xg = a.x + (long long)b * a.x_bs;
+  for (int i = tid; i < NARROW_TT + 16; i += 256) {
+    const int tin = t0 - a.pad_left + i;
+    int idx;
+    if (a.pad_mode == FAC_PAD_REFLECT) idx = reflect_index(tin, a.T_in, a.T_ext);
+    else idx = (tin >= 0 && tin < a.T_in) ? tin : -1;
+    xs[i] = (i < NARROW_TT + K - 1 && idx >= 0) ? xg[idx] : 0.f;
+  }
+  __syncthreads();
+  const int t = t0 + 4 * tid;
+  if (t >= a.T_out) return;
+  const float4* xr = reinterpret_cast<const float4*>(xs + 4 * tid);
+  const float4 q0 = xr[0], q1 = xr[1], q2 = xr[2];
+  const float win[12] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w};
+  float* yg = a.y ? a.y + (long long)b * a.y_bs : nullptr;
+  float* y2g = a.y2 ? a.y2 + (long long)b * a.y_bs : nullptr;
+  const bool full = t + 3 < a.T_out && (a.y_cs & 3) == 0 && (a.y_bs & 3) == 0 &&
+                    (!yg || (reinterpret_cast<unsigned long long>(a.y) & 15) == 0) &&
+                    (!y2g || (reinterpret_cast<unsigned long long>(a.y2) & 15) == 0);
+  for (int co = 0; co < a.C_out; ++co) {
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < CIN1_KMAX; ++k) {
+      if (k >= K) break;
+      const float w = a.w[(long long)k * a.C_out_pad + co];       // packed (cin_pad, K, C_out_pad), channel 0
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = fmaf(w, win[k + j], v[j]);
+    }
+    const float bs = a.bias ? a.bias[co] : 0.f;
+    const float al = a.alpha_out ? a.alpha_out[co] : 0.f;
+    const float inv = a.alpha_out ? snake_inv(al) : 0.f;
+    float w2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float x = v[j] + bs;
+      if (a.alpha_out) x = snake_apply(x, al, inv);
+      if (a.act != FAC_ACT_NONE) x = apply_act_slow(x, a.act);
+      v[j] = x;
+    }
+    if (y2g) {
+      const float a2 = a.alpha2[co], i2 = snake_inv(a2);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) w2[j] = snake_apply(v[j], a2, i2);
+    }
+    const long long o = (long long)co * a.y_cs + t;
+    if (full) {
+      if (yg) *reinterpret_cast<float4*>(yg + o) = make_float4(v[0], v[1], v[2], v[3]);
+      if (y2g) *reinterpret_cast<float4*>(y2g + o) = make_float4(w2[0], w2[1], w2[2], w2[3]);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (t + j >= a.T_out) continue;
+        if (yg) yg[o + j] = v[j];
+        if (y2g) y2g[o + j] = w2[j];
+      }
+    }
+  }
+}
+
+bool conv_cin1_ok(const ConvArgs& a) {
+  return a.C_in == 1 && a.C_out > 2 && a.K <= CIN1_KMAX && a.stride == 1 && a.dil == 1 && a.n_phase == 1 && a.phase_shift == 0 &&
+         a.y_tstride == 1 && !a.alpha_in && !a.res && !a.w1 && !a.w_batched && a.B <= 65535 && !conv_two_level(a);
+}
+
+int conv_dispatch_cin1(ConvArgs& a, hipStream_t s) {
+  dim3 grid((a.T_out + NARROW_TT - 1) / NARROW_TT, a.B);
+  hipLaunchKernelGGL(conv1d_cin1_kernel, grid, dim3(256), 0, s, a);
+  return check_launch("conv1d_cin1");
+}
+
 int conv_dispatch_narrow(ConvArgs& a, hipStream_t s) {
-  const int XW = NARROW_TT + (a.K - 1) * a.dil;
+  const int XW = (NARROW_TT + (a.K - 1) * a.dil + 3) & ~3;
   const size_t lds = ((size_t)NARROW_CIC * XW + (size_t)NARROW_CIC * a.K * 2) * sizeof(float);
   if (lds > 64 * 1024 || (a.K - 1) * a.dil > 64) {
     set_error("conv1d(narrow): receptive field too wide (K=%d dil=%d)", a.K, a.dil);

@@ -66,6 +66,13 @@ CONV_CASES = [
     (3, 512, 1024, 30, 12, 6, 1, False, False, False, 1, "zero"),
     (1, 384, 200, 61, 7, 1, 9, False, True, True, 0, "zero"),         # C_out not a multiple of 128 / 32
     (8, 1024, 2048, 1, 1, 1, 1, False, False, False, 0, "zero"),      # per-clip Linear
+    # one input channel (store-stream kernel) / one output channel (VALU kernel): ragged lengths, short taps, zero padding
+    (3, 1, 64, 2051, 7, 1, 1, False, True, False, 0, "reflect"),
+    (2, 1, 45, 1030, 3, 1, 1, False, False, False, 1, "zero"),
+    (1, 1, 32, 5, 7, 1, 1, False, False, False, 0, "reflect"),
+    (2, 50, 1, 1027, 3, 1, 1, False, False, False, 0, "zero"),
+    (2, 24, 2, 2049, 9, 1, 1, True, False, False, 0, "reflect"),
+    (140, 16, 1, 1500, 5, 1, 1, False, False, False, 0, "zero"),
 ]
 
 
@@ -125,6 +132,22 @@ def test_conv_second_output_is_snake_of_first(O, ops, cuda):
     assert rel(y, y_ref) < OP_TOL and rel(y2, O.snake(y_ref, a2.view(1, -1, 1))) < OP_TOL
     none_y, y2b = ops.conv1d(x.to(cuda), wp, 96, 7, bias=b.to(cuda), dilation=3, res=r.to(cuda), alpha_y2=a2.to(cuda),
                              want_y=False)
+    assert none_y is None and torch.equal(y2b, y2)
+
+
+def test_first_conv_two_outputs(O, ops, cuda):
+    """Encoder input conv (1 -> 64, k = 7: dac/model/dac.py:84) with the pre-activated second output, ragged length (scalar
+    tail stores) and the y2-only form."""
+    g = _g(33)
+    x = torch.randn(3, 1, 4098, generator=g)
+    w = torch.randn(64, 1, 7, generator=g) / 2.6
+    b = torch.randn(64, generator=g) * 0.1
+    a2 = 1 + 0.2 * torch.rand(64, generator=g)
+    y_ref = O.sconv1d(x, w, b)
+    wp = ops.pack_conv_weight(w.to(cuda))
+    y, y2 = ops.conv1d(x.to(cuda), wp, 64, 7, bias=b.to(cuda), alpha_y2=a2.to(cuda))
+    assert rel(y, y_ref) < OP_TOL and rel(y2, O.snake(y_ref, a2.view(1, -1, 1))) < OP_TOL
+    none_y, y2b = ops.conv1d(x.to(cuda), wp, 64, 7, bias=b.to(cuda), alpha_y2=a2.to(cuda), want_y=False)
     assert none_y is None and torch.equal(y2b, y2)
 
 
