@@ -82,6 +82,7 @@ extern "C" int fac_conv1d_fwd(const fac_conv_desc* d, fac_stream_t stream) {
   const bool two_level = conv_two_level(a);
   if (!two_level && conv_skinny_ok(a, d->ws, d->ws_bytes)) return conv_dispatch_skinny(a, d->ws, d->ws_bytes, s);
   if (!two_level && narrow_ok(d)) return conv_dispatch_narrow(a, s);
+  if (conv_thin_ok(a, d->ws, d->ws_bytes)) return conv_dispatch_thin(a, d->ws, s);   // C_out <= 2 without enough tiles for narrow
   if (conv_cin1_ok(a)) return conv_dispatch_cin1(a, s);
   if (d->w_split) {
     if (conv_bsplit_ok(a)) {
@@ -129,9 +130,19 @@ extern "C" int fac_conv1d_variant(const fac_conv_desc* d, char* name, int name_l
   }
   {
     ConvArgs a{};
+    a.C_in = d->C_in; a.C_out = d->C_out; a.K = d->K; a.stride = d->stride; a.n_phase = d->n_phase; a.phase_shift = d->phase_shift;
+    a.y_tstride = d->y_tstride; a.res = d->res; a.y2 = d->y2; a.w1 = d->w_k1; a.w_batched = d->w_batched; a.y = d->y; a.B = d->B;
+    a.T_out = d->T_out; a.K1 = d->K1 > 0 ? d->K1 : d->K;
+    if (conv_thin_ok(a, d->ws, d->ws_bytes)) {
+      if (name && name_len > 0) snprintf(name, name_len, "conv1d_thin_kernel (VALU, C_out<=2, split channels)");
+      return 13;
+    }
+  }
+  {
+    ConvArgs a{};
     a.C_in = d->C_in; a.C_out = d->C_out; a.K = d->K; a.stride = d->stride; a.dil = d->dilation; a.n_phase = d->n_phase;
     a.phase_shift = d->phase_shift; a.y_tstride = d->y_tstride; a.alpha_in = d->alpha_in; a.res = d->res; a.w1 = d->w_k1;
-    a.w_batched = d->w_batched; a.B = d->B; a.K1 = d->K1 > 0 ? d->K1 : d->K;
+    a.w_batched = d->w_batched; a.B = d->B; a.K1 = d->K1 > 0 ? d->K1 : d->K; a.T_out = d->T_out;
     if (conv_cin1_ok(a)) {
       if (name && name_len > 0) snprintf(name, name_len, "conv1d_cin1_kernel (VALU, C_in=1, store stream)");
       return 12;

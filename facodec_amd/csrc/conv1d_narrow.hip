@@ -206,13 +206,104 @@ __global__ __launch_bounds__(256) void conv1d_cin1_kernel(ConvArgs a) {
 
 bool conv_cin1_ok(const ConvArgs& a) {
   return a.C_in == 1 && a.C_out > 2 && a.K <= CIN1_KMAX && a.stride == 1 && a.dil == 1 && a.n_phase == 1 && a.phase_shift == 0 &&
-         a.y_tstride == 1 && !a.alpha_in && !a.res && !a.w1 && !a.w_batched && a.B <= 65535 && !conv_two_level(a);
+         a.y_tstride == 1 && !a.alpha_in && !a.res && !a.w1 && !a.w_batched && a.B <= 65535 && !conv_two_level(a) &&
+         // one workgroup per (batch, 1024-step tile) walks every output channel: needs a chip's worth of tiles (the period
+         // discriminators' 1 -> 1024 data gradient over one row-concatenated signal has ~20 and belongs on the MFMA tile)
+         (long long)a.B * ((a.T_out + NARROW_TT - 1) / NARROW_TT) >= 256 && a.C_out <= 256;
 }
 
 int conv_dispatch_cin1(ConvArgs& a, hipStream_t s) {
   dim3 grid((a.T_out + NARROW_TT - 1) / NARROW_TT, a.B);
   hipLaunchKernelGGL(conv1d_cin1_kernel, grid, dim3(256), 0, s, a);
   return check_launch("conv1d_cin1");
+}
+
+// One or two output channels over FEW (batch, 1024-step) tiles but many input channels (the period discriminators' 1024 -> 1
+// output conv over one row-concatenated signal, dac/model/discriminator.py:35): 40 MB of input for 60 MFLOP, and only ~10 tiles
+// to spread over 256 CUs -- so the reduction over input channels is split as well: workgroup (t tile, channel chunk, batch)
+// writes the partial sums of its 64 channels, a second pass adds the chunks in fixed order (deterministic) and applies bias /
+// Snake / activation.  (The 32 x 256 MFMA tile did this layer in 250 us -- 39 workgroups each walking all 1024 channels.)
+constexpr int THIN_TT = 256;
+constexpr int THIN_CC = 64;
+constexpr int THIN_KMAX = 9;
+
+template <int CO>
+__global__ __launch_bounds__(THIN_TT) void conv1d_thin_part_kernel(ConvArgs a, float* __restrict__ part) {
+  const int t = blockIdx.x * THIN_TT + threadIdx.x;
+  const int z = blockIdx.y, b = blockIdx.z;
+  if (t >= a.T_out) return;
+  const float* xg = a.x + (long long)b * a.x_bs;
+  int idx[THIN_KMAX];
+#pragma unroll
+  for (int k = 0; k < THIN_KMAX; ++k) {
+    const int tin = t - a.pad_left + k * a.dil;
+    int i = -1;
+    if (k < a.K) {
+      if (a.pad_mode == FAC_PAD_REFLECT) i = reflect_index(tin, a.T_in, a.T_ext);
+      else i = (tin >= 0 && tin < a.T_in) ? tin : -1;
+    }
+    idx[k] = i;
+  }
+  float acc[CO];
+#pragma unroll
+  for (int c = 0; c < CO; ++c) acc[c] = 0.f;
+  const int c_end = min(a.C_in, (z + 1) * THIN_CC);
+  for (int ci = z * THIN_CC; ci < c_end; ++ci) {
+    const float* xrow = xg + (long long)ci * a.x_cs;
+    const float al = a.alpha_in ? a.alpha_in[ci] : 0.f;
+    const float inv = a.alpha_in ? snake_inv(al) : 0.f;
+#pragma unroll
+    for (int k = 0; k < THIN_KMAX; ++k) {
+      if (k >= a.K) break;
+      float x = idx[k] >= 0 ? xrow[idx[k]] : 0.f;
+      if (a.alpha_in) x = snake_apply(x, al, inv);
+#pragma unroll
+      for (int c = 0; c < CO; ++c) acc[c] = fmaf(a.w[((long long)ci * a.K + k) * a.C_out_pad + c], x, acc[c]);
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < CO; ++c)
+    if (c < a.C_out) part[(((long long)z * a.B + b) * CO + c) * a.T_out + t] = acc[c];
+}
+
+template <int CO>
+__global__ __launch_bounds__(256) void conv1d_thin_sum_kernel(ConvArgs a, const float* __restrict__ part, int n_chunks) {
+  const long long n = (long long)a.B * a.C_out * a.T_out;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const int t = (int)(i % a.T_out);
+    const int c = (int)((i / a.T_out) % a.C_out);
+    const int b = (int)(i / ((long long)a.T_out * a.C_out));
+    float v = 0.f;
+    for (int z = 0; z < n_chunks; ++z) v += part[(((long long)z * a.B + b) * CO + c) * a.T_out + t];
+    v += a.bias ? a.bias[c] : 0.f;
+    if (a.alpha_out) v = snake_apply(v, a.alpha_out[c], snake_inv(a.alpha_out[c]));
+    if (a.act != FAC_ACT_NONE) v = apply_act_slow(v, a.act);
+    a.y[(long long)b * a.y_bs + (long long)c * a.y_cs + t] = v;
+  }
+}
+
+bool conv_thin_ok(const ConvArgs& a, const void* ws, long long ws_bytes) {
+  if (!(a.C_out <= 2 && a.C_in >= 2 * THIN_CC && a.K <= THIN_KMAX && a.stride == 1 && a.n_phase == 1 && a.phase_shift == 0 &&
+        a.y_tstride == 1 && !a.res && !a.y2 && !a.w1 && !a.w_batched && a.y && ws && a.B <= 65535 && !conv_two_level(a)))
+    return false;
+  const long long chunks = (a.C_in + THIN_CC - 1) / THIN_CC;
+  return chunks <= 65535 && ws_bytes >= chunks * a.B * 2 * a.T_out * (long long)sizeof(float);
+}
+
+int conv_dispatch_thin(ConvArgs& a, void* ws, hipStream_t s) {
+  const int chunks = (a.C_in + THIN_CC - 1) / THIN_CC;
+  float* part = reinterpret_cast<float*>(ws);
+  dim3 grid((a.T_out + THIN_TT - 1) / THIN_TT, chunks, a.B);
+  const long long n = (long long)a.B * a.C_out * a.T_out;
+  const int rb = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+  if (a.C_out == 1) {
+    hipLaunchKernelGGL(conv1d_thin_part_kernel<1>, grid, dim3(THIN_TT), 0, s, a, part);
+    hipLaunchKernelGGL(conv1d_thin_sum_kernel<1>, dim3(rb), dim3(256), 0, s, a, part, chunks);
+  } else {
+    hipLaunchKernelGGL(conv1d_thin_part_kernel<2>, grid, dim3(THIN_TT), 0, s, a, part);
+    hipLaunchKernelGGL(conv1d_thin_sum_kernel<2>, dim3(rb), dim3(256), 0, s, a, part, chunks);
+  }
+  return check_launch("conv1d_thin");
 }
 
 int conv_dispatch_narrow(ConvArgs& a, hipStream_t s) {

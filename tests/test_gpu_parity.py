@@ -73,6 +73,11 @@ CONV_CASES = [
     (2, 50, 1, 1027, 3, 1, 1, False, False, False, 0, "zero"),
     (2, 24, 2, 2049, 9, 1, 1, True, False, False, 0, "reflect"),
     (140, 16, 1, 1500, 5, 1, 1, False, False, False, 0, "zero"),
+    (2, 16, 24, 700, 9, 1, 2, True, False, False, 0, "reflect"),      # plain k = 9 / 27 on the run-time tap loop
+    (1, 6, 32, 900, 27, 1, 1, False, False, False, 0, "zero"),
+    # one / two output channels, too few tiles for the VALU kernel: channel-split partial sums + fixed-order sum
+    (1, 1024, 1, 9001, 3, 1, 1, False, False, False, 0, "zero"),
+    (2, 300, 2, 1500, 5, 1, 2, True, True, False, 1, "reflect"),
 ]
 
 
