@@ -84,6 +84,8 @@ extern "C" int fac_conv1d_fwd(const fac_conv_desc* d, fac_stream_t stream) {
   if (!two_level && narrow_ok(d)) return conv_dispatch_narrow(a, s);
   if (conv_thin_ok(a, d->ws, d->ws_bytes)) return conv_dispatch_thin(a, d->ws, s);   // C_out <= 2 without enough tiles for narrow
   if (conv_cin1_ok(a)) return conv_dispatch_cin1(a, s);
+  static const bool pw_on = !(getenv("FAC_PW") && getenv("FAC_PW")[0] == '0');
+  if (pw_on && conv_pw_ok(a)) return conv_dispatch_pw(a, s);
   if (d->w_split) {
     if (conv_bsplit_ok(a)) {
       a.w = reinterpret_cast<const float*>(d->w_split);
@@ -146,6 +148,12 @@ extern "C" int fac_conv1d_variant(const fac_conv_desc* d, char* name, int name_l
     if (conv_cin1_ok(a)) {
       if (name && name_len > 0) snprintf(name, name_len, "conv1d_cin1_kernel (VALU, C_in=1, store stream)");
       return 12;
+    }
+    a.K = d->K; a.pad_left = d->pad_left; a.T_in = d->T_in; a.C_out_pad = d->C_out_pad; a.w = d->w;
+    static const bool pw_on = !(getenv("FAC_PW") && getenv("FAC_PW")[0] == '0');
+    if (pw_on && conv_pw_ok(a)) {
+      if (name && name_len > 0) snprintf(name, name_len, "conv1d_pw_kernel (k=1 streaming, W in LDS)");
+      return 14;
     }
   }
   if (d->w_split) {

@@ -721,6 +721,8 @@ int conv_dispatch_fused_ru(ConvArgs& a, hipStream_t s);
 int conv_dispatch_128x160(ConvArgs& a, hipStream_t s);
 int conv_dispatch_narrow(ConvArgs& a, hipStream_t s);
 bool conv_cin1_ok(const ConvArgs& a);
+bool conv_pw_ok(const ConvArgs& a);
+int conv_dispatch_pw(ConvArgs& a, hipStream_t s);
 bool conv_thin_ok(const ConvArgs& a, const void* ws, long long ws_bytes);
 int conv_dispatch_thin(ConvArgs& a, void* ws, hipStream_t s);
 int conv_dispatch_cin1(ConvArgs& a, hipStream_t s);

@@ -53,7 +53,43 @@ __global__ void probe(const float4* __restrict__ src, float* out, long long per_
   out[blockIdx.x * 1024 + tid] = acc.x + acc.y;
 }
 
+// Mixed traffic: out1 = a + b, out2 = a * b (two read streams, two write streams, float4 per lane, grid-stride) -- what an
+// ideal elementwise pass over the 1x1 conv's four tensors (input, residual, y, y2) would reach.
+__global__ void rw_probe(const float4* __restrict__ a, const float4* __restrict__ b, float4* __restrict__ o1, float4* __restrict__ o2,
+                         long long n, int nread, int nwrite) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    float4 x = a[i];
+    float4 y = nread > 1 ? b[i] : x;
+    float4 s = make_float4(x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w);
+    if (nwrite > 0) o1[i] = s;
+    if (nwrite > 1) o2[i] = make_float4(x.x * y.x, x.y * y.y, x.z * y.z, x.w * y.w);
+    if (nwrite == 0 && s.x == 123.456f) o1[i] = s;
+  }
+}
+
 int main() {
+  {
+    const long long n = (590ll << 20) / 16;      // 590 MB per stream, the C = 192, T = 24 000, B = 32 tensors
+    float4 *a, *b, *o1, *o2;
+    CK(hipMalloc(&a, n * 16)); CK(hipMalloc(&b, n * 16)); CK(hipMalloc(&o1, n * 16)); CK(hipMalloc(&o2, n * 16));
+    CK(hipMemset(a, 0, n * 16)); CK(hipMemset(b, 0, n * 16));
+    for (int cfg = 0; cfg < 5; ++cfg) {
+      const int nr = cfg == 0 ? 1 : cfg == 1 ? 2 : cfg == 2 ? 1 : cfg == 3 ? 2 : 2;
+      const int nw = cfg == 0 ? 0 : cfg == 1 ? 0 : cfg == 2 ? 1 : cfg == 3 ? 1 : 2;
+      hipEvent_t e0, e1;
+      CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+      for (int rep = 0; rep < 3; ++rep) {
+        CK(hipEventRecord(e0));
+        hipLaunchKernelGGL(rw_probe, dim3(256 * 16), dim3(256), 0, 0, a, b, o1, o2, n, nr, nw);
+        CK(hipEventRecord(e1));
+        CK(hipEventSynchronize(e1));
+      }
+      float ms;
+      CK(hipEventElapsedTime(&ms, e0, e1));
+      printf("elementwise %d read + %d write streams of 590 MB: %7.3f ms  %5.2f TB/s\n", nr, nw, ms, (double)(nr + nw) * n * 16 / ms / 1e9);
+    }
+    CK(hipFree(a)); CK(hipFree(b)); CK(hipFree(o1)); CK(hipFree(o2));
+  }
   const long long big = 4ll << 30;
   float4* src;
   float* out;
