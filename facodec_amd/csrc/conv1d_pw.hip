@@ -29,22 +29,34 @@ constexpr int PW_D = 16;           // B-fragment ring depth (K steps in flight; 
 // MBW: accumulator blocks per wave; NSPLIT: waves sharing a column block (C_out = 32 * MBW * NSPLIT)
 template <int MBW, int NSPLIT>
 __global__ __launch_bounds__(PW_WAVES * 64, 4) void conv1d_pw_kernel(ConvArgs a, int nblk, int n_items) {
-  constexpr int CO = 32 * MBW * NSPLIT;
+  constexpr int CO = 32 * MBW * NSPLIT;                       // output channels of this workgroup's weight slice
   extern __shared__ __attribute__((aligned(16))) float Ws[];   // [C_in][CO] weights, then [5][CO]: bias, alpha_out, 1/alpha_out, alpha_y2, 1/alpha_y2
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, kq = lane >> 5;
+  // Layers wider than the LDS holds (C = 256, 384) are cut into C_out slices of CO channels, one slice per workgroup.  The
+  // workgroups of one slice group are 8 apart in launch order, i.e. on the same XCD (blocks are dealt round-robin over the
+  // 8 XCDs), and walk the same column blocks: the input rows they all read come from that XCD's L2 after the first.
+  const int n_slices = a.C_out / CO;
+  const int slice = (blockIdx.x >> 3) % n_slices;
+  const int wg = (blockIdx.x & 7) + 8 * (blockIdx.x / (8 * n_slices));     // index among the workgroups of this slice
+  const int n_wg = gridDim.x / n_slices;
+  const int co_base = slice * CO;
   {
-    const int n4 = a.C_in * CO / 4;
-    const float4* src = reinterpret_cast<const float4*>(a.w);
-    for (int i = tid; i < n4; i += PW_WAVES * 64) reinterpret_cast<float4*>(Ws)[i] = src[i];
+    constexpr int CO4 = CO / 4;
+    const int n4 = a.C_in * CO4;
+    for (int i = tid; i < n4; i += PW_WAVES * 64) {
+      const int ci = i / CO4, c4 = i - ci * CO4;
+      reinterpret_cast<float4*>(Ws)[i] = *reinterpret_cast<const float4*>(a.w + (long long)ci * a.C_out_pad + co_base + 4 * c4);
+    }
     float* prm = Ws + a.C_in * CO;
     for (int i = tid; i < CO; i += PW_WAVES * 64) {
-      prm[i] = a.bias ? a.bias[i] : 0.f;
-      prm[CO + i] = a.alpha_out ? a.alpha_out[i] : 0.f;
-      prm[2 * CO + i] = a.alpha_out ? snake_inv(a.alpha_out[i]) : 0.f;
-      prm[3 * CO + i] = a.y2 ? a.alpha2[i] : 0.f;
-      prm[4 * CO + i] = a.y2 ? snake_inv(a.alpha2[i]) : 0.f;
+      const int co = co_base + i;
+      prm[i] = a.bias ? a.bias[co] : 0.f;
+      prm[CO + i] = a.alpha_out ? a.alpha_out[co] : 0.f;
+      prm[2 * CO + i] = a.alpha_out ? snake_inv(a.alpha_out[co]) : 0.f;
+      prm[3 * CO + i] = a.y2 ? a.alpha2[co] : 0.f;
+      prm[4 * CO + i] = a.y2 ? snake_inv(a.alpha2[co]) : 0.f;
     }
   }
   __syncthreads();
@@ -55,18 +67,18 @@ __global__ __launch_bounds__(PW_WAVES * 64, 4) void conv1d_pw_kernel(ConvArgs a,
   const int S = a.C_in >> 1;                                   // K steps of the 32x32x2 MFMA
   const long long xs2 = 2 * a.x_cs;
   const float* Wl = Ws + kq * CO + co0 + l31;                  // A fragment of step s, block m: Wl[2 s CO + 32 m]
-  const int stride_items = gridDim.x * (PW_WAVES / NSPLIT);
+  const int stride_items = n_wg * (PW_WAVES / NSPLIT);
 
   auto item_ptr = [&](int it, long long& yoff, bool& ok) -> const float* {
     const int b = it / nblk;
     const int t = (it - b * nblk) * 32 + l31;
     ok = t < a.T_out;
     const int tc = ok ? t : a.T_out - 1;                       // loads are unconditional (clamped), only stores are predicated
-    yoff = (long long)b * a.y_bs + (long long)(co0 + 4 * kq) * a.y_cs + tc;
+    yoff = (long long)b * a.y_bs + (long long)(co_base + co0 + 4 * kq) * a.y_cs + tc;
     return a.x + (long long)b * a.x_bs + (long long)kq * a.x_cs + tc;
   };
 
-  int item = blockIdx.x * (PW_WAVES / NSPLIT) + (wave / NSPLIT);
+  int item = wg * (PW_WAVES / NSPLIT) + (wave / NSPLIT);
   if (item >= n_items) return;
   long long yoff;
   bool ok;
@@ -147,15 +159,29 @@ __global__ __launch_bounds__(PW_WAVES * 64, 4) void conv1d_pw_kernel(ConvArgs a,
   }
 }
 
+// C_out -> (channels per weight slice, slices): the slice must fit the LDS next to nothing else, and a wave needs >= 2
+// MFMAs per input row it loads
+static int pw_slice_channels(int C_in, int C_out) {
+  if (C_in != C_out) return (C_out == 96 || C_out == 128 || C_out == 192) ? C_out : 0;
+  switch (C_out) {
+    case 96: case 128: case 192: return C_out;
+    case 256: return 128;
+    case 384: return 96;
+    default: return 0;
+  }
+}
+
 bool conv_pw_ok(const ConvArgs& a) {
   if (!(a.K == 1 && a.stride == 1 && a.n_phase == 1 && a.phase_shift == 0 && a.y_tstride == 1 && a.pad_left == 0 && !a.alpha_in &&
         !a.w1 && !a.w_batched && !conv_two_level(a) && a.T_in >= a.T_out))
     return false;
-  if (!(a.C_out == 96 || a.C_out == 128 || a.C_out == 192) || a.C_out_pad != a.C_out) return false;
+  const int co = pw_slice_channels(a.C_in, a.C_out);
+  if (!co || a.C_out_pad != a.C_out) return false;
   if (a.C_in % (2 * PW_D) != 0 || a.C_in < 2 * PW_D) return false;
-  if (((size_t)a.C_in * a.C_out + 5 * a.C_out) * sizeof(float) > 160 * 1024) return false;
-  // a chip's worth of column blocks (16 waves x 256 CUs), each wave at least a few blocks long
-  return (long long)a.B * ((a.T_out + 31) / 32) >= 2 * PW_WAVES * 256 && (reinterpret_cast<unsigned long long>(a.w) & 15) == 0;
+  if (((size_t)a.C_in * co + 5 * co) * sizeof(float) > 160 * 1024) return false;
+  // a chip's worth of column blocks per slice group, each wave at least a few blocks long
+  const long long items = (long long)a.B * ((a.T_out + 31) / 32);
+  return items * (a.C_out / co) >= 2 * PW_WAVES * 256 && (reinterpret_cast<unsigned long long>(a.w) & 15) == 0;
 }
 
 template <int MBW, int NSPLIT>
@@ -182,17 +208,21 @@ static int pw_launch(ConvArgs& a, hipStream_t s) {
     if (n_cu <= 0) n_cu = 256;
   }
   constexpr int per_wg = PW_WAVES / NSPLIT;             // column blocks a workgroup works on at a time
-  long long grid = n_cu;                                // one persistent workgroup per CU
-  if (grid * per_wg > n_items) grid = (n_items + per_wg - 1) / per_wg;
-  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(PW_WAVES * 64), lds, s, a, nblk, (int)n_items);
+  const int n_slices = a.C_out / CO;
+  // one persistent workgroup per CU, in groups of 8 x n_slices (8 XCDs x the slices of one set of column blocks)
+  long long groups = n_cu / (8 * n_slices);
+  const long long need = (n_items + 8 * per_wg - 1) / (8 * per_wg);
+  if (groups > need) groups = need;
+  if (groups < 1) groups = 1;
+  hipLaunchKernelGGL(kern, dim3((unsigned)(groups * 8 * n_slices)), dim3(PW_WAVES * 64), lds, s, a, nblk, (int)n_items);
   return check_launch("conv1d_pw");
 }
 
 int conv_dispatch_pw(ConvArgs& a, hipStream_t s) {
-  switch (a.C_out) {
-    case 96: return pw_launch<3, 1>(a, s);
-    case 128: return pw_launch<2, 2>(a, s);
-    default: return pw_launch<3, 2>(a, s);
+  switch (pw_slice_channels(a.C_in, a.C_out)) {
+    case 96: return pw_launch<3, 1>(a, s);      // C = 96; C = 384 in four slices
+    case 128: return pw_launch<2, 2>(a, s);     // C = 128; C = 256 in two slices
+    default: return pw_launch<3, 2>(a, s);      // C = 192
   }
 }
 
