@@ -103,7 +103,7 @@ class ConvLaunchProfile:
 _PROFILE = None
 
 # k = 7 convs on the bf16 matrix pipe with fp32-exact operand splitting (conv1d_bsplit.hip).  Results have
-# fp32-MFMA-grade error (DESIGN.md 3.6); FAC_BF16_SPLIT=0 keeps every conv on the fp32 MFMA kernel.
+# fp32-MFMA-grade error (DESIGN.md 3.5); FAC_BF16_SPLIT=0 keeps every conv on the fp32 MFMA kernel.
 BF16_SPLIT = os.environ.get("FAC_BF16_SPLIT", "1") != "0"
 
 
