@@ -179,9 +179,11 @@ bool conv_pw_ok(const ConvArgs& a) {
   if (!co || a.C_out_pad != a.C_out) return false;
   if (a.C_in % (2 * PW_D) != 0 || a.C_in < 2 * PW_D) return false;
   if (((size_t)a.C_in * co + 5 * co) * sizeof(float) > 160 * 1024) return false;
-  // a chip's worth of column blocks per slice group, each wave at least a few blocks long
+  // enough column blocks that every wave slot of a 256-CU chip walks at least two of them
   const long long items = (long long)a.B * ((a.T_out + 31) / 32);
-  return items * (a.C_out / co) >= 2 * PW_WAVES * 256 && (reinterpret_cast<unsigned long long>(a.w) & 15) == 0;
+  const int nsplit = (co == 96) ? 1 : 2;                              // see conv_dispatch_pw
+  const long long slots = (256 / (a.C_out / co)) * (PW_WAVES / nsplit);
+  return items >= 2 * slots && (reinterpret_cast<unsigned long long>(a.w) & 15) == 0;
 }
 
 template <int MBW, int NSPLIT>

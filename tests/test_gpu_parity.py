@@ -140,7 +140,7 @@ def test_conv_second_output_is_snake_of_first(O, ops, cuda):
     assert none_y is None and torch.equal(y2b, y2)
 
 
-@pytest.mark.parametrize("C,T,B", [(96, 2100, 24), (128, 1531, 32), (192, 1200, 40), (256, 2100, 64), (384, 1101, 64)])
+@pytest.mark.parametrize("C,T,B", [(96, 4101, 64), (128, 4099, 32), (192, 4100, 32), (256, 2100, 64), (384, 1101, 64)])
 def test_pointwise_streaming_kernel(C, T, B, O, ops, cuda):
     """k = 1 ResidualUnit tail on the streaming kernel (conv1d_pw.hip: weights resident in LDS, inputs straight from global
     memory): bias + residual + second Snake output, ragged last column block, against the oracle and BIT-EQUAL to the tiled
@@ -153,17 +153,21 @@ def test_pointwise_streaming_kernel(C, T, B, O, ops, cuda):
     a2 = 1 + 0.2 * torch.rand(C, generator=g)
     y_ref = O.sconv1d(x, w, b) + r
     wp = ops.pack_conv_weight(w.to(cuda))
-    lib = ops._lib.load()
-    d_name = ops.C.create_string_buffer(96)
-    y, y2 = ops.conv1d(x.to(cuda), wp, C, 1, bias=b.to(cuda), res=r.to(cuda), alpha_y2=a2.to(cuda))
+    prof = ops.ConvLaunchProfile()
+    ops.set_conv_profile(prof)
+    try:
+        y, y2 = ops.conv1d(x.to(cuda), wp, C, 1, bias=b.to(cuda), res=r.to(cuda), alpha_y2=a2.to(cuda))
+        # few columns: the same layer on the tiled kernel (the streaming kernel wants a chip's worth of column blocks)
+        n = 3
+        y_t, y2_t = ops.conv1d(x[:n].to(cuda), wp, C, 1, bias=b.to(cuda), res=r[:n].to(cuda), alpha_y2=a2.to(cuda))
+        dx = ops.conv1d(x.to(cuda), ops.pack_conv_weight_bwd(w.to(cuda)), C, 1, pad_left=0, pad_mode=ops.PAD_ZERO, t_out=T)
+    finally:
+        ops.set_conv_profile(None)
+    names = [rec[0] for rec in prof.records]
+    assert names[0].startswith("conv1d_pw_kernel") and names[2].startswith("conv1d_pw_kernel") and "pw" not in names[1], names
     assert rel(y, y_ref) < OP_TOL and rel(y2, O.snake(y_ref, a2.view(1, -1, 1))) < OP_TOL
-    # few columns: the same layer on the tiled kernel (the streaming kernel wants a chip's worth of column blocks)
-    n = 3
-    y_t, y2_t = ops.conv1d(x[:n].to(cuda), wp, C, 1, bias=b.to(cuda), res=r[:n].to(cuda), alpha_y2=a2.to(cuda))
     assert torch.equal(y_t, y[:n]) and torch.equal(y2_t, y2[:n])
-    dx = ops.conv1d(x.to(cuda), ops.pack_conv_weight_bwd(w.to(cuda)), C, 1, pad_left=0, pad_mode=ops.PAD_ZERO, t_out=T)
     assert rel(dx, torch.einsum("oc,bot->bct", w[:, :, 0], x)) < OP_TOL
-    del lib, d_name
 
 
 def test_first_conv_two_outputs(O, ops, cuda):
