@@ -21,6 +21,12 @@ def per_kernel(path, counter):
                 key = "conv1d_bsplit_kernel<7>"
             elif "conv1d_skinny_kernel" in r["Kernel_Name"]:
                 key = "conv1d_skinny_kernel"
+            elif "conv1d_pw_kernel" in r["Kernel_Name"]:
+                key = "conv1d_pw_kernel" + re.search(r"<[^>]*>", r["Kernel_Name"]).group(0)
+            elif "conv1d_cin1_kernel" in r["Kernel_Name"]:
+                key = "conv1d_cin1_kernel"
+            elif "conv1d_narrow_kernel" in r["Kernel_Name"]:
+                key = "conv1d_narrow_kernel"
             else:
                 continue
         else:
