@@ -141,7 +141,9 @@ int fac_pack_conv_w_split(const float* v, const float* scale, void* out, int C_o
                           fac_stream_t stream);
 /* Which kernel instantiation fac_conv1d_fwd picks for this descriptor: returns its id (>= 0) and
  * writes a printable name; lets a profiler attribute per-launch timings without re-deriving
- * the tile-selection rule. */
+ * the tile-selection rule.  Ids: 0-6, 8 MFMA tile shapes, 7 fused ResidualUnit, 9 VALU kernel for C_out <= 2, 10 split-reduction
+ * kernel (<= 640 columns), 11 split-bf16 kernel (k = 5 / 7), 12 store-stream kernel for C_in = 1, 13 channel-split kernel for
+ * C_out <= 2 over few tiles, 14 streaming k = 1 kernel (weights resident in LDS, C <= 384). */
 int fac_conv1d_variant(const fac_conv_desc* d, char* name, int name_len);
 
 /* Standalone Snake  y = x + sin(alpha*x)^2 / (alpha + 1e-9)  (dac/nn/layers.py:18-33) for the
