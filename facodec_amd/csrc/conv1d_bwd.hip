@@ -22,14 +22,18 @@ namespace fac {
 // the caller up to fac_cin_pad(C_out) rows and CP = pad32(C_in) columns)
 __global__ void pack_conv_bwd_kernel(const float* __restrict__ v, const float* __restrict__ scale,
                                      float* __restrict__ packed, int C_out, int C_in, int K, int CP, long long n) {
+  // n covers the whole padded buffer (cin_pad(C_out) rows x K x CP columns): padding rows / columns are written as zeros
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-    const int ci = (int)(i % C_in);
-    const long long r = i / C_in;
+    const int ci = (int)(i % CP);
+    const long long r = i / CP;
     const int kp = (int)(r % K);
     const int co = (int)(r / K);
-    float w = v[((long long)co * C_in + ci) * K + (K - 1 - kp)];
-    if (scale) w = __fmul_rn(w, scale[co]);
-    packed[((long long)co * K + kp) * CP + ci] = w;
+    float w = 0.f;
+    if (co < C_out && ci < C_in) {
+      w = v[((long long)co * C_in + ci) * K + (K - 1 - kp)];
+      if (scale) w = __fmul_rn(w, scale[co]);
+    }
+    packed[i] = w;
   }
 }
 
@@ -265,7 +269,7 @@ extern "C" int fac_pack_conv_w_bwd(const float* v, const float* scale, float* pa
   using namespace fac;
   FAC_REQUIRE(v && packed && C_out > 0 && C_in > 0 && K > 0 && C_in_pad >= C_in && C_in_pad % 32 == 0,
               "pack_conv_w_bwd: bad arguments");
-  const long long n = (long long)C_out * C_in * K;
+  const long long n = (long long)cin_pad_dev(C_out) * K * C_in_pad;     // the whole padded buffer
   const int blocks = (int)((n + 255) / 256 < 65535 ? (n + 255) / 256 : 65535);
   hipLaunchKernelGGL(pack_conv_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, v, scale, packed, C_out, C_in,
                      K, C_in_pad, n);

@@ -37,7 +37,7 @@ __global__ __launch_bounds__(256) void wn_scale_kernel(const float* __restrict__
 __global__ __launch_bounds__(256) void pack_conv_kernel(const float* __restrict__ v,
                                                         const float* __restrict__ scale,
                                                         float* __restrict__ out, int C_out, int R,
-                                                        int C_out_pad) {
+                                                        int C_out_pad, int R_pad) {
   __shared__ float tile[32][33];
   const int r0 = blockIdx.x * 32;
   const int c0 = blockIdx.y * 32;
@@ -59,7 +59,7 @@ __global__ __launch_bounds__(256) void pack_conv_kernel(const float* __restrict_
   for (int j = 0; j < 4; ++j) {
     const int r = r0 + ty + 8 * j;
     const int co = c0 + tx;
-    if (r < R && co < C_out_pad) out[(long long)r * C_out_pad + co] = tile[tx][ty + 8 * j];
+    if (r < R_pad && co < C_out_pad) out[(long long)r * C_out_pad + co] = tile[tx][ty + 8 * j];   // rows R..R_pad: zeros
   }
 }
 
@@ -71,15 +71,16 @@ __global__ __launch_bounds__(256) void pack_convtr_kernel(const float* __restric
                                                           int C_out, int s, int C_out_pad) {
   extern __shared__ float tl[];  // [32][K+1]
   const int K = 2 * s;
-  const int ci = blockIdx.x;
+  const int ci = blockIdx.x;                       // up to cin_pad(C_in): the padding channels get zero rows
   const int c0 = blockIdx.y * 32;
-  const float sc = scale ? scale[ci] : 1.0f;
-  const float* src = v + ((long long)ci * C_out + c0) * K;
+  const bool real = ci < C_in;
+  const float sc = (scale && real) ? scale[ci] : 1.0f;
+  const float* src = v + ((long long)(real ? ci : 0) * C_out + c0) * K;
   const int n = 32 * K;
   for (int i = threadIdx.x; i < n; i += 256) {
     const int co = i / K, k = i - co * K;
     float val = 0.f;
-    if (c0 + co < C_out) val = __fmul_rn(src[i], sc);
+    if (real && c0 + co < C_out) val = __fmul_rn(src[i], sc);
     tl[co * (K + 1) + k] = val;
   }
   __syncthreads();
@@ -131,9 +132,10 @@ extern "C" int fac_pack_conv_w(const float* v, const float* scale, float* packed
   FAC_REQUIRE(v && packed && C_out > 0 && C_in > 0 && K > 0, "pack_conv_w: bad arguments");
   FAC_REQUIRE(C_out_pad % 32 == 0 && C_out_pad >= C_out, "pack_conv_w: C_out_pad must be a multiple of 32");
   const int R = C_in * K;
-  dim3 grid((R + 31) / 32, C_out_pad / 32);
+  const int R_pad = cin_pad_dev(C_in) * K;              // the zero rows of the padding channels are written too
+  dim3 grid((R_pad + 31) / 32, C_out_pad / 32);
   hipLaunchKernelGGL(pack_conv_kernel, grid, dim3(256), 0, (hipStream_t)stream, v, scale, packed,
-                     C_out, R, C_out_pad);
+                     C_out, R, C_out_pad, R_pad);
   return check_launch("pack_conv_w");
 }
 
@@ -142,7 +144,7 @@ extern "C" int fac_pack_convtr_w(const float* v, const float* scale, float* pack
   using namespace fac;
   FAC_REQUIRE(v && packed && C_out > 0 && C_in > 0 && stride > 0, "pack_convtr_w: bad arguments");
   FAC_REQUIRE(C_out_pad % 32 == 0 && C_out_pad >= C_out, "pack_convtr_w: C_out_pad must be a multiple of 32");
-  dim3 grid(C_in, C_out_pad / 32);
+  dim3 grid(cin_pad_dev(C_in), C_out_pad / 32);
   const size_t lds = (size_t)32 * (2 * stride + 1) * sizeof(float);
   hipLaunchKernelGGL(pack_convtr_kernel, grid, dim3(256), lds, (hipStream_t)stream, v, scale,
                      packed, C_in, C_out, stride, C_out_pad);

@@ -52,7 +52,7 @@ def wn_scale(v, g):
 
 def pack_conv_weight(v, g=None, out=None):
     """(C_out, C_in, K) [+ weight-norm gain g (C_out,1,1)] -> packed (cin_pad(C_in), K, pad32(C_out));
-    rows beyond C_in stay zero (the buffer is zero-initialised once and reused)."""
+    the rows of the padding channels are written as zeros by the kernel (no separate fill)."""
     v = _dev(v, "weight")
     if v.dim() == 2:
         v = v.unsqueeze(-1)
@@ -60,7 +60,7 @@ def pack_conv_weight(v, g=None, out=None):
     cp = pad32(c_out)
     scale = wn_scale(v, g) if g is not None else None
     if out is None:
-        out = torch.zeros(cin_pad(c_in), k, cp, device=v.device, dtype=torch.float32)
+        out = torch.empty(cin_pad(c_in), k, cp, device=v.device, dtype=torch.float32)
     _lib.check(_lib.load().fac_pack_conv_w(_ptr(v), _ptr(scale), _ptr(out), c_out, c_in, k, cp, _stream()),
                "fac_pack_conv_w")
     return out
@@ -75,7 +75,7 @@ def pack_convtr_weight(v, g, stride, out=None):
     cp = pad32(c_out)
     scale = wn_scale(v, g) if g is not None else None
     if out is None:
-        out = torch.zeros(stride, cin_pad(c_in), 2, cp, device=v.device, dtype=torch.float32)
+        out = torch.empty(stride, cin_pad(c_in), 2, cp, device=v.device, dtype=torch.float32)
     _lib.check(_lib.load().fac_pack_convtr_w(_ptr(v), _ptr(scale), _ptr(out), c_in, c_out, stride, cp, _stream()),
                "fac_pack_convtr_w")
     return out
@@ -479,7 +479,7 @@ def pack_conv_weight_bwd(v, g=None):
     """(C_out, C_in, K) [weight-normed] -> packed weights of the bwd-data conv (taps flipped, channels swapped)."""
     v = _dev(v, "weight")
     c_out, c_in, k = v.shape
-    packed = torch.zeros(cin_pad(c_out), k, pad32(c_in), device=v.device, dtype=torch.float32)
+    packed = torch.empty(cin_pad(c_out), k, pad32(c_in), device=v.device, dtype=torch.float32)
     scale = wn_scale(v, g) if g is not None else None
     _lib.check(_lib.load().fac_pack_conv_w_bwd(_ptr(v), _ptr(scale), _ptr(packed), c_out, c_in, k, pad32(c_in), _stream()),
                "fac_pack_conv_w_bwd")

@@ -57,15 +57,15 @@ int fac_wn_scale(const float* v, const float* g, float* scale, int n_slices, int
 
 /* Conv1d / Linear weight v (C_out, C_in, K) -> packed (C_in_pad, K, C_out_pad), co fastest,
  * packed[ci][k][co] = v[co][ci][k] * scale[co]; columns C_out..C_out_pad-1 and rows
- * C_in..C_in_pad-1 must be zero: the caller zero-initialises the buffer once, this call writes the
- * valid rows.  C_out_pad = fac_pad32(C_out), C_in_pad = fac_cin_pad(C_in). scale may be NULL (== 1). */
+ * C_in..C_in_pad-1 are zero: this call writes the WHOLE (C_in_pad, K, C_out_pad) buffer, padding included (an
+ * uninitialised allocation is fine).  C_out_pad = fac_pad32(C_out), C_in_pad = fac_cin_pad(C_in). scale may be NULL (== 1). */
 int fac_pack_conv_w(const float* v, const float* scale, float* packed, int C_out, int C_in,
                     int K, int C_out_pad, fac_stream_t stream);
 
 /* ConvTranspose1d weight v (C_in, C_out, K = 2*stride) with weight-norm over dim 0 (= C_in,
  * dac/model/encodec.py:163) -> `stride` polyphase 2-tap sub-filters:
  * packed[p][ci][j][co] = v[ci][co][p + stride*(1-j)] * scale[ci],  p < stride, j in {0,1},
- * ci < C_in_pad (rows >= C_in zero, as above).
+ * ci < C_in_pad (rows >= C_in written as zeros, as above).
  * Output phase p of the transposed conv is then a causal 2-tap conv (see fac_conv1d_fwd). */
 int fac_pack_convtr_w(const float* v, const float* scale, float* packed, int C_in, int C_out,
                       int stride, int C_out_pad, fac_stream_t stream);

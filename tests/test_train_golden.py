@@ -239,3 +239,21 @@ def test_train_step_batch16_linearity_full_size(cuda):
         assert n_full > 0 and abs(n_full - n_mean) / n_full < 1e-4, (k, n_full, n_mean)
         assert float((full[k] - mean).double().norm()) / n_full < 2e-3, k
         assert abs(float(out_full["grad_norm"][k]) - n_full) / n_full < 1e-4, k
+
+
+def test_train_step_identical_with_and_without_streaming_kernel():
+    """configs[2] at its real size (B = 16 x 2 s), two seeded iterations, once with the streaming k = 1 kernel (forward and
+    data gradient of the C <= 384 ResidualUnit tails) and once with FAC_PW=0 (tiled kernel): same summation order, so every loss
+    and every gradient norm must agree to the last bit.  Separate processes: the switch is read once per process."""
+    import json
+    import subprocess
+    import sys
+    script = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "tune", "pw_check.py")
+    outs = []
+    for flag in ("0", "1"):
+        env = dict(os.environ, FAC_PW=flag)
+        r = subprocess.run([sys.executable, script, "2"], env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("PW=")][-1]
+        outs.append(json.loads(line.split(" ", 1)[1]))
+    assert outs[0] == outs[1], outs
