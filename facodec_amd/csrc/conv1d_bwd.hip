@@ -215,18 +215,39 @@ __global__ __launch_bounds__(256) void snake_bwd_kernel(const float* __restrict_
   if (tid == 0) part[c * RED_NS + sl] = red[0];
 }
 
+// db[c] = sum over (b, t) of dy: workgroup (c, slice) sums its contiguous share of the flattened (b, t) range -- walked clip by
+// clip (no per-element division), 16 bytes per lane where the rows allow it, four independent partial sums per thread -- and a
+// second pass adds the RED_NS slices in fixed order.
 __global__ __launch_bounds__(256) void bias_grad_kernel(const float* __restrict__ dy, float* __restrict__ part, int B, int C, int T) {
   __shared__ float red[256];
   const int c = blockIdx.x, sl = blockIdx.y, tid = threadIdx.x;
   const long long n = (long long)B * T;
   const long long per = (n + RED_NS - 1) / RED_NS;
   const long long lo = sl * per, hi = lo + per < n ? lo + per : n;
-  float s = 0.f;
-  for (long long p = lo + tid; p < hi; p += 256) {
-    const long long b = p / T, t = p - b * T;
-    s += dy[(b * C + c) * T + t];
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (lo < hi) {
+    const int b_lo = (int)(lo / T), b_hi = (int)((hi - 1) / T);
+    const bool vec = (T & 3) == 0 && (reinterpret_cast<unsigned long long>(dy) & 15) == 0;
+    for (int b = b_lo; b <= b_hi; ++b) {
+      const long long base = (long long)b * T;
+      int t0 = (int)(lo > base ? lo - base : 0);
+      const int t1 = (int)(hi < base + T ? hi - base : T);
+      const float* row = dy + ((long long)b * C + c) * T;
+      if (vec) {
+        const int a0 = (t0 + 3) & ~3, a1 = t1 & ~3;              // aligned interior [a0, a1), scalar edges
+        if (a0 < a1) {
+          for (int t = t0 + tid; t < a0; t += 256) s0 += row[t];
+          for (int t = a0 + 4 * tid; t < a1; t += 1024) {
+            const float4 v = *reinterpret_cast<const float4*>(row + t);
+            s0 += v.x; s1 += v.y; s2 += v.z; s3 += v.w;
+          }
+          t0 = a1;
+        }
+      }
+      for (int t = t0 + tid; t < t1; t += 256) s0 += row[t];
+    }
   }
-  red[tid] = s;
+  red[tid] = (s0 + s1) + (s2 + s3);
   __syncthreads();
   for (int o = 128; o > 0; o >>= 1) {
     if (tid < o) red[tid] += red[tid + o];

@@ -35,6 +35,31 @@ __global__ void leaky_bwd_kernel(const float* __restrict__ x, const float* __res
   }
 }
 
+// Four consecutive positions per thread (16-byte accesses, one position decode per quad).  Needs T and the pitch to be
+// multiples of 4 (a quad never straddles two rows) and 16-byte aligned tensors; the scalar kernels above take the rest.
+template <bool BWD>
+__global__ void leaky_quad_kernel(const float4* __restrict__ x, const float4* __restrict__ dy, float4* __restrict__ out, float slope,
+                                  int T, int pitch, int valid, int rpg, int vrows, long long n4) {
+  GRID_STRIDE(q, n4) {
+    const float4 xv = x[q];
+    const float4 gv = BWD ? dy[q] : xv;
+    int left = 4;                                   // how many of the quad's positions carry data
+    if (pitch != 0) {
+      const long long i = 4 * q;
+      const int pos = (i >> 31) == 0 ? (int)((unsigned)i % (unsigned)T) : (int)(i % T);
+      const int row = pos / pitch;
+      const int c = pos - row * pitch;
+      left = (rpg == 0 || row % rpg < vrows) ? valid - c : 0;
+    }
+    float4 o;
+    o.x = left > 0 ? (xv.x > 0.f ? gv.x : gv.x * slope) : 0.f;
+    o.y = left > 1 ? (xv.y > 0.f ? gv.y : gv.y * slope) : 0.f;
+    o.z = left > 2 ? (xv.z > 0.f ? gv.z : gv.z * slope) : 0.f;
+    o.w = left > 3 ? (xv.w > 0.f ? gv.w : gv.w * slope) : 0.f;
+    out[q] = o;
+  }
+}
+
 // out[(b*p + j)*pitch + l] = xr[l*p + j] for l < L (zero for L <= l < pitch), xr = x reflect-extended on the right to
 // L*p samples (MPD.pad_to_period + rearrange); rows (b, j) laid one after another with `pitch` columns each
 __global__ void period_fold_kernel(const float* __restrict__ x, float* __restrict__ out, int T, int p, int L, int pitch, long long n) {
@@ -220,7 +245,16 @@ extern "C" int fac_leaky_relu(const float* x, const float* dy, float* out, int64
                               int rows_per_group, int valid_rows, fac_stream_t stream) {
   FAC_REQUIRE(x && out && n > 0 && (pitch == 0 || (T > 0 && valid > 0 && valid <= pitch)), "leaky_relu: bad arguments");
   FAC_REQUIRE(rows_per_group == 0 || (pitch > 0 && valid_rows > 0 && valid_rows <= rows_per_group), "leaky_relu: bad row groups");
-  if (dy) L1(leaky_bwd_kernel, n, x, dy, out, slope, T > 0 ? T : 1, pitch, valid, rows_per_group, valid_rows, (long long)n);
+  const bool quad = (n & 3) == 0 && (pitch == 0 || ((T & 3) == 0 && (pitch & 3) == 0)) &&
+                    ((reinterpret_cast<unsigned long long>(x) | reinterpret_cast<unsigned long long>(out) |
+                      reinterpret_cast<unsigned long long>(dy)) & 15) == 0;
+  if (quad) {
+    const long long n4 = n / 4;
+    const float4 *x4 = reinterpret_cast<const float4*>(x), *d4 = reinterpret_cast<const float4*>(dy);
+    float4* o4 = reinterpret_cast<float4*>(out);
+    if (dy) L1(leaky_quad_kernel<true>, n4, x4, d4, o4, slope, T > 0 ? T : 1, pitch, valid, rows_per_group, valid_rows, n4);
+    else L1(leaky_quad_kernel<false>, n4, x4, d4, o4, slope, T > 0 ? T : 1, pitch, valid, rows_per_group, valid_rows, n4);
+  } else if (dy) L1(leaky_bwd_kernel, n, x, dy, out, slope, T > 0 ? T : 1, pitch, valid, rows_per_group, valid_rows, (long long)n);
   else L1(leaky_fwd_kernel, n, x, out, slope, T > 0 ? T : 1, pitch, valid, rows_per_group, valid_rows, (long long)n);
   return fac::check_launch("leaky_relu");
 }
