@@ -162,9 +162,9 @@ __global__ __launch_bounds__(PW_WAVES * 64, 4) void conv1d_pw_kernel(ConvArgs a,
 // C_out -> (channels per weight slice, slices): the slice must fit the LDS next to nothing else, and a wave needs >= 2
 // MFMAs per input row it loads
 static int pw_slice_channels(int C_in, int C_out) {
-  if (C_in != C_out) return (C_out == 96 || C_out == 128 || C_out == 192) ? C_out : 0;
+  if (C_in != C_out) return (C_out == 64 || C_out == 96 || C_out == 128 || C_out == 192) ? C_out : 0;
   switch (C_out) {
-    case 96: case 128: case 192: return C_out;
+    case 64: case 96: case 128: case 192: return C_out;
     case 256: return 128;
     case 384: return 96;
     default: return 0;
@@ -181,7 +181,7 @@ bool conv_pw_ok(const ConvArgs& a) {
   if (((size_t)a.C_in * co + 5 * co) * sizeof(float) > 160 * 1024) return false;
   // enough column blocks that every wave slot of a 256-CU chip walks at least two of them
   const long long items = (long long)a.B * ((a.T_out + 31) / 32);
-  const int nsplit = (co == 96) ? 1 : 2;                              // see conv_dispatch_pw
+  const int nsplit = (co == 96 || co == 64) ? 1 : 2;                  // see conv_dispatch_pw
   const long long slots = (256 / (a.C_out / co)) * (PW_WAVES / nsplit);
   return items >= 2 * slots && (reinterpret_cast<unsigned long long>(a.w) & 15) == 0;
 }
@@ -222,6 +222,7 @@ static int pw_launch(ConvArgs& a, hipStream_t s) {
 
 int conv_dispatch_pw(ConvArgs& a, hipStream_t s) {
   switch (pw_slice_channels(a.C_in, a.C_out)) {
+    case 64: return pw_launch<2, 1>(a, s);      // C = 64
     case 96: return pw_launch<3, 1>(a, s);      // C = 96; C = 384 in four slices
     case 128: return pw_launch<2, 2>(a, s);     // C = 128; C = 256 in two slices
     default: return pw_launch<3, 2>(a, s);      // C = 192

@@ -50,7 +50,10 @@ class ResidualUnit(nn.Module):
         Returns (y, snake(y, alpha_next)); y is None when want_raw is False."""
         b = self.block
         k7, k1 = b[1], b[3]
-        if k7.w.c_out in FUSED_RU_CHANNELS and x_act.shape[-1] == x.shape[-1]:
+        # big batches take the split-bf16 k = 7 kernel + the streaming k = 1 kernel instead (same time for the k = 7 part,
+        # the 1x1 tail at HBM speed: 1.05 vs 1.30 ms per unit at B = 32); the streaming kernel wants >= 8192 column blocks
+        streaming = ops.BF16_SPLIT and x.shape[0] * ((x.shape[-1] + 31) // 32) >= 8192
+        if k7.w.c_out in FUSED_RU_CHANNELS and x_act.shape[-1] == x.shape[-1] and not streaming:
             # whole unit in one launch: the 1x1 conv runs out of the k7 accumulators (conv1d_fused_ru.hip)
             return_pair = ops.conv1d(x_act, k7.w.packed(), k7.w.c_out, 7, bias=k7.w.bias, dilation=k7.dilation,
                                      alpha_out=b[2].flat(), res=x, w_k1=k1.w.packed(), bias_k1=k1.w.bias,

@@ -140,7 +140,7 @@ def test_conv_second_output_is_snake_of_first(O, ops, cuda):
     assert none_y is None and torch.equal(y2b, y2)
 
 
-@pytest.mark.parametrize("C,T,B", [(96, 4101, 64), (128, 4099, 32), (192, 4100, 32), (256, 2100, 64), (384, 1101, 64)])
+@pytest.mark.parametrize("C,T,B", [(64, 4101, 64), (96, 4101, 64), (128, 4099, 32), (192, 4100, 32), (256, 2100, 64), (384, 1101, 64)])
 def test_pointwise_streaming_kernel(C, T, B, O, ops, cuda):
     """k = 1 ResidualUnit tail on the streaming kernel (conv1d_pw.hip: weights resident in LDS, inputs straight from global
     memory): bias + residual + second Snake output, ragged last column block, against the oracle and BIT-EQUAL to the tiled
