@@ -126,6 +126,9 @@ __global__ __launch_bounds__((NMW + NSW) * 64, (NMW + NSW) / 4) void conv1d_bspl
   const int n_chunks = (a.C_in + 8 * G - 1) / (8 * G);
   const int dil = a.dil;
 
+#ifdef FAC_PROF
+  unsigned long long pf0 = 0, pf1 = 0, pf2 = 0;
+#endif
   if (wave >= NMW) {
     // ===================== staging waves
     const int lw = wave - NMW;
@@ -149,7 +152,7 @@ __global__ __launch_bounds__((NMW + NSW) * 64, (NMW + NSW) / 4) void conv1d_bspl
       u_idx[j] = u_c[j] >= 0 ? idx : -1;
     }
     auto stage_w = [&](int chunk, int buf) {   // weights: one contiguous slab, 16 B per lane
-#ifndef FAC_ABL_NOSTAGE
+#if !defined(FAC_ABL_NOSTAGE) && !defined(FAC_ABL_NOSTAGE_W)
       constexpr int N16 = W_STAGE / 16;
       const unsigned char* src = wsrc + (long long)chunk * W_STAGE;
       unsigned char* dst = Wbuf + buf * W_STAGE;
@@ -160,20 +163,28 @@ __global__ __launch_bounds__((NMW + NSW) * 64, (NMW + NSW) / 4) void conv1d_bspl
       }
 #endif
     };
+    // Every instruction of the staging waves costs the SIMD's MFMA wave issue time (measured: a stage takes 3.0 us with the
+    // staging work removed, 4.7 us with it), so the loads are kept to one instruction each: the channel row is a uniform
+    // (scalar) base, the column a per-lane 32-bit offset resolved once per tile; lanes on padding read a clamped column and
+    // are zeroed by a select (no exec-mask branches), and C_in % (8 G) == 0 (dispatcher) makes every channel of a stage real.
+    int u_off[BS_XU];
+#pragma unroll
+    for (int j = 0; j < BS_XU; ++j) u_off[j] = u_idx[j] >= 0 ? u_idx[j] : 0;
     auto load_x = [&](int chunk, float (&xr)[BS_XU][8]) {
-#ifndef FAC_ABL_NOSTAGE
+#if !defined(FAC_ABL_NOSTAGE) && !defined(FAC_ABL_NOSTAGE_X)
 #pragma unroll
       for (int j = 0; j < BS_XU; ++j) {
+        const float* grp = xg + (long long)((chunk * G + u_g[j]) * 8) * xcs;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-          const int ci = (chunk * G + u_g[j]) * 8 + i;
-          xr[j][i] = (u_idx[j] >= 0 && ci < a.C_in) ? xg[ci * xcs + u_idx[j]] : 0.f;   // 32-bit offset off a uniform base
+          const float v = (grp + (long long)i * xcs)[u_off[j]];
+          xr[j][i] = u_idx[j] >= 0 ? v : 0.f;
         }
       }
 #endif
     };
     auto write_x = [&](int buf, const float (&xr)[BS_XU][8]) {
-#ifndef FAC_ABL_NOSTAGE
+#if !defined(FAC_ABL_NOSTAGE) && !defined(FAC_ABL_NOSTAGE_X)
       unsigned char* xd = Xbuf + buf * X_STAGE;
 #pragma unroll
       for (int j = 0; j < BS_XU; ++j) {
@@ -309,6 +320,7 @@ __global__ __launch_bounds__((NMW + NSW) * 64, (NMW + NSW) / 4) void conv1d_bspl
 
 #ifdef FAC_PROF
   const unsigned long long tp2 = wall_clock64();
+  pf0 = tp0; pf1 = tp1; pf2 = tp2;
 #endif
   // ---- accumulators -> LDS (both stage buffers are free now): tile[co][t] fp32, row pitch BS_TT + 4 floats.
   // C/D layout of the 32x32 block: register r <-> row (r & 3) + 8 (r >> 2) + 4 kq, column l31.
@@ -389,6 +401,12 @@ __global__ __launch_bounds__((NMW + NSW) * 64, (NMW + NSW) / 4) void conv1d_bspl
       }
     }
   }
+#ifdef FAC_PROF
+  if (a.dbg && tid == 0) {
+    unsigned long long* d = a.dbg + (long long)blockIdx.x * 8;
+    d[0] = pf0; d[1] = pf1; d[2] = pf2; d[3] = wall_clock64(); d[4] = 0; d[5] = 0;
+  }
+#endif
 }
 
 bool conv_bsplit_ok(const ConvArgs& a) {

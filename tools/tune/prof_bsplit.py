@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 from facodec_amd import ops, _lib
 lib = _lib.load()
 dev = torch.device("cuda:0")
-for (C, T) in ((128, 24000), (768, 960), (64, 48000)):
+for (C, T) in ((96, 48000), (192, 24000), (768, 960)):
     B = 32
     x = torch.randn(B, C, T, device=dev)
     w = torch.randn(C, C, 7, device=dev) * 0.01
@@ -26,6 +26,7 @@ for (C, T) in ((128, 24000), (768, 960), (64, 48000)):
     t0, t1, t2, t3 = (d[:, i].astype(np.float64) for i in range(4))
     us = 1e6 / 100e6     # wall_clock64: 100 MHz
     print(f"C={C} T={T}: WGs {len(d)}  kernel span {(t3.max() - t0.min()) * us:.0f} us | per WG: prologue {np.mean(t1 - t0) * us:.1f}  loop {np.mean(t2 - t1) * us:.1f}  epilogue {np.mean(t3 - t2) * us:.1f}  total {np.mean(t3 - t0) * us:.1f} us")
+    continue
     # gaps between consecutive workgroups on the same CU (hw id + xcc)
     key = d[:, 4] * 16 + d[:, 5]
     gaps = []
