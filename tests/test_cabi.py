@@ -68,3 +68,56 @@ def test_product_refuses_cpu_tensors():
     from facodec_amd import ops
     with pytest.raises(_lib.FacodecHipError):
         ops.conv1d(torch.zeros(1, 2, 8), torch.zeros(2, 1, 32), 4, 1)
+
+
+def _desc(B, c_in, c_out, T_in, T_out, K, stride=1, dil=1, pad_left=0, n_phase=1, res=False, y2=False, split=False, ws=True,
+          alpha_out=False):
+    d = _lib.ConvDesc()
+    fake = ctypes.c_void_p(0x10000)          # never dereferenced: fac_conv1d_variant only reads the descriptor
+    d.x, d.w, d.y = fake, fake, fake
+    d.bias = fake
+    d.res = fake if res else None
+    d.y2 = fake if y2 else None
+    d.alpha_y2 = fake if y2 else None
+    d.alpha_out = fake if alpha_out else None
+    d.w_split = fake if split else None
+    d.ws, d.ws_bytes = (fake, 32 << 20) if ws else (None, 0)
+    d.x_bs, d.x_cs, d.y_bs, d.y_cs = c_in * T_in, T_in, c_out * T_out * (n_phase if n_phase > 1 else 1), T_out * (n_phase if n_phase > 1 else 1)
+    d.B, d.C_in, d.T_in, d.C_out, d.C_out_pad, d.T_out = B, c_in, T_in, c_out, (c_out + 31) // 32 * 32, T_out
+    d.K, d.stride, d.dilation, d.pad_left, d.pad_mode = K, stride, dil, pad_left, 0
+    d.n_phase, d.y_tstride, d.phase_shift, d.act, d.w_batched, d.w_bs = n_phase, n_phase, 0, 0, 0, 0
+    return d
+
+
+def test_kernel_selection_for_the_benchmark_shapes():
+    """Which kernel fac_conv1d_fwd takes for the layer shapes of configs[1] (B = 32 x 2 s) and for their small-batch
+    counterparts -- host logic only (fac_conv1d_variant reads the descriptor, nothing is launched)."""
+    lib = _lib.load()
+
+    def variant(d):
+        buf = ctypes.create_string_buffer(96)
+        return lib.fac_conv1d_variant(ctypes.byref(d), buf, 96), buf.value.decode()
+
+    B = 32
+    # k = 7 ResidualUnit convs with pre-split weights: the split-bf16 kernel, for every channel count of the codec
+    for c, t in ((64, 48000), (96, 48000), (128, 24000), (192, 24000), (384, 4800), (768, 960)):
+        for dil in (1, 3, 9):
+            vid, name = variant(_desc(B, c, c, t, t, 7, dil=dil, pad_left=6 * dil, split=True, alpha_out=True))
+            assert vid == 11, (c, dil, name)
+    # k = 1 tails: streaming kernel up to 384 channels at benchmark size, tiled kernel beyond and for small batches
+    for c, t, want in ((64, 48000, 14), (96, 48000, 14), (128, 24000, 14), (192, 24000, 14), (256, 4800, 14), (384, 4800, 14),
+                       (512, 960, 5), (768, 960, 5)):
+        vid, name = variant(_desc(B, c, c, t, t, 1, res=True, y2=True))
+        assert vid == want, (c, name)
+    vid, name = variant(_desc(2, 192, 192, 24000, 24000, 1, res=True, y2=True))
+    assert vid == 6, name                                             # two clips: not enough column blocks to stream
+    # edge convs
+    assert variant(_desc(B, 1, 64, 48000, 48000, 7, pad_left=6, y2=True))[0] == 12
+    assert variant(_desc(B, 96, 1, 48000, 48000, 7, pad_left=6))[0] == 9
+    assert variant(_desc(1, 1024, 1, 9856, 9856, 3, pad_left=1))[0] == 13      # MPD conv_post over one row-concatenated signal
+    # LSTM-sized problems: few columns -> split reduction; the input projection GEMM -> wide k = 1 tile
+    assert variant(_desc(1, 6144, 1536, 32, 32, 1))[0] == 10
+    assert variant(_desc(1, 1536, 6144, 5120, 5120, 1))[0] == 5
+    # transposed conv (polyphase, n_phase = stride) stays on the fp32 tiles
+    vid, name = variant(_desc(B, 384, 192, 4800, 4800, 2, pad_left=1, n_phase=5, y2=True))
+    assert vid in (3, 4), name
