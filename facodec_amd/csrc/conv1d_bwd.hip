@@ -196,15 +196,25 @@ __global__ __launch_bounds__(256) void snake_bwd_kernel(const float* __restrict_
   const long long per = (n + RED_NS - 1) / RED_NS;
   const long long lo = sl * per, hi = lo + per < n ? lo + per : n;
   float s = 0.f;
-  for (long long p = lo + tid; p < hi; p += 256) {
-    const long long b = p / T, t = p - b * T;
-    const long long o = (b * C + c) * T + t;
-    const float xv = x[o], g = dy[o];
-    const float ax = al * xv;
-    const float sn = sinf(ax), cs = cosf(ax);
-    const float s2 = 2.f * sn * cs;
-    dx[o] = g * (1.f + al * s2 / ae);
-    s += g * (xv * s2 * ae - sn * sn) / (ae * ae);
+  if (lo < hi) {                                    // clip by clip: no per-element index division
+    const int b_lo = (int)(lo / T), b_hi = (int)((hi - 1) / T);
+    for (int b = b_lo; b <= b_hi; ++b) {
+      const long long base = (long long)b * T;
+      const int t0 = (int)(lo > base ? lo - base : 0);
+      const int t1 = (int)(hi < base + T ? hi - base : T);
+      const long long ro = ((long long)b * C + c) * T;
+      // the slice's elements keep the order p = lo + tid, lo + tid + 256, ... of the flat walk (same partial sums)
+      const int first = (int)((256 - ((base + t0 - lo) % 256) + tid) % 256);
+      for (int t = t0 + first; t < t1; t += 256) {
+        const long long o = ro + t;
+        const float xv = x[o], g = dy[o];
+        const float ax = al * xv;
+        const float sn = sinf(ax), cs = cosf(ax);
+        const float s2 = 2.f * sn * cs;
+        dx[o] = g * (1.f + al * s2 / ae);
+        s += g * (xv * s2 * ae - sn * sn) / (ae * ae);
+      }
+    }
   }
   red[tid] = s;
   __syncthreads();

@@ -33,6 +33,18 @@ __global__ void snake_kernel(const float* __restrict__ x, const float* __restric
   }
 }
 
+// Row-wise form for long rows: workgroup = (time chunk, row (b, c)); alpha and its reciprocal once per workgroup, no
+// per-element index division (the flat kernel above spends more on `(i / T) % C` and the division than on the sine).
+__global__ __launch_bounds__(256) void snake_rows_kernel(const float* __restrict__ x, const float* __restrict__ alpha,
+                                                         float* __restrict__ y, int C, int T) {
+  const long long row = blockIdx.y;
+  const float al = alpha[(int)(row % C)];
+  const float inv = snake_inv(al);
+  const float* xr = x + row * T;
+  float* yr = y + row * T;
+  for (int t = blockIdx.x * 1024 + threadIdx.x; t < T && t < (blockIdx.x + 1) * 1024; t += 256) yr[t] = snake_apply(xr[t], al, inv);
+}
+
 // modules/commons.py:113-120; g (B, 2C) is the per-clip conditioning row added before the gate
 // (WN with gin_channels: g_l broadcast over time, modules/wavenet.py:146-155), or NULL.
 __global__ void gate_kernel(const float* __restrict__ a, const float* __restrict__ g,
@@ -585,7 +597,11 @@ extern "C" int fac_snake_fwd(const float* x, const float* alpha, float* y, int B
                              fac_stream_t stream) {
   FAC_REQUIRE(x && alpha && y && B > 0 && C > 0 && T > 0, "snake_fwd: bad arguments");
   const long long n = (long long)B * C * T;
-  EW_LAUNCH(snake_kernel, n, x, alpha, y, C, T, n);
+  if (T >= 1024 && (long long)B * C <= 65535) {
+    hipLaunchKernelGGL(snake_rows_kernel, dim3((T + 1023) / 1024, B * C), dim3(256), 0, (hipStream_t)stream, x, alpha, y, C, T);
+  } else {
+    EW_LAUNCH(snake_kernel, n, x, alpha, y, C, T, n);
+  }
   return check_launch("snake_fwd");
 }
 
