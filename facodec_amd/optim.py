@@ -14,6 +14,8 @@ Per model key there are four contiguous arenas (parameters, gradients, first / s
     that received a gradient; parameters whose gradient autograd never produced are skipped exactly like torch's
     AdamW skips `grad is None` -- no weight decay, no moment update).
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -96,7 +98,11 @@ class FlatAdamW:
         """Data-parallel exchange: one asynchronous all-reduce(mean) of the whole arena (RCCL over xGMI under backend
         'nccl'; it runs on the process group's stream, after everything already queued on the current stream).
         only_if_complete: called from inside backward (gradient hooks) -- launch only when `backward_complete()`."""
-        if self._work is not None or not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+        if self._work is not None or not (dist.is_available() and dist.is_initialized()):
+            return
+        # a single rank has nothing to exchange; FAC_FORCE_ALLREDUCE=1 still issues the collective (smoke-tests the RCCL path --
+        # AVG op, async work handle, stream hand-over -- on a one-GPU box: the mean over one rank is the identity)
+        if dist.get_world_size() == 1 and os.environ.get("FAC_FORCE_ALLREDUCE") != "1":
             return
         if only_if_complete and not self.backward_complete():
             return
