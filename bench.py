@@ -38,9 +38,11 @@ SAMPLE_RATE = 24000
 # Algorithmic work of the forward path per 2 s clip (SURVEY.md 8d / BASELINE.md 2, hook-counted on
 # the reference): 118.44 GMAC = 236.88 GFLOP, i.e. 118.44 GFLOP per audio-second.
 FLOP_PER_AUDIO_S = 118.44e9
-# Train step (configs[2]), SURVEY.md 8d estimate: 3 x (118.44 + 20.51 predictors) + ~10 x 34.8 discriminator GMAC per clip
-# = 0.77 TFLOP per audio-second (the predictor heads are not part of the timed step: their targets come from external models).
-TRAIN_FLOP_PER_AUDIO_S = 0.77e12
+# Train step (configs[2]): SURVEY.md 8d ESTIMATES 3 x (118.44 + 20.51 predictors) + ~10 x 34.8 discriminator GMAC per clip
+# = 0.77 TFLOP per audio-second; the line reports the figure COUNTED at the C-ABI call sites of one real step instead
+# (facodec_amd.ops.FlopCounter: conv forward / data-gradient / weight-gradient launches and LSTM recurrences, 2 FLOP per
+# multiply-add of the mathematical definition; DFT-as-GEMM front-ends booked separately and not included).
+TRAIN_FLOP_PER_AUDIO_S_SURVEY = 0.77e12
 TRAIN_BATCH = 16
 FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 BF16_MFMA_PEAK_TFLOPS = 2516.6  # MI355X_MICROARCH.md: dense bf16 MFMA peak
@@ -92,25 +94,53 @@ def check_codes(model, device):
     return total == 0
 
 
+def synthetic_predictor_targets(batch, frames, device, seed=3):
+    """What train.py:214-262 obtains from the external pitch extractor / CTC phoneme model / speaker model, as synthetic
+    tensors of the same shapes and ranges (tests/golden/make_golden_train.py uses the same recipe): normalised log-F0 with
+    -10 on unvoiced frames, log-normalised mel energy, phone ids in [0, 1024), speaker ids in [0, 20000)."""
+    g = torch.Generator().manual_seed(seed)
+    f0 = torch.randn(batch, frames, generator=g)
+    f0[torch.rand(batch, frames, generator=g) < 0.3] = -10.0
+    t = dict(f0=f0, uv=torch.randn(batch, frames, generator=g) * 0.5, phones=torch.randint(0, 1024, (batch, frames), generator=g),
+             speaker=torch.randint(0, 20000, (batch,), generator=g))
+    return {k: v.to(device) for k, v in t.items()}
+
+
 def train_leg(model, device, rank, world, steps, warmup):
-    """configs[2]: discriminator step + generator step on 16 clips per GPU, gradient all-reduce (RCCL) inside the timing."""
+    """configs[2]: discriminator step + generator step WITH the predictor heads (train.py:270,314-365) on 16 clips per GPU,
+    gradient all-reduce (RCCL) inside the timing."""
     import torch.distributed as dist
     from facodec_amd.train import TrainStep
-    synth.load_synthetic(model.discriminator, seed=0, prefix="discriminator.")
-    model.discriminator.to(device)
-    step = TrainStep(model)
-    wave = synth.synth_clips(TRAIN_BATCH, int(CLIP_SECONDS * SAMPLE_RATE), seed=1, rank=rank).to(device)
+    for k in ("discriminator", "fa_predictors"):
+        synth.load_synthetic(model[k], seed=0, prefix=k + ".")
+        model[k].to(device)
+    step = TrainStep(model, with_predictors=True)
+    n_samples = int(CLIP_SECONDS * SAMPLE_RATE)
+    wave = synth.synth_clips(TRAIN_BATCH, n_samples, seed=1, rank=rank).to(device)
+    targets = synthetic_predictor_targets(TRAIN_BATCH, n_samples // 300, device, seed=3 + rank)
     last = {}
 
     def fn():
-        last.update(step(wave))
+        last.update(step(wave, targets=targets))
 
     torch.cuda.reset_peak_memory_stats()
     elapsed = benchutil.timed_steps(fn, steps, warmup, torch.cuda.synchronize, device)
     units = benchutil.aggregate_units(TRAIN_BATCH * CLIP_SECONDS * steps, device)
-    finite = all(bool(torch.isfinite(last[k]).all()) for k in ("loss", "loss_d", "mel", "feature"))
+    peak_mem = torch.cuda.max_memory_allocated()
+    finite = all(bool(torch.isfinite(last[k]).all()) for k in ("loss", "loss_d", "mel", "feature", "f0_loss", "content_loss", "spk_loss"))
+    # one more (untimed) step with the FLOP counter and the exchange stopwatch on
+    fc = ops.FlopCounter()
+    ops.set_flop_counter(fc)
+    for o in step.opt.values():
+        o.time_exchange = True
+    fn()
+    torch.cuda.synchronize()
+    ops.set_flop_counter(None)
+    exchange = step.exchange_report()
+    for o in step.opt.values():
+        o.time_exchange = False
     ar_ms, ar_bytes = None, sum(o.g.numel() * 4 for o in step.opt.values())
-    if world > 1:   # the exchange alone (all four arenas back to back, blocking): what the overlap has to hide
+    if world > 1:   # the exchange alone (all five arenas back to back, blocking): what the overlap has to hide
         torch.cuda.synchronize()
         dist.barrier()
         t0 = time.perf_counter()
@@ -120,22 +150,65 @@ def train_leg(model, device, rank, world, steps, warmup):
         torch.cuda.synchronize()
         ar_ms = 1e3 * (time.perf_counter() - t0) / 3
     value = units / elapsed
-    per_gpu_tflops = value / world * TRAIN_FLOP_PER_AUDIO_S / 1e12
+    flop_per_audio_s = fc.total / (TRAIN_BATCH * CLIP_SECONDS)
+    per_gpu_tflops = value / world * flop_per_audio_s / 1e12
     return {
         "value": round(value, 2), "unit": "audio-s/s", "ms_per_step": round(1e3 * elapsed / steps, 2), "steps": steps, "warmup": warmup,
-        "workload": f"configs[2]: train.py iteration, {TRAIN_BATCH} clips/GPU x 2 s: encoder -> FA-quantizer -> decoder forward + backward, "
-                    "5 MPD + 3 MRD discriminators (discriminator step, then generator step with adversarial + feature-matching), "
-                    "7-scale mel loss, commitment + codebook losses, 4 x (clip + AdamW + ExponentialLR); predictor heads excluded "
-                    "(their targets come from external networks)",
+        "workload": f"configs[2]: train.py iteration, {TRAIN_BATCH} clips/GPU x 2 s: encoder -> FA-quantizer -> decoder + predictor heads "
+                    "forward + backward, 5 MPD + 3 MRD discriminators (discriminator step, then generator step with adversarial + "
+                    "feature-matching), 7-scale mel loss, commitment + codebook + F0 / UV / content(focal) / speaker losses with "
+                    "synthetic targets, 5 x (clip + AdamW + ExponentialLR)",
+        "with_predictors": True,
         "parallelism": f"dp{world}: one all-reduce(mean) per model key over RCCL, launched asynchronously under backward",
         "allreduce_bytes_per_step": ar_bytes, "allreduce_ms_standalone": None if ar_ms is None else round(ar_ms, 2),
+        "allreduce_overlap": {"launched_early": [k for k, e in exchange.items() if e["launched"] == "hook"],
+                              "launched_after_backward": [k for k, e in exchange.items() if e["launched"] == "end"],
+                              "wait_ms": {k: (None if e["wait_ms"] is None else round(e["wait_ms"], 3)) for k, e in exchange.items()},
+                              "note": "launched_early = the key's collective was issued from a gradient hook inside backward; wait_ms = "
+                                      "stall of the compute stream at the key's optimiser step (what the overlap failed to hide)"},
         "losses_finite": finite, "loss": round(float(last["loss"]), 4), "mel": round(float(last["mel"]), 4),
-        "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
+        "peak_mem_GB": round(peak_mem / 2 ** 30, 1),
+        "counted_flops": {"per_step_TFLOP": round(fc.total / 1e12, 3), "per_audio_s_TFLOP": round(flop_per_audio_s / 1e12, 4),
+                          "by_kind_TFLOP": {k: round(v / 1e12, 3) for k, v in fc.flops.items()},
+                          "launches": dict(fc.launches),
+                          "survey_estimate_per_audio_s_TFLOP": TRAIN_FLOP_PER_AUDIO_S_SURVEY / 1e12,
+                          "basis": "counted at the C-ABI call sites of one real step (facodec_amd/ops.py FlopCounter): conv fwd / "
+                                   "data-grad / weight-grad launches + LSTM recurrences, batch padding excluded; 'dft' = windowed-DFT "
+                                   "and mel GEMMs of the STFT front-ends, NOT part of the total"},
         "roofline": {"bound": "mfma", "achieved": round(per_gpu_tflops, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(per_gpu_tflops / FP32_MFMA_PEAK_TFLOPS, 4),
-                     "basis": "whole step, per GPU: audio-s/s x 0.77 TFLOP per audio-second (SURVEY.md 8d estimate) against the fp32 "
-                              "MFMA peak; per-kernel numbers in profiles/"},
+                     "basis": "whole step, per GPU: audio-s/s x COUNTED TFLOP per audio-second against the fp32 MFMA peak; "
+                              "per-kernel numbers in profiles/"},
     }
+
+
+def streaming_leg(model, device, hops=2000):
+    """configs[4], short: 480-sample hops through the streaming session (HIP-graph replay), per-hop latency measured on the
+    host around push() + device sync.  tools/stream_bench.py is the 30-minute version."""
+    from facodec_amd.streaming import HOP, StreamingCodec
+    loop = synth.synth_clips(1, SAMPLE_RATE * 20, seed=0).to(device)
+    with torch.no_grad():
+        enrol = loop[:, :, :48000]
+        timbre = model.quantizer(model.encoder(enrol), enrol, n_c=2)[4]
+        sess = StreamingCodec(model, timbre, n_c=2, use_graphs=True)
+        sess.prime(loop[:, :, :4800])
+        torch.cuda.synchronize()
+        lat, pos = [], 4800
+        t_all = time.perf_counter()
+        for _ in range(hops):
+            if pos + HOP > loop.shape[-1]:
+                pos = 0
+            hop = loop[:, :, pos:pos + HOP]
+            pos += HOP
+            t0 = time.perf_counter()
+            sess.push(hop)
+            torch.cuda.synchronize()
+            lat.append(time.perf_counter() - t0)
+        wall = time.perf_counter() - t_all
+    steady = sorted(lat[10:])
+    q = lambda p: round(1e3 * steady[min(len(steady) - 1, int(p * len(steady)))], 4)  # noqa: E731
+    return {"workload": f"configs[4] (short): {hops} hops of {HOP} samples, one stream, carried conv / LSTM state, HIP-graph replay",
+            "hops": hops, "p50_ms": q(0.5), "p99_ms": q(0.99), "rtf": round(wall / (hops * HOP / SAMPLE_RATE), 5)}
 
 
 def respawn_under_launcher(n):
@@ -188,6 +261,8 @@ def main():
     ap.add_argument("--no-train", action="store_true", help="skip the configs[2] train-step leg")
     ap.add_argument("--train-steps", type=int, default=4)
     ap.add_argument("--train-warmup", type=int, default=2)
+    ap.add_argument("--no-streaming", action="store_true", help="skip the configs[4] streaming-latency leg")
+    ap.add_argument("--stream-hops", type=int, default=2000)
     args = ap.parse_args()
 
     if not torch.cuda.is_available():
@@ -235,6 +310,10 @@ def main():
                         "note": "same step with FAC_BF16_SPLIT=0 (k=7 convs on v_mfma_f32_32x32x2_f32)"}
         finally:
             ops.BF16_SPLIT = True
+
+    streaming = None
+    if rank == 0 and world == 1 and not args.no_streaming:
+        streaming = streaming_leg(model, device, args.stream_hops)
 
     train = None
     if not args.no_train:
@@ -291,6 +370,8 @@ def main():
         }
     if train is not None:
         out["train_step"] = train
+    if streaming is not None:
+        out["streaming"] = streaming
     if fp32_ref is not None:
         out["fp32_mfma_only"] = fp32_ref
     if world == 1 and not args.no_cpu_baseline:

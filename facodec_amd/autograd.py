@@ -121,11 +121,12 @@ class _LSTM(Function):
         saved = []
         for l in range(L):
             w_ih, w_hh, b_ih, b_hh = (p.detach() for p in params[4 * l: 4 * l + 4])
-            pre = ops.conv1d(inp.view(1, H, T * BP), ops.pack_conv_weight(w_ih), 4 * H, 1, bias=ops.add(b_ih, b_hh),
-                             pad_left=0, t_out=T * BP, pad_mode=ops.PAD_ZERO)
-            gates = torch.empty(4 * H, T, BP, device=x.device)
-            cs = torch.empty(H, T, BP, device=x.device)
-            yT = ops.lstm_layer(pre.view(4 * H, T, BP), ops.pack_lstm_whh(w_hh), H, save=(gates, cs))
+            with ops.flop_scale(B / BP):
+                pre = ops.conv1d(inp.view(1, H, T * BP), ops.pack_conv_weight(w_ih), 4 * H, 1, bias=ops.add(b_ih, b_hh),
+                                 pad_left=0, t_out=T * BP, pad_mode=ops.PAD_ZERO)
+                gates = torch.empty(4 * H, T, BP, device=x.device)
+                cs = torch.empty(H, T, BP, device=x.device)
+                yT = ops.lstm_layer(pre.view(4 * H, T, BP), ops.pack_lstm_whh(w_hh), H, save=(gates, cs))
             saved.append((inp, yT, gates, cs))
             inp = yT
         ctx.saved = saved
@@ -137,6 +138,11 @@ class _LSTM(Function):
     def backward(ctx, dy):
         x, *params = ctx.saved_tensors
         B, H, T, BP = ctx.dims
+        with ops.flop_scale(B / BP):                                  # batch padding is not algorithmic work
+            return _LSTM._backward(ctx, dy, x, params, B, H, T, BP)
+
+    @staticmethod
+    def _backward(ctx, dy, x, params, B, H, T, BP):
         L = len(params) // 4
         dy = dy.contiguous()
         d_out = ops.lstm_to_time_major(dy)                            # gradient w.r.t. the top layer's h sequence

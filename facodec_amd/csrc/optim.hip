@@ -58,7 +58,81 @@ __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
   }
 }
 
+// ---- masked step: which parameters take part is decided ON THE DEVICE from per-parameter flags that travelled with the
+// gradient arena through the data-parallel all-reduce (flag > 0 on any rank -> every rank steps the parameter, like torch
+// AdamW under DDP steps every parameter whose .grad is set).  No host read of the flags, one launch per key.
+// prepare: steps[j] += 1 and the bias corrections of parameter j where flags[j] > 0; bc[2j] = 0 marks "skip".
+__global__ void adamw_prepare_kernel(const float* __restrict__ flags, int* __restrict__ steps, float* __restrict__ bc, int P,
+                                     float b1, float b2) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= P) return;
+  if (flags[j] > 0.f) {
+    const int s = ++steps[j];
+    bc[2 * j] = (float)(1.0 - pow((double)b1, (double)s));
+    bc[2 * j + 1] = (float)sqrt(1.0 - pow((double)b2, (double)s));
+  } else {
+    bc[2 * j] = 0.f;
+    bc[2 * j + 1] = 1.f;
+  }
+}
+
+constexpr int ADAMW_CHUNK = 2048;   // elements per workgroup trip
+
+__global__ __launch_bounds__(256) void adamw_masked_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                           float* __restrict__ v, long long n, const long long* __restrict__ off,
+                                                           int P, const float* __restrict__ bc, float lr, float b1, float b2,
+                                                           float eps, float wd, const float* __restrict__ clip) {
+  const float gs = clip ? clip[1] : 1.f;
+  const long long n_chunks = (n + ADAMW_CHUNK - 1) / ADAMW_CHUNK;
+  for (long long c = blockIdx.x; c < n_chunks; c += gridDim.x) {
+    const long long base = c * ADAMW_CHUNK;
+    // parameter that owns the chunk's first element: largest j with off[j] <= base (uniform over the workgroup)
+    int lo = 0, hi = P - 1;
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (off[mid] <= base) lo = mid; else hi = mid - 1;
+    }
+    int j = lo;
+    long long next = off[j + 1];
+    float bc1 = bc[2 * j], bc2s = bc[2 * j + 1];
+#pragma unroll
+    for (int k = 0; k < ADAMW_CHUNK / 256; ++k) {
+      const long long i = base + k * 256 + threadIdx.x;
+      if (i >= n) break;
+      while (i >= next) {
+        ++j;
+        next = off[j + 1];
+        bc1 = bc[2 * j];
+        bc2s = bc[2 * j + 1];
+      }
+      if (bc1 == 0.f) continue;
+      const float gi = g[i] * gs;
+      float pi = p[i] * (1.f - lr * wd);
+      const float mi = b1 * m[i] + (1.f - b1) * gi;
+      const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+      m[i] = mi;
+      v[i] = vi;
+      pi -= (lr / bc1) * mi / (sqrtf(vi) / bc2s + eps);
+      p[i] = pi;
+    }
+  }
+}
+
 }  // namespace fac
+
+extern "C" int fac_adamw_step_masked(float* p, const float* g, float* m, float* v, int64_t n, const int64_t* offsets,
+                                     int n_params, const float* flags, int32_t* steps, float* bc, float lr, float beta1,
+                                     float beta2, float eps, float weight_decay, const float* clip, fac_stream_t stream) {
+  using namespace fac;
+  FAC_REQUIRE(p && g && m && v && offsets && flags && steps && bc && n > 0 && n_params > 0, "adamw_step_masked: bad arguments");
+  hipLaunchKernelGGL(adamw_prepare_kernel, dim3((n_params + 255) / 256), dim3(256), 0, (hipStream_t)stream, flags, steps, bc,
+                     n_params, beta1, beta2);
+  const long long n_chunks = (n + ADAMW_CHUNK - 1) / ADAMW_CHUNK;
+  const int blocks = (int)(n_chunks < 16384 ? n_chunks : 16384);
+  hipLaunchKernelGGL(adamw_masked_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (long long)n,
+                     reinterpret_cast<const long long*>(offsets), n_params, bc, lr, beta1, beta2, eps, weight_decay, clip);
+  return check_launch("adamw_step_masked");
+}
 
 extern "C" int fac_grad_norm_clip(const float* g, int64_t n, float max_norm, float* scratch, float* norm_out, fac_stream_t stream) {
   using namespace fac;

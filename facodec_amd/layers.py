@@ -181,7 +181,8 @@ class SLSTM(nn.Module):
             whh = ops.pack_lstm_whh(getattr(p, f"weight_hh_l{l}").detach())
             T_, BP = inp.shape[1], inp.shape[2]
             # one GEMM over every (t, b): the channel-major buffer is a (1, H, T*BP) "signal"
-            pre = ops.conv1d(inp.view(1, H, T_ * BP), w_ih, 4 * H, 1, bias=bias, pad_left=0, t_out=T_ * BP,
-                             pad_mode=ops.PAD_ZERO)
-            inp = ops.lstm_layer(pre.view(4 * H, T_, BP), whh, H)
+            with ops.flop_scale(B / BP):
+                pre = ops.conv1d(inp.view(1, H, T_ * BP), w_ih, 4 * H, 1, bias=bias, pad_left=0, t_out=T_ * BP,
+                                 pad_mode=ops.PAD_ZERO)
+                inp = ops.lstm_layer(pre.view(4 * H, T_, BP), whh, H)
         return ops.lstm_from_time_major(inp, x if self.skip else None, B, alpha_out)

@@ -48,11 +48,13 @@ class _SpectralScale:
         N, T = waves.shape
         frames_n = 1 + T // self.hop
         fr = ops.stft_frames(waves, self.win, frames_n, self.hop, self.n_fft // 2, self.off)
-        spec = ops.conv1d(fr, self.basis, 2 * self.F, 1, pad_left=0, pad_mode=ops.PAD_ZERO, t_out=frames_n)
+        with ops.flop_key("dft"):
+            spec = ops.conv1d(fr, self.basis, 2 * self.F, 1, pad_left=0, pad_mode=ops.PAD_ZERO, t_out=frames_n)
         return ops.spec_power(spec, power)
 
     def mel(self, spec):
-        return ops.conv1d(spec, self.fb, self.n_mels, 1, pad_left=0, pad_mode=ops.PAD_ZERO, t_out=spec.shape[-1])
+        with ops.flop_key("dft"):
+            return ops.conv1d(spec, self.fb, self.n_mels, 1, pad_left=0, pad_mode=ops.PAD_ZERO, t_out=spec.shape[-1])
 
     def backward_to_wave(self, waves, terms, use_mel):
         """d/d waves of sum_i scale_i * pair_term(mode_i)(S(waves), target) for S = mel or magnitude spectrogram.
@@ -61,19 +63,21 @@ class _SpectralScale:
         N, T = waves.shape
         frames_n = 1 + T // self.hop
         fr = ops.stft_frames(waves, self.win, frames_n, self.hop, self.n_fft // 2, self.off)
-        spec = ops.conv1d(fr, self.basis, 2 * self.F, 1, pad_left=0, pad_mode=ops.PAD_ZERO, t_out=frames_n)
+        with ops.flop_key("dft"):
+            spec = ops.conv1d(fr, self.basis, 2 * self.F, 1, pad_left=0, pad_mode=ops.PAD_ZERO, t_out=frames_n)
         mag = ops.spec_power(spec, 1)
         feat = self.mel(mag) if use_mel else mag
         target = self._target
         dfeat = torch.empty_like(feat)
         for i, (mode, eps, scale) in enumerate(terms):
             ops.pair_bwd(feat, target, dfeat, mode, eps, scale, accumulate=i > 0)
-        if use_mel:
-            dmag = ops.conv1d(dfeat, self.fb_bwd, self.F, 1, pad_left=0, pad_mode=ops.PAD_ZERO, t_out=frames_n)
-        else:
-            dmag = dfeat
-        dspec = ops.spec_power_bwd(spec, dmag, 1)
-        dfr = ops.conv1d(dspec, self.basis_bwd, self.win, 1, pad_left=0, pad_mode=ops.PAD_ZERO, t_out=frames_n)
+        with ops.flop_key("dft"):
+            if use_mel:
+                dmag = ops.conv1d(dfeat, self.fb_bwd, self.F, 1, pad_left=0, pad_mode=ops.PAD_ZERO, t_out=frames_n)
+            else:
+                dmag = dfeat
+            dspec = ops.spec_power_bwd(spec, dmag, 1)
+            dfr = ops.conv1d(dspec, self.basis_bwd, self.win, 1, pad_left=0, pad_mode=ops.PAD_ZERO, t_out=frames_n)
         return ops.stft_frames_bwd(dfr, T, self.hop, self.n_fft // 2, self.off)
 
 

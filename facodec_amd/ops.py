@@ -102,6 +102,73 @@ class ConvLaunchProfile:
 
 _PROFILE = None
 
+
+class FlopCounter:
+    """Algorithmic FLOPs of the GEMM-shaped work, counted where the C ABI is called (2 FLOP per multiply-add of the
+    mathematical definition -- padding, tile remainders, the polyphase zero taps and the six-term bf16 split are NOT
+    counted): conv forward / data gradients 2 B C_out T_out C_in K (a stride-s data gradient as the transposed conv it
+    is: 2 B C_in T_in C_out K / s per ... i.e. one MAC per (output sample, tap that exists)), weight gradients
+    2 B C_out C_in K T_out, LSTM recurrences 2 * 4H * H per (clip, step).  Elementwise work, FFT-free losses' small GEMMs
+    booked as "dft" and left out of `total`, attention score products excluded (< 0.1 %).  Install with set_flop_counter();
+    by key: conv, wgrad, lstm, dft."""
+
+    def __init__(self):
+        self.flops = dict(conv=0.0, wgrad=0.0, lstm=0.0, dft=0.0)
+        self.launches = dict(conv=0, wgrad=0, lstm=0, dft=0)
+
+    def add(self, key, f):
+        self.flops[key] += f * _FLOP_SCALE
+        self.launches[key] += 1
+
+    @property
+    def total(self):
+        """Model MACs x 2: everything but the DFT-as-GEMM front-ends."""
+        return sum(v for k, v in self.flops.items() if k != "dft")
+
+
+_FLOPS = None
+_FLOP_SCALE = 1.0
+
+
+def set_flop_counter(c):
+    global _FLOPS
+    _FLOPS = c
+
+
+_FLOP_KEY = "conv"
+
+
+class flop_key:
+    """Conv launches inside are booked under `key` instead of "conv": the windowed-DFT and mel-filterbank GEMMs of the STFT
+    front-ends ("dft") are this build's way of doing an FFT, not MACs of the model."""
+
+    def __init__(self, key):
+        self.key = key
+
+    def __enter__(self):
+        global _FLOP_KEY
+        self.prev, _FLOP_KEY = _FLOP_KEY, self.key
+
+    def __exit__(self, *a):
+        global _FLOP_KEY
+        _FLOP_KEY = self.prev
+
+
+class flop_scale:
+    """Launches inside count `s` times their nominal FLOPs: the LSTM buffers carry the batch padded to 32 columns per time
+    step, and the padding is not algorithmic work (s = B / BP)."""
+
+    def __init__(self, s):
+        self.s = s
+
+    def __enter__(self):
+        global _FLOP_SCALE
+        self.prev, _FLOP_SCALE = _FLOP_SCALE, self.s
+
+    def __exit__(self, *a):
+        global _FLOP_SCALE
+        _FLOP_SCALE = self.prev
+
 # k = 7 convs on the bf16 matrix pipe with fp32-exact operand splitting (conv1d_bsplit.hip).  Results have
 # fp32-MFMA-grade error (DESIGN.md 3.5); FAC_BF16_SPLIT=0 keeps every conv on the fp32 MFMA kernel.
 BF16_SPLIT = os.environ.get("FAC_BF16_SPLIT", "1") != "0"
@@ -129,6 +196,8 @@ def _launch_conv(d, what):
     lib = _lib.load()
     ws = _conv_workspace(torch.device("cuda", torch.cuda.current_device()))
     d.ws, d.ws_bytes = ws.data_ptr(), CONV_WS_BYTES
+    if _FLOPS is not None:
+        _FLOPS.add(_FLOP_KEY, 2.0 * d.B * d.n_phase * d.C_out * d.T_out * d.C_in * d.K + (2.0 * d.B * d.C_out * d.T_out * d.C_out if d.w_k1 else 0.0))
     if _PROFILE is None:
         _lib.check(lib.fac_conv1d_fwd(C.byref(d), _stream()), what)
         return
@@ -289,6 +358,8 @@ def lstm_layer(pre, whh_packed, H, state=None, step0=0, save=None):
     session with `step0` steps already taken (None: fresh zero state).  save = (gates (4H,T,BP), c (H,T,BP)):
     training mode, the activations back-propagation through time needs are stored there."""
     _, T, BP = pre.shape
+    if _FLOPS is not None:
+        _FLOPS.add("lstm", 2.0 * 4 * H * H * T * BP)
     yT = torch.empty(H, T, BP, device=pre.device, dtype=torch.float32)
     if state is None:
         state = torch.empty(3, H, BP, device=pre.device, dtype=torch.float32)   # cell state + 2 fragment-ordered h
@@ -534,6 +605,8 @@ def _bwd_weight_launch(x, dy, dw, B, c_in, t_in, c_out, t_out, k, stride, dilati
     """dW on the bf16 matrix pipe with fp32-exact splitting (conv1d_wgrad_split.hip) when the shape qualifies and
     FAC_BF16_SPLIT is on, else on the fp32 MFMA kernel."""
     lib = _lib.load()
+    if _FLOPS is not None:
+        _FLOPS.add("wgrad", 2.0 * B * c_out * c_in * k * t_out)
     nbytes = lib.fac_conv1d_bwd_weight_split_ws_bytes(B, c_in, t_in, c_out, t_out, k, stride, dilation, k1, dilation2) if BF16_SPLIT else -1
     if nbytes > 0:
         ws = torch.empty(nbytes // 4, device=x.device, dtype=torch.float32)

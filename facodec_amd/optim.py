@@ -10,9 +10,18 @@ Per model key there are four contiguous arenas (parameters, gradients, first / s
     few, large collectives for the point-to-point xGMI links), launched asynchronously (`launch_all_reduce`) as soon
     as that key's backward is complete and waited for only in `step` -- RCCL runs it on its own stream under the
     rest of the backward pass;
-  * the step is `fac_grad_norm_clip` (two-stage reduction) + `fac_adamw_step` (one launch per run of parameters
-    that received a gradient; parameters whose gradient autograd never produced are skipped exactly like torch's
-    AdamW skips `grad is None` -- no weight decay, no moment update).
+  * WHICH parameters are stepped is decided on the device.  One flag per parameter ("autograd produced a gradient for
+    it on this rank") rides at the tail of the gradient arena through the same all-reduce, so after the exchange a
+    flag is > 0 iff ANY rank reached the parameter; `fac_adamw_step_masked` steps exactly those on every rank (their
+    slice holds the averaged gradient everywhere) with a per-parameter step count kept on the device, and leaves the
+    others alone -- no weight decay, no moment update -- like torch's AdamW skips `grad is None`.  Ranks therefore
+    cannot drift apart when a parameter is reached on one rank only, and no host read sits between backward and step;
+  * the step is `fac_grad_norm_clip` (two-stage reduction) + `fac_adamw_step_masked` (one launch per key).
+
+Gradients written by hand.  Autograd's accumulation marks a parameter through a post-accumulate-grad hook; assigning a
+new tensor to `p.grad` is folded into the arena and marked by `gather_grads()` / `step()`; an IN-PLACE write into the
+pre-bound view (`p.grad.copy_(...)`, `p.grad.add_(...)`) is invisible to both -- call `mark_grads()` (all parameters, or
+the ones given) after writing gradients that way, otherwise those parameters are skipped like `grad is None`.
 """
 import os
 
@@ -22,22 +31,35 @@ import torch.distributed as dist
 from . import _lib, ops
 
 
+def _dist_on():
+    return dist.is_available() and dist.is_initialized()
+
+
 class FlatAdamW:
-    def __init__(self, params, lr=1e-4, betas=(0.9, 0.98), eps=1e-9, weight_decay=0.1, gamma=0.999996, max_norm=1000.0):
+    def __init__(self, params, lr=1e-4, betas=(0.9, 0.98), eps=1e-9, weight_decay=0.1, gamma=0.999996, max_norm=1000.0,
+                 data_parallel=True):
+        """data_parallel=False: the gradients are averaged by somebody else (the modules are wrapped in torch's
+        DistributedDataParallel as train.py:110-111 does) -- no arena all-reduce, only the tiny flag exchange."""
         self.params = [p for p in params if p.requires_grad]
         if not self.params:
             raise ValueError("no trainable parameters")
         dev = self.params[0].device
         n = sum(p.numel() for p in self.params)
+        P = len(self.params)
+        self.n, self.data_parallel = n, data_parallel
         self.p = torch.empty(n, device=dev, dtype=torch.float32)
-        self.g = torch.zeros(n, device=dev, dtype=torch.float32)
+        self._gx = torch.zeros(n + P, device=dev, dtype=torch.float32)     # gradients | per-parameter flags
+        self.g = self._gx[:n]
+        self._flags = self._gx[n:]
         self.m = torch.zeros(n, device=dev, dtype=torch.float32)
         self.v = torch.zeros(n, device=dev, dtype=torch.float32)
         self._scratch = torch.empty(1024, device=dev, dtype=torch.float32)
+        self._bc = torch.empty(2 * P, device=dev, dtype=torch.float32)
+        self._steps_dev = torch.zeros(P, device=dev, dtype=torch.int32)    # torch AdamW keeps one step count per parameter
         self.norm = torch.zeros(2, device=dev, dtype=torch.float32)
         off = 0
         self.slices = []
-        self._touched = [False] * len(self.params)
+        self._touched = [False] * P
         for i, p in enumerate(self.params):
             k = p.numel()
             self.p[off:off + k].copy_(p.data.reshape(-1))
@@ -46,29 +68,57 @@ class FlatAdamW:
             p.register_post_accumulate_grad_hook(self._mark(i))
             self.slices.append((off, k))
             off += k
+        self._offsets = torch.tensor([s[0] for s in self.slices] + [n], dtype=torch.int64).to(dev)
         self.lr, self.base_lr = lr, lr
         self.betas, self.eps, self.wd, self.gamma, self.max_norm = betas, eps, weight_decay, gamma, max_norm
-        self.param_steps = [0] * len(self.params)            # torch AdamW keeps one step count per parameter
         self.lr_epochs = 0                                    # ExponentialLR.last_epoch
         self._work = None
         self._need_scale = False
+        self._flags_final = False                             # flags uploaded (and exchanged) for the pending step
+        self._flags_pat, self._flags_cache = None, None
         self._expected = None                                 # parameters the previous step's backward reached
+        self.exchange_log = []                                # per step: "hook" (launched from inside backward) | "end" | "none"
+        self._launched_from = "none"
+        self.time_exchange, self._wait_events = False, None
 
     def _mark(self, i):
         def hook(_p):
             self._touched[i] = True
         return hook
 
+    # ------------------------------------------------------------------------------------------ torch-optimizer shims
+    @property
+    def param_groups(self):
+        """What the reference's loop reads from an optimiser / scheduler (train.py:384 `get_last_lr()[0]`)."""
+        return [dict(params=self.params, lr=self.lr, betas=tuple(self.betas), eps=self.eps, weight_decay=self.wd,
+                     initial_lr=self.base_lr)]
+
+    def get_last_lr(self):
+        return [self.lr]
+
+    @property
+    def param_steps(self):
+        """Per-parameter step counts (device-side state; reading them synchronises -- checkpoints and tests only)."""
+        return [int(s) for s in self._steps_dev.tolist()]
+
     @property
     def steps(self):
         return max(self.param_steps)
 
     # ------------------------------------------------------------------------------------------ gradients
-    def zero_grad(self):
-        """One memset of the gradient arena; the `.grad` views stay bound (torch's zero_grad(set_to_none) would unbind)."""
+    def _drain(self):
+        """A pending asynchronous exchange must finish before anybody writes into the arena."""
+        if self._work is not None:
+            self.wait_all_reduce()
+
+    def zero_grad(self, set_to_none=False):
+        """One memset of the gradient arena (+ flags); the `.grad` views stay bound (set_to_none is accepted and ignored:
+        unbinding would only force a re-bind)."""
+        self._drain()
         self._rebind()
-        self.g.zero_()
+        self._gx.zero_()
         self._touched = [False] * len(self.params)
+        self._flags_final = False
 
     def _rebind(self):
         """`p.grad` must be the arena view (someone may have set it to None or to a foreign tensor), `p.data` must still
@@ -81,24 +131,50 @@ class FlatAdamW:
             if p.grad is None:
                 p.grad = self.g[off:off + k].view_as(p)
             elif p.grad.data_ptr() != base_g + 4 * off:       # foreign gradient tensor: fold it in once, then rebind
+                self._drain()
                 self.g[off:off + k].copy_(p.grad.reshape(-1))
                 p.grad = self.g[off:off + k].view_as(p)
                 self._touched[i] = True
+                self._flags_final = False
 
-    def gather_grads(self):
-        """Compatibility with callers that assign `.grad` tensors by hand: folds them into the arena (no-op for views)."""
+    def gather_grads(self, mark_all=False):
+        """Compatibility with callers that assign `.grad` tensors by hand: folds them into the arena (no-op for views).
+        mark_all: also count every parameter as having a gradient (for in-place writes into the views)."""
         self._rebind()
+        if mark_all:
+            self.mark_grads()
+
+    def mark_grads(self, params=None):
+        """Declare hand-written (in-place) gradients: all parameters, or the given ones."""
+        if params is None:
+            self._touched = [True] * len(self.params)
+        else:
+            ids = {id(p) for p in params}
+            for i, p in enumerate(self.params):
+                if id(p) in ids:
+                    self._touched[i] = True
+        self._flags_final = False
 
     def backward_complete(self):
         """True once every parameter the previous step's backward reached has been reached again (the usage pattern of
         the model is static, so all ranks agree): the arena is final and may be handed to the collective early."""
         return self._expected is not None and all(t or not e for t, e in zip(self._touched, self._expected))
 
+    def _upload_flags(self):
+        """Local flags -> tail of the gradient arena.  The usage pattern of the model is static after the first step, so the
+        pattern is kept as a device tensor and re-used (a device-to-device copy, no host transfer in the steady state)."""
+        pat = tuple(self._touched)
+        if pat != self._flags_pat:
+            self._flags_cache = torch.tensor(pat, dtype=torch.float32).to(self._gx.device)
+            self._flags_pat = pat
+        self._flags.copy_(self._flags_cache)
+
     def launch_all_reduce(self, only_if_complete=False):
-        """Data-parallel exchange: one asynchronous all-reduce(mean) of the whole arena (RCCL over xGMI under backend
-        'nccl'; it runs on the process group's stream, after everything already queued on the current stream).
-        only_if_complete: called from inside backward (gradient hooks) -- launch only when `backward_complete()`."""
-        if self._work is not None or not (dist.is_available() and dist.is_initialized()):
+        """Data-parallel exchange: one asynchronous all-reduce(mean) of the whole arena, flags included (RCCL over xGMI
+        under backend 'nccl'; it runs on the process group's stream, after everything already queued on the current
+        stream).  only_if_complete: called from inside backward (gradient hooks) -- launch only when
+        `backward_complete()`."""
+        if self._work is not None or self._flags_final or not _dist_on():
             return
         # a single rank has nothing to exchange; FAC_FORCE_ALLREDUCE=1 still issues the collective (smoke-tests the RCCL path --
         # AVG op, async work handle, stream hand-over -- on a one-GPU box: the mean over one rank is the identity)
@@ -106,58 +182,74 @@ class FlatAdamW:
             return
         if only_if_complete and not self.backward_complete():
             return
-        if dist.get_backend() == "nccl":          # RCCL: the mean is part of the collective
-            self._work = dist.all_reduce(self.g, op=dist.ReduceOp.AVG, async_op=True)
+        self._upload_flags()
+        self._flags_final = True
+        self._launched_from = "hook" if only_if_complete else "end"
+        if not self.data_parallel:     # gradients already averaged by a DDP wrapper: only the flags travel (MAX: any rank)
+            self._work = dist.all_reduce(self._flags, op=dist.ReduceOp.MAX, async_op=True)
+        elif dist.get_backend() == "nccl":          # RCCL: the mean is part of the collective
+            self._work = dist.all_reduce(self._gx, op=dist.ReduceOp.AVG, async_op=True)
         else:   # gloo (CPU test scaffold, or two ranks sharing one GPU in a smoke run) has no AVG
-            self._work = dist.all_reduce(self.g, op=dist.ReduceOp.SUM, async_op=True)
+            self._work = dist.all_reduce(self._gx, op=dist.ReduceOp.SUM, async_op=True)
             self._need_scale = True
 
     def wait_all_reduce(self):
         if self._work is not None:
-            self._work.wait()                                 # makes the current stream wait for the collective
-            self._work = None
+            work, self._work = self._work, None               # cleared first: an exception in wait() must not wedge the next step
+            timed = self.time_exchange and self._gx.is_cuda
+            if timed:                                         # how long the compute stream stalls for the collective: what the
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)   # overlap failed to hide
+                e0.record()
+            work.wait()                                       # makes the current stream wait for the collective
+            if timed:
+                e1.record()
+                self._wait_events = (e0, e1)
             if self._need_scale:
-                self.g.mul_(1.0 / dist.get_world_size())
+                self._gx.mul_(1.0 / dist.get_world_size())
                 self._need_scale = False
 
     def all_reduce_mean(self):
         self.launch_all_reduce()
         self.wait_all_reduce()
 
-    # ------------------------------------------------------------------------------------------ step
-    def _active_runs(self):
-        """Maximal runs of consecutive parameters that received a gradient and share a step count -> (offset, n, step)."""
-        runs = []
-        for i, (off, k) in enumerate(self.slices):
-            if not self._touched[i]:
-                continue
-            st = self.param_steps[i] + 1
-            if runs and runs[-1][0] + runs[-1][1] == off and runs[-1][2] == st:
-                runs[-1][1] += k
-            else:
-                runs.append([off, k, st])
-        return runs
+    def exchange_wait_ms(self):
+        """Stall of the compute stream at the last `wait_all_reduce` (needs `time_exchange = True`; synchronises)."""
+        if self._wait_events is None:
+            return None
+        e0, e1 = self._wait_events
+        e1.synchronize()
+        return e0.elapsed_time(e1)
 
+    def broadcast_parameters(self, src=0):
+        """Construction-time parameter broadcast of DistributedDataParallel (train.py:110-111 via accelerator.prepare) as ONE
+        collective over the parameter arena: every rank starts from rank `src`'s weights."""
+        if _dist_on() and dist.get_world_size() > 1:
+            dist.broadcast(self.p, src=src)
+
+    # ------------------------------------------------------------------------------------------ step
     def step(self, zero_grad=True, advance_lr=True):
         lib = _lib.load()
-        n = self.p.numel()
         st = ops._stream()
+        self._drain()                                          # nothing may write into the arena under a running collective
         self._rebind()
         self.all_reduce_mean()
+        if not self._flags_final:                              # single rank (or no process group): local flags
+            self._upload_flags()
         clip = None
         if self.max_norm is not None:
-            _lib.check(lib.fac_grad_norm_clip(ops._ptr(self.g), n, self.max_norm, ops._ptr(self._scratch), ops._ptr(self.norm), st),
+            _lib.check(lib.fac_grad_norm_clip(ops._ptr(self.g), self.n, self.max_norm, ops._ptr(self._scratch), ops._ptr(self.norm), st),
                        "fac_grad_norm_clip")
             clip = self.norm
-        for off, k, step in self._active_runs():
-            sl = slice(off, off + k)
-            _lib.check(lib.fac_adamw_step(ops._ptr(self.p[sl]), ops._ptr(self.g[sl]), ops._ptr(self.m[sl]), ops._ptr(self.v[sl]), k,
-                                          self.lr, self.betas[0], self.betas[1], self.eps, self.wd, step, ops._ptr(clip), st),
-                       "fac_adamw_step")
-        for i, t in enumerate(self._touched):
-            if t:
-                self.param_steps[i] += 1
+        _lib.check(lib.fac_adamw_step_masked(ops._ptr(self.p), ops._ptr(self.g), ops._ptr(self.m), ops._ptr(self.v), self.n,
+                                             ops._ptr(self._offsets), len(self.params), ops._ptr(self._flags), ops._ptr(self._steps_dev),
+                                             ops._ptr(self._bc), self.lr, self.betas[0], self.betas[1], self.eps, self.wd,
+                                             ops._ptr(clip), st), "fac_adamw_step_masked")
         self._expected = tuple(self._touched)
+        self.exchange_log.append(self._launched_from)
+        self._launched_from = "none"
+        if len(self.exchange_log) > 64:
+            del self.exchange_log[:-64]
+        self._flags_final = False
         if advance_lr:
             self.scheduler_step()
         if zero_grad:
@@ -173,7 +265,7 @@ class FlatAdamW:
         return self.norm[0].clone()
 
     def params_without_grad(self):
-        """Indices of the parameters the last backward did not reach."""
+        """Indices of the parameters the last backward did not reach on THIS rank."""
         return [i for i, t in enumerate(self._touched) if not t]
 
     # ------------------------------------------------------------------------------------------ checkpoint state
@@ -181,9 +273,10 @@ class FlatAdamW:
         """torch.optim.AdamW.state_dict() layout (what the reference's checkpoints carry per key, optimizers.py:17-20):
         state[i] = {step, exp_avg, exp_avg_sq} for the parameters that have been stepped, one param group."""
         state = {}
+        steps = self.param_steps
         for i, (p, (off, k)) in enumerate(zip(self.params, self.slices)):
-            if self.param_steps[i] > 0:
-                state[i] = dict(step=torch.tensor(float(self.param_steps[i])),
+            if steps[i] > 0:
+                state[i] = dict(step=torch.tensor(float(steps[i])),
                                 exp_avg=self.m[off:off + k].view_as(p).clone(), exp_avg_sq=self.v[off:off + k].view_as(p).clone())
         group = dict(lr=self.lr, betas=tuple(self.betas), eps=self.eps, weight_decay=self.wd, amsgrad=False, maximize=False,
                      foreach=None, capturable=False, differentiable=False, fused=None, initial_lr=self.base_lr,
@@ -191,23 +284,33 @@ class FlatAdamW:
         return dict(state=state, param_groups=[group])
 
     def load_state_dict(self, sd):
+        """Validates everything BEFORE touching any state (torch's load_state_dict fails without side effects, and the
+        reference's MultiOptimizer prints 'Unloaded' and carries on with the optimiser as it was, optimizers.py:27-32)."""
         group = sd["param_groups"][0]
         if len(group["params"]) != len(self.params):
             raise ValueError(f"optimizer state has {len(group['params'])} parameters, this key has {len(self.params)}")
-        self.lr = float(group["lr"])
-        self.base_lr = float(group.get("initial_lr", self.base_lr))
-        self.betas, self.eps, self.wd = tuple(group["betas"]), float(group["eps"]), float(group["weight_decay"])
-        self.m.zero_()
-        self.v.zero_()
-        self.param_steps = [0] * len(self.params)
+        lr, base_lr = float(group["lr"]), float(group.get("initial_lr", self.base_lr))
+        betas, eps, wd = tuple(float(b) for b in group["betas"]), float(group["eps"]), float(group["weight_decay"])
+        todo = []
         for idx, pid in enumerate(group["params"]):
             st = sd["state"].get(pid)
             if st is None:
                 continue
             off, k = self.slices[idx]
-            self.m[off:off + k].copy_(st["exp_avg"].reshape(-1))
-            self.v[off:off + k].copy_(st["exp_avg_sq"].reshape(-1))
-            self.param_steps[idx] = int(float(st["step"]))
+            for name in ("exp_avg", "exp_avg_sq"):
+                if st[name].numel() != k:
+                    raise ValueError(f"optimizer state {name}[{pid}] has {st[name].numel()} elements, parameter {idx} has {k}")
+            todo.append((idx, off, k, st["exp_avg"], st["exp_avg_sq"], int(float(st["step"]))))
+        self._drain()
+        self.lr, self.base_lr, self.betas, self.eps, self.wd = lr, base_lr, betas, eps, wd
+        self.m.zero_()
+        self.v.zero_()
+        steps = [0] * len(self.params)
+        for idx, off, k, m, v, s in todo:
+            self.m[off:off + k].copy_(m.reshape(-1))
+            self.v[off:off + k].copy_(v.reshape(-1))
+            steps[idx] = s
+        self._steps_dev.copy_(torch.tensor(steps, dtype=torch.int32))
 
     def scheduler_state_dict(self):
         """torch ExponentialLR.state_dict() keys the reference's checkpoints hold (optimizers.py:22-25)."""
@@ -215,20 +318,39 @@ class FlatAdamW:
                     _last_lr=[self.lr])
 
     def load_scheduler_state_dict(self, sd):
-        self.gamma = float(sd["gamma"])
-        self.base_lr = float(sd["base_lrs"][0])
-        self.lr_epochs = int(sd["last_epoch"])
+        gamma, base_lr, epochs = float(sd["gamma"]), float(sd["base_lrs"][0]), int(sd["last_epoch"])
+        self.gamma, self.base_lr, self.lr_epochs = gamma, base_lr, epochs
         self.lr = float(sd["_last_lr"][0]) if "_last_lr" in sd else self.base_lr * self.gamma ** self.lr_epochs
+
+
+class _SchedulerView:
+    """`optimizer.schedulers[key]` of optimizers.py:11-16: the object train.py:384 asks for `get_last_lr()`."""
+
+    def __init__(self, opt):
+        self._opt = opt
+
+    def get_last_lr(self):
+        return self._opt.get_last_lr()
+
+    def step(self, *args):
+        self._opt.scheduler_step()
+
+    def state_dict(self):
+        return self._opt.scheduler_state_dict()
+
+    def load_state_dict(self, sd):
+        self._opt.load_scheduler_state_dict(sd)
 
 
 class MultiOptimizer:
     """optimizers.py:11-70 over FlatAdamW: `step(key)`, `scheduler(key=)`, `zero_grad(key)`, and the (key, state) list
     formats of `state_dict` / `scheduler_state_dict` that modules/commons.py:446-471 `load_checkpoint` and train.py's
-    checkpoint writer exchange."""
+    checkpoint writer exchange.  `step` includes FlatAdamW's own clip at the key's max_norm: after the caller's
+    `clip_grad_norm_` with the same bound (train.py:290,362-365) the second clip coefficient is 1."""
 
     def __init__(self, optimizers):
         self.optimizers = dict(optimizers)
-        self.schedulers = self.optimizers                     # the LR schedule lives in the same object
+        self.schedulers = {k: _SchedulerView(o) for k, o in self.optimizers.items()}
         self.keys = list(self.optimizers)
 
     def state_dict(self):
@@ -252,6 +374,8 @@ class MultiOptimizer:
                 print("Unloaded %s" % k)
 
     def step(self, key=None, scaler=None):
+        if scaler is not None:
+            raise NotImplementedError("GradScaler is not supported: the step is fp32 (train.py runs without mixed precision)")
         for k in ([key] if key is not None else self.keys):
             self.optimizers[k].step(zero_grad=False, advance_lr=False)
 
@@ -264,9 +388,38 @@ class MultiOptimizer:
             self.optimizers[k].scheduler_step()
 
 
-def build_optimizer(model_dict, scheduler_params_dict=None, lr=1e-4, type="AdamW"):
-    """optimizers.py:72-108 (AdamW only; ScaledAdam belongs to the unused transformer_modules tree)."""
+def _unwrap(m):
+    return m.module if isinstance(m, torch.nn.parallel.DistributedDataParallel) else m
+
+
+def sync_module_states(model_dict, src=0):
+    """What DistributedDataParallel's constructor does for train.py:110-111: every rank starts from rank `src`'s parameters
+    and buffers.  For modules NOT wrapped in DDP (the arena path); per key one broadcast of the parameters flattened into
+    one tensor, one of the float buffers."""
+    if not (_dist_on() and dist.get_world_size() > 1):
+        return
+    for m in model_dict.values():
+        tensors = [p.data for p in _unwrap(m).parameters()] + [b for b in _unwrap(m).buffers() if b.is_floating_point()]
+        if not tensors:
+            continue
+        flat = torch.cat([t.reshape(-1).to(torch.float32) for t in tensors])
+        dist.broadcast(flat, src=src)
+        off = 0
+        with torch.no_grad():
+            for t in tensors:
+                t.copy_(flat[off:off + t.numel()].view_as(t))
+                off += t.numel()
+
+
+def build_optimizer(model_dict, scheduler_params_dict=None, lr=1e-4, type="AdamW", broadcast=True):
+    """optimizers.py:72-108 (AdamW only; ScaledAdam belongs to the unused transformer_modules tree).  A key wrapped in
+    DistributedDataParallel (train.py:110-111) keeps DDP's own gradient averaging; an unwrapped key gets the arena
+    all-reduce, and -- broadcast=True, process group initialised -- starts from rank 0's parameters like DDP would."""
     if type != "AdamW":
         raise ValueError("Unknown optimizer type: %s" % type)
     max_norm = {"discriminator": 10.0}                       # train.py:290 vs :362-365
-    return MultiOptimizer({k: FlatAdamW(m.parameters(), lr=lr, max_norm=max_norm.get(k, 1000.0)) for k, m in model_dict.items()})
+    ddp = torch.nn.parallel.DistributedDataParallel
+    if broadcast:
+        sync_module_states({k: m for k, m in model_dict.items() if not isinstance(m, ddp)})
+    return MultiOptimizer({k: FlatAdamW(m.parameters(), lr=lr, max_norm=max_norm.get(k, 1000.0),
+                                        data_parallel=not isinstance(m, ddp)) for k, m in model_dict.items()})

@@ -40,8 +40,11 @@ def crop_segments(waves, mel_input_length, max_frame_len=80, hop=300, starts=Non
 class GeneratorStep:
     """Generator half without the GAN / predictor terms: 15 mel + 0.25 commitment + codebook (train.py:357-358 subset)."""
 
-    def __init__(self, model, lr=1e-4, sample_rate=24000):
+    def __init__(self, model, lr=1e-4, sample_rate=24000, broadcast=True):
+        """broadcast: with a process group of more than one rank, every rank starts from rank 0's parameters (what
+        DistributedDataParallel's constructor does for train.py:110-111) -- one broadcast of each key's parameter arena."""
         self.model = model
+        self._broadcast = broadcast
         for k in ("encoder", "quantizer", "decoder"):
             model[k].train()
         self.mel = losses.MelSpectrogramLoss(n_mels=[5, 10, 20, 40, 80, 160, 320], window_lengths=[32, 64, 128, 256, 512, 1024, 2048],
@@ -50,6 +53,40 @@ class GeneratorStep:
         self.opt = {"encoder": optim.FlatAdamW(model.encoder.parameters(), lr=lr),
                     "quantizer": optim.FlatAdamW(model.quantizer.parameters(), lr=lr),
                     "decoder": optim.FlatAdamW(model.decoder.parameters(), lr=lr)}
+        self._sync_start(self.opt.values())
+
+    def _sync_start(self, opts):
+        if self._broadcast:
+            for o in opts:
+                o.broadcast_parameters(0)
+
+    def _early_exchange(self, outs, z):
+        """Launch each key's gradient exchange from inside backward, as soon as the key is final.  Autograd runs ready nodes
+        latest-created first, so when the gradient of the decoder input `outs` is handed on, every decoder parameter has been
+        accumulated, and when the gradient of the encoder output `z` is handed on, the predictor heads and the whole
+        quantizer (side branches included: they were created after the encoder) are done: the decoder's 342 MB ride under
+        the quantizer + encoder backward, the quantizer's / predictors' under the encoder backward.  `only_if_complete`
+        double-checks against the previous step's usage pattern; a key that is not complete simply launches after backward.
+        Every rank issues the collectives in the same order because the usage pattern of this model is static
+        (FAC_EARLY_EXCHANGE=0 switches the hooks off)."""
+        import os
+        if os.environ.get("FAC_EARLY_EXCHANGE", "1") == "0":
+            return
+        opt = self.opt
+        outs.register_hook(lambda g: opt["decoder"].launch_all_reduce(only_if_complete=True))
+
+        def at_z(g):
+            for k in ("fa_predictors", "quantizer"):
+                if k in opt and (k != "fa_predictors" or getattr(self, "with_predictors", False)):
+                    opt[k].launch_all_reduce(only_if_complete=True)
+        z.register_hook(at_z)
+
+    def exchange_report(self):
+        """Per key: where the last step's gradient exchange was launched from -- "hook" (inside backward: it overlaps the
+        rest of the backward pass), "end" (after backward: no overlap), "none" (single rank) -- and, with
+        `opt[k].time_exchange = True`, how long the compute stream stalled for it."""
+        return {k: dict(launched=(o.exchange_log[-1] if o.exchange_log else "none"), wait_ms=o.exchange_wait_ms())
+                for k, o in self.opt.items()}
 
     def _zero(self, keys):
         for k in keys:
@@ -63,7 +100,7 @@ class GeneratorStep:
         wave_hat = m.decoder(outs)
         mel = self.mel(wave_hat, wave)
         loss = 15.0 * mel + 0.25 * commitment + 1.0 * codebook
-        outs.register_hook(lambda g: self.opt["decoder"].launch_all_reduce(only_if_complete=True))
+        self._early_exchange(outs, z)
         loss.backward()
         return dict(loss=loss.detach(), mel=mel.detach(), commitment=commitment.detach(), codebook=codebook.detach())
 
@@ -83,14 +120,15 @@ class TrainStep(GeneratorStep):
     CTC phoneme model and a speaker model, none of which is part of this build).  After a call every `p.grad` still holds
     the (rank-averaged, unclipped) gradient of the step; the arenas are cleared at the start of the next call."""
 
-    def __init__(self, model, lr=1e-4, sample_rate=24000, with_predictors=False):
-        super().__init__(model, lr, sample_rate)
+    def __init__(self, model, lr=1e-4, sample_rate=24000, with_predictors=False, broadcast=True):
+        super().__init__(model, lr, sample_rate, broadcast)
         model.discriminator.train()
         self.opt["discriminator"] = optim.FlatAdamW(model.discriminator.parameters(), lr=lr, max_norm=10.0)
         self.with_predictors = with_predictors
         if with_predictors:
             model.fa_predictors.train()
             self.opt["fa_predictors"] = optim.FlatAdamW(model.fa_predictors.parameters(), lr=lr)
+        self._sync_start([self.opt[k] for k in ("discriminator", "fa_predictors") if k in self.opt])
         self.stft = losses.MultiScaleSTFTLoss()
         self.l1 = losses.L1Loss()
 
@@ -170,7 +208,7 @@ class TrainStep(GeneratorStep):
             loss = 15.0 * mel + 1.0 * loss_feat + 1.0 * loss_g + 0.25 * commitment + 1.0 * codebook
             if self.with_predictors:
                 loss = loss + pred_total
-            outs.register_hook(lambda g: opt["decoder"].launch_all_reduce(only_if_complete=True))
+            self._early_exchange(outs, z)
             loss.backward()
         finally:
             for p in opt["discriminator"].params:

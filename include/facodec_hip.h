@@ -217,6 +217,16 @@ int fac_rows_fma(const float* a, const float* w, const float* c, float* out, int
 int fac_grad_norm_clip(const float* g, int64_t n, float max_norm, float* scratch, float* norm_out, fac_stream_t stream);
 int fac_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
                    float weight_decay, int64_t step, const float* clip, fac_stream_t stream);
+/* The same step with the set of stepped parameters decided on the device: the arena holds n_params parameters, parameter j =
+ * elements [offsets[j], offsets[j+1]) (offsets: n_params + 1 int64 device values, offsets[0] = 0, offsets[n_params] = n);
+ * flags[j] > 0 <=> parameter j received a gradient on some rank (the flags ride at the tail of the gradient arena through
+ * the data-parallel all-reduce, so no host round trip decides this); such a parameter's step count steps[j] (int32, device)
+ * is advanced and it is updated with the bias correction of ITS count (torch keeps one count per parameter); the others are
+ * left untouched -- no weight decay, no moment update -- as torch.optim.AdamW skips `grad is None` (optimizers.py:72-108
+ * under accelerate's DDP, train.py:362-374).  bc: scratch of 2 * n_params floats. */
+int fac_adamw_step_masked(float* p, const float* g, float* m, float* v, int64_t n, const int64_t* offsets, int n_params,
+                          const float* flags, int32_t* steps, float* bc, float lr, float beta1, float beta2, float eps,
+                          float weight_decay, const float* clip, fac_stream_t stream);
 /* Training path of the FA-quantizer's side branches (modules/wavenet.py gate, modules/style_encoder.py Mish / GLU /
  * masked mean, modules/attentions.py attention): elementwise backward kernels, and attention with the probability
  * matrix P (B, H, T, T) kept in HBM so that dropout on it and the softmax backward are row kernels.

@@ -1,0 +1,116 @@
+"""Drop-in boundary: the pieces of the reference's callers that reach INTO the modules --
+`model.quantizer[.module].timbre_linear / .timbre_norm` (train.py:450-453, eval.py:155-158), the optimiser / scheduler
+objects train.py talks to (optimizers.py:11-70, train.py:384), and the DistributedDataParallel wrapping of train.py:110-111."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_quantizer_exposes_timbre_norm_without_state():
+    """modules/quantize.py:199: nn.LayerNorm(1024, elementwise_affine=False) -- callable attribute, no parameters / buffers."""
+    from facodec_amd.commons import build_model, default_model_params
+    q = build_model(default_model_params()).quantizer
+    assert callable(q.timbre_norm) and callable(q.timbre_linear)
+    assert list(q.timbre_norm.parameters()) == [] and list(q.timbre_norm.buffers()) == []
+    assert not any(k.startswith("timbre_norm") for k in q.state_dict())
+    assert q.timbre_norm.normalized_shape == (1024,) and q.timbre_norm.elementwise_affine is False
+    with pytest.raises(Exception):            # CPU tensors: the product path has no CPU fallback
+        q.timbre_norm(torch.zeros(1, 4, 1024))
+
+
+def test_multi_optimizer_surface_of_the_reference_loop():
+    """What train.py does with `optimizer`: schedulers[key].get_last_lr() (:384), step(key) without a scaler, scheduler(key=),
+    zero_grad(); state loading validates before it mutates."""
+    from facodec_amd.optim import FlatAdamW, MultiOptimizer
+    torch.manual_seed(0)
+    ps = [torch.nn.Parameter(torch.randn(4, 3)), torch.nn.Parameter(torch.randn(5))]
+    opt = FlatAdamW(ps, lr=1e-3, gamma=0.5)
+    multi = MultiOptimizer({"k": opt})
+    assert multi.schedulers["k"].get_last_lr() == [1e-3] and opt.param_groups[0]["lr"] == 1e-3
+    multi.scheduler(key="k")
+    assert multi.schedulers["k"].get_last_lr() == [5e-4]
+    with pytest.raises(NotImplementedError):
+        multi.step("k", scaler=object())
+    # a state dict with a wrong moment shape leaves the optimiser exactly as it was
+    opt.m.fill_(3.0)
+    opt.v.fill_(4.0)
+    good = opt.state_dict()
+    good["state"] = {0: dict(step=torch.tensor(2.0), exp_avg=torch.zeros(4, 3), exp_avg_sq=torch.zeros(4, 3)),
+                     1: dict(step=torch.tensor(2.0), exp_avg=torch.zeros(7), exp_avg_sq=torch.zeros(7))}      # 7 != 5
+    good["param_groups"][0]["lr"] = 123.0
+    multi.load_state_dict([("k", good)])          # prints "Unloaded k" like optimizers.py:27-32
+    assert opt.lr == 5e-4 and float(opt.m.min()) == 3.0 and float(opt.v.min()) == 4.0 and opt.param_steps == [0, 0]
+    # zero_grad drains / clears a pending exchange handle instead of wedging the next launch
+    class _Work:
+        def wait(self):
+            raise RuntimeError("collective failed")
+    opt._work = _Work()
+    with pytest.raises(RuntimeError):
+        opt.zero_grad()
+    assert opt._work is None
+    opt.zero_grad()
+
+
+@pytest.mark.gpu
+def test_train_py_sample_block_runs_verbatim(cuda):
+    """train.py:441-456 (the tensorboard sample dump) literally: decoder on the partial sums, then the timbre swap through
+    `model.quantizer.timbre_linear` / `.timbre_norm`.  With the clip's own timbre the swap must reproduce the quantizer's
+    output; `timbre_norm` equals torch's LayerNorm on the device."""
+    from facodec_amd import synth
+    from facodec_amd.commons import build_model, default_model_params
+    model = build_model(default_model_params())
+    for k in ("encoder", "quantizer", "decoder"):
+        synth.load_synthetic(model[k], seed=0, prefix=k + ".")
+        model[k].to(cuda)
+        model[k].eval()
+    wave = synth.synth_clips(2, 12000, seed=3).to(cuda)
+    with torch.no_grad():
+        z = model.encoder(wave)
+        z, quantized, commitment_loss, codebook_loss, timbre2 = model.quantizer(z, wave, n_c=2)
+        p_pred_wave = model.decoder(quantized[0])
+        pc_pred_wave = model.decoder(quantized[0] + quantized[1])
+        full_pred_wave = model.decoder(z)
+        x = quantized[0] + quantized[1] + quantized[2]
+        style2 = model.quantizer.timbre_linear(timbre2).unsqueeze(2)  # (B, 2d, 1)
+        gamma, beta = style2.chunk(2, 1)  # (B, d, 1)
+        x = x.transpose(1, 2)
+        xn = model.quantizer.timbre_norm(x)
+        ref_n = torch.nn.functional.layer_norm(x, (1024,))
+        x = xn.transpose(1, 2)
+        x = x * gamma + beta
+        vc_pred_wave = model.decoder(x)
+    assert p_pred_wave.shape == pc_pred_wave.shape == full_pred_wave.shape == vc_pred_wave.shape == (2, 1, 12000)
+    assert float((xn - ref_n).abs().max()) < 2e-5
+    assert float((x - z).abs().max() / z.abs().max()) < 1e-5
+    assert float((vc_pred_wave - full_pred_wave).abs().max()) < 1e-4
+    # differentiable like nn.LayerNorm
+    xr = (quantized[0] + quantized[1]).transpose(1, 2).detach().requires_grad_()
+    model.quantizer.timbre_norm(xr).square().sum().backward()
+    xt = xr.detach().clone().requires_grad_()
+    torch.nn.functional.layer_norm(xt, (1024,)).square().sum().backward()
+    assert float((xr.grad - xt.grad).abs().max() / xt.grad.abs().max()) < 1e-4
+
+
+@pytest.mark.gpu
+def test_modules_under_distributed_data_parallel(cuda):
+    """train.py:49-50,110-111: each model[k] wrapped in DistributedDataParallel(find_unused_parameters=True); two ranks
+    (gloo) share the one GPU.  tools/ddp_wrapped.py checks the construction-time broadcast, `.module.timbre_norm`, DDP's
+    averaged gradients against this build's arena all-reduce path, identical parameters across ranks after the steps."""
+    env = dict(os.environ, FAC_DIST_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29519", os.path.join(REPO, "tools", "ddp_wrapped.py")]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    os.makedirs(os.path.join(REPO, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(REPO, "gpurun_out", "ddp_wrapped.log"), "w") as f:
+        f.write(r.stdout + "\n--- stderr ---\n" + r.stderr[-8000:])
+    assert line, r.stderr[-3000:]
+    rep = json.loads(line[-1])
+    assert rep["ok_all_ranks"], rep
+    assert r.returncode == 0

@@ -171,3 +171,57 @@ def test_two_rank_async_exchange_order_and_empty_key():
     assert torch.equal(g0["unused"], torch.zeros(6)) and torch.allclose(g0["encoder"], torch.full((4,), 1.5))
     assert (e0, l0, e1, l1) == (False, True, False, True)
     assert torch.allclose(d0, torch.full((17,), 2.0)) and torch.equal(d0, d1)
+
+
+def _flag_worker(rank, world, port, q):
+    sys.path.insert(0, REPO)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from facodec_amd import benchutil
+    from facodec_amd.optim import FlatAdamW
+    benchutil.init_distributed("gloo")
+    out = {}
+    for mode, dp in (("arena", True), ("ddp_wrapped", False)):
+        torch.manual_seed(0)
+        params = [torch.nn.Parameter(torch.randn(3, 2)), torch.nn.Parameter(torch.randn(4)), torch.nn.Parameter(torch.randn(5))]
+        opt = FlatAdamW(params, data_parallel=dp)
+        (params[0] * float(rank + 1)).sum().backward()                      # every rank reaches parameter 0
+        if rank == 0:
+            (params[1] * 3.0).sum().backward()                              # only rank 0 reaches parameter 1
+        # parameter 2: no rank
+        local = list(opt._touched)
+        opt.all_reduce_mean()
+        out[mode] = (local, opt._flags.clone(), opt.g.clone())
+    # in-place writes into the views are invisible to the hooks until declared
+    opt.zero_grad()
+    params[2].grad.add_(1.0)
+    hidden = list(opt._touched)
+    opt.mark_grads([params[2]])
+    q.put((rank, out, hidden, list(opt._touched)))
+    torch.distributed.destroy_process_group()
+
+
+def test_two_rank_touched_flags_travel_with_the_gradients():
+    """which parameters are stepped must be the UNION over ranks -- a parameter reached on rank 0 only
+    receives the averaged gradient on both ranks and must be stepped on both.  The flags ride at the tail of the arena
+    through the same all-reduce (or, for DDP-wrapped modules whose gradients DDP averages, through a MAX of the flags)."""
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_flag_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=120) for _ in range(world)), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, o0, hid0, mk0), (_, o1, _, _) = res
+    assert o0["arena"][0] == [True, True, False] and o1["arena"][0] == [True, False, False]      # local views differ
+    for mode in ("arena", "ddp_wrapped"):
+        f0, f1 = o0[mode][1], o1[mode][1]
+        assert torch.equal(f0 > 0, torch.tensor([True, True, False])) and torch.equal(f0 > 0, f1 > 0), (mode, f0, f1)
+    assert torch.equal(o0["arena"][2], o1["arena"][2])                                          # averaged gradients agree
+    assert torch.allclose(o0["arena"][2][6:10], torch.full((4,), 1.5))                          # (3 + 0) / 2 on BOTH ranks
+    assert torch.allclose(o1["ddp_wrapped"][2][6:10], torch.zeros(4))                           # no arena exchange in DDP mode
+    assert hid0 == [False, False, False] and mk0 == [False, False, True]

@@ -248,3 +248,53 @@ def test_train_iteration_oracle_against_reference(golden_dir):
             n = key[len("param_after.discriminator."):-len(".probe")]
             flat = d_after[n].reshape(-1)
             assert np.abs(flat[TR.probe_index(flat.numel())].numpy() - fx[key]).max() < 1e-6, n
+
+
+def test_gradient_probe_conditioning_justifies_the_gpu_bars(golden_dir):
+    """Why tests/test_train_golden.py holds gradient PROBES (single entries) to 3e-3 / 5e-4 while losses sit at 1e-5: the
+    loss of train.py:282-358 is kinked everywhere (L1 of log-mel magnitudes, L1 feature matching, LeakyReLU, code
+    assignment), so a change of the input at rounding level moves individual gradient entries orders of magnitude more than
+    it moves the losses or the key norms.  Experiment: scale the waveforms by (1 + 1e-7) -- one or two
+    ulps -- and replay the whole iteration through the oracle.  Recorded in gpurun_out/gradient_conditioning.json; the
+    asserts pin the regime the GPU bars rely on."""
+    import json
+    import os
+    from facodec_amd.commons import build_model, default_model_params
+    import train_replay as TR
+    fx = TR.load_fixture(golden_dir)
+    model = build_model(default_model_params())
+    for k in TR.KEYS:
+        synth.load_synthetic(model[k], seed=0, prefix=k + ".")
+    sds, names = TR.product_state(model)
+    sc0, g0, n0, _ = TR.oracle_iteration(O, sds, names, fx)
+    fx2 = dict(fx)
+    t = dict(fx["t"])
+    t["wav_seg"] = t["wav_seg"] * (1.0 + 1e-7)
+    t["waves"] = t["waves"] * (1.0 + 1e-7)
+    fx2["t"] = t
+    sc1, g1, n1, _ = TR.oracle_iteration(O, sds, names, fx2)
+    loss_move = {k: abs(sc1[k] - sc0[k]) / abs(sc0[k]) for k in TR.SCALARS}
+    norm_move = {k: abs(n1[k] - n0[k]) / n0[k] for k in TR.KEYS}
+    probe_move, worst = {}, {}
+    for k in TR.KEYS:
+        w = ("", 0.0)
+        for n in TR.grad_probe_names(fx, k):
+            a, b = g0[k][n].reshape(-1), g1[k][n].reshape(-1)
+            idx = TR.probe_index(a.numel())
+            e = float((a[idx] - b[idx]).abs().max() / max(float(a[idx].abs().max()), 1e-30))
+            if e > w[1]:
+                w = (n, e)
+        probe_move[k], worst[k] = w[1], w[0]
+    report = dict(perturbation="waveforms * (1 + 1e-7)", loss_rel_move=loss_move, key_norm_rel_move=norm_move,
+                  worst_probe_rel_move=probe_move, worst_probe_tensor=worst)
+    out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    os.makedirs(out_dir, exist_ok=True)
+    json.dump(report, open(os.path.join(out_dir, "gradient_conditioning.json"), "w"), indent=1)
+    assert max(loss_move.values()) < 1e-6, loss_move                       # the losses barely notice ...
+    assert max(norm_move.values()) < 1e-4, norm_move                       # ... nor do the key norms (GPU bar: 2e-4)
+    # ... while single gradient entries of the discriminator move at the 1e-4 .. 1e-3 level (GPU bar 3e-3); everything the
+    # generator and predictor heads own stays an order of magnitude below (GPU bar 5e-4)
+    assert probe_move["discriminator"] < 3e-3, (worst["discriminator"], probe_move["discriminator"])
+    for k in ("encoder", "quantizer", "decoder", "fa_predictors"):
+        assert probe_move[k] < 2.5e-4, (k, worst[k], probe_move[k])
+    assert probe_move["discriminator"] > 20 * max(loss_move.values())      # the conditioning gap the comment claims

@@ -14,6 +14,7 @@ from facodec_amd import synth
 pytestmark = pytest.mark.gpu
 
 LOSS_TOL = 1e-5          # north_star asks for 1e-4 relative; measured <= 2.2e-7
+PROBE_BAR = dict(discriminator=3e-3, encoder=1e-3, quantizer=1e-3, decoder=1e-3, fa_predictors=5e-5)
 
 
 def _model(cuda, keys=TR.KEYS):
@@ -55,7 +56,7 @@ def test_train_step_against_reference_golden(cuda, golden_dir):
     for k in TR.KEYS:
         report["grad_norm_rel"][k] = abs(float(out["grad_norm"][k]) - float(fx[f"grad_norm64_{k}"])) / float(fx[f"grad_norm64_{k}"])
         grads = {n: p.grad for n, p in model[k].named_parameters()}
-        report["worst_grad"][k] = TR.compare_grads(fx, k, grads, 2e-4, 3e-3)
+        report["worst_grad"][k] = TR.compare_grads(fx, k, grads, 2e-4, PROBE_BAR[k])
     os.makedirs("gpurun_out", exist_ok=True)
     json.dump(report, open("gpurun_out/train_golden_report.json", "w"), indent=1)
     for k, e in report["loss_rel"].items():
@@ -68,11 +69,15 @@ def test_train_step_against_reference_golden(cuda, golden_dir):
     # Measured on MI355X against the reference: losses <= 2.2e-7 always; key norms 2e-6 .. 4.5e-5, per-tensor norms <= 6.5e-5,
     # probes 6.3e-5 .. 1.14e-3 (relative to the probe's max) depending on the conv tiling in use -- and 1.07e-3 with every
     # conv on the exact fp32 pipe (FAC_BF16_SPLIT=0), so the spread is the loss's, not the bf16 split's
-    # (profiles/r02_train_golden_report*.json).  Bars: 2e-4 on norms, 3e-3 on probe values.
+    # (profiles/r02_train_golden_report*.json).  The conditioning experiment itself is a CPU test now
+    # (tests/test_oracle_golden.py::test_gradient_probe_conditioning_justifies_the_gpu_bars, profiles/r03_gradient_conditioning_cpu.json:
+    # a 1-ulp change of the waveforms moves discriminator probes by 1.08e-3, generator probes by <= 5.5e-5, predictor probes by
+    # 8e-7, losses by <= 2e-7).  Bars: 2e-4 on norms; probe values per key (PROBE_BAR): discriminator 3e-3, generator keys 1e-3
+    # (measured 6e-5 .. 4.4e-4 across tilings), predictor heads 5e-5 (measured 1e-6).
     for k, e in report["grad_norm_rel"].items():
         assert e < 2e-4, (k, e)
     for k, w in report["worst_grad"].items():
-        assert w[1] < 2e-4 and w[2] < 3e-3, w
+        assert w[1] < 2e-4 and w[2] < PROBE_BAR[k], w
     for k, missing in fx["no_grad"].items():
         names = [n for n, _ in model[k].named_parameters()]
         idx = step.opt[k].params_without_grad()
@@ -156,8 +161,8 @@ def test_optimizer_state_dict_roundtrip(cuda):
         for i, (r, o, gr) in enumerate(zip(ref, ours, gs)):
             r.grad = gr
             if gr is not None:
-                o.grad.copy_(gr.to(cuda))
-                opt._touched[i] = True
+                o.grad.copy_(gr.to(cuda))        # in-place write into the arena view: declared through the public call
+                opt.mark_grads([o])
         opt_ref.step()
         sch.step()
         multi.step("k")
