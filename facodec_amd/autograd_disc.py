@@ -57,7 +57,8 @@ class PlainConv(Function):
                 # polyphase transposed conv (no zero-inserted columns: 1.2x the useful flops for k = 5, s = 3 instead of 3x)
                 v6 = torch.cat([vd, vd.new_zeros(c_out, c_in, 2 * stride - k)], dim=2) if k < 2 * stride else vd
                 dy_ext = torch.cat([dy, dy.new_zeros(B, c_out, 1)], dim=2)
-                dxp = ops.conv_transpose1d(dy_ext, ops.pack_convtr_weight(v6, gd, stride), c_in, stride)
+                with ops.flop_scale(k / (2.0 * stride)):      # the zero taps that pad k to 2 * stride are not algorithmic work
+                    dxp = ops.conv_transpose1d(dy_ext, ops.pack_convtr_weight(v6, gd, stride), c_in, stride)
                 if dxp.shape[-1] < pad + t_in:
                     dxp = torch.cat([dxp, dxp.new_zeros(B, c_in, pad + t_in - dxp.shape[-1])], dim=2)
                 dx = dxp[:, :, pad:pad + t_in].contiguous()
@@ -73,8 +74,9 @@ class PlainConv(Function):
                     ws = ops.pack_conv_weight_split(w.permute(1, 0, 2).flip(2).contiguous())
                     dxp = ops.conv1d(up, None, c_in, k, pad_left=k - 1, pad_mode=ops.PAD_ZERO, t_out=tp, w_split=ws)
                 else:
-                    dxp = ops.conv1d(up, ops.pack_conv_weight_bwd(vd, gd), c_in, k, pad_left=max_off, pad_mode=ops.PAD_ZERO, t_out=tp,
-                                     k1=k1, dilation2=dil2)
+                    with ops.flop_scale(1.0 / stride):        # zero-inserted columns (stride > 1) are not algorithmic work
+                        dxp = ops.conv1d(up, ops.pack_conv_weight_bwd(vd, gd), c_in, k, pad_left=max_off, pad_mode=ops.PAD_ZERO, t_out=tp,
+                                         k1=k1, dilation2=dil2)
                 if tp < pad + t_in:       # trailing inputs no window reads
                     dxp = torch.cat([dxp, torch.zeros(B, c_in, pad + t_in - tp, device=dy.device)], dim=2)
                 dx = dxp[:, :, pad:pad + t_in].contiguous()

@@ -68,7 +68,9 @@ extern "C" int fac_conv1d_fwd(const fac_conv_desc* d, fac_stream_t stream) {
   a.phase_shift = d->phase_shift;
   a.K1 = d->K1 > 0 ? d->K1 : d->K; a.dil2 = d->dilation2;
   FAC_REQUIRE(a.K1 <= d->K && d->K % a.K1 == 0 && (a.K1 == d->K || d->dilation2 > 0), "conv1d: bad two-level taps (K=%d K1=%d)", d->K, d->K1);
-  FAC_REQUIRE(!conv_two_level(a) || (!d->w_k1 && d->n_phase == 1 && !d->w_split), "conv1d: two-level taps need a plain conv");
+  FAC_REQUIRE(!conv_two_level(a) || (!d->w_k1 && d->n_phase == 1 && !d->w_split && d->pad_mode == FAC_PAD_ZERO && !d->w_batched),
+              "conv1d: two-level taps need a plain, zero-padded conv");
+  conv_set_virtual(a);
   FAC_REQUIRE(d->phase_shift >= 0 && d->phase_shift < d->n_phase + (d->n_phase == 1), "conv1d: bad phase_shift");
   // length of pad1d's temporary zero extension (only differs from T_in for inputs shorter than the pad)
   {

@@ -50,6 +50,12 @@ struct ConvArgs {
   int n_phase, y_tstride, act, w_batched;
   int phase_shift;   // left trim of a non-causal transposed conv (0 = causal)
   int K1, dil2;      // two-level taps: tap k = k2*K1 + k1 at offset k2*dil2 + k1*dil (K1 == K: plain conv)
+  // Two-level taps run as K2v = K / K1 VIRTUAL input channels per real one: virtual channel v = ci*K2v + k2 is row ci read
+  // k2*dil2 columns further on, with KV = K1 taps.  The packed weights need no change: row (ci*K + k2*K1 + k1) of
+  // (C_in_pad, K, C_out_pad) IS row (v*K1 + k1).  The stage then holds only the K1-tap receptive field of each virtual
+  // channel instead of the whole K2-row span (3.2x fewer staged columns for the (3, 9) convs of the spectrogram
+  // discriminator at pitch 272), and the tap loop is the compile-time one.  Plain convs: K2v = 1, KV = K, CV = C_in.
+  int K2v, KV, CV;
   int cic;  // input channels per LDS stage (multiple of 2*UC)
   int XW;   // staged input width = (T_TILE-1)*stride + (K-1)*dil + 1
   int XB;   // 64-wide column blocks per staged row = ceil(XW/64)
@@ -67,6 +73,12 @@ __host__ __device__ inline int conv_max_tap_offset(const ConvArgs& a) {
   return (a.K / K1 - 1) * a.dil2 + (K1 - 1) * a.dil;
 }
 __host__ __device__ inline bool conv_two_level(const ConvArgs& a) { return a.K1 > 0 && a.K1 < a.K; }
+// fills K2v / KV / CV from K, K1 (call once the descriptor fields are set)
+inline void conv_set_virtual(ConvArgs& a) {
+  a.KV = conv_two_level(a) ? a.K1 : a.K;
+  a.K2v = a.K / a.KV;
+  a.CV = a.C_in * a.K2v;
+}
 
 template <int KT>
 struct ConvUnroll {
@@ -123,14 +135,14 @@ __global__ __launch_bounds__((WM * WN + 4) * 64, (WM * WN == 4 ? FAC_CONV_WPE : 
     tap_shift = 1;
   }
 
-  const int K = KT > 0 ? KT : a.K;
+  const int K = KT > 0 ? KT : a.KV;       // taps per (virtual) input channel
   const int cic = KT > 0 ? ConvUnroll<KT>::CIC : a.cic;
   const int XW = a.XW, XB = a.XB;
   const int w_stage = cic * K * CO_TILE;  // floats
   const int x_stage = cic * XW;
   float* Wbuf = smem;                 // [2][cic][K][CO_TILE]
   float* Xbuf = smem + 2 * w_stage;   // [2][cic][XW]
-  const int n_chunks = (a.C_in + cic - 1) / cic;
+  const int n_chunks = (a.CV + cic - 1) / cic;
 
   if (wave >= NMW) {
     // ===================== staging waves: HBM/L2 -> LDS for chunk c+1 while chunk c is multiplied
@@ -144,7 +156,7 @@ __global__ __launch_bounds__((WM * WN + 4) * 64, (WM * WN == 4 ? FAC_CONV_WPE : 
     __builtin_amdgcn_s_setprio(3);
 #endif
     const float* xg = a.x + (long long)b * a.x_bs;
-    const int w_rows_total = cin_pad_dev(a.C_in) * K;   // rows C_in*K.. are zero (fac_pack_conv_w)
+    const int w_rows_total = cin_pad_dev(a.C_in) * a.K;   // rows C_in*K.. are zero (fac_pack_conv_w); a.K = K2v * K
     const float* wg = a.w + (long long)phase * w_rows_total * a.C_out_pad +
                       (a.w_batched ? (long long)b * a.w_bs : 0ll);
     const int tin0 = t0 * a.stride - a.pad_left - a.x_off;   // multiple of 4 by construction
@@ -153,7 +165,9 @@ __global__ __launch_bounds__((WM * WN + 4) * 64, (WM * WN == 4 ? FAC_CONV_WPE : 
     const int r_first = lw / XB, cb_first = lw - r_first * XB;
     // pure-DMA input staging: no Snake prologue, 16-B aligned rows, and the whole slab inside the
     // signal (no reflection / zero padding / ragged tail in this tile)
-    const bool x_dma = a.alpha_in == nullptr && vec_ok && tin0 >= 0 && tin0 + XW <= a.T_in;
+    const int K2v = a.K2v, dil2 = a.dil2;
+    const bool x_dma = a.alpha_in == nullptr && vec_ok && tin0 >= 0 && tin0 + (K2v - 1) * dil2 + XW <= a.T_in &&
+                       (K2v == 1 || (dil2 & 3) == 0);
 
 #ifdef FAC_PROF
     unsigned long long lt_issue = 0, lt_wait = 0, lt_store = 0, lt_bar = 0;
@@ -204,9 +218,10 @@ __global__ __launch_bounds__((WM * WN + 4) * 64, (WM * WN == 4 ? FAC_CONV_WPE : 
           const int r = it / XB;
           const int c4 = (it - r * XB) * 64 + lane;
           if (c4 < XW4) {
-            int ci = ci0 + r;
-            ci = ci < a.C_in ? ci : a.C_in - 1;
-            const float* src = xg + (long long)ci * a.x_cs + tin0 + 4 * c4;
+            int v = ci0 + r;
+            v = v < a.CV ? v : a.CV - 1;
+            const int ci = v / K2v, k2 = v - ci * K2v;
+            const float* src = xg + (long long)ci * a.x_cs + tin0 + k2 * dil2 + 4 * c4;
             __builtin_amdgcn_global_load_lds((glb_void_t*)src, (lds_void_t*)(dst + r * XW + (it - r * XB) * 256), 16, 0, 0);
           }
         }
@@ -224,11 +239,12 @@ __global__ __launch_bounds__((WM * WN + 4) * 64, (WM * WN == 4 ? FAC_CONV_WPE : 
           float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
           float al = 0.f;
           const int c4 = cb * 64 + lane;
-          const int ci = ci0 + r;
-          if (r < cic && c4 < XW4 && ci < a.C_in) {
-            const int tin = tin0 + 4 * c4;
+          const int vch = ci0 + r;
+          const int ci = vch / K2v, k2 = vch - ci * K2v;
+          if (r < cic && c4 < XW4 && vch < a.CV) {
+            const int tin = tin0 + 4 * c4 + k2 * dil2;
             const float* xrow = xg + (long long)ci * a.x_cs;
-            if (vec_ok && tin >= 0 && tin + 3 < a.T_in) {
+            if (vec_ok && (tin & 3) == 0 && tin >= 0 && tin + 3 < a.T_in) {
               v = *reinterpret_cast<const float4*>(xrow + tin);
             } else {
               float e[4];
@@ -400,27 +416,21 @@ __global__ __launch_bounds__((WM * WN + 4) * 64, (WM * WN == 4 ? FAC_CONV_WPE : 
         __builtin_amdgcn_sched_barrier(0);
       }
     } else {
-      const int K1 = conv_two_level(a) ? a.K1 : K;      // tap k = k2*K1 + k1 at offset k2*dil2 + k1*dil
-      const int K2 = K / K1;
       for (int c2 = 0; c2 < cic; c2 += 2) {
-        const float* wp = Wb + c2 * wrow_stride;
-        const float* xp0 = Xb + c2 * XW;
-        for (int k2 = 0; k2 < K2; ++k2) {
-          const float* wq = wp + k2 * K1 * CO_TILE;
-          const float* xp = xp0 + k2 * a.dil2;
+        const float* wq = Wb + c2 * wrow_stride;
+        const float* xp = Xb + c2 * XW;
 #pragma unroll 2
-          for (int kk = 0; kk < K1; ++kk) {
-            float av[MB], bv[NB];
+        for (int kk = 0; kk < K; ++kk) {
+          float av[MB], bv[NB];
 #pragma unroll
-            for (int m = 0; m < MB; ++m) av[m] = wq[kk * CO_TILE + m * 32];
+          for (int m = 0; m < MB; ++m) av[m] = wq[kk * CO_TILE + m * 32];
 #pragma unroll
-            for (int n = 0; n < NB; ++n) bv[n] = xp[kk * dil + n * nstride];
+          for (int n = 0; n < NB; ++n) bv[n] = xp[kk * dil + n * nstride];
 #pragma unroll
-            for (int m = 0; m < MB; ++m)
+          for (int m = 0; m < MB; ++m)
 #pragma unroll
-              for (int n = 0; n < NB; ++n)
-                acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m], bv[n], acc[m][n], 0, 0, 0);
-          }
+            for (int n = 0; n < NB; ++n)
+              acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m], bv[n], acc[m][n], 0, 0, 0);
         }
       }
     }
@@ -647,14 +657,11 @@ int launch_cfg(ConvArgs& a, hipStream_t s) {
   // staged slab = receptive field of the tile, extended on the left to a 16-byte boundary and on the
   // right to a multiple of 4 columns, so interior slabs move as float4
   a.x_off = ((-a.pad_left) % 4 + 4) % 4;
-  if constexpr (KT > 0) {
-    if (conv_two_level(a)) return launch_cfg<MB, NB, WM, WN, 0, FUSE>(a, s);     // two-level taps: run-time tap loop only
-  }
-  a.XW = (((T_TILE - 1) * a.stride + conv_max_tap_offset(a) + 1 + a.x_off + (a.phase_shift > 0 ? 1 : 0)) + 3) & ~3;
+  a.XW = (((T_TILE - 1) * a.stride + (a.KV - 1) * a.dil + 1 + a.x_off + (a.phase_shift > 0 ? 1 : 0)) + 3) & ~3;
   a.XB = (a.XW / 4 + 63) / 64;   // 64-lane blocks of float4 columns per staged row
   a.XQ = 4 / a.XB;
   a.XR = 4 % a.XB;
-  const int per_ci = a.K * CO_TILE + a.XW;       // floats per staged input channel
+  const int per_ci = a.KV * CO_TILE + a.XW;      // floats per staged (virtual) input channel
   int cic;
   if constexpr (KT > 0) {
     cic = ConvUnroll<KT>::CIC;
@@ -669,7 +676,7 @@ int launch_cfg(ConvArgs& a, hipStream_t s) {
     if (lim > 32) lim = 32;
     lim = (lim / STEP) * STEP;
     if (lim < STEP) lim = STEP;
-    const int cin_r = ((a.C_in + STEP - 1) / STEP) * STEP;
+    const int cin_r = ((a.CV + STEP - 1) / STEP) * STEP;
     cic = lim < cin_r ? lim : cin_r;
     // prefer a chunk size that divides the (rounded) channel count: no half-empty last chunk
     for (int c = cic; c >= STEP && c * 2 > cic; c -= STEP)

@@ -3,7 +3,7 @@
 
 namespace fac {
 int conv_dispatch_128x128(ConvArgs& a, hipStream_t s) {
-  switch (a.K) {
+  switch (a.KV) {
     case 1: return launch_cfg<2,2,2,2, 1>(a, s);
     case 2: return launch_cfg<2,2,2,2, 2>(a, s);
     case 3: return launch_cfg<2,2,2,2, 3>(a, s);

@@ -5,7 +5,7 @@
 
 namespace fac {
 int conv_dispatch_128x256(ConvArgs& a, hipStream_t s) {
-  switch (a.K) {
+  switch (a.KV) {
     case 1: return launch_cfg<2,2,2,4, 1>(a, s);
     case 7: return launch_cfg<2,2,2,4, 7>(a, s);
     default: return launch_cfg<2,2,2,4, 0>(a, s);
@@ -13,7 +13,7 @@ int conv_dispatch_128x256(ConvArgs& a, hipStream_t s) {
 }
 // 96 x 256: 8 MFMA waves of 96 x 32 each (C_out = 96 / 192 layers of the decoder).
 int conv_dispatch_96x256(ConvArgs& a, hipStream_t s) {
-  switch (a.K) {
+  switch (a.KV) {
     case 1: return launch_cfg<3,1,1,8, 1>(a, s);
     default: return launch_cfg<3,1,1,8, 0>(a, s);
   }
@@ -21,7 +21,7 @@ int conv_dispatch_96x256(ConvArgs& a, hipStream_t s) {
 // 128 x 160: four MFMA waves stacked along C_out, each 32 rows x 160 columns -- the latent-rate layers
 // of a 2 s clip (160 frames) fit one tile exactly.
 int conv_dispatch_128x160(ConvArgs& a, hipStream_t s) {
-  switch (a.K) {
+  switch (a.KV) {
     case 1: return launch_cfg<1,5,4,1, 1>(a, s);
     case 2: return launch_cfg<1,5,4,1, 2>(a, s);
     case 3: return launch_cfg<1,5,4,1, 3>(a, s);

@@ -3,7 +3,7 @@
 
 namespace fac {
 int conv_dispatch_128x32(ConvArgs& a, hipStream_t s) {
-  switch (a.K) {
+  switch (a.KV) {
     case 1: return launch_cfg<1,1,4,1, 1>(a, s);
     default: return launch_cfg<1,1,4,1, 0>(a, s);
   }

@@ -3,7 +3,7 @@
 
 namespace fac {
 int conv_dispatch_64x128(ConvArgs& a, hipStream_t s) {
-  switch (a.K) {
+  switch (a.KV) {
     case 1: return launch_cfg<2,1,1,4, 1>(a, s);
     case 7: return launch_cfg<2,1,1,4, 7>(a, s);
     default: return launch_cfg<2,1,1,4, 0>(a, s);

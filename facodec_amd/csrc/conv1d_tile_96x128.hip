@@ -3,7 +3,7 @@
 
 namespace fac {
 int conv_dispatch_96x128(ConvArgs& a, hipStream_t s) {
-  switch (a.K) {
+  switch (a.KV) {
     case 1: return launch_cfg<3,1,1,4, 1>(a, s);
     case 2: return launch_cfg<3,1,1,4, 2>(a, s);
     case 7: return launch_cfg<3,1,1,4, 7>(a, s);

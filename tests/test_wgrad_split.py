@@ -112,14 +112,18 @@ def test_convtr_wgrad_on_split_kernel(cuda):
     assert float((dw.cpu().double() - w.grad).abs().max() / w.grad.abs().max()) < 1e-5
 
 
-@pytest.mark.parametrize("sf,kf,F0,P", [(1, 9, 25, 32), (2, 9, 51, 64), (2, 9, 26, 32), (1, 3, 13, 16)])
-def test_two_level_conv_is_conv2d(sf, kf, F0, P, cuda):
+@pytest.mark.parametrize("sf,kf,F0,P,T", [(1, 9, 25, 32, 7), (2, 9, 51, 64, 7), (2, 9, 26, 32, 7), (1, 3, 13, 16, 7),
+                                           # long enough for interior tiles (LDS-DMA staging of the virtual channels), a row
+                                           # pitch that is not a multiple of 4 (register staging), the model's 272 / 136 pitches
+                                           (1, 9, 25, 32, 40), (1, 9, 26, 34, 40), (2, 9, 51, 68, 40), (1, 3, 30, 34, 40),
+                                           (1, 9, 256, 272, 9), (2, 9, 128, 136, 9)])
+def test_two_level_conv_is_conv2d(sf, kf, F0, P, T, cuda):
     """(3, kf) Conv2d with stride (1, sf), padding (1, kf // 2) (dac/model/discriminator.py:110-120) as ONE 1-D conv with
     two-level taps over the row-concatenated (frame, frequency) signal: forward, data gradient and weight gradient (split
     kernel and fp32 kernel) against torch's conv2d in fp64."""
     from facodec_amd import autograd_disc as AD
     g = torch.Generator().manual_seed(11 + kf + sf)
-    B, T, ci, co = 2, 7, 6, 32
+    B, ci, co = 2, 6, 32
     pf = kf // 2
     x4 = torch.randn(B, ci, T, F0, generator=g)
     w = torch.randn(co, ci, 3, kf, generator=g) * 0.2
