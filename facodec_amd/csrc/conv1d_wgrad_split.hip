@@ -25,6 +25,7 @@
 //     VALU in the MFMA waves, any (K, dilation, stride) through per-lane base offsets computed once.
 // Partial tiles of the S slices are added in slice order by wgrad_split_reduce_kernel (deterministic).
 #include "conv1d_mfma.h"
+#include <stdlib.h>
 
 namespace fac {
 
@@ -411,6 +412,267 @@ static int ws_geometry(int B, int C_in_real, int T_in, int C_out, int T_out, int
   return 0;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// k-major variant (round 3): the B operand staged the way the A operand is.
+//
+// In the kernel above a 32-lane B fragment covers ~4.6 input channels x K taps, i.e. 32 DIFFERENT (row, shift) pairs: the
+// ds_read_b64 pairs hit the LDS banks irregularly whatever the row pitch (measured SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE =
+// 0.42-0.51, profiles/r02_pmc_mfma_wgrad.json), and the shifted copies cost up to 4x the staged bytes.  Here the 128 tile
+// columns are four BLOCKS of 32, block = (tap k, group of 32 consecutive (virtual) input channels): all 32 lanes of a B
+// fragment read the SAME time window of 32 different rows.  So each block's rows are staged once, already shifted by the
+// block's own tap offset (the shift moves into the global-load address, any alignment), as 32 rows x 32 steps x 3 planes with
+// the A operand's 80-byte pitch: a B fragment is ONE aligned, conflict-free ds_read_b128, exactly like an A fragment.
+// No shifted copies, no constraint on K * dilation (the d = 9 layers used to fall back to the fp32 kernel), the same
+// staging code for both operands (12 x 16 bytes per staging lane and stage).
+// Blocks are numbered gb = group * K + k; partial sums are written block-wise ([slice][co][gb][32], 128-byte runs) and the
+// reduction kernel scatters them into dW (C_out, C_in, K) -- the scattered side is the 1x dW, not the S x partials.
+constexpr int WK_PITCH = 80;                       // bytes per staged row: 32 bf16 + 16 B pad (16 lanes x b128 cover all 64 banks)
+constexpr int WK_PLANE = 128 * WK_PITCH;           // one plane of one operand
+constexpr int WK_OPND = 3 * WK_PLANE;              // one operand
+constexpr int WK_STAGE = 2 * WK_OPND;              // 61 440 B
+constexpr int WK_PIECES = 6;                       // 16-byte pieces per staging lane, operand and stage
+
+struct WkArgs {
+  const unsigned char* ap;   // dy planes [3][B*C_out][UA]
+  const unsigned char* bp;   // x planes  [3][B*C_in_real*stride][UB]
+  float* part;               // [S][C_out][NBk][32]
+  long long a_plane_bytes, b_plane_bytes;
+  int UA, UB;
+  int B, C_in_real, CV, C_out, K, stride, dil, K2, dil2s;
+  int NBk;                   // blocks = ceil(CV / 32) * K
+  int n_tt, tiles_per_split;
+};
+
+template <int D>
+__global__ __launch_bounds__(512, 2) void conv1d_wgrad_kmajor_kernel(WkArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int co0 = blockIdx.x * 128;
+  const int gb0 = blockIdx.y * 4;
+  const int z = blockIdx.z;
+  const int tile_lo = z * a.tiles_per_split;
+  const int tile_hi = min(a.B * a.n_tt, tile_lo + a.tiles_per_split);
+  const int n_chunks = tile_hi - tile_lo;
+  const int s = a.stride;
+
+  if (wave >= 4) {
+    // ===================================================================== staging waves: planes -> LDS, copies only
+    const int sl = tid - 256;
+    __builtin_amdgcn_s_setprio(3);
+    unsigned a_off[WK_PIECES], b_off[WK_PIECES];
+    int lds_off[WK_PIECES];                       // same (plane, row, piece) slot in either operand
+#pragma unroll
+    for (int j = 0; j < WK_PIECES; ++j) {
+      const int id = sl + 256 * j;                // [0, 1536): plane, row, 16-byte piece
+      const int plane = id >> 9, rem = id & 511;
+      const int row = rem >> 2, pc = rem & 3;
+      lds_off[j] = plane * WK_PLANE + row * WK_PITCH + pc * 16;
+      const int co = co0 + row < a.C_out ? co0 + row : a.C_out - 1;        // rows past C_out: computed, never stored
+      a_off[j] = (unsigned)(plane * a.a_plane_bytes + ((long long)co * a.UA + 8 * pc) * 2);
+      int gb = gb0 + (row >> 5);
+      gb = gb < a.NBk ? gb : a.NBk - 1;                                    // blocks past the end: never stored
+      const int g = gb / a.K, k = gb - g * a.K;
+      int v = g * 32 + (row & 31);
+      v = v < a.CV ? v : a.CV - 1;                                         // channels past the end: never stored
+      const int ci = v / a.K2, k2 = v - ci * a.K2;
+      const int kd = k * a.dil, shift = kd / s, ph = kd - shift * s;
+      b_off[j] = (unsigned)(plane * a.b_plane_bytes + ((long long)(ci * s + ph) * a.UB + shift + k2 * a.dil2s + 8 * pc) * 2);
+    }
+    constexpr int LPT = 2 * WK_PIECES;
+    constexpr int WAITN = (D - 1) * LPT < 63 ? (D - 1) * LPT : 63;
+    auto load_tile = [&](int chunk, f32x4 (&ra)[WK_PIECES], f32x4 (&rb)[WK_PIECES]) {
+      const int tile = tile_lo + (chunk < n_chunks ? chunk : n_chunks - 1);     // past the end: reload the last tile (keeps LPT)
+      const int b = tile / a.n_tt;
+      const int t0 = (tile - b * a.n_tt) * WS_TT;
+      const unsigned char* ab = a.ap + ((long long)b * a.C_out * a.UA + t0) * 2;                 // uniform
+      const unsigned char* bb = a.bp + ((long long)b * a.C_in_real * s * a.UB + t0) * 2;        // uniform
+#pragma unroll
+      for (int j = 0; j < WK_PIECES; ++j)
+        asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(ra[j]) : "v"(a_off[j]), "s"(ab) : "memory");
+#pragma unroll
+      for (int j = 0; j < WK_PIECES; ++j)
+        asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(rb[j]) : "v"(b_off[j]), "s"(bb) : "memory");
+    };
+    auto wait_tile = [&](f32x4 (&ra)[WK_PIECES], f32x4 (&rb)[WK_PIECES]) {
+      asm volatile("s_waitcnt vmcnt(%12)"
+                   : "+v"(ra[0]), "+v"(ra[1]), "+v"(ra[2]), "+v"(ra[3]), "+v"(ra[4]), "+v"(ra[5]), "+v"(rb[0]), "+v"(rb[1]), "+v"(rb[2]),
+                     "+v"(rb[3]), "+v"(rb[4]), "+v"(rb[5])
+                   : "n"(WAITN) : "memory");
+    };
+    auto write_tile = [&](int buf, const f32x4 (&ra)[WK_PIECES], const f32x4 (&rb)[WK_PIECES]) {
+      unsigned char* st = sm + buf * WK_STAGE;
+#pragma unroll
+      for (int j = 0; j < WK_PIECES; ++j) *reinterpret_cast<f32x4*>(st + lds_off[j]) = ra[j];
+#pragma unroll
+      for (int j = 0; j < WK_PIECES; ++j) *reinterpret_cast<f32x4*>(st + WK_OPND + lds_off[j]) = rb[j];
+    };
+    // ring of D tiles in registers, as in the kernel above
+    f32x4 ra[D][WK_PIECES], rb[D][WK_PIECES];
+#pragma unroll
+    for (int i = 0; i < D; ++i) load_tile(i, ra[i], rb[i]);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    wait_tile(ra[0], rb[0]);
+    write_tile(0, ra[0], rb[0]);
+    load_tile(D, ra[0], rb[0]);
+    __syncthreads();
+    constexpr int U = (D % 2 == 0) ? D : 2 * D;
+    for (int base = 0; base < n_chunks; base += U) {
+#pragma unroll
+      for (int i = 0; i < U; ++i) {
+        const int c = base + i;
+        if (c < n_chunks) {
+          if (c + 1 < n_chunks) {
+            wait_tile(ra[(i + 1) % D], rb[(i + 1) % D]);
+            write_tile((i + 1) & 1, ra[(i + 1) % D], rb[(i + 1) % D]);
+            load_tile(c + 1 + D, ra[(i + 1) % D], rb[(i + 1) % D]);
+          }
+          __syncthreads();
+        }
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    return;
+  }
+
+  // ========================================================================= MFMA waves: 64 x 64 each (2 x 2 blocks)
+  const int l31 = lane & 31, kq = lane >> 5;
+  const int mh = wave >> 1, nh = wave & 1;
+  const int aoff = (mh * 64 + l31) * WK_PITCH + kq * 16;
+  const int boff = WK_OPND + (nh * 64 + l31) * WK_PITCH + kq * 16;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+
+  auto ld_frags = [&](const unsigned char* st, int ks, bf16x8 (&A)[2][3], bf16x8 (&Bf)[2][3]) {
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+        A[m][p] = *reinterpret_cast<const bf16x8*>(st + aoff + p * WK_PLANE + m * 32 * WK_PITCH + ks * 32);
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+      for (int n = 0; n < 2; ++n)
+        Bf[n][p] = *reinterpret_cast<const bf16x8*>(st + boff + p * WK_PLANE + n * 32 * WK_PITCH + ks * 32);
+  };
+
+  __syncthreads();   // tile 0 staged
+  bf16x8 A[2][2][3], Bf[2][2][3];
+  for (int chunk = 0; chunk < n_chunks; ++chunk) {
+    const unsigned char* st = sm + (chunk & 1) * WK_STAGE;
+    ld_frags(st, 0, A[0], Bf[0]);
+#pragma unroll
+    for (int ks = 0; ks < WS_TT / 16; ++ks) {
+      if (ks + 1 < WS_TT / 16) ld_frags(st, ks + 1, A[(ks + 1) & 1], Bf[(ks + 1) & 1]);
+      __builtin_amdgcn_sched_barrier(0);
+      constexpr int TA[6] = {1, 2, 0, 1, 0, 0}, TB[6] = {1, 0, 2, 0, 1, 0};     // smallest terms first (see above)
+#pragma unroll
+      for (int q = 0; q < 6; ++q)
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+          for (int n = 0; n < 2; ++n)
+            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[ks & 1][m][TA[q]], Bf[ks & 1][n][TB[q]], acc[m][n], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();
+  }
+
+  // partial dW of this slice, block-wise: [co][gb][32 channels] -- 128-byte runs per (row, block)
+  float* pz = a.part + (long long)z * a.C_out * a.NBk * 32;
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+      const int gb = gb0 + nh * 2 + n;
+      if (gb >= a.NBk) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = co0 + mh * 64 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * kq;
+        if (co < a.C_out) pz[((long long)co * a.NBk + gb) * 32 + l31] = acc[m][n][r];
+      }
+    }
+}
+
+// dW[co][v * K + k] = sum over the S slices (eight interleaved chains in a fixed order, as wgrad_split_reduce_kernel) of
+// part[z][co][g * K + k][v % 32], g = v / 32: one thread per partial element -- coalesced reads of the S x larger side.
+__global__ __launch_bounds__(256) void wgrad_kmajor_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int S, int C_out,
+                                                                  int NBk, int K, int CV) {
+  const long long n = (long long)C_out * NBk * 32;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const int cl = (int)(i & 31);
+    const long long r = i >> 5;
+    const int gb = (int)(r % NBk);
+    const int co = (int)(r / NBk);
+    const int g = gb / K, k = gb - g * K;
+    const int v = g * 32 + cl;
+    if (v >= CV) continue;
+    float c[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const float* p = part + i;
+    int z = 0;
+    for (; z + 8 <= S; z += 8) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) c[j] += p[(long long)(z + j) * n];
+    }
+    for (int j = 0; z + j < S; ++j) c[j] += p[(long long)(z + j) * n];
+    dw[((long long)co * CV + v) * K + k] = ((c[0] + c[1]) + (c[2] + c[3])) + ((c[4] + c[5]) + (c[6] + c[7]));
+  }
+}
+
+// Geometry of the k-major kernel; returns 0 when the shape runs on it.  Used for (virtual) channel counts >= 16: below that a
+// block of 32 lanes would hold one or two useful columns (the 1- and 2-channel input layers), where the kernel above is better.
+static int wk_geometry(int B, int C_in_real, int T_in, int C_out, int T_out, int K_total, int stride, int dil, int K1, int dil2,
+                       WkArgs* a, int* splits) {
+  static const bool on = !(getenv("FAC_WGRAD_KMAJOR") && getenv("FAC_WGRAD_KMAJOR")[0] == '0');
+  if (!on) return -1;
+  if (K1 <= 0 || K1 > K_total) K1 = K_total;
+  if (K_total % K1 != 0) return -1;
+  const int K2 = K_total / K1, K = K1, CV = C_in_real * K2;
+  if (K2 > 1 && (dil2 <= 0 || dil2 % stride != 0)) return -1;
+  if (CV < 16 || K < 1 || stride < 1 || dil < 1) return -1;
+  a->K2 = K2;
+  a->dil2s = K2 > 1 ? dil2 / stride : 0;
+  a->K = K; a->stride = stride; a->dil = dil; a->B = B; a->C_in_real = C_in_real; a->CV = CV; a->C_out = C_out;
+  a->NBk = ((CV + 31) / 32) * K;
+  const int max_shift = ((K - 1) * dil) / stride;
+  a->n_tt = (T_out + WS_TT - 1) / WS_TT;
+  a->UA = a->n_tt * WS_TT;
+  a->UB = (a->n_tt * WS_TT + max_shift + (K2 - 1) * a->dil2s + 8 + 7) & ~7;
+  a->a_plane_bytes = (long long)B * C_out * a->UA * 2;
+  a->b_plane_bytes = (long long)B * C_in_real * stride * a->UB * 2;
+  if (3 * a->a_plane_bytes >= (1ll << 32) || 3 * a->b_plane_bytes >= (1ll << 32)) return -1;     // 32-bit per-lane offsets
+  const long long tiles = (long long)B * a->n_tt;
+  const long long wgs = (long long)((C_out + 127) / 128) * ((a->NBk + 3) / 4);
+  const long long per_split_bytes = (long long)C_out * a->NBk * 32 * 4;
+  long long s_max = (2048 + wgs - 1) / wgs;
+  if (s_max > tiles) s_max = tiles;
+  if (s_max > 2048) s_max = 2048;
+  if (s_max * per_split_bytes > (512ll << 20)) s_max = (512ll << 20) / per_split_bytes;
+  if (s_max < 1) s_max = 1;
+  long long s_min = (768 + wgs - 1) / wgs;
+  if (s_min > s_max) s_min = s_max;
+  long long S = s_min;
+  double best = -1.0;
+  for (long long c = s_min; c <= s_max; ++c) {        // same cost model as ws_geometry: one workgroup per CU, equal lengths
+    const long long per = (tiles + c - 1) / c, real = (tiles + per - 1) / per;
+    const long long total = wgs * real, rounds = (total + 255) / 256;
+    const double cost = (double)rounds * (double)(per + 3);
+    const double eff = (double)(wgs * tiles) / (256.0 * cost);
+    if (eff > best + 1e-9) { best = eff; S = c; }
+  }
+  a->tiles_per_split = (int)((tiles + S - 1) / S);
+  *splits = (int)((tiles + a->tiles_per_split - 1) / a->tiles_per_split);
+  return 0;
+}
+
 template <int NB, int D>
 static void ws_launch(const WsArgs& a, dim3 grid, size_t lds, hipStream_t stream) {
   auto kern = conv1d_wgrad_planes_kernel<NB, D>;
@@ -429,6 +691,12 @@ static long long ws_align(long long v) { return (v + 255) & ~255ll; }
 // workspace = [partials | dy planes | x planes]
 extern "C" int64_t fac_conv1d_bwd_weight_split_ws_bytes(int B, int C_in, int T_in, int C_out, int T_out, int K, int stride,
                                                         int dilation, int K1, int dilation2) {
+  {
+    fac::WkArgs k;
+    int S;
+    if (fac::wk_geometry(B, C_in, T_in, C_out, T_out, K, stride, dilation, K1, dilation2, &k, &S) == 0)
+      return fac::ws_align((int64_t)S * C_out * k.NBk * 32 * 4) + fac::ws_align(3 * k.a_plane_bytes) + fac::ws_align(3 * k.b_plane_bytes);
+  }
   fac::WsArgs a;
   int S;
   size_t lds;
@@ -443,6 +711,46 @@ extern "C" int fac_conv1d_bwd_weight_split(const float* x, const float* dy, floa
   FAC_REQUIRE(x && dy && dw && ws && B > 0 && C_in > 0 && C_out > 0 && T_in > 0 && T_out > 0 && K > 0 && stride > 0 &&
                   dilation > 0 && pad_left >= 0,
               "conv1d_bwd_weight_split: bad arguments");
+  {
+    WkArgs k;
+    int S;
+    if (wk_geometry(B, C_in, T_in, C_out, T_out, K, stride, dilation, K1, dilation2, &k, &S) == 0) {
+      const long long part_bytes = ws_align((long long)S * C_out * k.NBk * 32 * 4);
+      FAC_REQUIRE(ws_bytes >= part_bytes + ws_align(3 * k.a_plane_bytes) + ws_align(3 * k.b_plane_bytes),
+                  "conv1d_bwd_weight_split: workspace too small");
+      unsigned char* wsb = reinterpret_cast<unsigned char*>(ws);
+      k.part = reinterpret_cast<float*>(ws);
+      unsigned char* ap = wsb + part_bytes;
+      unsigned char* bp = ap + ws_align(3 * k.a_plane_bytes);
+      k.ap = ap; k.bp = bp;
+      const hipStream_t st = (hipStream_t)stream;
+      const int K2 = k.K2, K1e = k.K;
+      long long last = (long long)(T_out - 1) * stride + (long long)(K2 - 1) * (K2 > 1 ? dilation2 : 0) + (long long)(K1e - 1) * dilation - pad_left;
+      const int pad_right = last >= T_in ? (int)(last - T_in + 1) : 0;
+      const int max_pad = pad_left > pad_right ? pad_left : pad_right;
+      const int T_ext = T_in > max_pad ? T_in : max_pad + 1;
+      const int T_pad = (int)(pad_left + (last + 1 > T_in ? last + 1 : T_in));
+      const long long na = (long long)B * C_out * (k.UA / 8), nb = (long long)B * C_in * stride * (k.UB / 8);
+      const int ga = (int)((na + 255) / 256 < 65535 * 16 ? (na + 255) / 256 : 65535 * 16);
+      const int gb = (int)((nb + 255) / 256 < 65535 * 16 ? (nb + 255) / 256 : 65535 * 16);
+      hipLaunchKernelGGL(split_planes_kernel, dim3(ga), dim3(256), 0, st, dy, ap, (long long)B * C_out, T_out, T_out, T_out, 1, k.UA, 0,
+                         FAC_PAD_ZERO, k.a_plane_bytes);
+      hipLaunchKernelGGL(split_planes_kernel, dim3(gb), dim3(256), 0, st, x, bp, (long long)B * C_in, T_in, T_ext, T_pad, stride, k.UB,
+                         pad_left, pad_mode, k.b_plane_bytes);
+      auto kern = conv1d_wgrad_kmajor_kernel<3>;
+      static bool attr_set = false;
+      if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+      }
+      dim3 grid((C_out + 127) / 128, (k.NBk + 3) / 4, S);
+      hipLaunchKernelGGL(kern, grid, dim3(512), (size_t)2 * WK_STAGE, st, k);
+      const long long n = (long long)C_out * k.NBk * 32;
+      const int blocks = (int)((n + 255) / 256 < 65535 ? (n + 255) / 256 : 65535);
+      hipLaunchKernelGGL(wgrad_kmajor_reduce_kernel, dim3(blocks), dim3(256), 0, st, k.part, dw, S, C_out, k.NBk, k.K, k.CV);
+      return check_launch("conv1d_bwd_weight_split(k-major)");
+    }
+  }
   WsArgs a;
   int S;
   size_t lds;

@@ -601,6 +601,23 @@ def conv1d_bwd_weight(x, dy, k, stride=1, dilation=1, pad_mode=PAD_REFLECT, caus
     return dw
 
 
+# One grow-only scratch per device for the split weight-gradient kernel (bf16 planes of both operands + partial sums): every
+# launch goes to torch's current stream in program order, so consecutive layers can share it -- no per-layer allocation of
+# hundreds of MB, and its size shows up once in peak_mem instead of as allocator churn.  FAC_WGRAD_WS_GB caps it.
+_WGRAD_WS = {}
+WGRAD_WS_CAP = int(float(os.environ.get("FAC_WGRAD_WS_GB", "6")) * (1 << 30))
+
+
+def _wgrad_workspace(device, nbytes):
+    ws = _WGRAD_WS.get(device)
+    if ws is None or ws.numel() * 4 < nbytes:
+        if ws is not None:
+            del _WGRAD_WS[device]
+            ws = None
+        ws = _WGRAD_WS[device] = torch.empty((nbytes + (64 << 20)) // 4, device=device, dtype=torch.float32)
+    return ws
+
+
 def _bwd_weight_launch(x, dy, dw, B, c_in, t_in, c_out, t_out, k, stride, dilation, pad_left, pad_mode, k1=0, dilation2=0):
     """dW on the bf16 matrix pipe with fp32-exact splitting (conv1d_wgrad_split.hip) when the shape qualifies and
     FAC_BF16_SPLIT is on, else on the fp32 MFMA kernel."""
@@ -608,8 +625,10 @@ def _bwd_weight_launch(x, dy, dw, B, c_in, t_in, c_out, t_out, k, stride, dilati
     if _FLOPS is not None:
         _FLOPS.add("wgrad", 2.0 * B * c_out * c_in * k * t_out)
     nbytes = lib.fac_conv1d_bwd_weight_split_ws_bytes(B, c_in, t_in, c_out, t_out, k, stride, dilation, k1, dilation2) if BF16_SPLIT else -1
+    if nbytes > WGRAD_WS_CAP:       # beyond the workspace budget: the fp32 kernel (no operand planes) takes the layer
+        nbytes = -1
     if nbytes > 0:
-        ws = torch.empty(nbytes // 4, device=x.device, dtype=torch.float32)
+        ws = _wgrad_workspace(x.device, nbytes)
         _lib.check(lib.fac_conv1d_bwd_weight_split(_ptr(x), _ptr(dy), _ptr(dw), _ptr(ws), nbytes, B, c_in, t_in, c_out, t_out, k,
                                                    stride, dilation, pad_left, pad_mode, k1, dilation2, _stream()),
                    "fac_conv1d_bwd_weight_split")

@@ -56,6 +56,12 @@ CASES = [
     (2, 64, 64, 5, 7, 1, 1, 6, ops.PAD_REFLECT),          # signal shorter than the pad
     (2, 20, 256, 40, 1, 1, 1, 0, ops.PAD_ZERO),
     (1, 1536, 1536, 160, 7, 1, 1, 6, ops.PAD_REFLECT),    # largest layer shape (decoder input conv)
+    # k-major kernel edges: channel counts that are not multiples of its 32-channel blocks, the smallest count it takes (16),
+    # more blocks than one column tile row (K = 7 x 2 groups), odd shifts (unaligned 16-byte plane loads), 130 output rows
+    (2, 48, 64, 300, 5, 1, 1, 2, ops.PAD_ZERO),
+    (2, 16, 32, 200, 7, 1, 1, 6, ops.PAD_REFLECT),
+    (3, 80, 130, 257, 7, 1, 3, 18, ops.PAD_REFLECT),
+    (2, 40, 96, 301, 3, 1, 1, 1, ops.PAD_ZERO),
 ]
 
 
