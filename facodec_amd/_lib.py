@@ -28,7 +28,7 @@ class ConvDesc(C.Structure):
         ("pad_mode", C.c_int32), ("n_phase", C.c_int32), ("y_tstride", C.c_int32), ("phase_shift", C.c_int32),
         ("act", C.c_int32),
         ("w_batched", C.c_int32), ("w_bs", _i64), ("ws", _p), ("ws_bytes", _i64), ("w_split", _p),
-        ("K1", C.c_int32), ("dilation2", C.c_int32),
+        ("K1", C.c_int32), ("dilation2", C.c_int32), ("row_phases", C.c_int32),
     ]
 
 
@@ -47,6 +47,7 @@ SIGNATURES = {
     "fac_last_error": (C.c_char_p, []),
     "fac_wn_scale": (_i, [_p, _p, _p, _i, _i, _p]),
     "fac_pack_conv_w": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
+    "fac_pack_convtr_w_rows": (_i, [_p, _p, _p, _i, _i, _i, _p]),
     "fac_conv_w_split_bytes": (_i64, [_i, _i, _i]),
     "fac_pack_conv_w_split": (_i, [_p, _p, _p, _i, _i, _i, _p]),
     "fac_pack_conv_w_bwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),

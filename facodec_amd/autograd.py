@@ -67,7 +67,7 @@ class _ConvTr(Function):
     @staticmethod
     def forward(ctx, x, v, g, bias, stride):
         vd, gd = v.detach(), (g.detach() if g is not None else None)
-        y = ops.conv_transpose1d(x.detach(), ops.pack_convtr_weight(vd, gd, stride), v.shape[1], stride,
+        y = ops.conv_transpose1d(x.detach(), ops.convtr_weight_for(vd, gd, stride, x.shape[-1]), v.shape[1], stride,
                                  bias=bias.detach() if bias is not None else None)
         ctx.stride = stride
         ctx.save_for_backward(x, v, g, bias)

@@ -7,6 +7,7 @@ namespace fac {
 // Tile selection: M tile by output channels, narrow-N tile for short sequences (LSTM batches).
 static int select_variant(const fac_conv_desc* d) {
   const int co = d->C_out;
+  if (d->row_phases > 1) return 5;      // (channel, phase) rows: the 128 x 256 tile with the all-waves LDS epilogue
   if (d->T_out <= 32) return 0;
   if (co <= 32) return 1;
   if (co <= 64) return 2;
@@ -48,7 +49,7 @@ extern "C" int fac_conv1d_fwd(const fac_conv_desc* d, fac_stream_t stream) {
               d->T_in, d->T_out);
   FAC_REQUIRE(d->K >= 1 && d->stride >= 1 && d->dilation >= 1 && d->pad_left >= 0,
               "conv1d: bad K/stride/dilation/pad");
-  FAC_REQUIRE(d->C_out_pad % 32 == 0 && d->C_out_pad >= d->C_out, "conv1d: C_out_pad must be a multiple of 32");
+  FAC_REQUIRE(d->C_out_pad % 32 == 0 && (d->C_out_pad >= d->C_out || d->row_phases > 1), "conv1d: C_out_pad must be a multiple of 32");
   FAC_REQUIRE(d->n_phase >= 1 && d->y_tstride >= 1, "conv1d: bad phase config");
   FAC_REQUIRE((long long)d->B * d->n_phase <= 65535, "conv1d: B*n_phase too large for grid.z");
   ConvArgs a;
@@ -66,6 +67,12 @@ extern "C" int fac_conv1d_fwd(const fac_conv_desc* d, fac_stream_t stream) {
   a.pad_left = d->pad_left; a.pad_mode = d->pad_mode; a.n_phase = d->n_phase;
   a.y_tstride = d->y_tstride; a.act = d->act; a.w_batched = d->w_batched;
   a.phase_shift = d->phase_shift;
+  a.rp = d->row_phases > 1 ? d->row_phases : 1;
+  if (a.rp > 1) {
+    FAC_REQUIRE(d->n_phase == 1 && d->y_tstride == 1 && d->phase_shift == 0 && d->stride == 1 && a.rp <= 128 && !d->w_k1 &&
+                    !d->w_batched && d->C_out_pad == fac_convtr_rows(d->C_out, a.rp) && !(d->K1 > 0 && d->K1 < d->K),
+                "conv1d: row_phases needs a plain stride-1 launch on weights from fac_pack_convtr_w_rows");
+  }
   a.K1 = d->K1 > 0 ? d->K1 : d->K; a.dil2 = d->dilation2;
   FAC_REQUIRE(a.K1 <= d->K && d->K % a.K1 == 0 && (a.K1 == d->K || d->dilation2 > 0), "conv1d: bad two-level taps (K=%d K1=%d)", d->K, d->K1);
   FAC_REQUIRE(!conv_two_level(a) || (!d->w_k1 && d->n_phase == 1 && !d->w_split && d->pad_mode == FAC_PAD_ZERO && !d->w_batched),
@@ -81,6 +88,7 @@ extern "C" int fac_conv1d_fwd(const fac_conv_desc* d, fac_stream_t stream) {
   }
   hipStream_t s = (hipStream_t)stream;
   if (d->w_k1) return conv_dispatch_fused_ru(a, s);
+  if (a.rp > 1) return conv_dispatch_128x256(a, s);
   const bool two_level = conv_two_level(a);
   if (!two_level && conv_skinny_ok(a, d->ws, d->ws_bytes)) return conv_dispatch_skinny(a, d->ws, d->ws_bytes, s);
   if (!two_level && narrow_ok(d)) return conv_dispatch_narrow(a, s);
@@ -117,6 +125,10 @@ extern "C" int fac_conv1d_variant(const fac_conv_desc* d, char* name, int name_l
   if (d->w_k1) {
     if (name && name_len > 0) snprintf(name, name_len, "conv1d_mfma_kernel<C/32,1,1,4,7,fused RU> Cx128");
     return 7;
+  }
+  if (d->row_phases > 1) {
+    if (name && name_len > 0) snprintf(name, name_len, "conv1d_mfma_kernel<2,2,2,4,2> 128x256 (convtr, all phases per tile)");
+    return 5;
   }
   {
     ConvArgs a{};

@@ -65,6 +65,8 @@ struct ConvArgs {
   unsigned long long* dbg;   // per-workgroup cycle counters (tuning builds only)
 #endif
   int x_off;   // columns staged to the left of the receptive field so that the slab starts 16-B aligned
+  int rp;      // > 1: output rows are (channel, phase) pairs, phase fastest, CO_TILE / rp channels per tile (all-phases
+               // ConvTranspose1d, fac_conv_desc.row_phases); the all-waves epilogue interleaves them into contiguous runs
 };
 
 // largest tap offset of a (possibly two-level) conv
@@ -588,6 +590,61 @@ __global__ __launch_bounds__((WM * WN + 4) * 64, (WM * WN == 4 ? FAC_CONV_WPE : 
                         (!yg || (reinterpret_cast<unsigned long long>(a.y) & 15) == 0) &&
                         (!y2g || (reinterpret_cast<unsigned long long>(a.y2) & 15) == 0) &&
                         (!rg || (reinterpret_cast<unsigned long long>(a.res) & 15) == 0);
+    if (a.rp > 1) {
+      // ---- all-phases transposed conv: tile rows = (channel cl, phase p), p fastest; a lane emits four CONSECUTIVE output
+      // samples u = t * rp + p of one channel (gathered from rp rows of the accumulator tile), so y / y2 leave as 16-byte
+      // pieces of contiguous runs instead of rp interleaved strided streams.
+      const int rp = a.rp, cpt = CO_TILE / rp;
+      const int QPRp = (T_TILE * rp) / 4;                   // T_TILE * rp outputs per channel in this tile
+      const long long u0 = (long long)t0 * rp, T_tot = (long long)a.T_out * rp;
+      const int ch0 = (co0 / CO_TILE) * cpt;
+      for (int q = tid; q < cpt * QPRp; q += NTH) {
+        const int cl = q / QPRp, uq = q - cl * QPRp;
+        const int co = ch0 + cl;
+        const long long u = u0 + 4 * uq;
+        if (co >= a.C_out || u >= T_tot) continue;
+        float v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int ul = 4 * uq + i, tl = ul / rp, p = ul - tl * rp;
+          v[i] = smem[(cl * rp + p) * EP + tl];
+        }
+        const float bs = a.bias ? a.bias[co] : 0.f;
+        const float al = a.alpha_out ? a.alpha_out[co] : 0.f;
+        const float inv = a.alpha_out ? snake_inv(al) : 0.f;
+        const long long o = (long long)co * a.y_cs + u;
+        const bool full = vec_ok && u + 3 < T_tot;
+        float rv[4] = {0.f, 0.f, 0.f, 0.f};
+        if (rg) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) rv[i] = u + i < T_tot ? rg[o + i] : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          float x = v[i] + bs;
+          if (a.alpha_out) x = snake_apply(x, al, inv);
+          if (a.act != FAC_ACT_NONE) x = apply_act_slow(x, a.act);
+          v[i] = x + rv[i];
+        }
+        float w[4] = {0.f, 0.f, 0.f, 0.f};
+        if (y2g) {
+          const float a2 = a.alpha2[co], i2 = snake_inv(a2);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) w[i] = snake_apply(v[i], a2, i2);
+        }
+        if (full) {
+          if (yg) *reinterpret_cast<float4*>(yg + o) = make_float4(v[0], v[1], v[2], v[3]);
+          if (y2g) *reinterpret_cast<float4*>(y2g + o) = make_float4(w[0], w[1], w[2], w[3]);
+        } else {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            if (u + i >= T_tot) continue;
+            if (yg) yg[o + i] = v[i];
+            if (y2g) y2g[o + i] = w[i];
+          }
+        }
+      }
+    } else
     for (int q = tid; q < CO_TILE * QPR; q += NTH) {
       const int row = q / QPR, tq = q - row * QPR;
       const int co = co0 + row, t = t0 + 4 * tq;
@@ -707,7 +764,12 @@ int launch_cfg(ConvArgs& a, hipStream_t s) {
 #ifdef FAC_PROF
   a.dbg = g_conv_dbg;
 #endif
-  const long long n_wg = (long long)a.n_t_tiles * ((a.C_out + CO_TILE - 1) / CO_TILE) * a.B * a.n_phase;
+  if (a.rp > 1 && !((WM * WN == 8) && !FUSE && CO_TILE == 128)) {
+    set_error("conv1d: row_phases needs the 128-row all-waves-epilogue tile");
+    return FAC_ERR_ARG;
+  }
+  const int n_co_tiles = a.rp > 1 ? a.C_out_pad / CO_TILE : (a.C_out + CO_TILE - 1) / CO_TILE;
+  const long long n_wg = (long long)a.n_t_tiles * n_co_tiles * a.B * a.n_phase;
   if (n_wg > 0x7fffffffll) {
     set_error("conv1d: too many workgroups (%lld)", n_wg);
     return FAC_ERR_ARG;

@@ -7,6 +7,7 @@ namespace fac {
 int conv_dispatch_128x256(ConvArgs& a, hipStream_t s) {
   switch (a.KV) {
     case 1: return launch_cfg<2,2,2,4, 1>(a, s);
+    case 2: return launch_cfg<2,2,2,4, 2>(a, s);      // all-phases ConvTranspose1d (row_phases)
     case 7: return launch_cfg<2,2,2,4, 7>(a, s);
     default: return launch_cfg<2,2,2,4, 0>(a, s);
   }

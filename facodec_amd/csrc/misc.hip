@@ -587,7 +587,7 @@ __global__ __launch_bounds__(256) void logdiff_rms_stage1(const float* __restric
 
 using namespace fac;
 
-extern "C" int fac_version(void) { return 1; }
+extern "C" int fac_version(void) { return 3; }   // round 3: fac_conv_desc.row_phases, fac_adamw_step_masked, fac_pack_convtr_w_rows
 extern "C" const char* fac_last_error(void) { return fac::g_err; }
 
 #define EW_LAUNCH(kern, n, ...)                                                         \

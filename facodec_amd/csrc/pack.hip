@@ -94,6 +94,29 @@ __global__ __launch_bounds__(256) void pack_convtr_kernel(const float* __restric
   }
 }
 
+// ConvTranspose1d v (C_in, C_out, K = 2s) -> packed[ci][j][row] for the all-phases launch: row = tile*128 + (co % cpt)*s + p,
+// cpt = 128 / s channels per tile (see fac_pack_convtr_w_rows).  One thread per output element, rows fastest.
+__global__ __launch_bounds__(256) void pack_convtr_rows_kernel(const float* __restrict__ v, const float* __restrict__ scale,
+                                                               float* __restrict__ out, int C_in, int C_out, int s, int R_pad,
+                                                               long long n) {
+  const int cpt = 128 / s;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const int row = (int)(i % R_pad);
+    const long long r2 = i / R_pad;
+    const int j = (int)(r2 & 1);
+    const int ci = (int)(r2 >> 1);
+    const int tile = row >> 7, rl = row & 127;
+    const int cl = rl / s, p = rl - cl * s;
+    const int co = tile * cpt + cl;
+    float val = 0.f;
+    if (ci < C_in && cl < cpt && co < C_out) {
+      val = v[((long long)ci * C_out + co) * (2 * s) + p + s * (1 - j)];
+      if (scale) val = __fmul_rn(val, scale[ci]);
+    }
+    out[i] = val;
+  }
+}
+
 // W_hh (4H, H) -> packed[ublk][kg][kq][i][4]: for unit block ublk (8 hidden units) the 32 gate
 // rows i = gate*8 + u, k = kg*8 + 2*jj + kq  (jj = 0..3 is the float4 component).
 __global__ __launch_bounds__(256) void pack_whh_kernel(const float* __restrict__ w,
@@ -149,6 +172,18 @@ extern "C" int fac_pack_convtr_w(const float* v, const float* scale, float* pack
   hipLaunchKernelGGL(pack_convtr_kernel, grid, dim3(256), lds, (hipStream_t)stream, v, scale,
                      packed, C_in, C_out, stride, C_out_pad);
   return check_launch("pack_convtr_w");
+}
+
+extern "C" int fac_pack_convtr_w_rows(const float* v, const float* scale, float* packed, int C_in, int C_out, int stride,
+                                      fac_stream_t stream) {
+  using namespace fac;
+  FAC_REQUIRE(v && packed && C_out > 0 && C_in > 0 && stride > 0 && stride <= 128, "pack_convtr_w_rows: bad arguments");
+  const int R_pad = fac_convtr_rows(C_out, stride);
+  const long long n = (long long)cin_pad_dev(C_in) * 2 * R_pad;
+  const int blocks = (int)((n + 255) / 256 < 65535 ? (n + 255) / 256 : 65535);
+  hipLaunchKernelGGL(pack_convtr_rows_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, v, scale, packed, C_in, C_out,
+                     stride, R_pad, n);
+  return check_launch("pack_convtr_w_rows");
 }
 
 extern "C" int fac_pack_lstm_whh(const float* w_hh, float* packed, int H, fac_stream_t stream) {

@@ -40,6 +40,7 @@ class ConvWeights(nn.Module):
         self.bias = nn.Parameter(_uniform_(torch.empty(c_out), 1.0 / math.sqrt(fan_in))) if bias else None
         self._packed = None
         self._split = None
+        self._rows = None
         self.freeze_packed = False
 
     def packed(self):
@@ -54,6 +55,15 @@ class ConvWeights(nn.Module):
             self._packed = ops.pack_conv_weight(v.detach(), g.detach() if g is not None else None, out=self._packed)
         return self._packed
 
+    def packed_rows(self):
+        """ConvTranspose1d weights for the all-phases launch (ops.pack_convtr_weight_rows)."""
+        if self._rows is not None and self.freeze_packed:
+            return self._rows
+        v = self.weight_v if self.weight_norm else self.weight
+        g = self.weight_g if self.weight_norm else None
+        self._rows = ops.pack_convtr_weight_rows(v.detach(), g.detach() if g is not None else None, self.stride, out=self._rows)
+        return self._rows
+
     def packed_split(self):
         """The same weights as three exact bf16 planes (ops.pack_conv_weight_split) for the k = 7 convs."""
         if self._split is not None and self.freeze_packed:
@@ -66,6 +76,7 @@ class ConvWeights(nn.Module):
     def _apply(self, fn, *a, **kw):
         self._packed = None  # device / dtype moves invalidate the packed copies
         self._split = None
+        self._rows = None
         return super()._apply(fn, *a, **kw)
 
 
@@ -126,7 +137,8 @@ class SConvTranspose1d(nn.Module):
 
     def run(self, x, alpha_in=None, alpha_y2=None):
         w = self.w
-        return ops.conv_transpose1d(x, w.packed(), w.c_out, self.stride, bias=w.bias, alpha_in=alpha_in,
+        wp = w.packed_rows() if ops.convtr_rows_ok(x.shape[-1], self.stride, self.causal) else w.packed()
+        return ops.conv_transpose1d(x, wp, w.c_out, self.stride, bias=w.bias, alpha_in=alpha_in,
                                     alpha_y2=alpha_y2, causal=self.causal)
 
     def forward(self, x):

@@ -81,6 +81,42 @@ def pack_convtr_weight(v, g, stride, out=None):
     return out
 
 
+# All-phases-per-workgroup launch of the causal ConvTranspose1d (fac_conv_desc.row_phases): contiguous stores through the
+# LDS epilogue instead of `stride` interleaved strided streams (2.9x the algorithmic HBM traffic).  Needs the 256-column
+# tile, so it takes over from CONVTR_ROWS_MIN_T input columns; FAC_CONVTR_ROWS=0 keeps the polyphase launch everywhere.
+CONVTR_ROWS = os.environ.get("FAC_CONVTR_ROWS", "1") != "0"
+CONVTR_ROWS_MIN_T = 512
+
+
+def convtr_rows_pad(c_out, stride):
+    cpt = 128 // stride
+    return -(-c_out // cpt) * 128
+
+
+def convtr_rows_ok(t_in, stride, causal=True):
+    return CONVTR_ROWS and causal and 2 <= stride <= 16 and t_in >= CONVTR_ROWS_MIN_T
+
+
+def pack_convtr_weight_rows(v, g, stride, out=None):
+    """ConvTranspose1d (C_in, C_out, 2*stride) -> (cin_pad(C_in), 2, rows) with rows = (channel, phase) pairs in 128-row
+    tiles (fac_pack_convtr_w_rows); conv_transpose1d recognises the layout by its 3 dimensions."""
+    v = _dev(v, "weight")
+    c_in, c_out, k = v.shape
+    if k != 2 * stride:
+        raise _lib.FacodecHipError(f"ConvTranspose1d needs kernel_size == 2*stride (got {k}, {stride})")
+    scale = wn_scale(v, g) if g is not None else None
+    if out is None:
+        out = torch.empty(cin_pad(c_in), 2, convtr_rows_pad(c_out, stride), device=v.device, dtype=torch.float32)
+    _lib.check(_lib.load().fac_pack_convtr_w_rows(_ptr(v), _ptr(scale), _ptr(out), c_in, c_out, stride, _stream()),
+               "fac_pack_convtr_w_rows")
+    return out
+
+
+def convtr_weight_for(v, g, stride, t_in, causal=True):
+    """The packed weights conv_transpose1d wants for an input of t_in columns."""
+    return pack_convtr_weight_rows(v, g, stride) if convtr_rows_ok(t_in, stride, causal) else pack_convtr_weight(v, g, stride)
+
+
 # --------------------------------------------------------------------------------- conv (K1-K4)
 class ConvLaunchProfile:
     """Opt-in per-launch timing of the conv kernel with HIP events recorded on the launch stream
@@ -197,7 +233,7 @@ def _launch_conv(d, what):
     ws = _conv_workspace(torch.device("cuda", torch.cuda.current_device()))
     d.ws, d.ws_bytes = ws.data_ptr(), CONV_WS_BYTES
     if _FLOPS is not None:
-        _FLOPS.add(_FLOP_KEY, 2.0 * d.B * d.n_phase * d.C_out * d.T_out * d.C_in * d.K + (2.0 * d.B * d.C_out * d.T_out * d.C_out if d.w_k1 else 0.0))
+        _FLOPS.add(_FLOP_KEY, 2.0 * d.B * d.n_phase * max(1, d.row_phases) * d.C_out * d.T_out * d.C_in * d.K + (2.0 * d.B * d.C_out * d.T_out * d.C_out if d.w_k1 else 0.0))
     if _PROFILE is None:
         _lib.check(lib.fac_conv1d_fwd(C.byref(d), _stream()), what)
         return
@@ -207,7 +243,7 @@ def _launch_conv(d, what):
     e0.record()
     _lib.check(lib.fac_conv1d_fwd(C.byref(d), _stream()), what)
     e1.record()
-    flops = 2.0 * d.B * d.n_phase * d.C_out * d.T_out * d.C_in * d.K
+    flops = 2.0 * d.B * d.n_phase * max(1, d.row_phases) * d.C_out * d.T_out * d.C_in * d.K
     if d.w_k1:
         flops += 2.0 * d.B * d.C_out * d.T_out * d.C_out   # fused 1x1 conv
     _PROFILE.records.append((buf.value.decode(), flops, e0, e1))
@@ -314,6 +350,10 @@ def conv_transpose1d(x, w_packed, c_out, stride, bias=None, alpha_in=None, out=N
     d.n_phase, d.y_tstride, d.act, d.w_batched, d.w_bs = stride, stride, ACT_NONE, 0, 0
     # non-causal: trim ceil(s/2) on the left, floor(s/2) on the right (dac/model/encodec.py:265-269)
     d.phase_shift = 0 if causal else stride - stride // 2
+    if w_packed.dim() == 3:          # rows layout (pack_convtr_weight_rows): all phases per workgroup, contiguous stores
+        if not causal or has_history:
+            raise _lib.FacodecHipError("the all-phases ConvTranspose1d launch is causal and offline only")
+        d.n_phase, d.y_tstride, d.phase_shift, d.row_phases = 1, 1, 0, stride
     _launch_conv(d, "fac_conv1d_fwd(convtr)")
     return (out, y2) if alpha_y2 is not None else out
 
@@ -580,7 +620,7 @@ def conv1d_bwd_data(dy, v, g, t_in, stride=1, dilation=1, pad_mode=PAD_REFLECT, 
         if k != 2 * stride or dilation != 1:
             raise NotImplementedError("strided bwd_data is built for the model's k = 2*stride convs")
         dy_ext = torch.cat([dy, torch.zeros(B, c_out, 1, device=dy.device)], dim=2)
-        dxpad = conv_transpose1d(dy_ext, pack_convtr_weight(v, g, stride), c_in, stride)
+        dxpad = conv_transpose1d(dy_ext, convtr_weight_for(v, g, stride, dy_ext.shape[-1]), c_in, stride)
         assert dxpad.shape[-1] == tp, (dxpad.shape, tp)
     dx = torch.empty(B, c_in, t_in, device=dy.device, dtype=torch.float32)
     _lib.check(_lib.load().fac_pad_fold_bwd(_ptr(dxpad), _ptr(dx), B, c_in, t_in, tp, pad_left, pad_mode, _stream()),

@@ -70,6 +70,17 @@ int fac_pack_conv_w(const float* v, const float* scale, float* packed, int C_out
 int fac_pack_convtr_w(const float* v, const float* scale, float* packed, int C_in, int C_out,
                       int stride, int C_out_pad, fac_stream_t stream);
 
+/* The same sub-filters for the all-phases-per-workgroup launch (fac_conv_desc.row_phases = stride): rows r = (co, p), phase
+ * fastest, in tiles of 128 rows holding cpt = 128 / stride channels each (rows cpt * stride .. 127 of a tile are zero):
+ * packed[ci][j][tile * 128 + (co % cpt) * stride + p] = v[ci][co][p + stride * (1 - j)] * scale[ci], tile = co / cpt;
+ * the buffer is (fac_cin_pad(C_in), 2, fac_convtr_rows(C_out, stride)) floats, written completely. */
+static inline int fac_convtr_rows(int C_out, int stride) {
+  const int cpt = 128 / stride;
+  return ((C_out + cpt - 1) / cpt) * 128;
+}
+int fac_pack_convtr_w_rows(const float* v, const float* scale, float* packed, int C_in, int C_out, int stride,
+                           fac_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * K1-K4  Conv1d / polyphase ConvTranspose1d as implicit GEMM on fp32 MFMA
  * (v_mfma_f32_32x32x2_f32), with fused Snake prologue, bias, Snake/tanh epilogue and
@@ -130,6 +141,13 @@ typedef struct fac_conv_desc {
    * discriminator, dac/model/discriminator.py:101-170 -- is such a conv along the concatenated axis: K1 = k taps along
    * frequency, dilation2 = the row pitch.  Runs on the generic fp32-MFMA tile. */
   int32_t K1, dilation2;
+  /* Optional (0 / 1 = off): causal ConvTranspose1d with ALL `row_phases` = stride output phases computed by one workgroup.
+   * The GEMM's output rows are (channel, phase) pairs, phase fastest, 128 / row_phases channels per 128-row tile
+   * (weights from fac_pack_convtr_w_rows, C_out_pad = its padded row count, n_phase = 1, K = 2, pad_left = 1, y_tstride = 1,
+   * T_out = input length); the epilogue interleaves the phases through LDS and stores CONTIGUOUS runs of y (B, C_out,
+   * T_out * row_phases).  (The polyphase launch, n_phase = stride, lets every phase store with stride `stride`: partial
+   * cache lines, measured 2.9x the algorithmic HBM traffic.) */
+  int32_t row_phases;
 } fac_conv_desc;
 
 int fac_conv1d_fwd(const fac_conv_desc* d, fac_stream_t stream);

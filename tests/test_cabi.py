@@ -11,7 +11,7 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _header_symbols():
     hdr = open(os.path.join(REPO, "include", "facodec_hip.h")).read()
     hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
-    return set(re.findall(r"\b(fac_[a-z0-9_]+)\s*\(", hdr)) - {"fac_pad32", "fac_cin_pad"}
+    return set(re.findall(r"\b(fac_[a-z0-9_]+)\s*\(", hdr)) - {"fac_pad32", "fac_cin_pad", "fac_convtr_rows"}   # static inline helpers
 
 
 def test_library_exports_every_declared_symbol():

@@ -122,6 +122,33 @@ def test_conv_transpose_against_oracle(B, ci, co, T, s, O, ops, cuda):
     assert yg.shape == y.shape and rel(yg, y) < OP_TOL
 
 
+@pytest.mark.parametrize("B,ci,co,T,s", [(2, 192, 96, 1000, 2), (2, 96, 40, 777, 5), (1, 128, 64, 1333, 6), (3, 64, 22, 512, 3)])
+def test_conv_transpose_all_phases_launch(B, ci, co, T, s, O, ops, cuda):
+    """The all-phases-per-workgroup ConvTranspose1d (fac_conv_desc.row_phases: (channel, phase) rows, phases interleaved
+    through the LDS epilogue, contiguous stores) against the oracle and against the polyphase launch, with bias, Snake
+    prologue and the pre-activated second output; channel counts that do not fill the 128 / stride channels of a tile,
+    ragged last time tile."""
+    g = _g(40 + s)
+    x = torch.randn(B, ci, T, generator=g)
+    v = torch.randn(ci, co, 2 * s, generator=g) / (ci * 2) ** 0.5
+    gg = torch.rand(ci, 1, 1, generator=g) + 0.5
+    b = torch.randn(co, generator=g) * 0.1
+    al = 1 + 0.2 * torch.rand(ci, generator=g)
+    a2 = 1 + 0.2 * torch.rand(co, generator=g)
+    y = O.sconvtr1d(O.snake(x, al.view(1, -1, 1)), O.weight_norm_weight(v, gg), b, s, causal=True)
+    assert ops.convtr_rows_ok(T, s)
+    wr = ops.pack_convtr_weight_rows(v.to(cuda), gg.to(cuda), s)
+    assert wr.dim() == 3 and wr.shape[-1] == ops.convtr_rows_pad(co, s)
+    yg, y2 = ops.conv_transpose1d(x.to(cuda), wr, co, s, bias=b.to(cuda), alpha_in=al.to(cuda), alpha_y2=a2.to(cuda))
+    assert yg.shape == y.shape and rel(yg, y) < OP_TOL
+    assert rel(y2, O.snake(y, a2.view(1, -1, 1))) < OP_TOL
+    yp = ops.conv_transpose1d(x.to(cuda), ops.pack_convtr_weight(v.to(cuda), gg.to(cuda), s), co, s, bias=b.to(cuda), alpha_in=al.to(cuda))
+    assert rel(yg, yp) < 1e-6
+    # what the layer picks by itself
+    w2 = ops.convtr_weight_for(v.to(cuda), gg.to(cuda), s, T)
+    assert w2.dim() == 3 and ops.convtr_weight_for(v.to(cuda), gg.to(cuda), s, 100).dim() == 4
+
+
 def test_conv_second_output_is_snake_of_first(O, ops, cuda):
     """y2 = snake(y, alpha_y2) (the pre-activated copy a following Snake->conv consumes by LDS-DMA);
     also exercises the pure-DMA input path (no Snake prologue, interior tiles) against the oracle."""

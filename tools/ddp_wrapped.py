@@ -120,14 +120,7 @@ def main():
     loss_gen_all.backward()
     for k in GEN:
         got[k] = optimizer.optimizers[k].g.clone()
-    norms = {k: float(torch.nn.utils.clip_grad_norm_(ddp[k].parameters(), 1000.0)) for k in GEN}
-    for k in GEN:
-        optimizer.step(k)
-    for k in GEN:
-        optimizer.scheduler(key=k)
-    report["last_lr"] = optimizer.schedulers["encoder"].get_last_lr()[0]            # train.py:384
-
-    # train.py:450-453 through the wrapper
+    # train.py:450-453 through the wrapper (before the optimiser moves timbre_linear)
     with torch.no_grad():
         style2 = ddp.quantizer.module.timbre_linear(timbre.detach()).unsqueeze(2)
         gamma, beta = style2.chunk(2, 1)
@@ -137,6 +130,13 @@ def main():
         x = x.transpose(1, 2)
         x = x * gamma + beta
     report["timbre_norm_vs_forward"] = float((x - z.detach()).abs().max() / z.detach().abs().max())
+
+    norms = {k: float(torch.nn.utils.clip_grad_norm_(ddp[k].parameters(), 1000.0)) for k in GEN}
+    for k in GEN:
+        optimizer.step(k)
+    for k in GEN:
+        optimizer.scheduler(key=k)
+    report["last_lr"] = optimizer.schedulers["encoder"].get_last_lr()[0]            # train.py:384
 
     torch.cuda.synchronize()
     rel = {}

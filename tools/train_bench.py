@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--generator-only", action="store_true", help="skip the discriminator step and the GAN terms")
+    ap.add_argument("--predictors", action="store_true", help="include the predictor heads with synthetic targets (bench.py's step)")
     a = ap.parse_args()
     rank, local_rank, world = benchutil.init_distributed()
     dev = torch.device(f"cuda:{local_rank % torch.cuda.device_count()}")
@@ -33,14 +34,21 @@ def main():
     for k in ("encoder", "quantizer", "decoder", "discriminator"):
         synth.load_synthetic(model[k], seed=0, prefix=k + ".")
         model[k].to(dev)
-    step = GeneratorStep(model) if a.generator_only else TrainStep(model)
+    kw = {}
+    if a.predictors:
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        from bench import synthetic_predictor_targets
+        synth.load_synthetic(model.fa_predictors, seed=0, prefix="fa_predictors.")
+        model.fa_predictors.to(dev)
+        kw["targets"] = synthetic_predictor_targets(a.batch, 160, dev, seed=3 + rank)
+    step = GeneratorStep(model) if a.generator_only else TrainStep(model, with_predictors=a.predictors)
     wave = synth.synth_clips(a.batch, 48000, seed=0, rank=rank).to(dev)
     for _ in range(a.warmup):
-        out = step(wave)
+        out = step(wave, **kw)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(a.steps):
-        out = step(wave)
+        out = step(wave, **kw)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / a.steps
     if rank == 0:
