@@ -89,6 +89,14 @@ struct ConvUnroll {
   static constexpr int CIC = KT == 1 ? 24 : (KT == 2 || KT == 3) ? 16 : (KT >= 4 && KT <= 7) ? 8 : (KT > 7 ? 4 : 0);
 };
 
+// Channels per stage of the compile-time tap loops.  On the 256-column tiles a staged row of a 2- or 3-tap conv is two 64-lane
+// float4 blocks wide, and 16 channels would need 32 (row, block) register slots per staging wave where CONV_XMAX gives 24 --
+// the launch then fell back to the run-time tap loop (no fragment prefetch ring): 8 channels per stage there.
+template <int KT, int T_TILE>
+constexpr int conv_cic() {
+  return ((KT == 2 || KT == 3) && T_TILE >= 256) ? 8 : ConvUnroll<KT>::CIC;
+}
+
 #ifndef FAC_CONV_WPE
 #define FAC_CONV_WPE 4
 #endif
@@ -138,7 +146,7 @@ __global__ __launch_bounds__((WM * WN + 4) * 64, (WM * WN == 4 ? FAC_CONV_WPE : 
   }
 
   const int K = KT > 0 ? KT : a.KV;       // taps per (virtual) input channel
-  const int cic = KT > 0 ? ConvUnroll<KT>::CIC : a.cic;
+  const int cic = KT > 0 ? conv_cic<KT, T_TILE>() : a.cic;
   const int XW = a.XW, XB = a.XB;
   const int w_stage = cic * K * CO_TILE;  // floats
   const int x_stage = cic * XW;
@@ -383,7 +391,7 @@ __global__ __launch_bounds__((WM * WN + 4) * 64, (WM * WN == 4 ? FAC_CONV_WPE : 
       // Straight-line chunk: P = CIC/2*KT (channel pair, tap) positions of MB*NB MFMAs each.  The
       // fragments of position p+2 are requested from LDS before the MFMAs of position p are issued
       // (3-deep register ring, static indices), so ds_read latency never stalls the matrix pipe.
-      constexpr int CICc = ConvUnroll<KT>::CIC;
+      constexpr int CICc = conv_cic<KT, T_TILE>();
       constexpr int P = CICc / 2 * KT;
       float av[3][MB], bv[3][NB];
       auto ldfrag = [&](int pos, float* avp, float* bvp) {
@@ -721,7 +729,7 @@ int launch_cfg(ConvArgs& a, hipStream_t s) {
   const int per_ci = a.KV * CO_TILE + a.XW;      // floats per staged (virtual) input channel
   int cic;
   if constexpr (KT > 0) {
-    cic = ConvUnroll<KT>::CIC;
+    cic = conv_cic<KT, T_TILE>();
     // the compile-time stage must fit the register slots and ~half the LDS; otherwise use the
     // run-time-sized generic path (unusual stride / dilation for this tap count)
     if (cic * a.XB > 4 * CONV_XMAX || (size_t)2 * cic * per_ci * sizeof(float) > (WM * WN == 4 ? 80 : 160) * 1024)

@@ -427,10 +427,21 @@ static int ws_geometry(int B, int C_in_real, int T_in, int C_out, int T_out, int
 // staging code for both operands (12 x 16 bytes per staging lane and stage).
 // Blocks are numbered gb = group * K + k; partial sums are written block-wise ([slice][co][gb][32], 128-byte runs) and the
 // reduction kernel scatters them into dW (C_out, C_in, K) -- the scattered side is the 1x dW, not the S x partials.
-constexpr int WK_PITCH = 80;                       // bytes per staged row: 32 bf16 + 16 B pad (16 lanes x b128 cover all 64 banks)
-constexpr int WK_PLANE = 128 * WK_PITCH;           // one plane of one operand
-constexpr int WK_OPND = 3 * WK_PLANE;              // one operand
-constexpr int WK_STAGE = 2 * WK_OPND;              // 61 440 B
+// Staging (round 3, second step): the planes are pure copies, and a CU pulls only ~15.6 B/clk from L2 into VGPRs against
+// 45-52 B/clk by LDS-DMA (tools/microbench/cu_stream_probe.hip).  A stage of this kernel is 48 KB per 48 MFMAs per wave
+// (1536 matrix-pipe cycles) = 32 B/clk: through registers the MFMA waves wait for the copies half of the time (measured MFMA
+// busy 36-41 % on either variant).  So both operands move by global_load_lds (16 B per lane, no VGPR, no ds_write), three
+// LDS stages deep (loads of stage c + 2 in flight while stage c is multiplied; explicit s_waitcnt vmcnt on the in-order load
+// queue, raw s_barrier).  LDS-DMA writes 64 lanes x 16 B contiguously, so rows cannot carry padding: a row is 64 bytes =
+// four 16-byte pieces, and piece p of row r lives in slot p ^ ((r >> 2) & 3) -- the 16 lanes of one ds_read_b128 phase
+// (rows r .. r + 15, same piece) then cover all 16 four-bank groups (conflict-free), and the DMA side only has to pick, per
+// lane, WHICH global piece it fetches for its fixed slot.
+// FAC_WGRAD_DMA_B=0 keeps the B operand on the register path (its sources are only 2-byte aligned for odd tap shifts).
+constexpr int WK_ROWB = 64;                        // bytes per staged row: 32 bf16
+constexpr int WK_PLANE = 128 * WK_ROWB;            // one plane of one operand (8 KB)
+constexpr int WK_OPND = 3 * WK_PLANE;              // one operand (24 KB = 24 DMA blocks of 1 KB)
+constexpr int WK_STAGE = 2 * WK_OPND;              // 48 KB
+constexpr int WK_NST = 3;                          // LDS stages
 constexpr int WK_PIECES = 6;                       // 16-byte pieces per staging lane, operand and stage
 
 struct WkArgs {
@@ -444,7 +455,13 @@ struct WkArgs {
   int n_tt, tiles_per_split;
 };
 
-template <int D>
+__device__ __forceinline__ void wk_barrier() {
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
+template <bool DMAB>
 __global__ __launch_bounds__(512, 2) void conv1d_wgrad_kmajor_kernel(WkArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
   const int tid = threadIdx.x;
@@ -459,19 +476,18 @@ __global__ __launch_bounds__(512, 2) void conv1d_wgrad_kmajor_kernel(WkArgs a) {
   const int s = a.stride;
 
   if (wave >= 4) {
-    // ===================================================================== staging waves: planes -> LDS, copies only
-    const int sl = tid - 256;
+    // ===================================================================== staging waves: planes -> LDS by LDS-DMA
+    const int lw = wave - 4;
     __builtin_amdgcn_s_setprio(3);
     unsigned a_off[WK_PIECES], b_off[WK_PIECES];
-    int lds_off[WK_PIECES];                       // same (plane, row, piece) slot in either operand
 #pragma unroll
     for (int j = 0; j < WK_PIECES; ++j) {
-      const int id = sl + 256 * j;                // [0, 1536): plane, row, 16-byte piece
-      const int plane = id >> 9, rem = id & 511;
-      const int row = rem >> 2, pc = rem & 3;
-      lds_off[j] = plane * WK_PLANE + row * WK_PITCH + pc * 16;
+      const int blk = j * 4 + lw;                 // 1 KB block of the operand: 16 rows of one plane
+      const int plane = blk >> 3;
+      const int row = (blk & 7) * 16 + (lane >> 2);
+      const int piece = (lane & 3) ^ ((row >> 2) & 3);      // the global piece that belongs in this lane's slot
       const int co = co0 + row < a.C_out ? co0 + row : a.C_out - 1;        // rows past C_out: computed, never stored
-      a_off[j] = (unsigned)(plane * a.a_plane_bytes + ((long long)co * a.UA + 8 * pc) * 2);
+      a_off[j] = (unsigned)(plane * a.a_plane_bytes + ((long long)co * a.UA + 8 * piece) * 2);
       int gb = gb0 + (row >> 5);
       gb = gb < a.NBk ? gb : a.NBk - 1;                                    // blocks past the end: never stored
       const int g = gb / a.K, k = gb - g * a.K;
@@ -479,57 +495,62 @@ __global__ __launch_bounds__(512, 2) void conv1d_wgrad_kmajor_kernel(WkArgs a) {
       v = v < a.CV ? v : a.CV - 1;                                         // channels past the end: never stored
       const int ci = v / a.K2, k2 = v - ci * a.K2;
       const int kd = k * a.dil, shift = kd / s, ph = kd - shift * s;
-      b_off[j] = (unsigned)(plane * a.b_plane_bytes + ((long long)(ci * s + ph) * a.UB + shift + k2 * a.dil2s + 8 * pc) * 2);
+      b_off[j] = (unsigned)(plane * a.b_plane_bytes + ((long long)(ci * s + ph) * a.UB + shift + k2 * a.dil2s + 8 * piece) * 2);
     }
-    constexpr int LPT = 2 * WK_PIECES;
-    constexpr int WAITN = (D - 1) * LPT < 63 ? (D - 1) * LPT : 63;
-    auto load_tile = [&](int chunk, f32x4 (&ra)[WK_PIECES], f32x4 (&rb)[WK_PIECES]) {
+    constexpr int LPT = 2 * WK_PIECES;            // loads per lane and stage (DMA and register loads share the vmcnt queue)
+    f32x4 rb[2][WK_PIECES];                       // register path of the B operand only (!DMAB)
+    auto issue = [&](int chunk, int buf, f32x4 (&r)[WK_PIECES]) {
       const int tile = tile_lo + (chunk < n_chunks ? chunk : n_chunks - 1);     // past the end: reload the last tile (keeps LPT)
       const int b = tile / a.n_tt;
       const int t0 = (tile - b * a.n_tt) * WS_TT;
       const unsigned char* ab = a.ap + ((long long)b * a.C_out * a.UA + t0) * 2;                 // uniform
       const unsigned char* bb = a.bp + ((long long)b * a.C_in_real * s * a.UB + t0) * 2;        // uniform
-#pragma unroll
-      for (int j = 0; j < WK_PIECES; ++j)
-        asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(ra[j]) : "v"(a_off[j]), "s"(ab) : "memory");
-#pragma unroll
-      for (int j = 0; j < WK_PIECES; ++j)
-        asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(rb[j]) : "v"(b_off[j]), "s"(bb) : "memory");
-    };
-    auto wait_tile = [&](f32x4 (&ra)[WK_PIECES], f32x4 (&rb)[WK_PIECES]) {
-      asm volatile("s_waitcnt vmcnt(%12)"
-                   : "+v"(ra[0]), "+v"(ra[1]), "+v"(ra[2]), "+v"(ra[3]), "+v"(ra[4]), "+v"(ra[5]), "+v"(rb[0]), "+v"(rb[1]), "+v"(rb[2]),
-                     "+v"(rb[3]), "+v"(rb[4]), "+v"(rb[5])
-                   : "n"(WAITN) : "memory");
-    };
-    auto write_tile = [&](int buf, const f32x4 (&ra)[WK_PIECES], const f32x4 (&rb)[WK_PIECES]) {
       unsigned char* st = sm + buf * WK_STAGE;
 #pragma unroll
-      for (int j = 0; j < WK_PIECES; ++j) *reinterpret_cast<f32x4*>(st + lds_off[j]) = ra[j];
+      for (int j = 0; j < WK_PIECES; ++j)
+        __builtin_amdgcn_global_load_lds((glb_void_t*)(ab + a_off[j]), (lds_void_t*)(st + (j * 4 + lw) * 1024), 16, 0, 0);
+      if constexpr (DMAB) {
 #pragma unroll
-      for (int j = 0; j < WK_PIECES; ++j) *reinterpret_cast<f32x4*>(st + WK_OPND + lds_off[j]) = rb[j];
+        for (int j = 0; j < WK_PIECES; ++j)
+          __builtin_amdgcn_global_load_lds((glb_void_t*)(bb + b_off[j]), (lds_void_t*)(st + WK_OPND + (j * 4 + lw) * 1024), 16, 0, 0);
+      } else {
+#pragma unroll
+        for (int j = 0; j < WK_PIECES; ++j)
+          asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(r[j]) : "v"(b_off[j]), "s"(bb) : "memory");
+      }
     };
-    // ring of D tiles in registers, as in the kernel above
-    f32x4 ra[D][WK_PIECES], rb[D][WK_PIECES];
+    // everything but the youngest stage's loads has landed (loads return in order)
+    auto landed = [&](bool younger_in_flight, f32x4 (&r)[WK_PIECES]) {
+      if (younger_in_flight)
+        asm volatile("s_waitcnt vmcnt(%6)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]) : "n"(LPT) : "memory");
+      else
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]) : : "memory");
+    };
+    auto write_b = [&](int buf, const f32x4 (&r)[WK_PIECES]) {
+      if constexpr (!DMAB) {
+        unsigned char* st = sm + buf * WK_STAGE + WK_OPND;
 #pragma unroll
-    for (int i = 0; i < D; ++i) load_tile(i, ra[i], rb[i]);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    wait_tile(ra[0], rb[0]);
-    write_tile(0, ra[0], rb[0]);
-    load_tile(D, ra[0], rb[0]);
-    __syncthreads();
-    constexpr int U = (D % 2 == 0) ? D : 2 * D;
-    for (int base = 0; base < n_chunks; base += U) {
+        for (int j = 0; j < WK_PIECES; ++j) *reinterpret_cast<f32x4*>(st + (j * 4 + lw) * 1024 + lane * 16) = r[j];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      }
+    };
+    issue(0, 0, rb[0]);
+    issue(1, 1, rb[1]);
+    landed(true, rb[0]);
+    write_b(0, rb[0]);
+    wk_barrier();                                 // stage 0 visible to the MFMA waves
+    for (int base = 0; base < n_chunks; base += 6) {
 #pragma unroll
-      for (int i = 0; i < U; ++i) {
+      for (int i = 0; i < 6; ++i) {               // static LDS stage (i % 3) and register slot (i % 2)
         const int c = base + i;
         if (c < n_chunks) {
+          // stage (c + 2) % 3 was read during iteration c - 1, which every wave has left
+          if (c + 2 < n_chunks) issue(c + 2, (i + 2) % 3, rb[i % 2]);
           if (c + 1 < n_chunks) {
-            wait_tile(ra[(i + 1) % D], rb[(i + 1) % D]);
-            write_tile((i + 1) & 1, ra[(i + 1) % D], rb[(i + 1) % D]);
-            load_tile(c + 1 + D, ra[(i + 1) % D], rb[(i + 1) % D]);
+            landed(c + 2 < n_chunks, rb[(i + 1) % 2]);
+            write_b((i + 1) % 3, rb[(i + 1) % 2]);
           }
-          __syncthreads();
+          wk_barrier();
         }
       }
     }
@@ -540,8 +561,12 @@ __global__ __launch_bounds__(512, 2) void conv1d_wgrad_kmajor_kernel(WkArgs a) {
   // ========================================================================= MFMA waves: 64 x 64 each (2 x 2 blocks)
   const int l31 = lane & 31, kq = lane >> 5;
   const int mh = wave >> 1, nh = wave & 1;
-  const int aoff = (mh * 64 + l31) * WK_PITCH + kq * 16;
-  const int boff = WK_OPND + (nh * 64 + l31) * WK_PITCH + kq * 16;
+  const int sw = (l31 >> 2) & 3;
+  const int aoff = (mh * 64 + l31) * WK_ROWB;
+  const int boff = WK_OPND + (nh * 64 + l31) * WK_ROWB;
+  int poff[WS_TT / 16];
+#pragma unroll
+  for (int ks = 0; ks < WS_TT / 16; ++ks) poff[ks] = ((ks * 2 + kq) ^ sw) * 16;
 
   f32x16 acc[2][2];
 #pragma unroll
@@ -556,34 +581,40 @@ __global__ __launch_bounds__(512, 2) void conv1d_wgrad_kmajor_kernel(WkArgs a) {
     for (int p = 0; p < 3; ++p)
 #pragma unroll
       for (int m = 0; m < 2; ++m)
-        A[m][p] = *reinterpret_cast<const bf16x8*>(st + aoff + p * WK_PLANE + m * 32 * WK_PITCH + ks * 32);
+        A[m][p] = *reinterpret_cast<const bf16x8*>(st + aoff + p * WK_PLANE + m * 32 * WK_ROWB + poff[ks]);
 #pragma unroll
     for (int p = 0; p < 3; ++p)
 #pragma unroll
       for (int n = 0; n < 2; ++n)
-        Bf[n][p] = *reinterpret_cast<const bf16x8*>(st + boff + p * WK_PLANE + n * 32 * WK_PITCH + ks * 32);
+        Bf[n][p] = *reinterpret_cast<const bf16x8*>(st + boff + p * WK_PLANE + n * 32 * WK_ROWB + poff[ks]);
   };
 
-  __syncthreads();   // tile 0 staged
+  wk_barrier();   // stage 0 staged
   bf16x8 A[2][2][3], Bf[2][2][3];
-  for (int chunk = 0; chunk < n_chunks; ++chunk) {
-    const unsigned char* st = sm + (chunk & 1) * WK_STAGE;
-    ld_frags(st, 0, A[0], Bf[0]);
+  for (int base = 0; base < n_chunks; base += 3) {
 #pragma unroll
-    for (int ks = 0; ks < WS_TT / 16; ++ks) {
-      if (ks + 1 < WS_TT / 16) ld_frags(st, ks + 1, A[(ks + 1) & 1], Bf[(ks + 1) & 1]);
-      __builtin_amdgcn_sched_barrier(0);
-      constexpr int TA[6] = {1, 2, 0, 1, 0, 0}, TB[6] = {1, 0, 2, 0, 1, 0};     // smallest terms first (see above)
+    for (int i = 0; i < 3; ++i) {
+      const int chunk = base + i;
+      if (chunk < n_chunks) {
+        const unsigned char* st = sm + i * WK_STAGE;
+        ld_frags(st, 0, A[0], Bf[0]);
 #pragma unroll
-      for (int q = 0; q < 6; ++q)
+        for (int ks = 0; ks < WS_TT / 16; ++ks) {
+          if (ks + 1 < WS_TT / 16) ld_frags(st, ks + 1, A[(ks + 1) & 1], Bf[(ks + 1) & 1]);
+          __builtin_amdgcn_sched_barrier(0);
+          constexpr int TA[6] = {1, 2, 0, 1, 0, 0}, TB[6] = {1, 0, 2, 0, 1, 0};     // smallest terms first (see above)
 #pragma unroll
-        for (int m = 0; m < 2; ++m)
+          for (int q = 0; q < 6; ++q)
 #pragma unroll
-          for (int n = 0; n < 2; ++n)
-            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[ks & 1][m][TA[q]], Bf[ks & 1][n][TB[q]], acc[m][n], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+              for (int n = 0; n < 2; ++n)
+                acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[ks & 1][m][TA[q]], Bf[ks & 1][n][TB[q]], acc[m][n], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        wk_barrier();
+      }
     }
-    __syncthreads();
   }
 
   // partial dW of this slice, block-wise: [co][gb][32 channels] -- 128-byte runs per (row, block)
@@ -737,14 +768,18 @@ extern "C" int fac_conv1d_bwd_weight_split(const float* x, const float* dy, floa
                          FAC_PAD_ZERO, k.a_plane_bytes);
       hipLaunchKernelGGL(split_planes_kernel, dim3(gb), dim3(256), 0, st, x, bp, (long long)B * C_in, T_in, T_ext, T_pad, stride, k.UB,
                          pad_left, pad_mode, k.b_plane_bytes);
-      auto kern = conv1d_wgrad_kmajor_kernel<3>;
+      static const bool dma_b = !(getenv("FAC_WGRAD_DMA_B") && getenv("FAC_WGRAD_DMA_B")[0] == '0');
       static bool attr_set = false;
       if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv1d_wgrad_kmajor_kernel<true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv1d_wgrad_kmajor_kernel<false>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
       }
       dim3 grid((C_out + 127) / 128, (k.NBk + 3) / 4, S);
-      hipLaunchKernelGGL(kern, grid, dim3(512), (size_t)2 * WK_STAGE, st, k);
+      if (dma_b) hipLaunchKernelGGL(conv1d_wgrad_kmajor_kernel<true>, grid, dim3(512), (size_t)WK_NST * WK_STAGE, st, k);
+      else hipLaunchKernelGGL(conv1d_wgrad_kmajor_kernel<false>, grid, dim3(512), (size_t)WK_NST * WK_STAGE, st, k);
       const long long n = (long long)C_out * k.NBk * 32;
       const int blocks = (int)((n + 255) / 256 < 65535 ? (n + 255) / 256 : 65535);
       hipLaunchKernelGGL(wgrad_kmajor_reduce_kernel, dim3(blocks), dim3(256), 0, st, k.part, dw, S, C_out, k.NBk, k.K, k.CV);

@@ -583,6 +583,34 @@ __global__ __launch_bounds__(256) void logdiff_rms_stage1(const float* __restric
   if (threadIdx.x == 0) scratch[blockIdx.x] = (part[0] + part[1]) + (part[2] + part[3]);
 }
 
+// Backward of logdiff_rms w.r.t. b: db[m] (+)= scale * d/db_m sqrt(mean_m d^2), d_m = log(|a_m|+eps) - log(|b_m|+eps):
+// -(d_m / (M r)) * sign(b_m) / (|b_m| + eps), r = sqrt(mean d^2) (0 where r == 0).  One thread per (b, t) column.
+__global__ __launch_bounds__(256) void logdiff_rms_bwd_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                              float* __restrict__ db, int M, int T, long long n_cols, float eps,
+                                                              float scale, int accumulate) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n_cols; i += (long long)gridDim.x * 256) {
+    const long long bb = i / T;
+    const int t = (int)(i - bb * T);
+    const float* pa = a + bb * M * T + t;
+    const float* pb = b + bb * M * T + t;
+    float* pd = db + bb * M * T + t;
+    float q = 0.f;
+    for (int m = 0; m < M; ++m) {
+      const float d = logf(fabsf(pa[(long long)m * T]) + eps) - logf(fabsf(pb[(long long)m * T]) + eps);
+      q = fmaf(d, d, q);
+    }
+    const float r = sqrtf(q / (float)M);
+    const float k = r > 0.f ? scale / ((float)M * r) : 0.f;
+    for (int m = 0; m < M; ++m) {
+      const float bv = pb[(long long)m * T];
+      const float d = logf(fabsf(pa[(long long)m * T]) + eps) - logf(fabsf(bv) + eps);
+      const float sg = bv > 0.f ? 1.f : (bv < 0.f ? -1.f : 0.f);
+      const float g = -k * d * sg / (fabsf(bv) + eps);
+      pd[(long long)m * T] = accumulate ? pd[(long long)m * T] + g : g;
+    }
+  }
+}
+
 }  // namespace fac
 
 using namespace fac;
@@ -751,6 +779,17 @@ extern "C" int fac_logdiff_rms(const float* a, const float* b, float* out, float
   hipLaunchKernelGGL(reduce_pair_stage2, dim3(1), dim3(256), 0, (hipStream_t)stream, scratch, out, (int)g, scale,
                      accumulate);
   return check_launch("logdiff_rms");
+}
+
+extern "C" int fac_logdiff_rms_bwd(const float* a, const float* b, float* db, int B, int M, int T, float eps, float scale,
+                                   int accumulate, fac_stream_t stream) {
+  FAC_REQUIRE(a && b && db && B > 0 && M > 0 && T > 0, "logdiff_rms_bwd: bad arguments");
+  const long long n_cols = (long long)B * T;
+  long long g = (n_cols + 255) / 256;
+  if (g > 4096) g = 4096;
+  hipLaunchKernelGGL(logdiff_rms_bwd_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)stream, a, b, db, M, T, n_cols, eps, scale,
+                     accumulate);
+  return check_launch("logdiff_rms_bwd");
 }
 
 extern "C" int fac_aa_snakebeta_fwd(const float* x, const float* alpha_log, const float* beta_log,

@@ -211,10 +211,16 @@ class L1Loss(_LossBase):
 _RECON_CACHE = {}
 
 
-def reconstruction_loss(x, G_x, eps=1e-7):
-    """losses.py:65-89: 100*MSE + sum_{s=64..2048} [ L1(mel) + sqrt(s/2) * mean_t RMS_mel(log diff) ] with
-    torchaudio MelSpectrogram(sample_rate=16000, n_fft=max(s,512), win_length=s, hop=s//4, n_mels=64)."""
-    xs, gs = _audio(x).contiguous(), _audio(G_x).contiguous()
+def _recon_scale(dev, s):
+    n_fft = max(s, 512)
+    key = (dev, s)
+    if key not in _RECON_CACHE:
+        fb = dsp.mel_fbank_htk(n_fft // 2 + 1, 64, 16000).T.copy()          # (64, F)
+        _RECON_CACHE[key] = _SpectralScale(dev, n_fft, s, s // 4, fb)
+    return _RECON_CACHE[key]
+
+
+def _reconstruction_value(xs, gs, eps):
     B = xs.shape[0]
     dev = xs.device
     out = torch.zeros(1, device=dev, dtype=torch.float32)
@@ -223,14 +229,61 @@ def reconstruction_loss(x, G_x, eps=1e-7):
     both = torch.cat([xs, gs], 0).contiguous()
     for i in range(6, 12):
         s = 2 ** i
-        n_fft = max(s, 512)
-        key = (dev, s)
-        if key not in _RECON_CACHE:
-            fb = dsp.mel_fbank_htk(n_fft // 2 + 1, 64, 16000).T.copy()          # (64, F)
-            _RECON_CACHE[key] = _SpectralScale(dev, n_fft, s, s // 4, fb)
-        sc = _RECON_CACHE[key]
+        sc = _recon_scale(dev, s)
         mel = sc.mel(sc.spectrum(both, 2))                                       # (2B, 64, frames)
         n = mel[:B].numel()
         ops.reduce_pair(mel[:B], mel[B:], out, scratch, 0, 0.0, 1.0 / n, True)
         ops.logdiff_rms(mel[:B], mel[B:], out, scratch, eps, math.sqrt(s / 2) / (B * mel.shape[-1]), True)
     return out[0]
+
+
+def _reconstruction_grad(xs, gs, eps):
+    """d reconstruction_loss / d G_x: MSE term + per scale the adjoint chain pair / log-RMS derivative -> transposed mel GEMM
+    -> |.|^2 adjoint -> transposed windowed-DFT GEMM -> framing adjoint (the kernels of the mel-loss backward)."""
+    B, T = gs.shape
+    dev = gs.device
+    dg = torch.empty_like(gs)
+    ops.pair_bwd(gs, xs, dg, 2, 0.0, 100.0 / xs.numel(), accumulate=False)      # d/dG 100 * mean (x - G)^2
+    for i in range(6, 12):
+        s = 2 ** i
+        sc = _recon_scale(dev, s)
+        frames_n = 1 + T // sc.hop
+        mel_x = sc.mel(sc.spectrum(xs, 2))
+        fr = ops.stft_frames(gs, sc.win, frames_n, sc.hop, sc.n_fft // 2, sc.off)
+        with ops.flop_key("dft"):
+            spec = ops.conv1d(fr, sc.basis, 2 * sc.F, 1, pad_left=0, pad_mode=ops.PAD_ZERO, t_out=frames_n)
+        mel_g = sc.mel(ops.spec_power(spec, 2))
+        dmel = torch.empty_like(mel_g)
+        ops.pair_bwd(mel_g, mel_x, dmel, 0, 0.0, 1.0 / mel_g.numel(), accumulate=False)
+        ops.logdiff_rms_bwd(mel_x, mel_g, dmel, eps, math.sqrt(s / 2) / (B * mel_g.shape[-1]), accumulate=True)
+        with ops.flop_key("dft"):
+            dpow = ops.conv1d(dmel, sc.fb_bwd, sc.F, 1, pad_left=0, pad_mode=ops.PAD_ZERO, t_out=frames_n)
+            dspec = ops.spec_power_bwd(spec, dpow, 2)
+            dfr = ops.conv1d(dspec, sc.basis_bwd, sc.win, 1, pad_left=0, pad_mode=ops.PAD_ZERO, t_out=frames_n)
+        dg = ops.add(dg, ops.stft_frames_bwd(dfr, T, sc.hop, sc.n_fft // 2, sc.off))
+    return dg
+
+
+class _ReconstructionLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, G_x, eps):
+        xs, gs = _audio(x).contiguous(), _audio(G_x).contiguous()
+        ctx.save_for_backward(xs, gs)
+        ctx.eps, ctx.shape = eps, G_x.shape
+        return _reconstruction_value(xs.detach(), gs.detach(), eps).clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        xs, gs = ctx.saved_tensors
+        if ctx.needs_input_grad[0]:
+            raise NotImplementedError("reconstruction_loss is differentiated w.r.t. the estimate G_x only")
+        return None, (_reconstruction_grad(xs.detach(), gs.detach(), ctx.eps) * g).reshape(ctx.shape), None
+
+
+def reconstruction_loss(x, G_x, eps=1e-7):
+    """losses.py:65-89: 100*MSE + sum_{s=64..2048} [ L1(mel) + sqrt(s/2) * mean_t RMS_mel(log diff) ] with
+    torchaudio MelSpectrogram(sample_rate=16000, n_fft=max(s,512), win_length=s, hop=s//4, n_mels=64).  Differentiable
+    w.r.t. the estimate G_x (forward and backward on the HIP kernels)."""
+    if torch.is_grad_enabled() and torch.is_tensor(G_x) and G_x.requires_grad:
+        return _ReconstructionLossFn.apply(x, G_x, eps)
+    return _reconstruction_value(_audio(x).contiguous(), _audio(G_x).contiguous(), eps)

@@ -575,6 +575,14 @@ def logdiff_rms(a, b, out, scratch, eps, scale=1.0, accumulate=False):
     return out
 
 
+def logdiff_rms_bwd(a, b, db, eps, scale=1.0, accumulate=False):
+    """db (+)= scale * d/db sum_{b,t} sqrt(mean_m (log(|a|+eps) - log(|b|+eps))^2); a, b, db (B, M, T)."""
+    a, b = _dev(a), _dev(b)
+    B, M, T = a.shape
+    _lib.check(_lib.load().fac_logdiff_rms_bwd(_ptr(a), _ptr(b), _ptr(db), B, M, T, eps, scale, 1 if accumulate else 0, _stream()),
+               "fac_logdiff_rms_bwd")
+
+
 def aa_snakebeta(x, alpha_log, beta_log, filter12):
     """Anti-aliased SnakeBeta (Activation1d(SnakeBeta(alpha_logscale=True)))."""
     x = _dev(x)

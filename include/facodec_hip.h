@@ -458,6 +458,11 @@ int fac_aa_snakebeta_fwd(const float* x, const float* alpha_log, const float* be
 int fac_logdiff_rms(const float* a, const float* b, float* out, float* scratch, int B, int M, int T,
                     float eps, float scale, int accumulate, fac_stream_t stream);
 
+/* Backward of fac_logdiff_rms w.r.t. its SECOND operand (the estimate of losses.py:65-89 reconstruction_loss):
+ * db (+)= scale * d/db sum_{b,t} sqrt( mean_m (log(|a|+eps) - log(|b|+eps))^2 ). */
+int fac_logdiff_rms_bwd(const float* a, const float* b, float* db, int B, int M, int T, float eps, float scale,
+                        int accumulate, fac_stream_t stream);
+
 static inline int fac_pad32(int n) { return (n + 31) & ~31; }
 /* packed weights carry zero rows up to a multiple of 48 input channels (lcm of the kernel's
  * channels-per-stage choices), so a partially filled last stage multiplies zeros */

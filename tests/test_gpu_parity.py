@@ -925,6 +925,23 @@ def test_mel_loss_backward_against_autograd(O, cuda):
     assert rel(xg.grad, 3.0 * x.grad) < 5e-5          # measured on MI355X: 3.1e-6 (profiles/r02_tolerance_report.json)
 
 
+def test_reconstruction_loss_backward_against_autograd(O, cuda):
+    """d reconstruction_loss / d G_x (losses.py:65-89: 100 MSE + six mel scales of L1 + sqrt(s/2) log-RMS) against autograd
+    through the oracle's restatement; the value is unchanged by the autograd wrapper."""
+    from facodec_amd import losses
+    x = synth.synth_clips(2, 16000, seed=31)[:, 0]
+    gx = (0.7 * x + 0.05 * synth.synth_clips(2, 16000, seed=32)[:, 0]).contiguous().requires_grad_()
+    ref = O.reconstruction_loss(x, gx)
+    ref.backward()
+    gg = gx.detach().to(cuda).requires_grad_()
+    got = losses.reconstruction_loss(x.to(cuda), gg)
+    assert abs(float(got) - float(ref)) / float(ref) < E2E_TOL
+    assert abs(float(got) - float(losses.reconstruction_loss(x.to(cuda), gg.detach()))) / float(ref) < 1e-6
+    (2.0 * got).backward()
+    _record("reconstruction_loss_input_gradient", rel(gg.grad, 2.0 * gx.grad))
+    assert rel(gg.grad, 2.0 * gx.grad) < 1e-4
+
+
 def test_rvq_backward_against_autograd(O, cuda):
     """Training-mode RVQ (3 quantizers, quantizer-dropout masks, straight-through, commitment 0.25 + codebook 1.0 as
     in train.py:357-358): gradients of the input and of every in_proj / codebook / out_proj parameter."""
