@@ -20,6 +20,8 @@ from . import ops
 
 
 def _split_ok(c_out, c_in, k, stride, x):
+    if k == 1 and stride == 1:          # 1x1 with many channels: split-bf16 GEMM (conv1d_gemm_split.hip)
+        return ops.gemm_split_ok(c_out, c_in, 1, x.shape[0] * x.shape[-1])
     return (ops.BF16_SPLIT and k == 7 and stride == 1 and c_in % 16 == 0 and c_out % 16 == 0 and c_out > 2
             and x.shape[0] * x.shape[-1] > 640)
 
@@ -67,7 +69,7 @@ class _ConvTr(Function):
     @staticmethod
     def forward(ctx, x, v, g, bias, stride):
         vd, gd = v.detach(), (g.detach() if g is not None else None)
-        y = ops.conv_transpose1d(x.detach(), ops.convtr_weight_for(vd, gd, stride, x.shape[-1]), v.shape[1], stride,
+        y = ops.conv_transpose1d(x.detach(), ops.convtr_weight_for(vd, gd, stride, x.shape[-1], batch=x.shape[0]), v.shape[1], stride,
                                  bias=bias.detach() if bias is not None else None)
         ctx.stride = stride
         ctx.save_for_backward(x, v, g, bias)
@@ -122,8 +124,10 @@ class _LSTM(Function):
         for l in range(L):
             w_ih, w_hh, b_ih, b_hh = (p.detach() for p in params[4 * l: 4 * l + 4])
             with ops.flop_scale(B / BP):
-                pre = ops.conv1d(inp.view(1, H, T * BP), ops.pack_conv_weight(w_ih), 4 * H, 1, bias=ops.add(b_ih, b_hh),
-                                 pad_left=0, t_out=T * BP, pad_mode=ops.PAD_ZERO)
+                use_split = ops.gemm_split_ok(4 * H, H, 1, T * BP)
+                pre = ops.conv1d(inp.view(1, H, T * BP), None if use_split else ops.pack_conv_weight(w_ih), 4 * H, 1,
+                                 bias=ops.add(b_ih, b_hh), pad_left=0, t_out=T * BP, pad_mode=ops.PAD_ZERO,
+                                 w_split=ops.pack_gemm_weight_split(w_ih) if use_split else None)
                 gates = torch.empty(4 * H, T, BP, device=x.device)
                 cs = torch.empty(H, T, BP, device=x.device)
                 yT = ops.lstm_layer(pre.view(4 * H, T, BP), ops.pack_lstm_whh(w_hh), H, save=(gates, cs))
@@ -171,8 +175,12 @@ class _LSTM(Function):
             db = ops.bias_grad(dg_flat)
             grads[4 * l + 2], grads[4 * l + 3] = db, db.clone()
             # gradient w.r.t. this layer's input sequence: W_ih^T dgates, one GEMM over every (t, b)
-            d_out = ops.conv1d(dg_flat, ops.pack_conv_weight(w_ih.t().contiguous().unsqueeze(-1)), H, 1, pad_left=0,
-                               pad_mode=ops.PAD_ZERO, t_out=T * BP).view(H, T, BP)
+            if ops.gemm_split_ok(H, 4 * H, 1, T * BP):
+                d_out = ops.conv1d(dg_flat, None, H, 1, pad_left=0, pad_mode=ops.PAD_ZERO, t_out=T * BP,
+                                   w_split=ops.pack_gemm_weight_split_t(w_ih)).view(H, T, BP)
+            else:
+                d_out = ops.conv1d(dg_flat, ops.pack_conv_weight(w_ih.t().contiguous().unsqueeze(-1)), H, 1, pad_left=0,
+                                   pad_mode=ops.PAD_ZERO, t_out=T * BP).view(H, T, BP)
         dx = ops.lstm_from_time_major(d_out, dy if ctx.skip else None, B)
         return (dx, None, *grads)
 

@@ -58,7 +58,7 @@ class PlainConv(Function):
                 v6 = torch.cat([vd, vd.new_zeros(c_out, c_in, 2 * stride - k)], dim=2) if k < 2 * stride else vd
                 dy_ext = torch.cat([dy, dy.new_zeros(B, c_out, 1)], dim=2)
                 with ops.flop_scale(k / (2.0 * stride)):      # the zero taps that pad k to 2 * stride are not algorithmic work
-                    dxp = ops.conv_transpose1d(dy_ext, ops.convtr_weight_for(v6, gd, stride, dy_ext.shape[-1]), c_in, stride)
+                    dxp = ops.conv_transpose1d(dy_ext, ops.convtr_weight_for(v6, gd, stride, dy_ext.shape[-1], batch=B), c_in, stride)
                 if dxp.shape[-1] < pad + t_in:
                     dxp = torch.cat([dxp, dxp.new_zeros(B, c_in, pad + t_in - dxp.shape[-1])], dim=2)
                 dx = dxp[:, :, pad:pad + t_in].contiguous()

@@ -42,7 +42,7 @@ extern "C" void fac_debug_set_buffer(void* p) { fac::g_conv_dbg = (unsigned long
 
 extern "C" int fac_conv1d_fwd(const fac_conv_desc* d, fac_stream_t stream) {
   using namespace fac;
-  FAC_REQUIRE(d && d->x && d->w && (d->y || d->y2), "conv1d: null pointer");
+  FAC_REQUIRE(d && d->x && (d->w || d->w_split) && (d->y || d->y2), "conv1d: null pointer");
   FAC_REQUIRE(!d->y2 || d->alpha_y2, "conv1d: y2 needs alpha_y2");
   FAC_REQUIRE(d->B > 0 && d->C_in > 0 && d->C_out > 0 && d->T_in > 0 && d->T_out > 0,
               "conv1d: bad shape B=%d C_in=%d C_out=%d T_in=%d T_out=%d", d->B, d->C_in, d->C_out,
@@ -88,7 +88,16 @@ extern "C" int fac_conv1d_fwd(const fac_conv_desc* d, fac_stream_t stream) {
   }
   hipStream_t s = (hipStream_t)stream;
   if (d->w_k1) return conv_dispatch_fused_ru(a, s);
-  if (a.rp > 1) return conv_dispatch_128x256(a, s);
+  a.gflat = 0;
+  // 1- / 2-tap convs with split weights in the GEMM layout (fac_pack_gemm_w_split): the bf16 matrix pipe, fp32-exact
+  if (d->w_split && (d->K == 1 || d->K == 2) && conv_gsplit_ok(a) && !conv_skinny_ok(a, d->ws, d->ws_bytes)) {
+    a.w = reinterpret_cast<const float*>(d->w_split);
+    return conv_dispatch_gsplit(a, s);
+  }
+  if (a.rp > 1) {
+    FAC_REQUIRE(d->w != nullptr && d->w != (const float*)d->w_split, "conv1d: row_phases launch outside the split kernel's shapes needs fp32 weights");
+    return conv_dispatch_128x256(a, s);
+  }
   const bool two_level = conv_two_level(a);
   if (!two_level && conv_skinny_ok(a, d->ws, d->ws_bytes)) return conv_dispatch_skinny(a, d->ws, d->ws_bytes, s);
   if (!two_level && narrow_ok(d)) return conv_dispatch_narrow(a, s);
@@ -125,6 +134,17 @@ extern "C" int fac_conv1d_variant(const fac_conv_desc* d, char* name, int name_l
   if (d->w_k1) {
     if (name && name_len > 0) snprintf(name, name_len, "conv1d_mfma_kernel<C/32,1,1,4,7,fused RU> Cx128");
     return 7;
+  }
+  if (d->w_split && (d->K == 1 || d->K == 2)) {
+    ConvArgs a{};
+    a.K = d->K; a.stride = d->stride; a.dil = d->dilation; a.n_phase = d->n_phase; a.phase_shift = d->phase_shift; a.y_tstride = d->y_tstride;
+    a.alpha_in = d->alpha_in; a.w1 = d->w_k1; a.w_batched = d->w_batched; a.C_in = d->C_in; a.C_out = d->C_out; a.C_out_pad = d->C_out_pad;
+    a.K1 = d->K; a.pad_left = d->pad_left; a.pad_mode = d->pad_mode; a.T_in = d->T_in; a.T_out = d->T_out; a.B = d->B; a.x_bs = d->x_bs;
+    a.rp = d->row_phases > 1 ? d->row_phases : 1; a.x_cs = d->x_cs;
+    if (conv_gsplit_ok(a) && !conv_skinny_ok(a, d->ws, d->ws_bytes)) {
+      if (name && name_len > 0) snprintf(name, name_len, "conv1d_gemm_split_kernel<%d> 128x128 (bf16x3 split GEMM, fp32-exact)", d->K);
+      return 15;
+    }
   }
   if (d->row_phases > 1) {
     if (name && name_len > 0) snprintf(name, name_len, "conv1d_mfma_kernel<2,2,2,4,2> 128x256 (convtr, all phases per tile)");

@@ -65,6 +65,7 @@ struct ConvArgs {
   unsigned long long* dbg;   // per-workgroup cycle counters (tuning builds only)
 #endif
   int x_off;   // columns staged to the left of the receptive field so that the slab starts 16-B aligned
+  int gflat;   // conv1d_gemm_split.hip: columns are the flattened (clip, time) index (K = 1)
   int rp;      // > 1: output rows are (channel, phase) pairs, phase fastest, CO_TILE / rp channels per tile (all-phases
                // ConvTranspose1d, fac_conv_desc.row_phases); the all-waves epilogue interleaves them into contiguous runs
 };
@@ -803,6 +804,8 @@ int conv_dispatch_pw(ConvArgs& a, hipStream_t s);
 bool conv_thin_ok(const ConvArgs& a, const void* ws, long long ws_bytes);
 int conv_dispatch_thin(ConvArgs& a, void* ws, hipStream_t s);
 int conv_dispatch_cin1(ConvArgs& a, hipStream_t s);
+bool conv_gsplit_ok(const ConvArgs& a);
+int conv_dispatch_gsplit(ConvArgs& a, hipStream_t s);
 bool conv_bsplit_ok(const ConvArgs& a);
 int conv_dispatch_bsplit(ConvArgs& a, hipStream_t s);
 bool conv_skinny_ok(const ConvArgs& a, const void* ws, long long ws_bytes);

@@ -436,7 +436,7 @@ static int ws_geometry(int B, int C_in_real, int T_in, int C_out, int T_out, int
 // four 16-byte pieces, and piece p of row r lives in slot p ^ ((r >> 2) & 3) -- the 16 lanes of one ds_read_b128 phase
 // (rows r .. r + 15, same piece) then cover all 16 four-bank groups (conflict-free), and the DMA side only has to pick, per
 // lane, WHICH global piece it fetches for its fixed slot.
-// FAC_WGRAD_DMA_B=0 keeps the B operand on the register path (its sources are only 2-byte aligned for odd tap shifts).
+// (The B sources are only 2-byte aligned for odd tap shifts: global_load_lds takes them, tests/test_wgrad_split.py.)
 constexpr int WK_ROWB = 64;                        // bytes per staged row: 32 bf16
 constexpr int WK_PLANE = 128 * WK_ROWB;            // one plane of one operand (8 KB)
 constexpr int WK_OPND = 3 * WK_PLANE;              // one operand (24 KB = 24 DMA blocks of 1 KB)
@@ -461,7 +461,6 @@ __device__ __forceinline__ void wk_barrier() {
   asm volatile("" ::: "memory");
 }
 
-template <bool DMAB>
 __global__ __launch_bounds__(512, 2) void conv1d_wgrad_kmajor_kernel(WkArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
   const int tid = threadIdx.x;
@@ -497,9 +496,8 @@ __global__ __launch_bounds__(512, 2) void conv1d_wgrad_kmajor_kernel(WkArgs a) {
       const int kd = k * a.dil, shift = kd / s, ph = kd - shift * s;
       b_off[j] = (unsigned)(plane * a.b_plane_bytes + ((long long)(ci * s + ph) * a.UB + shift + k2 * a.dil2s + 8 * piece) * 2);
     }
-    constexpr int LPT = 2 * WK_PIECES;            // loads per lane and stage (DMA and register loads share the vmcnt queue)
-    f32x4 rb[2][WK_PIECES];                       // register path of the B operand only (!DMAB)
-    auto issue = [&](int chunk, int buf, f32x4 (&r)[WK_PIECES]) {
+    constexpr int LPT = 2 * WK_PIECES;            // DMA instructions per lane and stage
+    auto issue = [&](int chunk, int buf) {
       const int tile = tile_lo + (chunk < n_chunks ? chunk : n_chunks - 1);     // past the end: reload the last tile (keeps LPT)
       const int b = tile / a.n_tt;
       const int t0 = (tile - b * a.n_tt) * WS_TT;
@@ -509,47 +507,27 @@ __global__ __launch_bounds__(512, 2) void conv1d_wgrad_kmajor_kernel(WkArgs a) {
 #pragma unroll
       for (int j = 0; j < WK_PIECES; ++j)
         __builtin_amdgcn_global_load_lds((glb_void_t*)(ab + a_off[j]), (lds_void_t*)(st + (j * 4 + lw) * 1024), 16, 0, 0);
-      if constexpr (DMAB) {
 #pragma unroll
-        for (int j = 0; j < WK_PIECES; ++j)
-          __builtin_amdgcn_global_load_lds((glb_void_t*)(bb + b_off[j]), (lds_void_t*)(st + WK_OPND + (j * 4 + lw) * 1024), 16, 0, 0);
-      } else {
-#pragma unroll
-        for (int j = 0; j < WK_PIECES; ++j)
-          asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(r[j]) : "v"(b_off[j]), "s"(bb) : "memory");
-      }
+      for (int j = 0; j < WK_PIECES; ++j)
+        __builtin_amdgcn_global_load_lds((glb_void_t*)(bb + b_off[j]), (lds_void_t*)(st + WK_OPND + (j * 4 + lw) * 1024), 16, 0, 0);
     };
     // everything but the youngest stage's loads has landed (loads return in order)
-    auto landed = [&](bool younger_in_flight, f32x4 (&r)[WK_PIECES]) {
-      if (younger_in_flight)
-        asm volatile("s_waitcnt vmcnt(%6)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]) : "n"(LPT) : "memory");
-      else
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]) : : "memory");
+    auto landed = [&](bool younger_in_flight) {
+      if (younger_in_flight) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(LPT) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     };
-    auto write_b = [&](int buf, const f32x4 (&r)[WK_PIECES]) {
-      if constexpr (!DMAB) {
-        unsigned char* st = sm + buf * WK_STAGE + WK_OPND;
-#pragma unroll
-        for (int j = 0; j < WK_PIECES; ++j) *reinterpret_cast<f32x4*>(st + (j * 4 + lw) * 1024 + lane * 16) = r[j];
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      }
-    };
-    issue(0, 0, rb[0]);
-    issue(1, 1, rb[1]);
-    landed(true, rb[0]);
-    write_b(0, rb[0]);
+    issue(0, 0);
+    issue(1, 1);
+    landed(true);
     wk_barrier();                                 // stage 0 visible to the MFMA waves
-    for (int base = 0; base < n_chunks; base += 6) {
+    for (int base = 0; base < n_chunks; base += 3) {
 #pragma unroll
-      for (int i = 0; i < 6; ++i) {               // static LDS stage (i % 3) and register slot (i % 2)
+      for (int i = 0; i < 3; ++i) {               // static LDS stage
         const int c = base + i;
         if (c < n_chunks) {
           // stage (c + 2) % 3 was read during iteration c - 1, which every wave has left
-          if (c + 2 < n_chunks) issue(c + 2, (i + 2) % 3, rb[i % 2]);
-          if (c + 1 < n_chunks) {
-            landed(c + 2 < n_chunks, rb[(i + 1) % 2]);
-            write_b((i + 1) % 3, rb[(i + 1) % 2]);
-          }
+          if (c + 2 < n_chunks) issue(c + 2, (i + 2) % 3);
+          if (c + 1 < n_chunks) landed(c + 2 < n_chunks);
           wk_barrier();
         }
       }
@@ -768,18 +746,14 @@ extern "C" int fac_conv1d_bwd_weight_split(const float* x, const float* dy, floa
                          FAC_PAD_ZERO, k.a_plane_bytes);
       hipLaunchKernelGGL(split_planes_kernel, dim3(gb), dim3(256), 0, st, x, bp, (long long)B * C_in, T_in, T_ext, T_pad, stride, k.UB,
                          pad_left, pad_mode, k.b_plane_bytes);
-      static const bool dma_b = !(getenv("FAC_WGRAD_DMA_B") && getenv("FAC_WGRAD_DMA_B")[0] == '0');
       static bool attr_set = false;
       if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv1d_wgrad_kmajor_kernel<true>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv1d_wgrad_kmajor_kernel<false>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv1d_wgrad_kmajor_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  160 * 1024);
         attr_set = true;
       }
       dim3 grid((C_out + 127) / 128, (k.NBk + 3) / 4, S);
-      if (dma_b) hipLaunchKernelGGL(conv1d_wgrad_kmajor_kernel<true>, grid, dim3(512), (size_t)WK_NST * WK_STAGE, st, k);
-      else hipLaunchKernelGGL(conv1d_wgrad_kmajor_kernel<false>, grid, dim3(512), (size_t)WK_NST * WK_STAGE, st, k);
+      hipLaunchKernelGGL(conv1d_wgrad_kmajor_kernel, grid, dim3(512), (size_t)WK_NST * WK_STAGE, st, k);
       const long long n = (long long)C_out * k.NBk * 32;
       const int blocks = (int)((n + 255) / 256 < 65535 ? (n + 255) / 256 : 65535);
       hipLaunchKernelGGL(wgrad_kmajor_reduce_kernel, dim3(blocks), dim3(256), 0, st, k.part, dw, S, C_out, k.NBk, k.K, k.CV);

@@ -41,6 +41,7 @@ class ConvWeights(nn.Module):
         self._packed = None
         self._split = None
         self._rows = None
+        self._rows_split = None
         self.freeze_packed = False
 
     def packed(self):
@@ -64,6 +65,16 @@ class ConvWeights(nn.Module):
         self._rows = ops.pack_convtr_weight_rows(v.detach(), g.detach() if g is not None else None, self.stride, out=self._rows)
         return self._rows
 
+    def packed_rows_split(self):
+        """ConvTranspose1d weights for the all-phases launch on the split-bf16 GEMM kernel: (buffer, rows)."""
+        if self._rows_split is not None and self.freeze_packed:
+            return self._rows_split
+        v = self.weight_v if self.weight_norm else self.weight
+        g = self.weight_g if self.weight_norm else None
+        prev = self._rows_split[0] if self._rows_split is not None else None
+        self._rows_split = ops.pack_convtr_weight_rows_split(v.detach(), g.detach() if g is not None else None, self.stride, out=prev)
+        return self._rows_split
+
     def packed_split(self):
         """The same weights as three exact bf16 planes (ops.pack_conv_weight_split) for the k = 7 convs."""
         if self._split is not None and self.freeze_packed:
@@ -77,6 +88,7 @@ class ConvWeights(nn.Module):
         self._packed = None  # device / dtype moves invalidate the packed copies
         self._split = None
         self._rows = None
+        self._rows_split = None
         return super()._apply(fn, *a, **kw)
 
 
@@ -111,6 +123,9 @@ class SConv1d(nn.Module):
         if (ops.BF16_SPLIT and self.kernel_size == 7 and self.stride == 1 and alpha_in is None and w.c_in % 16 == 0
                 and w.c_out > 2 and x.shape[0] * x.shape[-1] > 640):
             split = w.packed_split()
+        elif (self.kernel_size == 1 and self.stride == 1 and alpha_in is None
+              and ops.gemm_split_ok(w.c_out, w.c_in, 1, x.shape[0] * x.shape[-1])):
+            split = w.packed_split()          # 1x1 with many channels: split-bf16 GEMM (conv1d_gemm_split.hip)
         return ops.conv1d(x, w.packed() if split is None else None, w.c_out, self.kernel_size, bias=w.bias,
                           stride=self.stride, dilation=self.dilation, pad_mode=self.pad_mode, alpha_in=alpha_in,
                           alpha_out=alpha_out, res=res, act=act, causal=self.causal, alpha_y2=alpha_y2, want_y=want_y,
@@ -137,7 +152,10 @@ class SConvTranspose1d(nn.Module):
 
     def run(self, x, alpha_in=None, alpha_y2=None):
         w = self.w
-        wp = w.packed_rows() if ops.convtr_rows_ok(x.shape[-1], self.stride, self.causal) else w.packed()
+        if ops.convtr_split_ok(w.c_in, w.c_out, self.stride, x.shape[0], x.shape[-1], self.causal, alpha_in):
+            wp = w.packed_rows_split()
+        else:
+            wp = w.packed_rows() if ops.convtr_rows_ok(x.shape[-1], self.stride, self.causal) else w.packed()
         return ops.conv_transpose1d(x, wp, w.c_out, self.stride, bias=w.bias, alpha_in=alpha_in,
                                     alpha_y2=alpha_y2, causal=self.causal)
 
@@ -188,13 +206,16 @@ class SLSTM(nn.Module):
         inp = ops.lstm_to_time_major(x)
         for l in range(self.num_layers):
             p = self.lstm
-            w_ih = ops.pack_conv_weight(getattr(p, f"weight_ih_l{l}").detach())
+            w_raw = getattr(p, f"weight_ih_l{l}").detach()
+            use_split = ops.gemm_split_ok(4 * H, H, 1, inp.shape[1] * inp.shape[2])
+            w_ih = None if use_split else ops.pack_conv_weight(w_raw)
+            w_ih_split = ops.pack_gemm_weight_split(w_raw) if use_split else None
             bias = ops.add(getattr(p, f"bias_ih_l{l}").detach(), getattr(p, f"bias_hh_l{l}").detach())
             whh = ops.pack_lstm_whh(getattr(p, f"weight_hh_l{l}").detach())
             T_, BP = inp.shape[1], inp.shape[2]
             # one GEMM over every (t, b): the channel-major buffer is a (1, H, T*BP) "signal"
             with ops.flop_scale(B / BP):
                 pre = ops.conv1d(inp.view(1, H, T_ * BP), w_ih, 4 * H, 1, bias=bias, pad_left=0, t_out=T_ * BP,
-                                 pad_mode=ops.PAD_ZERO)
+                                 pad_mode=ops.PAD_ZERO, w_split=w_ih_split)
                 inp = ops.lstm_layer(pre.view(4 * H, T_, BP), whh, H)
         return ops.lstm_from_time_major(inp, x if self.skip else None, B, alpha_out)

@@ -84,7 +84,7 @@ def pack_convtr_weight(v, g, stride, out=None):
 # All-phases-per-workgroup launch of the causal ConvTranspose1d (fac_conv_desc.row_phases): contiguous stores through the
 # LDS epilogue instead of `stride` interleaved strided streams (2.9x the algorithmic HBM traffic).  Needs the 256-column
 # tile, so it takes over from CONVTR_ROWS_MIN_T input columns; FAC_CONVTR_ROWS=0 keeps the polyphase launch everywhere.
-CONVTR_ROWS = os.environ.get("FAC_CONVTR_ROWS", "1") != "0"
+CONVTR_ROWS = os.environ.get("FAC_CONVTR_ROWS", "0") != "0"
 CONVTR_ROWS_MIN_T = 512
 
 
@@ -112,8 +112,17 @@ def pack_convtr_weight_rows(v, g, stride, out=None):
     return out
 
 
-def convtr_weight_for(v, g, stride, t_in, causal=True):
-    """The packed weights conv_transpose1d wants for an input of t_in columns."""
+def convtr_split_ok(c_in, c_out, stride, batch, t_in, causal=True, alpha_in=None):
+    """All-phases ConvTranspose1d on the split-bf16 GEMM kernel (conv1d_gemm_split.hip, K = 2): mirrors conv_gsplit_ok."""
+    return (BF16_SPLIT and GEMM_SPLIT and causal and alpha_in is None and 2 <= stride <= 16 and c_in % 32 == 0 and c_in >= 64
+            and t_in >= 256 and batch * t_in >= 1024 and c_out * stride >= 64)
+
+
+def convtr_weight_for(v, g, stride, t_in, causal=True, batch=1, alpha_in=None):
+    """The packed weights conv_transpose1d wants for an input of `batch` clips of t_in columns: (split GEMM buffer, rows) for the
+    bf16-pipe launch, the fp32 rows layout (opt-in) or the polyphase layout."""
+    if convtr_split_ok(v.shape[0], v.shape[1], stride, batch, t_in, causal, alpha_in):
+        return pack_convtr_weight_rows_split(v, g, stride)
     return pack_convtr_weight_rows(v, g, stride) if convtr_rows_ok(t_in, stride, causal) else pack_convtr_weight(v, g, stride)
 
 
@@ -249,10 +258,76 @@ def _launch_conv(d, what):
     _PROFILE.records.append((buf.value.decode(), flops, e0, e1))
 
 
+# 1- / 2-tap convs as split-bf16 GEMMs (conv1d_gemm_split.hip): policy of who packs the GEMM layout.  FAC_GEMM_SPLIT=0 off.
+GEMM_SPLIT = os.environ.get("FAC_GEMM_SPLIT", "1") != "0"
+GEMM_SPLIT_MIN_CIN = int(os.environ.get("FAC_GEMM_SPLIT_MIN_CIN", "256"))
+
+
+def gemm_split_ok(c_out, c_in, k, n_cols, t_out=None):
+    """1- / 2-tap stride-1 conv worth the bf16 pipe: many input channels (below ~256 the k = 1 layers are HBM-bound and the
+    streaming kernel conv1d_pw.hip is the right tool), at least half a row tile, enough columns."""
+    if not (BF16_SPLIT and GEMM_SPLIT and k in (1, 2)):
+        return False
+    if c_in % 32 or c_in < GEMM_SPLIT_MIN_CIN or c_out < 64 or n_cols < 1024:
+        return False
+    return k == 1 or (t_out is not None and t_out >= 256)
+
+
+def pack_gemm_weight_split(v, g=None, out=None):
+    """(C_out, C_in, K <= 2) [weight-normed with g over dim 0] -> fac_pack_gemm_w_split layout (uint8 buffer)."""
+    v = _dev(v, "weight")
+    if v.dim() == 2:
+        v = v.unsqueeze(-1)
+    c_out, c_in, k = v.shape
+    lib = _lib.load()
+    scale = wn_scale(v, g) if g is not None else None
+    nbytes = lib.fac_gemm_w_split_bytes(c_out, c_in, k)
+    if out is None:
+        out = torch.empty(nbytes, device=v.device, dtype=torch.uint8)
+    _lib.check(lib.fac_pack_gemm_w_split(_ptr(v), c_in * k, k, 1, _ptr(scale), out.data_ptr(), c_out, c_in, k, _stream()),
+               "fac_pack_gemm_w_split")
+    return out
+
+
+def pack_gemm_weight_split_t(w, out=None):
+    """Materialised conv weight w (C_out, C_in, 1) -> split GEMM weights of the TRANSPOSED 1x1 (rows = C_in, contraction over
+    C_out): the data gradient of a 1x1 conv, read through strides (no transposed copy)."""
+    w = _dev(w, "weight")
+    if w.dim() == 2:
+        w = w.unsqueeze(-1)
+    c_out, c_in, k = w.shape
+    assert k == 1
+    lib = _lib.load()
+    nbytes = lib.fac_gemm_w_split_bytes(c_in, c_out, 1)
+    if out is None:
+        out = torch.empty(nbytes, device=w.device, dtype=torch.uint8)
+    _lib.check(lib.fac_pack_gemm_w_split(_ptr(w), 1, c_in, 1, None, out.data_ptr(), c_in, c_out, 1, _stream()),
+               "fac_pack_gemm_w_split(transposed)")
+    return out
+
+
+def pack_convtr_weight_rows_split(v, g, stride, out=None):
+    """ConvTranspose1d (C_in, C_out, 2*stride) -> split GEMM weights of the all-phases launch: the (channel, phase) rows of
+    pack_convtr_weight_rows, each row's (C_in, 2) taps as bf16 planes.  Returns (split buffer, rows)."""
+    rows = pack_convtr_weight_rows(v, g, stride)                  # (cin_pad, 2, R) fp32, weight-norm applied
+    cip, _, R = rows.shape
+    c_in = v.shape[0]
+    lib = _lib.load()
+    nbytes = lib.fac_gemm_w_split_bytes(R, c_in, 2)
+    if out is None:
+        out = torch.empty(nbytes, device=v.device, dtype=torch.uint8)
+    _lib.check(lib.fac_pack_gemm_w_split(_ptr(rows), 1, 2 * R, R, None, out.data_ptr(), R, c_in, 2, _stream()),
+               "fac_pack_gemm_w_split(convtr rows)")
+    return out, R
+
+
 def pack_conv_weight_split(v, g=None, out=None):
-    """(C_out, C_in, K) [weight-normed with g] -> split-bf16 layout of fac_pack_conv_w_split (uint8 buffer)."""
+    """(C_out, C_in, K) [weight-normed with g] -> split-bf16 layout of fac_pack_conv_w_split (K = 5 / 7; uint8 buffer) or of
+    fac_pack_gemm_w_split (K = 1 / 2)."""
     v = _dev(v, "weight")
     c_out, c_in, k = v.shape
+    if k <= 2:
+        return pack_gemm_weight_split(v, g, out)
     lib = _lib.load()
     scale = wn_scale(v, g) if g is not None else None
     nbytes = lib.fac_conv_w_split_bytes(c_out, c_in, k)
@@ -333,11 +408,16 @@ def conv_transpose1d(x, w_packed, c_out, stride, bias=None, alpha_in=None, out=N
         assert causal
         t_in -= 1
     t_total = t_in * stride
-    cp = w_packed.shape[-1]
+    split_rows = isinstance(w_packed, tuple)       # (split GEMM buffer, rows) from pack_convtr_weight_rows_split
+    cp = w_packed[1] if split_rows else w_packed.shape[-1]
     if out is None:
         out = torch.empty(B, c_out, t_total, device=x.device, dtype=torch.float32)
     d = ConvDesc()
-    d.x, d.w, d.bias = x.data_ptr(), w_packed.data_ptr(), (bias.data_ptr() if bias is not None else None)
+    d.x, d.bias = x.data_ptr(), (bias.data_ptr() if bias is not None else None)
+    if split_rows:
+        d.w, d.w_split = None, w_packed[0].data_ptr()
+    else:
+        d.w = w_packed.data_ptr()
     d.alpha_in = alpha_in.data_ptr() if alpha_in is not None else None
     d.alpha_out, d.res, d.y = None, None, out.data_ptr()
     y2 = torch.empty_like(out) if alpha_y2 is not None else None
@@ -350,7 +430,7 @@ def conv_transpose1d(x, w_packed, c_out, stride, bias=None, alpha_in=None, out=N
     d.n_phase, d.y_tstride, d.act, d.w_batched, d.w_bs = stride, stride, ACT_NONE, 0, 0
     # non-causal: trim ceil(s/2) on the left, floor(s/2) on the right (dac/model/encodec.py:265-269)
     d.phase_shift = 0 if causal else stride - stride // 2
-    if w_packed.dim() == 3:          # rows layout (pack_convtr_weight_rows): all phases per workgroup, contiguous stores
+    if split_rows or w_packed.dim() == 3:          # rows layouts: all phases per workgroup, contiguous stores
         if not causal or has_history:
             raise _lib.FacodecHipError("the all-phases ConvTranspose1d launch is causal and offline only")
         d.n_phase, d.y_tstride, d.phase_shift, d.row_phases = 1, 1, 0, stride
@@ -621,6 +701,9 @@ def conv1d_bwd_data(dy, v, g, t_in, stride=1, dilation=1, pad_mode=PAD_REFLECT, 
         wt = w.permute(1, 0, 2).flip(2).contiguous()                       # (C_in, C_out, K) = weights of the bwd conv
         dxpad = conv1d(dy, None, c_in, k, dilation=dilation, pad_left=(k - 1) * dilation, pad_mode=PAD_ZERO, t_out=tp,
                        w_split=pack_conv_weight_split(wt))
+    elif stride == 1 and k == 1 and gemm_split_ok(c_in, c_out, 1, B * tp):
+        w = rows_fma(v, wn_scale(v, g)) if g is not None else v           # 1x1: the transposed GEMM on the bf16 pipe
+        dxpad = conv1d(dy, None, c_in, 1, pad_left=0, pad_mode=PAD_ZERO, t_out=tp, w_split=pack_gemm_weight_split_t(w))
     elif stride == 1:
         dxpad = conv1d(dy, pack_conv_weight_bwd(v, g), c_in, k, dilation=dilation, pad_left=(k - 1) * dilation,
                        pad_mode=PAD_ZERO, t_out=tp)
@@ -628,7 +711,7 @@ def conv1d_bwd_data(dy, v, g, t_in, stride=1, dilation=1, pad_mode=PAD_REFLECT, 
         if k != 2 * stride or dilation != 1:
             raise NotImplementedError("strided bwd_data is built for the model's k = 2*stride convs")
         dy_ext = torch.cat([dy, torch.zeros(B, c_out, 1, device=dy.device)], dim=2)
-        dxpad = conv_transpose1d(dy_ext, convtr_weight_for(v, g, stride, dy_ext.shape[-1]), c_in, stride)
+        dxpad = conv_transpose1d(dy_ext, convtr_weight_for(v, g, stride, dy_ext.shape[-1], batch=B), c_in, stride)
         assert dxpad.shape[-1] == tp, (dxpad.shape, tp)
     dx = torch.empty(B, c_in, t_in, device=dy.device, dtype=torch.float32)
     _lib.check(_lib.load().fac_pad_fold_bwd(_ptr(dxpad), _ptr(dx), B, c_in, t_in, tp, pad_left, pad_mode, _stream()),

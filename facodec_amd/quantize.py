@@ -144,6 +144,9 @@ class _PlainConv(nn.Module):
         self.c_in, self.c_out, self.k = c_in, c_out, k
 
     def run(self, x, pad=0, **kw):
+        if self.k == 1 and pad == 0 and ops.gemm_split_ok(self.c_out, self.c_in, 1, x.shape[0] * x.shape[-1]):
+            return ops.conv1d(x, None, self.c_out, 1, bias=self.bias.detach(), pad_left=0, pad_mode=ops.PAD_ZERO, t_out=x.shape[-1],
+                              w_split=ops.pack_gemm_weight_split(self.weight.detach()), **kw)      # 1x1, many channels: bf16 pipe
         return ops.conv1d(x, ops.pack_conv_weight(self.weight.detach()), self.c_out, self.k, bias=self.bias.detach(),
                           pad_left=pad, pad_mode=ops.PAD_ZERO, t_out=x.shape[-1], **kw)
 

@@ -132,9 +132,10 @@ typedef struct fac_conv_desc {
    * launch).  NULL: the tiled kernel is used for every shape. */
   void* ws;
   int64_t ws_bytes;
-  /* Optional: the same weights in the split-bf16 layout of fac_pack_conv_w_split.  When given and the shape
-   * qualifies (K = 7, stride 1, C_in % 16 == 0, no Snake prologue), the conv runs on the bf16 matrix pipe
-   * with fp32-exact operand splitting (conv1d_bsplit.hip); `w` is still required for every other shape. */
+  /* Optional: the same weights in the split-bf16 layout of fac_pack_conv_w_split (K = 5 / 7) or fac_pack_gemm_w_split
+   * (K = 1 / 2).  When given and the shape qualifies (stride 1, no Snake prologue, C_in % 16 == 0 resp. % 32 == 0, enough
+   * columns), the conv runs on the bf16 matrix pipe with fp32-exact operand splitting (conv1d_bsplit.hip /
+   * conv1d_gemm_split.hip); `w` is still required for every other shape. */
   const void* w_split;
   /* Optional two-level taps (0 = plain): tap k = k2 * K1 + k1 reads the input at offset k2 * dilation2 + k1 * dilation
    * (K % K1 == 0).  A (3, k) Conv2d over a row-concatenated (time, frequency) signal -- the multi-resolution
@@ -157,11 +158,18 @@ int fac_conv1d_fwd(const fac_conv_desc* d, fac_stream_t stream);
 int64_t fac_conv_w_split_bytes(int C_out, int C_in, int K);
 int fac_pack_conv_w_split(const float* v, const float* scale, void* out, int C_out, int C_in, int K,
                           fac_stream_t stream);
+/* Split weights of the 1- and 2-tap convs (conv1d_gemm_split.hip): rows r < R (output channels, or the (channel, phase) rows of
+ * fac_pack_convtr_w_rows), element (r, ci, k) read at v[r * row_stride + ci * ci_stride + k * k_stride] [* row_scale[r]], written
+ * as three bf16 planes per (128-row tile, 32-channel chunk) in the kernel's swizzled LDS image (one flat LDS-DMA copy per
+ * stage).  C_in is padded to a multiple of 32 with zeros.  Passed as fac_conv_desc.w_split of a K = 1 / K = 2 launch. */
+int64_t fac_gemm_w_split_bytes(int R, int C_in, int K);
+int fac_pack_gemm_w_split(const float* v, int64_t row_stride, int64_t ci_stride, int64_t k_stride, const float* row_scale, void* out,
+                          int R, int C_in, int K, fac_stream_t stream);
 /* Which kernel instantiation fac_conv1d_fwd picks for this descriptor: returns its id (>= 0) and
  * writes a printable name; lets a profiler attribute per-launch timings without re-deriving
  * the tile-selection rule.  Ids: 0-6, 8 MFMA tile shapes, 7 fused ResidualUnit, 9 VALU kernel for C_out <= 2, 10 split-reduction
  * kernel (<= 640 columns), 11 split-bf16 kernel (k = 5 / 7), 12 store-stream kernel for C_in = 1, 13 channel-split kernel for
- * C_out <= 2 over few tiles, 14 streaming k = 1 kernel (weights resident in LDS, C <= 384). */
+ * C_out <= 2 over few tiles, 14 streaming k = 1 kernel (weights resident in LDS, C <= 384), 15 split-bf16 GEMM kernel (k = 1 / 2). */
 int fac_conv1d_variant(const fac_conv_desc* d, char* name, int name_len);
 
 /* Standalone Snake  y = x + sin(alpha*x)^2 / (alpha + 1e-9)  (dac/nn/layers.py:18-33) for the

@@ -136,7 +136,6 @@ def test_conv_transpose_all_phases_launch(B, ci, co, T, s, O, ops, cuda):
     al = 1 + 0.2 * torch.rand(ci, generator=g)
     a2 = 1 + 0.2 * torch.rand(co, generator=g)
     y = O.sconvtr1d(O.snake(x, al.view(1, -1, 1)), O.weight_norm_weight(v, gg), b, s, causal=True)
-    assert ops.convtr_rows_ok(T, s)
     wr = ops.pack_convtr_weight_rows(v.to(cuda), gg.to(cuda), s)
     assert wr.dim() == 3 and wr.shape[-1] == ops.convtr_rows_pad(co, s)
     yg, y2 = ops.conv_transpose1d(x.to(cuda), wr, co, s, bias=b.to(cuda), alpha_in=al.to(cuda), alpha_y2=a2.to(cuda))
@@ -144,9 +143,16 @@ def test_conv_transpose_all_phases_launch(B, ci, co, T, s, O, ops, cuda):
     assert rel(y2, O.snake(y, a2.view(1, -1, 1))) < OP_TOL
     yp = ops.conv_transpose1d(x.to(cuda), ops.pack_convtr_weight(v.to(cuda), gg.to(cuda), s), co, s, bias=b.to(cuda), alpha_in=al.to(cuda))
     assert rel(yg, yp) < 1e-6
-    # what the layer picks by itself
-    w2 = ops.convtr_weight_for(v.to(cuda), gg.to(cuda), s, T)
-    assert w2.dim() == 3 and ops.convtr_weight_for(v.to(cuda), gg.to(cuda), s, 100).dim() == 4
+    # opt-in (FAC_CONVTR_ROWS=1): measured slower than the polyphase launch on the fp32 pipe, the default all-phases path is
+    # the split-bf16 GEMM (test_conv_transpose_on_split_gemm)
+    prev = ops.CONVTR_ROWS
+    try:
+        ops.CONVTR_ROWS = True
+        assert ops.convtr_rows_ok(T, s) and ops.convtr_weight_for(v.to(cuda), gg.to(cuda), s, T, alpha_in=al).dim() == 3
+        ops.CONVTR_ROWS = False
+        assert ops.convtr_weight_for(v.to(cuda), gg.to(cuda), s, T, alpha_in=al).dim() == 4
+    finally:
+        ops.CONVTR_ROWS = prev
 
 
 def test_conv_second_output_is_snake_of_first(O, ops, cuda):
@@ -794,6 +800,87 @@ def test_split_bf16_conv_matches_fp32_grade(B, C, T, d, mode, O, ops, cuda):
     e_fp32 = rel(ops.conv1d(x.to(cuda), ops.pack_conv_weight(w.to(cuda), gg.to(cuda)), C, 7, **kw0), y64)
     assert e_split < 1.5 * e_fp32 + 1e-7, (e_split, e_fp32)
     assert rel(y, yf) < OP_TOL
+
+
+@pytest.mark.parametrize("B,ci,co,T,act", [(8, 512, 512, 960, "none"), (32, 256, 512, 160, "mish"), (1, 1024, 4096, 5120, "none"),
+                                           (3, 320, 200, 333, "none"), (2, 768, 96, 1001, "none")])
+def test_gemm_split_1x1_matches_fp32_grade(B, ci, co, T, act, ops, cuda):
+    """conv1d_gemm_split.hip, K = 1: many-channel 1x1 convs as a split-bf16 GEMM over the flattened (clip, time) columns --
+    bias, activation, residual, second pre-activated output; row counts that do not fill a 128-row tile, T not a multiple of 4
+    (sample-wise epilogue), 160-frame clips sharing a column tile.  Bars as for the k = 7 split kernel: the fp32 kernel's
+    tolerance, and an fp64 error no larger than 1.5x the fp32-MFMA kernel's."""
+    import torch.nn.functional as F
+    g = _g(ci + co + T)
+    x = torch.randn(B, ci, T, generator=g)
+    w = torch.randn(co, ci, 1, generator=g) / ci ** 0.5
+    gg = torch.rand(co, 1, 1, generator=g) + 0.5
+    b = torch.randn(co, generator=g) * 0.1
+    r = torch.randn(B, co, T, generator=g)
+    a2 = 1 + 0.2 * torch.rand(co, generator=g)
+    wn = w * (gg / w.reshape(co, -1).norm(dim=1).reshape(co, 1, 1))
+    y64 = F.conv1d(x.double(), wn.double(), b.double())
+    if act == "mish":
+        y64 = y64 * torch.tanh(F.softplus(y64))
+    y64 = y64 + r.double()
+    al = a2.double().view(1, -1, 1)
+    y2_64 = y64 + torch.sin(al * y64) ** 2 / (al + 1e-9)
+    assert ops.gemm_split_ok(co, ci, 1, B * T)
+    ws = ops.pack_conv_weight_split(w.to(cuda), gg.to(cuda))
+    kw = dict(bias=b.to(cuda), pad_left=0, pad_mode=ops.PAD_ZERO, t_out=T, res=r.to(cuda), alpha_y2=a2.to(cuda),
+              act=ops.ACT_MISH if act == "mish" else ops.ACT_NONE)
+    prof = ops.ConvLaunchProfile()
+    ops.set_conv_profile(prof)
+    try:
+        y, y2 = ops.conv1d(x.to(cuda), None, co, 1, w_split=ws, **kw)
+        torch.cuda.synchronize()
+    finally:
+        ops.set_conv_profile(None)
+    assert any("gemm_split" in k for k in prof.summary()), prof.summary().keys()
+    yf, y2f = ops.conv1d(x.to(cuda), ops.pack_conv_weight(w.to(cuda), gg.to(cuda)), co, 1, **kw)
+    e_split, e_fp32 = rel(y, y64), rel(yf, y64)
+    assert e_split < OP_TOL and rel(y2, y2_64) < OP_TOL, (e_split, e_fp32)
+    assert e_split < 1.5 * e_fp32 + 1e-7, (e_split, e_fp32)
+    _record(f"gemm_split_1x1_{ci}to{co}_T{T}", e_split)
+    # transposed form (data gradient of the 1x1): dx = W^T dy
+    dy = torch.randn(B, co, T, generator=g)
+    dx64 = F.conv_transpose1d(dy.double(), wn.double())
+    if ops.gemm_split_ok(ci, co, 1, B * T):
+        wt = ops.pack_gemm_weight_split_t(wn.to(cuda))
+        dx = ops.conv1d(dy.to(cuda), None, ci, 1, pad_left=0, pad_mode=ops.PAD_ZERO, t_out=T, w_split=wt)
+        assert rel(dx, dx64) < OP_TOL
+
+
+@pytest.mark.parametrize("B,ci,co,T,s", [(2, 192, 96, 1000, 2), (2, 96, 40, 777, 5), (1, 128, 64, 1333, 6), (3, 64, 22, 512, 3),
+                                         (2, 384, 192, 960, 5)])
+def test_conv_transpose_on_split_gemm(B, ci, co, T, s, O, ops, cuda):
+    """Causal ConvTranspose1d with every output phase as a GEMM row on the split-bf16 GEMM kernel (K = 2, row_phases
+    epilogue): against the oracle, against fp64, with bias and the pre-activated second output."""
+    import torch.nn.functional as F
+    g = _g(50 + s + ci)
+    x = torch.randn(B, ci, T, generator=g)
+    v = torch.randn(ci, co, 2 * s, generator=g) / (ci * 2) ** 0.5
+    gg = torch.rand(ci, 1, 1, generator=g) + 0.5
+    b = torch.randn(co, generator=g) * 0.1
+    a2 = 1 + 0.2 * torch.rand(co, generator=g)
+    wn = O.weight_norm_weight(v, gg)
+    y = O.sconvtr1d(x, wn, b, s, causal=True)
+    assert ops.convtr_split_ok(ci, co, s, B, T)
+    wsr = ops.convtr_weight_for(v.to(cuda), gg.to(cuda), s, T, batch=B)
+    assert isinstance(wsr, tuple)
+    prof = ops.ConvLaunchProfile()
+    ops.set_conv_profile(prof)
+    try:
+        yg, y2 = ops.conv_transpose1d(x.to(cuda), wsr, co, s, bias=b.to(cuda), alpha_y2=a2.to(cuda))
+        torch.cuda.synchronize()
+    finally:
+        ops.set_conv_profile(None)
+    assert any("gemm_split" in k for k in prof.summary()), prof.summary().keys()
+    assert yg.shape == y.shape and rel(yg, y) < OP_TOL
+    assert rel(y2, O.snake(y, a2.view(1, -1, 1))) < OP_TOL
+    y64 = F.conv_transpose1d(x.double(), wn.double(), b.double(), stride=s)[..., : T * s]
+    yp = ops.conv_transpose1d(x.to(cuda), ops.pack_convtr_weight(v.to(cuda), gg.to(cuda), s), co, s, bias=b.to(cuda))
+    e_split, e_fp32 = rel(yg, y64), rel(yp, y64)
+    assert e_split < 1.5 * e_fp32 + 1e-7, (e_split, e_fp32)
 
 
 # ------------------------------------------------------------------------------ backward of the conv stack
