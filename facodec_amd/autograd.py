@@ -36,7 +36,9 @@ class _Conv(Function):
     def forward(ctx, x, v, g, bias, cfg):
         k, stride, dilation, pad_mode, causal, act = cfg
         vd, gd = v.detach(), (g.detach() if g is not None else None)
-        if _split_ok(v.shape[0], v.shape[1], k, stride, x):       # k = 7 convs: fp32-exact split on the bf16 pipe
+        if stride > 1 and dilation == 1 and ops.gemm_split_strided_ok(v.shape[0], v.shape[1], k, stride, x.shape[0], -(-x.shape[-1] // stride)):
+            wp, ws = None, ops.pack_gemm_weight_split(vd, gd, in_stride=stride)     # downsampling conv on the split GEMM kernel
+        elif _split_ok(v.shape[0], v.shape[1], k, stride, x):       # k = 7 / k = 1 convs: fp32-exact split on the bf16 pipe
             wp, ws = None, ops.pack_conv_weight_split(vd, gd)
         else:
             wp, ws = ops.pack_conv_weight(vd, gd), None

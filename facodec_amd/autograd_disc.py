@@ -31,7 +31,9 @@ class PlainConv(Function):
         max_off = (k // k1 - 1) * dil2 + (k1 - 1) if k1 else k - 1
         t_out = (t_in + 2 * pad - max_off - 1) // stride + 1
         vd, gd = v.detach().contiguous(), (g.detach().contiguous() if g is not None else None)
-        if not k1 and _split_ok(k, stride, c_in, v.shape[0], B * t_out):
+        if not k1 and stride > 1 and ops.gemm_split_strided_ok(v.shape[0], c_in, k, stride, B, t_out):
+            wp, ws = None, ops.pack_gemm_weight_split(vd, gd, in_stride=stride)     # (5, 1) stride-3 convs: split GEMM over 3 phases
+        elif not k1 and _split_ok(k, stride, c_in, v.shape[0], B * t_out):
             wp, ws = None, ops.pack_conv_weight_split(vd, gd)
         else:
             wp, ws = ops.pack_conv_weight(vd, gd), None

@@ -90,7 +90,8 @@ extern "C" int fac_conv1d_fwd(const fac_conv_desc* d, fac_stream_t stream) {
   if (d->w_k1) return conv_dispatch_fused_ru(a, s);
   a.gflat = 0;
   // 1- / 2-tap convs with split weights in the GEMM layout (fac_pack_gemm_w_split): the bf16 matrix pipe, fp32-exact
-  if (d->w_split && (d->K == 1 || d->K == 2) && conv_gsplit_ok(a) && !conv_skinny_ok(a, d->ws, d->ws_bytes)) {
+  if (d->w_split && (d->K <= 2 || (d->stride > 1 && d->K <= 2 * d->stride)) && conv_gsplit_ok(a) &&
+      !conv_skinny_ok(a, d->ws, d->ws_bytes)) {
     a.w = reinterpret_cast<const float*>(d->w_split);
     return conv_dispatch_gsplit(a, s);
   }
@@ -135,14 +136,15 @@ extern "C" int fac_conv1d_variant(const fac_conv_desc* d, char* name, int name_l
     if (name && name_len > 0) snprintf(name, name_len, "conv1d_mfma_kernel<C/32,1,1,4,7,fused RU> Cx128");
     return 7;
   }
-  if (d->w_split && (d->K == 1 || d->K == 2)) {
+  if (d->w_split && (d->K <= 2 || (d->stride > 1 && d->K <= 2 * d->stride))) {
     ConvArgs a{};
     a.K = d->K; a.stride = d->stride; a.dil = d->dilation; a.n_phase = d->n_phase; a.phase_shift = d->phase_shift; a.y_tstride = d->y_tstride;
     a.alpha_in = d->alpha_in; a.w1 = d->w_k1; a.w_batched = d->w_batched; a.C_in = d->C_in; a.C_out = d->C_out; a.C_out_pad = d->C_out_pad;
     a.K1 = d->K; a.pad_left = d->pad_left; a.pad_mode = d->pad_mode; a.T_in = d->T_in; a.T_out = d->T_out; a.B = d->B; a.x_bs = d->x_bs;
     a.rp = d->row_phases > 1 ? d->row_phases : 1; a.x_cs = d->x_cs;
     if (conv_gsplit_ok(a) && !conv_skinny_ok(a, d->ws, d->ws_bytes)) {
-      if (name && name_len > 0) snprintf(name, name_len, "conv1d_gemm_split_kernel<%d> 128x128 (bf16x3 split GEMM, fp32-exact)", d->K);
+      if (name && name_len > 0)
+        snprintf(name, name_len, "conv1d_gemm_split_kernel<%d> 128x128 (bf16x3 split GEMM, fp32-exact)", d->stride > 1 ? 2 : d->K);
       return 15;
     }
   }

@@ -50,12 +50,14 @@ __device__ __forceinline__ void gs_barrier() {
   asm volatile("" ::: "memory");
 }
 
-// Weights (R rows, C_in, K taps) given through strides (element (r, ci, k) at v[r*rs + ci*cs + k*ks]) [* row_scale[r]]
+// Weights (R rows, C_in, K_total taps) given through strides (element (r, ci, k) at v[r*rs + ci*cs + k*ks]) [* row_scale[r]]
 // -> [row tile][chunk][plane][tap][row 128][slot 4][8 bf16], slot = piece ^ ((row >> 2) & 3), piece = (ci % 32) / 8.
+// Input stride S > 1 (strided conv, K_total <= 2 S): chunk = (32 real channels, input phase p), p fastest; its K = 2 taps are
+// k = p and k = S + p (zero when >= K_total) -- the conv over the phase-p sub-signal x[S u + p].
 // One thread per (tile, chunk, tap, row, piece): three 16-byte stores.
 __global__ __launch_bounds__(256) void pack_gemm_split_kernel(const float* __restrict__ v, long long rs, long long cs, long long ks,
                                                               const float* __restrict__ row_scale, unsigned char* __restrict__ out,
-                                                              int R, int C_in, int K, int n_ch, long long n) {
+                                                              int R, int C_in, int K, int n_ch, int S, int K_total, long long n) {
   for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < n; idx += (long long)gridDim.x * 256) {
     const int piece = (int)(idx & 3);
     const int row = (int)((idx >> 2) & 127);
@@ -69,10 +71,11 @@ __global__ __launch_bounds__(256) void pack_gemm_split_kernel(const float* __res
     bf16x8 h, m, l;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      const int ci = ch * GS_CI + piece * 8 + i;
+      const int ci = (ch / S) * GS_CI + piece * 8 + i;
+      const int kk = S * k + ch % S;
       float w = 0.f;
-      if (rg < R && ci < C_in) {
-        w = v[(long long)rg * rs + (long long)ci * cs + (long long)k * ks];
+      if (rg < R && ci < C_in && kk < K_total) {
+        w = v[(long long)rg * rs + (long long)ci * cs + (long long)kk * ks];
         if (row_scale != nullptr) w = __fmul_rn(w, sc);
       }
       __bf16 a, b, c;
@@ -116,7 +119,8 @@ __global__ __launch_bounds__(512, 2) void conv1d_gemm_split_kernel(ConvArgs a) {
     row0 = (rest / nb) * GS_ROWS;
     n0 = tt * GS_COLS;
   }
-  const int n_chunks = a.C_in / GS_CI;
+  const int S = (K == 2 && a.stride > 1) ? a.stride : 1;      // input stride: S phase sub-signals as virtual channel chunks
+  const int n_chunks = (a.C_in / GS_CI) * S;
   const long long n_total = flat ? (long long)a.B * a.T_out : (long long)a.T_out;     // columns of this (clip | whole batch)
 
   if (wave >= 4) {
@@ -127,7 +131,7 @@ __global__ __launch_bounds__(512, 2) void conv1d_gemm_split_kernel(ConvArgs a) {
     const unsigned char* wsrc = reinterpret_cast<const unsigned char*>(a.w) + (long long)(row0 / GS_ROWS) * n_chunks * A_BYTES;
     // input units of this lane: column c of the staged window (row c of the B planes), 8-channel group g
     long long u_off[GS_NU];
-    int u_lds[GS_NU];
+    int u_lds[GS_NU], u_g[GS_NU];
     bool u_ok[GS_NU], u_in[GS_NU];
 #pragma unroll
     for (int j = 0; j < GS_NU; ++j) {
@@ -144,15 +148,18 @@ __global__ __launch_bounds__(512, 2) void conv1d_gemm_split_kernel(ConvArgs a) {
           off = bb * a.x_bs + (nn - bb * a.T_out);
           in = true;
         }
-      } else {
+      } else if (S == 1) {
         const int tin = n0 - a.pad_left + c;
         if (tin >= 0 && tin < a.T_in) {
           off = (long long)b * a.x_bs + tin;
           in = true;
         }
+      } else {
+        off = c;                                             // strided: resolved per chunk (phase-dependent), see load_b
       }
       u_in[j] = in && u_ok[j];
-      u_off[j] = off + (long long)(g * 8) * a.x_cs;
+      u_off[j] = off + (S == 1 ? (long long)(g * 8) * a.x_cs : 0ll);
+      u_g[j] = g;
     }
     auto issue_a = [&](int chunk, int buf) {
       const unsigned char* src = wsrc + (long long)chunk * A_BYTES;
@@ -165,17 +172,29 @@ __global__ __launch_bounds__(512, 2) void conv1d_gemm_split_kernel(ConvArgs a) {
     };
     // register loads by inline asm (invisible to hipcc's own s_waitcnt placement, as in conv1d_wgrad_split.hip): exactly
     // NBL loads per call, lanes without a real unit load a clamped address and are zeroed at the split
-    auto load_b = [&](int chunk, float (&xr)[GS_NU][8]) {
-      const float* xc = a.x + (long long)chunk * GS_CI * a.x_cs;
+    auto load_b = [&](int chunk, float (&xr)[GS_NU][8], bool (&uin)[GS_NU]) {
+      const int c32 = chunk / S, ph = chunk - c32 * S;
+      const float* xc = a.x + (long long)c32 * GS_CI * a.x_cs;
 #pragma unroll
       for (int j = 0; j < GS_NU; ++j) {
-        const float* p = xc + (u_in[j] ? u_off[j] : 0ll);
+        long long o = u_off[j];
+        bool in = u_in[j];
+        if (S > 1) {          // column c of the window <-> sample (n0 + c) * S + phase - pad_left of the padded signal
+          const int tin = (n0 + (int)u_off[j]) * S + ph - a.pad_left;
+          int idx;
+          if (a.pad_mode == FAC_PAD_REFLECT) idx = reflect_index(tin, a.T_in, a.T_ext);
+          else idx = (tin >= 0 && tin < a.T_in) ? tin : -1;
+          in = u_ok[j] && idx >= 0;
+          o = (long long)b * a.x_bs + (idx >= 0 ? idx : 0) + (long long)(u_g[j] * 8) * a.x_cs;
+        }
+        uin[j] = in;
+        const float* p = xc + (in ? o : 0ll);
 #pragma unroll
         for (int i = 0; i < 8; ++i)
           asm volatile("global_load_dword %0, %1, off" : "=v"(xr[j][i]) : "v"(p + (long long)i * a.x_cs) : "memory");
       }
     };
-    auto write_b = [&](int buf, float (&xr)[GS_NU][8]) {
+    auto write_b = [&](int buf, float (&xr)[GS_NU][8], const bool (&uin)[GS_NU]) {
       unsigned char* xd = sm + buf * STAGE + A_BYTES;
 #pragma unroll
       for (int j = 0; j < GS_NU; ++j) {
@@ -184,7 +203,7 @@ __global__ __launch_bounds__(512, 2) void conv1d_gemm_split_kernel(ConvArgs a) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
           __bf16 p0, p1, p2;
-          gs_split3(u_in[j] ? xr[j][i] : 0.f, p0, p1, p2);
+          gs_split3(uin[j] ? xr[j][i] : 0.f, p0, p1, p2);
           h[i] = p0; m[i] = p1; l[i] = p2;
         }
         *reinterpret_cast<bf16x8*>(xd + u_lds[j]) = h;
@@ -206,14 +225,15 @@ __global__ __launch_bounds__(512, 2) void conv1d_gemm_split_kernel(ConvArgs a) {
     };
 
     float xa[GS_NU][8], xb[GS_NU][8];
+    bool ia[GS_NU], ib[GS_NU];                    // which units of the register sets hold real samples
     // prologue: stage 0 complete; weight slabs of stages 1 .. D-1 and the inputs of chunk 1 in flight
     issue_a(0, 0);
-    load_b(0, xa);
+    load_b(0, xa, ia);
     int after = 0;
     if (D == 2 && n_chunks > 1) { issue_a(1, 1); after += NA; }
-    if (n_chunks > 1) { load_b(1, xb); after += NBL; }
+    if (n_chunks > 1) { load_b(1, xb, ib); after += NBL; }
     landed(after, xa);
-    write_b(0, xa);
+    write_b(0, xa, ia);
     gs_barrier();                                 // stage 0 visible to the MFMA waves
     for (int base = 0; base < n_chunks; base += 6) {
 #pragma unroll
@@ -227,12 +247,12 @@ __global__ __launch_bounds__(512, 2) void conv1d_gemm_split_kernel(ConvArgs a) {
             if (D == 2) aft += NA;                // D == 1: these are the weights of c + 1 themselves -- must land now
           }
           if (c + 2 < n_chunks) {
-            if (i % 2 == 0) load_b(c + 2, xa); else load_b(c + 2, xb);
+            if (i % 2 == 0) load_b(c + 2, xa, ia); else load_b(c + 2, xb, ib);
             aft += NBL;
           }
           if (c + 1 < n_chunks) {
-            if (i % 2 == 0) { landed(aft, xb); write_b((i + 1) % NST, xb); }
-            else { landed(aft, xa); write_b((i + 1) % NST, xa); }
+            if (i % 2 == 0) { landed(aft, xb); write_b((i + 1) % NST, xb, ib); }
+            else { landed(aft, xa); write_b((i + 1) % NST, xa, ia); }
           }
           gs_barrier();
         }
@@ -425,17 +445,23 @@ __global__ __launch_bounds__(512, 2) void conv1d_gemm_split_kernel(ConvArgs a) {
 bool conv_gsplit_ok(const ConvArgs& a) {
   static const bool on = !(getenv("FAC_GEMM_SPLIT") && getenv("FAC_GEMM_SPLIT")[0] == '0');
   if (!on) return false;
-  if (!((a.K == 1 || a.K == 2) && a.stride == 1 && a.dil == 1 && a.n_phase == 1 && a.phase_shift == 0 && a.y_tstride == 1 &&
-        !a.alpha_in && !a.w1 && !a.w_batched && !conv_two_level(a)))
+  const bool strided = a.stride > 1;          // K <= 2 * stride taps as 2 taps of `stride` phase sub-signals
+  if (!(a.dil == 1 && a.n_phase == 1 && a.phase_shift == 0 && a.y_tstride == 1 && !a.alpha_in && !a.w1 && !a.w_batched &&
+        !conv_two_level(a)))
     return false;
+  if (strided) {
+    if (!(a.K > a.stride && a.K <= 2 * a.stride && a.stride <= 16 && a.rp == 1)) return false;
+  } else if (!(a.K == 1 || a.K == 2)) {
+    return false;
+  }
   if (a.C_in % GS_CI != 0 || a.C_in < 64) return false;
-  if (a.K == 1 && (a.pad_left != 0 || a.T_in < a.T_out)) return false;
-  if (a.K == 2 && (a.pad_mode != FAC_PAD_ZERO || a.pad_left > 1)) return false;
+  if (!strided && a.K == 1 && (a.pad_left != 0 || a.T_in < a.T_out)) return false;
+  if (!strided && a.K == 2 && (a.pad_mode != FAC_PAD_ZERO || a.pad_left > 1)) return false;
   const int rows = a.rp > 1 ? a.C_out_pad : a.C_out;
   if (rows < 64) return false;
   const long long cols = (long long)a.B * a.T_out;
   if (cols < 1024) return false;
-  if (a.K == 2 && a.T_out < 256) return false;            // per-clip tiles: short clips leave half-empty tiles to the fp32 kernel
+  if ((strided || a.K == 2) && a.T_out < 256) return false;   // per-clip tiles: short clips leave half-empty tiles to the fp32 kernel
   return (long long)a.B * a.x_bs < (1ll << 40);
 }
 
@@ -464,25 +490,30 @@ static int gsplit_launch(ConvArgs& a, hipStream_t s) {
 }
 
 int conv_dispatch_gsplit(ConvArgs& a, hipStream_t s) {
-  return a.K == 1 ? gsplit_launch<1>(a, s) : gsplit_launch<2>(a, s);
+  return (a.K == 1 && a.stride == 1) ? gsplit_launch<1>(a, s) : gsplit_launch<2>(a, s);
 }
 
 }  // namespace fac
 
-extern "C" int64_t fac_gemm_w_split_bytes(int R, int C_in, int K) {
+// K: taps of the conv; in_stride S: 1, or the stride of a strided conv with S < K <= 2 S (stored as 2 taps x S phase chunks)
+extern "C" int64_t fac_gemm_w_split_bytes(int R, int C_in, int K, int in_stride) {
   using namespace fac;
-  const int64_t n_tiles = (R + GS_ROWS - 1) / GS_ROWS, n_ch = (C_in + GS_CI - 1) / GS_CI;
-  return n_tiles * n_ch * 3 * K * GS_APL;
+  const int S = in_stride > 1 ? in_stride : 1, Kt = S > 1 ? 2 : K;
+  const int64_t n_tiles = (R + GS_ROWS - 1) / GS_ROWS, n_ch = (int64_t)((C_in + GS_CI - 1) / GS_CI) * S;
+  return n_tiles * n_ch * 3 * Kt * GS_APL;
 }
 
 extern "C" int fac_pack_gemm_w_split(const float* v, int64_t row_stride, int64_t ci_stride, int64_t k_stride, const float* row_scale,
-                                     void* out, int R, int C_in, int K, fac_stream_t stream) {
+                                     void* out, int R, int C_in, int K, int in_stride, fac_stream_t stream) {
   using namespace fac;
-  FAC_REQUIRE(v && out && R > 0 && C_in > 0 && (K == 1 || K == 2), "pack_gemm_w_split: bad arguments (K must be 1 or 2)");
-  const int n_tiles = (R + GS_ROWS - 1) / GS_ROWS, n_ch = (C_in + GS_CI - 1) / GS_CI;
-  const long long n = (long long)n_tiles * n_ch * K * GS_ROWS * 4;
+  const int S = in_stride > 1 ? in_stride : 1;
+  FAC_REQUIRE(v && out && R > 0 && C_in > 0 && K >= 1 && ((S == 1 && K <= 2) || (S > 1 && K > S && K <= 2 * S)),
+              "pack_gemm_w_split: bad arguments (K must be 1 or 2, or in (S, 2S] for input stride S)");
+  const int Kt = S > 1 ? 2 : K;
+  const int n_tiles = (R + GS_ROWS - 1) / GS_ROWS, n_ch = ((C_in + GS_CI - 1) / GS_CI) * S;
+  const long long n = (long long)n_tiles * n_ch * Kt * GS_ROWS * 4;
   const int blocks = (int)((n + 255) / 256 < 65535 ? (n + 255) / 256 : 65535);
   hipLaunchKernelGGL(pack_gemm_split_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, v, (long long)row_stride,
-                     (long long)ci_stride, (long long)k_stride, row_scale, reinterpret_cast<unsigned char*>(out), R, C_in, K, n_ch, n);
+                     (long long)ci_stride, (long long)k_stride, row_scale, reinterpret_cast<unsigned char*>(out), R, C_in, Kt, n_ch, S, K, n);
   return check_launch("pack_gemm_w_split");
 }

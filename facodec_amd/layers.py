@@ -75,6 +75,15 @@ class ConvWeights(nn.Module):
         self._rows_split = ops.pack_convtr_weight_rows_split(v.detach(), g.detach() if g is not None else None, self.stride, out=prev)
         return self._rows_split
 
+    def packed_split_strided(self, stride):
+        """Split GEMM weights of a strided conv (stride < k <= 2 * stride), ops.pack_gemm_weight_split(in_stride=stride)."""
+        if self._split is not None and self.freeze_packed:
+            return self._split
+        v = self.weight_v if self.weight_norm else self.weight
+        g = self.weight_g if self.weight_norm else None
+        self._split = ops.pack_gemm_weight_split(v.detach(), g.detach() if g is not None else None, out=self._split, in_stride=stride)
+        return self._split
+
     def packed_split(self):
         """The same weights as three exact bf16 planes (ops.pack_conv_weight_split) for the k = 7 convs."""
         if self._split is not None and self.freeze_packed:
@@ -126,6 +135,9 @@ class SConv1d(nn.Module):
         elif (self.kernel_size == 1 and self.stride == 1 and alpha_in is None
               and ops.gemm_split_ok(w.c_out, w.c_in, 1, x.shape[0] * x.shape[-1])):
             split = w.packed_split()          # 1x1 with many channels: split-bf16 GEMM (conv1d_gemm_split.hip)
+        elif (self.stride > 1 and alpha_in is None and self.dilation == 1
+              and ops.gemm_split_strided_ok(w.c_out, w.c_in, self.kernel_size, self.stride, x.shape[0], -(-x.shape[-1] // self.stride))):
+            split = w.packed_split_strided(self.stride)     # downsampling conv: 2 taps over `stride` phase sub-signals
         return ops.conv1d(x, w.packed() if split is None else None, w.c_out, self.kernel_size, bias=w.bias,
                           stride=self.stride, dilation=self.dilation, pad_mode=self.pad_mode, alpha_in=alpha_in,
                           alpha_out=alpha_out, res=res, act=act, causal=self.causal, alpha_y2=alpha_y2, want_y=want_y,

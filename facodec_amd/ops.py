@@ -273,18 +273,26 @@ def gemm_split_ok(c_out, c_in, k, n_cols, t_out=None):
     return k == 1 or (t_out is not None and t_out >= 256)
 
 
-def pack_gemm_weight_split(v, g=None, out=None):
-    """(C_out, C_in, K <= 2) [weight-normed with g over dim 0] -> fac_pack_gemm_w_split layout (uint8 buffer)."""
+def gemm_split_strided_ok(c_out, c_in, k, stride, batch, t_out):
+    """Strided conv with stride < k <= 2 * stride (the encoder's k = 2 s downsampling convs, the period discriminators' k = 5
+    stride-3 convs) as a 2-tap split GEMM over the `stride` phase sub-signals: mirrors conv_gsplit_ok."""
+    return (BF16_SPLIT and GEMM_SPLIT and 1 < stride <= 16 and stride < k <= 2 * stride and c_in % 32 == 0 and c_in >= 64
+            and c_out >= 64 and t_out >= 256 and batch * t_out >= 1024)
+
+
+def pack_gemm_weight_split(v, g=None, out=None, in_stride=1):
+    """(C_out, C_in, K) [weight-normed with g over dim 0] -> fac_pack_gemm_w_split layout (uint8 buffer); K <= 2, or a strided
+    conv's taps (in_stride < K <= 2 * in_stride)."""
     v = _dev(v, "weight")
     if v.dim() == 2:
         v = v.unsqueeze(-1)
     c_out, c_in, k = v.shape
     lib = _lib.load()
     scale = wn_scale(v, g) if g is not None else None
-    nbytes = lib.fac_gemm_w_split_bytes(c_out, c_in, k)
+    nbytes = lib.fac_gemm_w_split_bytes(c_out, c_in, k, in_stride)
     if out is None:
         out = torch.empty(nbytes, device=v.device, dtype=torch.uint8)
-    _lib.check(lib.fac_pack_gemm_w_split(_ptr(v), c_in * k, k, 1, _ptr(scale), out.data_ptr(), c_out, c_in, k, _stream()),
+    _lib.check(lib.fac_pack_gemm_w_split(_ptr(v), c_in * k, k, 1, _ptr(scale), out.data_ptr(), c_out, c_in, k, in_stride, _stream()),
                "fac_pack_gemm_w_split")
     return out
 
@@ -298,10 +306,10 @@ def pack_gemm_weight_split_t(w, out=None):
     c_out, c_in, k = w.shape
     assert k == 1
     lib = _lib.load()
-    nbytes = lib.fac_gemm_w_split_bytes(c_in, c_out, 1)
+    nbytes = lib.fac_gemm_w_split_bytes(c_in, c_out, 1, 1)
     if out is None:
         out = torch.empty(nbytes, device=w.device, dtype=torch.uint8)
-    _lib.check(lib.fac_pack_gemm_w_split(_ptr(w), 1, c_in, 1, None, out.data_ptr(), c_in, c_out, 1, _stream()),
+    _lib.check(lib.fac_pack_gemm_w_split(_ptr(w), 1, c_in, 1, None, out.data_ptr(), c_in, c_out, 1, 1, _stream()),
                "fac_pack_gemm_w_split(transposed)")
     return out
 
@@ -313,10 +321,10 @@ def pack_convtr_weight_rows_split(v, g, stride, out=None):
     cip, _, R = rows.shape
     c_in = v.shape[0]
     lib = _lib.load()
-    nbytes = lib.fac_gemm_w_split_bytes(R, c_in, 2)
+    nbytes = lib.fac_gemm_w_split_bytes(R, c_in, 2, 1)
     if out is None:
         out = torch.empty(nbytes, device=v.device, dtype=torch.uint8)
-    _lib.check(lib.fac_pack_gemm_w_split(_ptr(rows), 1, 2 * R, R, None, out.data_ptr(), R, c_in, 2, _stream()),
+    _lib.check(lib.fac_pack_gemm_w_split(_ptr(rows), 1, 2 * R, R, None, out.data_ptr(), R, c_in, 2, 1, _stream()),
                "fac_pack_gemm_w_split(convtr rows)")
     return out, R
 

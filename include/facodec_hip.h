@@ -161,10 +161,13 @@ int fac_pack_conv_w_split(const float* v, const float* scale, void* out, int C_o
 /* Split weights of the 1- and 2-tap convs (conv1d_gemm_split.hip): rows r < R (output channels, or the (channel, phase) rows of
  * fac_pack_convtr_w_rows), element (r, ci, k) read at v[r * row_stride + ci * ci_stride + k * k_stride] [* row_scale[r]], written
  * as three bf16 planes per (128-row tile, 32-channel chunk) in the kernel's swizzled LDS image (one flat LDS-DMA copy per
- * stage).  C_in is padded to a multiple of 32 with zeros.  Passed as fac_conv_desc.w_split of a K = 1 / K = 2 launch. */
-int64_t fac_gemm_w_split_bytes(int R, int C_in, int K);
+ * stage).  C_in is padded to a multiple of 32 with zeros.  Passed as fac_conv_desc.w_split of a K = 1 / K = 2 launch.
+ * in_stride S > 1: a strided conv with S < K <= 2 S taps (the encoder's k = 2 s downsampling convs, the period discriminators'
+ * (5, 1) stride-3 convs): stored as 2 taps over S phase sub-signals x[S u + p] per 32-channel chunk; the launch passes
+ * stride = S, K = the conv's tap count. */
+int64_t fac_gemm_w_split_bytes(int R, int C_in, int K, int in_stride);
 int fac_pack_gemm_w_split(const float* v, int64_t row_stride, int64_t ci_stride, int64_t k_stride, const float* row_scale, void* out,
-                          int R, int C_in, int K, fac_stream_t stream);
+                          int R, int C_in, int K, int in_stride, fac_stream_t stream);
 /* Which kernel instantiation fac_conv1d_fwd picks for this descriptor: returns its id (>= 0) and
  * writes a printable name; lets a profiler attribute per-launch timings without re-deriving
  * the tile-selection rule.  Ids: 0-6, 8 MFMA tile shapes, 7 fused ResidualUnit, 9 VALU kernel for C_out <= 2, 10 split-reduction

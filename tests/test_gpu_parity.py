@@ -883,6 +883,43 @@ def test_conv_transpose_on_split_gemm(B, ci, co, T, s, O, ops, cuda):
     assert e_split < 1.5 * e_fp32 + 1e-7, (e_split, e_fp32)
 
 
+@pytest.mark.parametrize("B,ci,co,T,k,s,mode", [(4, 64, 128, 641, 4, 2, "reflect"), (2, 128, 256, 2603, 10, 5, "reflect"),
+                                                (2, 96, 192, 3070, 12, 6, "reflect"), (1, 128, 512, 3001, 5, 3, "zero"),
+                                                (2, 512, 1024, 1500, 5, 3, "zero")])
+def test_strided_conv_on_split_gemm(B, ci, co, T, k, s, mode, O, ops, cuda):
+    """Strided convs (stride < k <= 2 stride) as 2-tap split GEMMs over the `stride` phase sub-signals: the encoder's causal
+    reflect-padded k = 2 s downsampling convs (dac/model/dac.py:62-64) and the period discriminators' zero-padded k = 5 stride-3
+    convs (dac/model/discriminator.py:40-46), ragged last frames included, against the oracle / fp64 and the fp32 kernel."""
+    import torch.nn.functional as F
+    g = _g(70 + k + ci)
+    x = torch.randn(B, ci, T, generator=g)
+    w = torch.randn(co, ci, k, generator=g) / (ci * k) ** 0.5
+    gg = torch.rand(co, 1, 1, generator=g) + 0.5
+    b = torch.randn(co, generator=g) * 0.1
+    wn = O.weight_norm_weight(w, gg)
+    if mode == "reflect":
+        t_out = -(-T // s)
+        y_ref = O.sconv1d(x, wn, b, stride=s, causal=True)
+        kw = dict(bias=b.to(cuda), stride=s)
+    else:
+        pad = 2
+        y_ref = F.conv1d(x.double(), wn.double(), b.double(), stride=s, padding=pad).float()
+        t_out = y_ref.shape[-1]
+        kw = dict(bias=b.to(cuda), stride=s, pad_left=pad, pad_mode=ops.PAD_ZERO, t_out=t_out)
+    assert ops.gemm_split_strided_ok(co, ci, k, s, B, t_out)
+    ws = ops.pack_gemm_weight_split(w.to(cuda), gg.to(cuda), in_stride=s)
+    prof = ops.ConvLaunchProfile()
+    ops.set_conv_profile(prof)
+    try:
+        y = ops.conv1d(x.to(cuda), None, co, k, w_split=ws, **kw)
+        torch.cuda.synchronize()
+    finally:
+        ops.set_conv_profile(None)
+    assert any("gemm_split" in n for n in prof.summary()), prof.summary().keys()
+    yf = ops.conv1d(x.to(cuda), ops.pack_conv_weight(w.to(cuda), gg.to(cuda)), co, k, **kw)
+    assert y.shape == y_ref.shape and rel(y, y_ref) < OP_TOL and rel(y, yf) < OP_TOL
+
+
 # ------------------------------------------------------------------------------ backward of the conv stack
 BWD_TOL = 1e-4
 

@@ -19,6 +19,8 @@ def per_kernel(path, counter):
         if not m:
             if "conv1d_bsplit_kernel" in r["Kernel_Name"]:
                 key = "conv1d_bsplit_kernel<7>"
+            elif "conv1d_gemm_split_kernel" in r["Kernel_Name"]:
+                key = "conv1d_gemm_split_kernel" + re.search(r"<[^>]*>", r["Kernel_Name"]).group(0)
             elif "conv1d_skinny_kernel" in r["Kernel_Name"]:
                 key = "conv1d_skinny_kernel"
             elif "conv1d_pw_kernel" in r["Kernel_Name"]:
