@@ -103,6 +103,93 @@ class _Snake(Function):
         return dx, da.reshape(alpha.shape)
 
 
+class _SnakeDual(Function):
+    """(y, snake(y, alpha)) for a tensor that feeds a ResidualUnit: the raw tensor is the unit's skip input, the pre-activated copy
+    the input of its k = 7 conv (dac/model/dac.py:31-42).  One backward launch returns dy_raw + d snake: the engine never sees a
+    tensor with two consumers, so there is no separate fan-in add."""
+
+    @staticmethod
+    def forward(ctx, y, alpha):
+        ctx.save_for_backward(y, alpha)
+        return y, ops.snake(y.detach(), alpha.detach().reshape(-1))
+
+    @staticmethod
+    def backward(ctx, dy, dya):
+        y, alpha = ctx.saved_tensors
+        if dya is None:
+            return dy, None
+        dx, da, _ = ops.snake_bwd_fused(y.detach(), alpha.detach().reshape(-1), dya.contiguous(),
+                                        add=dy.contiguous() if dy is not None else None)
+        return dx, da.reshape(alpha.shape)
+
+
+def snake_dual(y, alpha):
+    return _SnakeDual.apply(y, alpha)
+
+
+class _ResUnit(Function):
+    """A whole ResidualUnit (dac/model/dac.py:25-42) as ONE autograd node with two launches forward:
+        h, ha = conv k7(xa) + b7, snake(h, a2)                    (second output from the conv's epilogue)
+        y, ya = conv k1(ha) + b1 + x, snake(y, a_next)            (residual and the NEXT Snake fused into the epilogue)
+    x: the unit's raw input (skip), xa = snake(x, a1) from the producer (previous unit's `ya`, or snake_dual); a_next: alpha of
+    the Snake that follows the unit (next unit's first Snake, or the block's own).  Backward: Snake backward kernels that also
+    add the skip gradient and leave the bias gradients (fac_snake_bwd_fused), conv data / weight gradients, weight-norm.
+    Saves xa, h, ha (y is the output)."""
+
+    @staticmethod
+    def forward(ctx, x, xa, v7, g7, b7, a2, v1, g1, b1, a_next, cfg):
+        dilation, pad_mode, causal = cfg
+        c = v7.shape[0]
+        xd, xad = x.detach(), xa.detach()
+        v7d, g7d, v1d, g1d = v7.detach(), g7.detach(), v1.detach(), g1.detach()
+        if _split_ok(c, v7.shape[1], 7, 1, xad):
+            wp, ws = None, ops.pack_conv_weight_split(v7d, g7d)
+        else:
+            wp, ws = ops.pack_conv_weight(v7d, g7d), None
+        h, ha = ops.conv1d(xad, wp, c, 7, bias=b7.detach(), dilation=dilation, pad_mode=pad_mode, causal=causal,
+                           alpha_y2=a2.detach().reshape(-1), w_split=ws)
+        if _split_ok(c, c, 1, 1, ha):
+            wp1, ws1 = None, ops.pack_conv_weight_split(v1d, g1d)
+        else:
+            wp1, ws1 = ops.pack_conv_weight(v1d, g1d), None
+        y, ya = ops.conv1d(ha, wp1, c, 1, bias=b1.detach(), pad_mode=pad_mode, causal=causal, res=xd,
+                           alpha_y2=a_next.detach().reshape(-1), w_split=ws1)
+        ctx.cfg = cfg
+        ctx.save_for_backward(xa, h, ha, y, v7, g7, a2, v1, g1, a_next)
+        return y, ya
+
+    @staticmethod
+    def backward(ctx, dy, dya):
+        xa, h, ha, y, v7, g7, a2, v1, g1, a_next = ctx.saved_tensors
+        dilation, pad_mode, causal = ctx.cfg
+        T = y.shape[-1]
+        v7d, g7d, v1d, g1d = v7.detach(), g7.detach(), v1.detach(), g1.detach()
+        # gradient of y: raw consumer (next unit's skip) + the following Snake; also the k1 bias gradient
+        if dya is not None:
+            dyt, da_next, db1 = ops.snake_bwd_fused(y.detach(), a_next.detach().reshape(-1), dya.contiguous(),
+                                                    add=dy.contiguous() if dy is not None else None, want_bias=True)
+            da_next = da_next.reshape(a_next.shape)
+        else:
+            dyt, da_next, db1 = dy.contiguous(), None, ops.bias_grad(dy.contiguous())
+        dha = ops.conv1d_bwd_data(dyt, v1d, g1d, T, pad_mode=pad_mode, causal=causal)
+        dv1, dg1 = ops.weight_norm_bwd(v1d, g1d, ops.conv1d_bwd_weight(ha.detach(), dyt, 1, pad_mode=pad_mode, causal=causal))
+        dh, da2, db7 = ops.snake_bwd_fused(h.detach(), a2.detach().reshape(-1), dha, want_bias=True)
+        dxa = ops.conv1d_bwd_data(dh, v7d, g7d, T, dilation=dilation, pad_mode=pad_mode, causal=causal)
+        dv7, dg7 = ops.weight_norm_bwd(v7d, g7d, ops.conv1d_bwd_weight(xa.detach(), dh, 7, dilation=dilation, pad_mode=pad_mode,
+                                                                       causal=causal))
+        return dyt, dxa, dv7, dg7, db7, da2.reshape(a2.shape), dv1, dg1, db1, da_next, None
+
+
+def res_unit(ru, x, xa, alpha_next):
+    """ResidualUnit module `ru` in training mode: (y, snake(y, alpha_next))."""
+    b = ru.block
+    k7, k1 = b[1], b[3]
+    if not (k7.w.weight_norm and k1.w.weight_norm):
+        raise NotImplementedError("fused ResidualUnit: weight-normed convs only (dac/model/dac.py:25-42)")
+    return _ResUnit.apply(x, xa, k7.w.weight_v, k7.w.weight_g, k7.w.bias, b[2].alpha, k1.w.weight_v, k1.w.weight_g, k1.w.bias,
+                          alpha_next, (k7.dilation, k7.pad_mode, k7.causal))
+
+
 class _Add(Function):
     @staticmethod
     def forward(ctx, a, b):

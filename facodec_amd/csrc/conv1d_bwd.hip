@@ -225,6 +225,55 @@ __global__ __launch_bounds__(256) void snake_bwd_kernel(const float* __restrict_
   if (tid == 0) part[c * RED_NS + sl] = red[0];
 }
 
+// The same backward with the neighbours fused in: dx = add + dy * dsnake/dx (the other gradient of a tensor with two consumers --
+// ResidualUnit skip + Snake -- arrives as `add`, no separate fan-in add), and the bias gradient of the conv that PRODUCED x
+// (db[c] = sum over (b, t) of dx) as a second partial sum (part2), so no extra pass over dx.
+__global__ __launch_bounds__(256) void snake_bwd_fused_kernel(const float* __restrict__ x, const float* __restrict__ alpha,
+                                                              const float* __restrict__ dy, const float* __restrict__ add,
+                                                              float* __restrict__ dx, float* __restrict__ part,
+                                                              float* __restrict__ part2, int B, int C, int T) {
+  __shared__ float red[2][256];
+  const int c = blockIdx.x, sl = blockIdx.y, tid = threadIdx.x;
+  const float al = alpha[c], ae = al + 1e-9f;
+  const long long n = (long long)B * T;
+  const long long per = (n + RED_NS - 1) / RED_NS;
+  const long long lo = sl * per, hi = lo + per < n ? lo + per : n;
+  float s = 0.f, sb = 0.f;
+  if (lo < hi) {
+    const int b_lo = (int)(lo / T), b_hi = (int)((hi - 1) / T);
+    for (int b = b_lo; b <= b_hi; ++b) {
+      const long long base = (long long)b * T;
+      const int t0 = (int)(lo > base ? lo - base : 0);
+      const int t1 = (int)(hi < base + T ? hi - base : T);
+      const long long ro = ((long long)b * C + c) * T;
+      const int first = (int)((256 - ((base + t0 - lo) % 256) + tid) % 256);
+      for (int t = t0 + first; t < t1; t += 256) {
+        const long long o = ro + t;
+        const float xv = x[o], g = dy[o];
+        const float ax = al * xv;
+        const float sn = sinf(ax), cs = cosf(ax);
+        const float s2 = 2.f * sn * cs;
+        float d = g * (1.f + al * s2 / ae);
+        if (add) d += add[o];
+        dx[o] = d;
+        s += g * (xv * s2 * ae - sn * sn) / (ae * ae);
+        sb += d;
+      }
+    }
+  }
+  red[0][tid] = s;
+  red[1][tid] = sb;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (tid < o) { red[0][tid] += red[0][tid + o]; red[1][tid] += red[1][tid + o]; }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    part[c * RED_NS + sl] = red[0][0];
+    if (part2) part2[c * RED_NS + sl] = red[1][0];
+  }
+}
+
 // db[c] = sum over (b, t) of dy: workgroup (c, slice) sums its contiguous share of the flattened (b, t) range -- walked clip by
 // clip (no per-element division), 16 bytes per lane where the rows allow it, four independent partial sums per thread -- and a
 // second pass adds the RED_NS slices in fixed order.
@@ -385,6 +434,19 @@ extern "C" int fac_snake_bwd(const float* x, const float* alpha, const float* dy
   hipLaunchKernelGGL(snake_bwd_kernel, dim3(C, RED_NS), dim3(256), 0, (hipStream_t)stream, x, alpha, dy, dx, scratch, B, C, T);
   hipLaunchKernelGGL(channel_reduce_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, scratch, dalpha, C);
   return check_launch("snake_bwd");
+}
+
+extern "C" int fac_snake_bwd_fused(const float* x, const float* alpha, const float* dy, const float* add, float* dx, float* dalpha,
+                                   float* dbias, float* scratch, int B, int C, int T, fac_stream_t stream) {
+  using namespace fac;
+  FAC_REQUIRE(x && alpha && dy && dx && dalpha && scratch && B > 0 && C > 0 && T > 0, "snake_bwd_fused: bad arguments");
+  float* part2 = dbias ? scratch + (long long)RED_NS * C : nullptr;
+  hipLaunchKernelGGL(snake_bwd_fused_kernel, dim3(C, RED_NS), dim3(256), 0, (hipStream_t)stream, x, alpha, dy, add, dx, scratch, part2,
+                     B, C, T);
+  hipLaunchKernelGGL(channel_reduce_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, scratch, dalpha, C);
+  if (dbias)
+    hipLaunchKernelGGL(channel_reduce_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, part2, dbias, C);
+  return check_launch("snake_bwd_fused");
 }
 
 extern "C" int fac_bias_grad(const float* dy, float* db, float* scratch, int B, int C, int T, fac_stream_t stream) {

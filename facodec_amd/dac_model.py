@@ -128,14 +128,18 @@ class Encoder(nn.Module):
         self.enc_dim = d_model
 
     def _forward_train(self, x):
+        """Training mode: one autograd node per ResidualUnit (A.res_unit), every Snake but the one after the LSTM fused into a
+        conv epilogue as a second output, no tensor with two autograd consumers."""
         mods = list(self.block)
         x = A.conv(mods[0], x)
         for m in mods[1:-2]:
             if isinstance(m, EncoderBlock):
                 b = m.block
-                for ru in (b[0], b[1], b[2]):
-                    x = ru(x)
-                x = A.conv(b[4], A.snake(b[3], x))
+                x, xa = A.snake_dual(x, b[0].block[0].alpha)
+                for j in range(3):
+                    nxt = b[j + 1].block[0].alpha if j < 2 else b[3].alpha      # next unit's first Snake / the block's Snake
+                    x, xa = A.res_unit(b[j], x, xa, nxt)
+                x = A.conv(b[4], xa)                                            # strided conv on the pre-activated tensor
             else:
                 x = A.slstm(m, x)
         return A.conv(mods[-1], A.snake(mods[-2], x))
@@ -204,17 +208,27 @@ class Decoder(nn.Module):
         self.model = nn.Sequential(*layers)
 
     def _forward_train(self, x):
+        """Training mode: see Encoder._forward_train.  The last ResidualUnit of a block emits the copy pre-activated with the
+        NEXT block's (or the output conv's) Snake."""
         mods = list(self.model)
+        blocks = [m for m in mods if isinstance(m, DecoderBlock)]
         x = A.conv(mods[0], x)
+        xa = None
         for m in mods[1:-3]:
             if isinstance(m, DecoderBlock):
                 b = m.block
-                x = A.conv_tr(b[1], A.snake(b[0], x))
-                for ru in (b[2], b[3], b[4]):
-                    x = ru(x)
+                if xa is None:
+                    xa = A.snake(b[0], x)                                       # first block: after the LSTM (or the input conv)
+                x = A.conv_tr(b[1], xa)
+                x, xa = A.snake_dual(x, b[2].block[0].alpha)
+                i = blocks.index(m)
+                after = blocks[i + 1].block[0].alpha if i + 1 < len(blocks) else mods[-3].alpha
+                for j in range(3):
+                    nxt = b[j + 3].block[0].alpha if j < 2 else after
+                    x, xa = A.res_unit(b[j + 2], x, xa, nxt)
             else:
                 x = A.slstm(m, x)
-        return A.conv(mods[-2], A.snake(mods[-3], x), act=ops.ACT_TANH)
+        return A.conv(mods[-2], xa, act=ops.ACT_TANH)
 
     def forward(self, x):
         if self.training:

@@ -798,6 +798,19 @@ def snake_bwd(x, alpha, dy):
     return dx, dalpha
 
 
+def snake_bwd_fused(x, alpha, dy, add=None, want_bias=False):
+    """Snake backward with the fan-in add and the producing conv's bias gradient fused in (fac_snake_bwd_fused):
+    dx = add + dy * dsnake/dx, dalpha, [dbias = sum over (b, t) of dx]."""
+    x, dy, add = _dev(x, "x"), _dev(dy, "dy"), _dev(add, "add")
+    B, c, t = x.shape
+    dx, dalpha = torch.empty_like(x), torch.empty(c, device=x.device, dtype=torch.float32)
+    db = torch.empty(c, device=x.device, dtype=torch.float32) if want_bias else None
+    scratch = torch.empty(64 * c, device=x.device, dtype=torch.float32)
+    _lib.check(_lib.load().fac_snake_bwd_fused(_ptr(x), _ptr(alpha), _ptr(dy), _ptr(add), _ptr(dx), _ptr(dalpha), _ptr(db),
+                                               _ptr(scratch), B, c, t, _stream()), "fac_snake_bwd_fused")
+    return dx, dalpha, db
+
+
 def bias_grad(dy):
     dy = _dev(dy, "dy")
     B, c, t = dy.shape

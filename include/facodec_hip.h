@@ -359,6 +359,11 @@ int fac_weight_norm_bwd(const float* v, const float* g, const float* dw, float* 
  * two-stage, fixed-order channel reductions). */
 int fac_snake_bwd(const float* x, const float* alpha, const float* dy, float* dx, float* dalpha, float* scratch, int B, int C,
                   int T, fac_stream_t stream);
+/* The same with its neighbours fused in: dx = add + dy * dsnake/dx (add: the second gradient of a tensor with two consumers, the
+ * ResidualUnit skip of dac/model/dac.py:38-42 -- NULL: none), dbias[c] = sum over (b, t) of dx (the bias gradient of the conv
+ * that produced x -- NULL: skipped).  scratch: 64*C floats. */
+int fac_snake_bwd_fused(const float* x, const float* alpha, const float* dy, const float* add, float* dx, float* dalpha,
+                        float* dbias, float* scratch, int B, int C, int T, fac_stream_t stream);
 /* db[c] = sum over (b, t) of dy; scratch: 32*C floats. */
 int fac_bias_grad(const float* dy, float* db, float* scratch, int B, int C, int T, fac_stream_t stream);
 
