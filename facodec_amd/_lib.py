@@ -49,6 +49,8 @@ SIGNATURES = {
     "fac_pack_conv_w": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
     "fac_pack_convtr_w_rows": (_i, [_p, _p, _p, _i, _i, _i, _p]),
     "fac_conv_w_split_bytes": (_i64, [_i, _i, _i]),
+    "fac_conv_w_split2_bytes": (_i64, [_i, _i, _i, _i]),
+    "fac_pack_conv_w_split2": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
     "fac_gemm_w_split_bytes": (_i64, [_i, _i, _i, _i]),
     "fac_pack_gemm_w_split": (_i, [_p, _i64, _i64, _i64, _p, _p, _i, _i, _i, _i, _p]),
     "fac_pack_conv_w_split": (_i, [_p, _p, _p, _i, _i, _i, _p]),

@@ -31,7 +31,9 @@ class PlainConv(Function):
         max_off = (k // k1 - 1) * dil2 + (k1 - 1) if k1 else k - 1
         t_out = (t_in + 2 * pad - max_off - 1) // stride + 1
         vd, gd = v.detach().contiguous(), (g.detach().contiguous() if g is not None else None)
-        if not k1 and stride > 1 and ops.gemm_split_strided_ok(v.shape[0], c_in, k, stride, B, t_out):
+        if ops.split2_ok(v.shape[0], k, k1, stride, B * t_out):
+            wp, ws = None, ops.pack_conv_weight_split2(vd, gd, k1)      # 32-channel (3, 9) / (3, 3) stacks: conv1d_bsplit2.hip
+        elif not k1 and stride > 1 and ops.gemm_split_strided_ok(v.shape[0], c_in, k, stride, B, t_out):
             wp, ws = None, ops.pack_gemm_weight_split(vd, gd, in_stride=stride)     # (5, 1) stride-3 convs: split GEMM over 3 phases
         elif not k1 and _split_ok(k, stride, c_in, v.shape[0], B * t_out):
             wp, ws = None, ops.pack_conv_weight_split(vd, gd)
@@ -71,7 +73,13 @@ class PlainConv(Function):
                 _call("fac_zero_insert", _p(dy), _p(up), B * c_out, t_out, stride)
             if up is not None:
                 tp = up.shape[-1] + max_off        # full correlation: dxpad[i] = sum_k wflip[k] up[i - max_off + off'_k]
-                if not k1 and _split_ok(k, 1, c_out, c_in, B * tp):
+                if ops.split2_ok(c_in, k, k1, 1, B * tp):
+                    w = ops.rows_fma(vd, ops.wn_scale(vd, gd)) if gd is not None else vd
+                    ws = ops.pack_conv_weight_split2(w.permute(1, 0, 2).flip(2).contiguous(), None, k1)
+                    with ops.flop_scale(1.0 / stride):
+                        dxp = ops.conv1d(up, None, c_in, k, pad_left=max_off, pad_mode=ops.PAD_ZERO, t_out=tp, w_split=ws,
+                                         k1=k1, dilation2=dil2)
+                elif not k1 and _split_ok(k, 1, c_out, c_in, B * tp):
                     w = ops.rows_fma(vd, ops.wn_scale(vd, gd)) if gd is not None else vd
                     ws = ops.pack_conv_weight_split(w.permute(1, 0, 2).flip(2).contiguous())
                     dxp = ops.conv1d(up, None, c_in, k, pad_left=k - 1, pad_mode=ops.PAD_ZERO, t_out=tp, w_split=ws)

@@ -75,7 +75,7 @@ extern "C" int fac_conv1d_fwd(const fac_conv_desc* d, fac_stream_t stream) {
   }
   a.K1 = d->K1 > 0 ? d->K1 : d->K; a.dil2 = d->dilation2;
   FAC_REQUIRE(a.K1 <= d->K && d->K % a.K1 == 0 && (a.K1 == d->K || d->dilation2 > 0), "conv1d: bad two-level taps (K=%d K1=%d)", d->K, d->K1);
-  FAC_REQUIRE(!conv_two_level(a) || (!d->w_k1 && d->n_phase == 1 && !d->w_split && d->pad_mode == FAC_PAD_ZERO && !d->w_batched),
+  FAC_REQUIRE(!conv_two_level(a) || (!d->w_k1 && d->n_phase == 1 && d->pad_mode == FAC_PAD_ZERO && !d->w_batched),
               "conv1d: two-level taps need a plain, zero-padded conv");
   conv_set_virtual(a);
   FAC_REQUIRE(d->phase_shift >= 0 && d->phase_shift < d->n_phase + (d->n_phase == 1), "conv1d: bad phase_shift");
@@ -89,6 +89,12 @@ extern "C" int fac_conv1d_fwd(const fac_conv_desc* d, fac_stream_t stream) {
   hipStream_t s = (hipStream_t)stream;
   if (d->w_k1) return conv_dispatch_fused_ru(a, s);
   a.gflat = 0;
+  // few-output-channel 9- / 3-tap convs (two-level taps included) with split weights of fac_pack_conv_w_split2
+  if (d->w_split && (a.KV == 9 || a.KV == 3) && d->C_out <= 32 && conv_bsplit2_ok(a)) {
+    a.w = reinterpret_cast<const float*>(d->w_split);
+    return conv_dispatch_bsplit2(a, s);
+  }
+  FAC_REQUIRE(!conv_two_level(a) || d->w, "conv1d: two-level taps outside the split kernel's shapes need fp32 weights");
   // 1- / 2-tap convs with split weights in the GEMM layout (fac_pack_gemm_w_split): the bf16 matrix pipe, fp32-exact
   if (d->w_split && (d->K <= 2 || (d->stride > 1 && d->K <= 2 * d->stride)) && conv_gsplit_ok(a) &&
       !conv_skinny_ok(a, d->ws, d->ws_bytes)) {
@@ -135,6 +141,17 @@ extern "C" int fac_conv1d_variant(const fac_conv_desc* d, char* name, int name_l
   if (d->w_k1) {
     if (name && name_len > 0) snprintf(name, name_len, "conv1d_mfma_kernel<C/32,1,1,4,7,fused RU> Cx128");
     return 7;
+  }
+  if (d->w_split && d->C_out <= 32) {
+    ConvArgs a{};
+    a.K = d->K; a.K1 = d->K1 > 0 ? d->K1 : d->K; a.C_in = d->C_in; a.dil2 = d->dilation2; conv_set_virtual(a);
+    a.stride = d->stride; a.dil = d->dilation; a.n_phase = d->n_phase; a.phase_shift = d->phase_shift; a.y_tstride = d->y_tstride;
+    a.rp = d->row_phases > 1 ? d->row_phases : 1; a.alpha_in = d->alpha_in; a.w1 = d->w_k1; a.w_batched = d->w_batched;
+    a.pad_mode = d->pad_mode; a.C_out = d->C_out; a.B = d->B; a.T_out = d->T_out; a.T_in = d->T_in; a.x_cs = d->x_cs;
+    if ((a.KV == 9 || a.KV == 3) && conv_bsplit2_ok(a)) {
+      if (name && name_len > 0) snprintf(name, name_len, "conv1d_bsplit2_kernel<%d,%d> 32x512 (bf16x3 split, fp32-exact)", a.KV, a.stride);
+      return 16;
+    }
   }
   if (d->w_split && (d->K <= 2 || (d->stride > 1 && d->K <= 2 * d->stride))) {
     ConvArgs a{};

@@ -804,6 +804,8 @@ int conv_dispatch_pw(ConvArgs& a, hipStream_t s);
 bool conv_thin_ok(const ConvArgs& a, const void* ws, long long ws_bytes);
 int conv_dispatch_thin(ConvArgs& a, void* ws, hipStream_t s);
 int conv_dispatch_cin1(ConvArgs& a, hipStream_t s);
+bool conv_bsplit2_ok(const ConvArgs& a);
+int conv_dispatch_bsplit2(ConvArgs& a, hipStream_t s);
 bool conv_gsplit_ok(const ConvArgs& a);
 int conv_dispatch_gsplit(ConvArgs& a, hipStream_t s);
 bool conv_bsplit_ok(const ConvArgs& a);

@@ -314,6 +314,31 @@ def pack_gemm_weight_split_t(w, out=None):
     return out
 
 
+BSPLIT2 = os.environ.get("FAC_BSPLIT2", "1") != "0"
+
+
+def split2_ok(c_out, k, k1, stride, n_cols):
+    """Few-output-channel 9- / 3-tap conv (plain or two-level, taps per level k1) for conv1d_bsplit2.hip: mirrors
+    conv_bsplit2_ok."""
+    kv = k1 if 0 < k1 < k else k
+    return (BF16_SPLIT and BSPLIT2 and 8 <= c_out <= 32 and ((kv == 9 and stride in (1, 2)) or (kv == 3 and stride == 1))
+            and n_cols >= 4096)
+
+
+def pack_conv_weight_split2(v, g=None, k1=0, out=None):
+    """(C_out <= 32, C_in, K) [weight-normed with g] -> fac_pack_conv_w_split2 layout (uint8 buffer); k1: taps per level."""
+    v = _dev(v, "weight")
+    c_out, c_in, k = v.shape
+    lib = _lib.load()
+    scale = wn_scale(v, g) if g is not None else None
+    nbytes = lib.fac_conv_w_split2_bytes(c_out, c_in, k, k1)
+    if out is None:
+        out = torch.empty(nbytes, device=v.device, dtype=torch.uint8)
+    _lib.check(lib.fac_pack_conv_w_split2(_ptr(v), _ptr(scale), out.data_ptr(), c_out, c_in, k, k1, _stream()),
+               "fac_pack_conv_w_split2")
+    return out
+
+
 def pack_convtr_weight_rows_split(v, g, stride, out=None):
     """ConvTranspose1d (C_in, C_out, 2*stride) -> split GEMM weights of the all-phases launch: the (channel, phase) rows of
     pack_convtr_weight_rows, each row's (C_in, 2) taps as bf16 planes.  Returns (split buffer, rows)."""

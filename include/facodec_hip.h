@@ -158,6 +158,11 @@ int fac_conv1d_fwd(const fac_conv_desc* d, fac_stream_t stream);
 int64_t fac_conv_w_split_bytes(int C_out, int C_in, int K);
 int fac_pack_conv_w_split(const float* v, const float* scale, void* out, int C_out, int C_in, int K,
                           fac_stream_t stream);
+/* Split weights of the few-output-channel 9- / 3-tap convs (conv1d_bsplit2.hip: C_out <= 32, K1 = 9 stride 1 / 2 or K1 = 3 stride
+ * 1, plain or two-level taps K = K2 * K1 -- the (3, 9) / (3, 3) Conv2d stacks of dac/model/discriminator.py:101-170): v (C_out,
+ * C_in, K) [* scale per C_out] as bf16 planes per (32-channel tile, 8 virtual channels).  Passed as fac_conv_desc.w_split. */
+int64_t fac_conv_w_split2_bytes(int C_out, int C_in, int K, int K1);
+int fac_pack_conv_w_split2(const float* v, const float* scale, void* out, int C_out, int C_in, int K, int K1, fac_stream_t stream);
 /* Split weights of the 1- and 2-tap convs (conv1d_gemm_split.hip): rows r < R (output channels, or the (channel, phase) rows of
  * fac_pack_convtr_w_rows), element (r, ci, k) read at v[r * row_stride + ci * ci_stride + k * k_stride] [* row_scale[r]], written
  * as three bf16 planes per (128-row tile, 32-channel chunk) in the kernel's swizzled LDS image (one flat LDS-DMA copy per
@@ -172,7 +177,8 @@ int fac_pack_gemm_w_split(const float* v, int64_t row_stride, int64_t ci_stride,
  * writes a printable name; lets a profiler attribute per-launch timings without re-deriving
  * the tile-selection rule.  Ids: 0-6, 8 MFMA tile shapes, 7 fused ResidualUnit, 9 VALU kernel for C_out <= 2, 10 split-reduction
  * kernel (<= 640 columns), 11 split-bf16 kernel (k = 5 / 7), 12 store-stream kernel for C_in = 1, 13 channel-split kernel for
- * C_out <= 2 over few tiles, 14 streaming k = 1 kernel (weights resident in LDS, C <= 384), 15 split-bf16 GEMM kernel (k = 1 / 2). */
+ * C_out <= 2 over few tiles, 14 streaming k = 1 kernel (weights resident in LDS, C <= 384), 15 split-bf16 GEMM kernel (k = 1 / 2),
+ * 16 split-bf16 kernel for few output channels (conv1d_bsplit2.hip). */
 int fac_conv1d_variant(const fac_conv_desc* d, char* name, int name_len);
 
 /* Standalone Snake  y = x + sin(alpha*x)^2 / (alpha + 1e-9)  (dac/nn/layers.py:18-33) for the

@@ -122,7 +122,9 @@ def test_convtr_wgrad_on_split_kernel(cuda):
                                            # long enough for interior tiles (LDS-DMA staging of the virtual channels), a row
                                            # pitch that is not a multiple of 4 (register staging), the model's 272 / 136 pitches
                                            (1, 9, 25, 32, 40), (1, 9, 26, 34, 40), (2, 9, 51, 68, 40), (1, 3, 30, 34, 40),
-                                           (1, 9, 256, 272, 9), (2, 9, 128, 136, 9)])
+                                           (1, 9, 256, 272, 9), (2, 9, 128, 136, 9),
+                                           # enough columns for the 32-row split kernel (conv1d_bsplit2.hip): (9, s1), (9, s2), (3, s1)
+                                           (1, 9, 25, 32, 100), (2, 9, 51, 64, 100), (1, 3, 13, 16, 300), (2, 9, 256, 272, 30)])
 def test_two_level_conv_is_conv2d(sf, kf, F0, P, T, cuda):
     """(3, kf) Conv2d with stride (1, sf), padding (1, kf // 2) (dac/model/discriminator.py:110-120) as ONE 1-D conv with
     two-level taps over the row-concatenated (frame, frequency) signal: forward, data gradient and weight gradient (split
@@ -154,8 +156,16 @@ def test_two_level_conv_is_conv2d(sf, kf, F0, P, T, cuda):
             xc = cat.reshape(1, ci, -1).to(cuda).requires_grad_()
             wc = w.reshape(co, ci, 3 * kf).to(cuda).requires_grad_()
             bc = bias.to(cuda).requires_grad_()
-            y = AD.PlainConv.apply(xc, wc, None, bc, 3 * kf, sf, P + pf, (kf, P))
+            prof = ops.ConvLaunchProfile()
+            ops.set_conv_profile(prof)
+            try:
+                y = AD.PlainConv.apply(xc, wc, None, bc, 3 * kf, sf, P + pf, (kf, P))
+                torch.cuda.synchronize()
+            finally:
+                ops.set_conv_profile(None)
             assert y.shape[-1] == B * (T + 1) * P_out
+            if split and ops.split2_ok(co, 3 * kf, kf, sf, y.shape[-1]):
+                assert any("bsplit2" in k for k in prof.summary()), prof.summary().keys()
             yv = y.detach().cpu().reshape(co, B, T + 1, P_out)[:, :, :T, :F1].permute(1, 0, 2, 3)
             assert float((yv.double() - y_ref.detach()).abs().max() / y_ref.detach().abs().max()) < 1e-5
             (y * rc.reshape(1, co, -1).to(cuda)).sum().backward()
