@@ -113,7 +113,7 @@ extern "C" int fac_conv1d_fwd(const fac_conv_desc* d, fac_stream_t stream) {
   static const bool pw_on = !(getenv("FAC_PW") && getenv("FAC_PW")[0] == '0');
   if (pw_on && conv_pw_ok(a)) return conv_dispatch_pw(a, s);
   if (d->w_split) {
-    if (conv_bsplit_ok(a)) {
+    if (!two_level && conv_bsplit_ok(a)) {
       a.w = reinterpret_cast<const float*>(d->w_split);
       return conv_dispatch_bsplit(a, s);
     }

@@ -410,7 +410,7 @@ __global__ __launch_bounds__((NMW + NSW) * 64, (NMW + NSW) / 4) void conv1d_bspl
 }
 
 bool conv_bsplit_ok(const ConvArgs& a) {
-  if (!((a.K == 7 || a.K == 5) && a.stride == 1 && a.n_phase == 1 && a.phase_shift == 0 && a.y_tstride == 1 && !a.alpha_in &&
+  if (!((a.K == 7 || a.K == 5 || a.K == 3) && a.stride == 1 && a.n_phase == 1 && a.phase_shift == 0 && a.y_tstride == 1 && !a.alpha_in &&
         !a.w1 && !a.w_batched && (long long)a.B * a.T_out > 640))
     return false;
   const int G = bs_group(a.C_in), tt = G == 2 ? 256 : 512;
@@ -450,8 +450,10 @@ static int bsplit_launch(ConvArgs& a, hipStream_t s) {
 }
 
 int conv_dispatch_bsplit(ConvArgs& a, hipStream_t s) {
-  if (a.K == 5)   // the discriminators' (5,1) convs and their data gradients
+  if (a.K == 5)   // the discriminators' (5,1) convs and their data gradients, the WaveNet / style-encoder k = 5 convs
     return bs_group(a.C_in) == 2 ? bsplit_launch<5, 2, 4, BS_NSW_WIDE>(a, s) : bsplit_launch<5, 1, 8, BS_NSW>(a, s);
+  if (a.K == 3)   // the encoder's output conv (1024 -> 1024)
+    return bs_group(a.C_in) == 2 ? bsplit_launch<3, 2, 4, BS_NSW_WIDE>(a, s) : bsplit_launch<3, 1, 8, BS_NSW>(a, s);
   return bs_group(a.C_in) == 2 ? bsplit_launch<7, 2, 4, BS_NSW_WIDE>(a, s) : bsplit_launch<7, 1, 8, BS_NSW>(a, s);
 }
 

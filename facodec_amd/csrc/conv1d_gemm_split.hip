@@ -454,7 +454,7 @@ bool conv_gsplit_ok(const ConvArgs& a) {
   } else if (!(a.K == 1 || a.K == 2)) {
     return false;
   }
-  if (a.C_in % GS_CI != 0 || a.C_in < 64) return false;
+  if (a.C_in % GS_CI != 0 || a.C_in < (strided ? 32 : 64)) return false;
   if (!strided && a.K == 1 && (a.pad_left != 0 || a.T_in < a.T_out)) return false;
   if (!strided && a.K == 2 && (a.pad_mode != FAC_PAD_ZERO || a.pad_left > 1)) return false;
   const int rows = a.rp > 1 ? a.C_out_pad : a.C_out;

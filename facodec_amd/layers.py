@@ -129,8 +129,8 @@ class SConv1d(nn.Module):
         """alpha_y2: additionally emit snake(y, alpha_y2) for the next Snake->conv (returns (y, y2))."""
         w = self.w
         split = None
-        if (ops.BF16_SPLIT and self.kernel_size == 7 and self.stride == 1 and alpha_in is None and w.c_in % 16 == 0
-                and w.c_out > 2 and x.shape[0] * x.shape[-1] > 640):
+        if (ops.BF16_SPLIT and self.kernel_size in (3, 5, 7) and self.stride == 1 and alpha_in is None and w.c_in % 16 == 0
+                and w.c_out > 2 and x.shape[0] * x.shape[-1] > 640 and (self.kernel_size == 7 or (w.c_in >= 64 and w.c_out > 32))):
             split = w.packed_split()
         elif (self.kernel_size == 1 and self.stride == 1 and alpha_in is None
               and ops.gemm_split_ok(w.c_out, w.c_in, 1, x.shape[0] * x.shape[-1])):

@@ -276,7 +276,7 @@ def gemm_split_ok(c_out, c_in, k, n_cols, t_out=None):
 def gemm_split_strided_ok(c_out, c_in, k, stride, batch, t_out):
     """Strided conv with stride < k <= 2 * stride (the encoder's k = 2 s downsampling convs, the period discriminators' k = 5
     stride-3 convs) as a 2-tap split GEMM over the `stride` phase sub-signals: mirrors conv_gsplit_ok."""
-    return (BF16_SPLIT and GEMM_SPLIT and 1 < stride <= 16 and stride < k <= 2 * stride and c_in % 32 == 0 and c_in >= 64
+    return (BF16_SPLIT and GEMM_SPLIT and 1 < stride <= 16 and stride < k <= 2 * stride and c_in % 32 == 0 and c_in >= 32
             and c_out >= 64 and t_out >= 256 and batch * t_out >= 1024)
 
 

@@ -147,6 +147,10 @@ class _PlainConv(nn.Module):
         if self.k == 1 and pad == 0 and ops.gemm_split_ok(self.c_out, self.c_in, 1, x.shape[0] * x.shape[-1]):
             return ops.conv1d(x, None, self.c_out, 1, bias=self.bias.detach(), pad_left=0, pad_mode=ops.PAD_ZERO, t_out=x.shape[-1],
                               w_split=ops.pack_gemm_weight_split(self.weight.detach()), **kw)      # 1x1, many channels: bf16 pipe
+        if (ops.BF16_SPLIT and self.k in (3, 5, 7) and self.c_in % 16 == 0 and self.c_in >= 64 and self.c_out > 32
+                and x.shape[0] * x.shape[-1] > 640):      # k = 5 convs of the style encoder: split-bf16 kernel (conv1d_bsplit.hip)
+            return ops.conv1d(x, None, self.c_out, self.k, bias=self.bias.detach(), pad_left=pad, pad_mode=ops.PAD_ZERO,
+                              t_out=x.shape[-1], w_split=ops.pack_conv_weight_split(self.weight.detach()), **kw)
         return ops.conv1d(x, ops.pack_conv_weight(self.weight.detach()), self.c_out, self.k, bias=self.bias.detach(),
                           pad_left=pad, pad_mode=ops.PAD_ZERO, t_out=x.shape[-1], **kw)
 

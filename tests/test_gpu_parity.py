@@ -920,6 +920,35 @@ def test_strided_conv_on_split_gemm(B, ci, co, T, k, s, mode, O, ops, cuda):
     assert y.shape == y_ref.shape and rel(y, y_ref) < OP_TOL and rel(y, yf) < OP_TOL
 
 
+@pytest.mark.parametrize("B,ci,co,T,k,mode", [(8, 256, 512, 160, 5, "zero"), (4, 1024, 1024, 160, 3, "reflect"), (2, 512, 1024, 333, 5, "zero")])
+def test_split_bf16_conv_3_and_5_taps(B, ci, co, T, k, mode, O, ops, cuda):
+    """conv1d_bsplit.hip with K = 3 / 5 (the WaveNet and style-encoder k = 5 convs, the encoder's k = 3 output conv at the
+    160-frame latent rate): same bars as the K = 7 test."""
+    import torch.nn.functional as F
+    g = _g(90 + k + ci)
+    x = torch.randn(B, ci, T, generator=g)
+    w = torch.randn(co, ci, k, generator=g) / (ci * k) ** 0.5
+    b = torch.randn(co, generator=g) * 0.1
+    if mode == "zero":
+        y64 = F.conv1d(x.double(), w.double(), b.double(), padding=k // 2)
+        kw = dict(bias=b.to(cuda), pad_left=k // 2, pad_mode=ops.PAD_ZERO, t_out=T)
+    else:
+        y64 = O.sconv1d(x.double(), w.double(), b.double(), causal=True)
+        kw = dict(bias=b.to(cuda))
+    ws = ops.pack_conv_weight_split(w.to(cuda))
+    prof = ops.ConvLaunchProfile()
+    ops.set_conv_profile(prof)
+    try:
+        y = ops.conv1d(x.to(cuda), None, co, k, w_split=ws, **kw)
+        torch.cuda.synchronize()
+    finally:
+        ops.set_conv_profile(None)
+    assert any("bsplit" in n for n in prof.summary()), prof.summary().keys()
+    yf = ops.conv1d(x.to(cuda), ops.pack_conv_weight(w.to(cuda)), co, k, **kw)
+    e_split, e_fp32 = rel(y, y64), rel(yf, y64)
+    assert e_split < OP_TOL and e_split < 1.5 * e_fp32 + 1e-7, (e_split, e_fp32)
+
+
 # ------------------------------------------------------------------------------ backward of the conv stack
 BWD_TOL = 1e-4
 
