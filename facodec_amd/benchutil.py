@@ -13,7 +13,8 @@ def init_distributed(backend=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    # a single rank gets a process group too when FAC_FORCE_ALLREDUCE=1 asks for the collective path on a one-GPU box
+    if (world > 1 or (os.environ.get("FAC_FORCE_ALLREDUCE") == "1" and "RANK" in os.environ)) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:

@@ -106,19 +106,21 @@ extern "C" int fac_conv1d_fwd(const fac_conv_desc* d, fac_stream_t stream) {
     return conv_dispatch_128x256(a, s);
   }
   const bool two_level = conv_two_level(a);
+  // K = 3 / 5 / 7 split kernel first (its shapes exclude the few-column launches the split-reduction kernel takes)
+  if (d->w_split && !two_level && conv_bsplit_ok(a) && !conv_cin1_ok(a)) {
+    a.w = reinterpret_cast<const float*>(d->w_split);
+    return conv_dispatch_bsplit(a, s);
+  }
+  // every kernel below reads fp32 weights: a split-only launch (w == w_split or NULL) must not get here
+  FAC_REQUIRE(d->w != nullptr && (const void*)d->w != d->w_split,
+              "conv1d: shape does not qualify for a split-bf16 kernel (K=%d stride=%d C_in=%d C_out=%d columns=%lld) and no fp32 "
+              "weights were given", d->K, d->stride, d->C_in, d->C_out, (long long)d->B * d->T_out);
   if (!two_level && conv_skinny_ok(a, d->ws, d->ws_bytes)) return conv_dispatch_skinny(a, d->ws, d->ws_bytes, s);
   if (!two_level && narrow_ok(d)) return conv_dispatch_narrow(a, s);
   if (conv_thin_ok(a, d->ws, d->ws_bytes)) return conv_dispatch_thin(a, d->ws, s);   // C_out <= 2 without enough tiles for narrow
   if (conv_cin1_ok(a)) return conv_dispatch_cin1(a, s);
   static const bool pw_on = !(getenv("FAC_PW") && getenv("FAC_PW")[0] == '0');
   if (pw_on && conv_pw_ok(a)) return conv_dispatch_pw(a, s);
-  if (d->w_split) {
-    if (!two_level && conv_bsplit_ok(a)) {
-      a.w = reinterpret_cast<const float*>(d->w_split);
-      return conv_dispatch_bsplit(a, s);
-    }
-    FAC_REQUIRE(d->w != d->w_split, "conv1d: shape does not qualify for the split-bf16 kernel and no fp32 weights were given");
-  }
   switch (select_variant(d)) {
     case 0: return conv_dispatch_128x32(a, s);
     case 1: return conv_dispatch_32x256(a, s);

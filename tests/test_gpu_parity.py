@@ -920,7 +920,7 @@ def test_strided_conv_on_split_gemm(B, ci, co, T, k, s, mode, O, ops, cuda):
     assert y.shape == y_ref.shape and rel(y, y_ref) < OP_TOL and rel(y, yf) < OP_TOL
 
 
-@pytest.mark.parametrize("B,ci,co,T,k,mode", [(8, 256, 512, 160, 5, "zero"), (4, 1024, 1024, 160, 3, "reflect"), (2, 512, 1024, 333, 5, "zero")])
+@pytest.mark.parametrize("B,ci,co,T,k,mode", [(8, 256, 512, 160, 5, "zero"), (5, 1024, 1024, 160, 3, "reflect"), (2, 512, 1024, 333, 5, "zero")])
 def test_split_bf16_conv_3_and_5_taps(B, ci, co, T, k, mode, O, ops, cuda):
     """conv1d_bsplit.hip with K = 3 / 5 (the WaveNet and style-encoder k = 5 convs, the encoder's k = 3 output conv at the
     160-frame latent rate): same bars as the K = 7 test."""
@@ -947,6 +947,10 @@ def test_split_bf16_conv_3_and_5_taps(B, ci, co, T, k, mode, O, ops, cuda):
     yf = ops.conv1d(x.to(cuda), ops.pack_conv_weight(w.to(cuda)), co, k, **kw)
     e_split, e_fp32 = rel(y, y64), rel(yf, y64)
     assert e_split < OP_TOL and e_split < 1.5 * e_fp32 + 1e-7, (e_split, e_fp32)
+    # a split-only launch whose shape no split kernel takes (640 columns: the split-reduction kernel's range) fails loudly
+    # instead of reading the bf16 planes as fp32 weights
+    with pytest.raises(Exception):
+        ops.conv1d(x[:1, :, :100].contiguous().to(cuda), None, co, k, w_split=ws, **{**kw, "t_out": 100} if mode == "zero" else kw)
 
 
 # ------------------------------------------------------------------------------ backward of the conv stack

@@ -34,8 +34,8 @@ def main():
         e0.record()
         orig(d, what)
         e1.record()
-        key = (d.B, d.C_in, d.C_out, d.T_out, d.K, d.K1, d.stride, d.dilation, d.dilation2, d.n_phase, buf.value.decode()[:40])
-        recs.append((key, 2.0 * d.B * d.n_phase * d.C_out * d.T_out * d.C_in * d.K, e0, e1))
+        key = (d.B, d.C_in, d.C_out, d.T_out, d.K, d.K1, d.stride, d.dilation, d.dilation2, d.n_phase, d.row_phases, buf.value.decode()[:44])
+        recs.append((key, 2.0 * d.B * d.n_phase * max(1, d.row_phases) * d.C_out * d.T_out * d.C_in * d.K, e0, e1))
 
     ops._launch_conv = spy
     step(wave)
