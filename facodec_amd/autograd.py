@@ -58,12 +58,15 @@ class _Conv(Function):
         vd, gd = v.detach(), (g.detach() if g is not None else None)
         dx = ops.conv1d_bwd_data(dy, vd, gd, x.shape[-1], stride=stride, dilation=dilation, pad_mode=pad_mode, causal=causal) \
             if ctx.needs_input_grad[0] else None
-        dw = ops.conv1d_bwd_weight(x.detach(), dy, k, stride=stride, dilation=dilation, pad_mode=pad_mode, causal=causal)
+        db = None
+        if bias is not None:
+            dw, db = ops.conv1d_bwd_weight(x.detach(), dy, k, stride=stride, dilation=dilation, pad_mode=pad_mode, causal=causal, want_db=True)
+        else:
+            dw = ops.conv1d_bwd_weight(x.detach(), dy, k, stride=stride, dilation=dilation, pad_mode=pad_mode, causal=causal)
         if g is not None:
             dv, dg = ops.weight_norm_bwd(vd, gd, dw)
         else:
             dv, dg = dw, None
-        db = ops.bias_grad(dy) if bias is not None else None
         return dx, dv, dg, db, None
 
 

@@ -91,13 +91,16 @@ class PlainConv(Function):
                     dxp = torch.cat([dxp, torch.zeros(B, c_in, pad + t_in - tp, device=dy.device)], dim=2)
                 dx = dxp[:, :, pad:pad + t_in].contiguous()
         dv = dg = db = None
+        want_db = bias is not None and ctx.needs_input_grad[3]
         if ctx.needs_input_grad[1]:       # frozen discriminator (generator step): no weight gradients
-            dw = ops.conv1d_bwd_weight(x.detach(), dy, k, stride=stride, pad_mode=ops.PAD_ZERO, pad_left=pad, k1=k1, dilation2=dil2)
+            r = ops.conv1d_bwd_weight(x.detach(), dy, k, stride=stride, pad_mode=ops.PAD_ZERO, pad_left=pad, k1=k1, dilation2=dil2,
+                                      want_db=want_db)
+            dw, db = r if want_db else (r, None)
             if g is not None:
                 dv, dg = ops.weight_norm_bwd(vd, gd, dw)
             else:
                 dv = dw
-        if bias is not None and ctx.needs_input_grad[3]:
+        elif want_db:
             db = ops.bias_grad(dy)
         return dx, dv, dg, db, None, None, None, None
 

@@ -113,6 +113,57 @@ __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restri
   }
 }
 
+// The dy operand's split pass with the bias gradient folded in (db[co] = sum over (b, t) of dy: one more pass over dy otherwise):
+// grid (chunks of 2048 steps, rows = B * C_out); a workgroup splits its chunk of one row and leaves the chunk's sum in
+// part[row][chunk]; bias_from_rowsums_kernel adds them per output channel in a fixed order (clip-major, then chunk).
+__global__ __launch_bounds__(256) void split_planes_rowsum_kernel(const float* __restrict__ src, unsigned char* __restrict__ dst,
+                                                                  float* __restrict__ part, int T, int U, int n_chunks,
+                                                                  long long plane_bytes) {
+  __shared__ float red[256];
+  const long long row = blockIdx.y;
+  const int uq = blockIdx.x * 256 + threadIdx.x;            // 8-step piece of the row
+  const float* xr = src + row * T;
+  float sum = 0.f;
+  if (uq * 8 < U) {
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int pos = uq * 8 + j;
+      v[j] = pos < T ? xr[pos] : 0.f;
+    }
+    sum = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+    bf16x8 h, m, l;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      __bf16 a, b, c;
+      split3w(v[j], a, b, c);
+      h[j] = a; m[j] = b; l[j] = c;
+    }
+    unsigned char* d = dst + (row * U + uq * 8) * 2;
+    *reinterpret_cast<bf16x8*>(d) = h;
+    *reinterpret_cast<bf16x8*>(d + plane_bytes) = m;
+    *reinterpret_cast<bf16x8*>(d + 2 * plane_bytes) = l;
+  }
+  red[threadIdx.x] = sum;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) part[row * n_chunks + blockIdx.x] = red[0];
+}
+
+__global__ void bias_from_rowsums_kernel(const float* __restrict__ part, float* __restrict__ db, int B, int C_out, int n_chunks) {
+  const int co = blockIdx.x * blockDim.x + threadIdx.x;
+  if (co >= C_out) return;
+  float s = 0.f;
+  for (int b = 0; b < B; ++b) {
+    const float* p = part + ((long long)b * C_out + co) * n_chunks;
+    for (int c = 0; c < n_chunks; ++c) s += p[c];
+  }
+  db[co] = s;
+}
+
 // NB: 8-byte B pieces per staging lane and stage (ceil(NCP * 3 * R * nq / 256));  D: depth of the register ring.
 template <int NB, int D>
 __global__ __launch_bounds__(512, 2) void conv1d_wgrad_planes_kernel(WsArgs a) {
@@ -704,18 +755,45 @@ extern "C" int64_t fac_conv1d_bwd_weight_split_ws_bytes(int B, int C_in, int T_i
     fac::WkArgs k;
     int S;
     if (fac::wk_geometry(B, C_in, T_in, C_out, T_out, K, stride, dilation, K1, dilation2, &k, &S) == 0)
-      return fac::ws_align((int64_t)S * C_out * k.NBk * 32 * 4) + fac::ws_align(3 * k.a_plane_bytes) + fac::ws_align(3 * k.b_plane_bytes);
+      return fac::ws_align((int64_t)S * C_out * k.NBk * 32 * 4) + fac::ws_align(3 * k.a_plane_bytes) + fac::ws_align(3 * k.b_plane_bytes) +
+             fac::ws_align((int64_t)B * C_out * ((k.UA + 2047) / 2048) * 4);
   }
   fac::WsArgs a;
   int S;
   size_t lds;
   if (fac::ws_geometry(B, C_in, T_in, C_out, T_out, K, stride, dilation, K1, dilation2, &a, &S, &lds)) return -1;
-  return fac::ws_align((int64_t)S * C_out * C_in * K * 4) + fac::ws_align(3 * a.a_plane_bytes) + fac::ws_align(3 * a.b_plane_bytes);
+  return fac::ws_align((int64_t)S * C_out * C_in * K * 4) + fac::ws_align(3 * a.a_plane_bytes) + fac::ws_align(3 * a.b_plane_bytes) +
+         fac::ws_align((int64_t)B * C_out * ((a.UA + 2047) / 2048) * 4);
+}
+
+static int bwd_weight_split_impl(const float* x, const float* dy, float* dw, float* db, void* ws, int64_t ws_bytes, int B, int C_in,
+                                 int T_in, int C_out, int T_out, int K, int stride, int dilation, int pad_left, int pad_mode, int K1,
+                                 int dilation2, fac_stream_t stream);
+
+extern "C" int fac_conv1d_bwd_weight_split_db_ok(int B, int C_in, int T_in, int C_out, int T_out, int K, int stride, int dilation, int K1,
+                                                 int dilation2) {
+  fac::WkArgs k;
+  int S;
+  return fac::wk_geometry(B, C_in, T_in, C_out, T_out, K, stride, dilation, K1, dilation2, &k, &S) == 0 && (long long)B * C_out <= 65535;
 }
 
 extern "C" int fac_conv1d_bwd_weight_split(const float* x, const float* dy, float* dw, void* ws, int64_t ws_bytes, int B,
                                            int C_in, int T_in, int C_out, int T_out, int K, int stride, int dilation,
                                            int pad_left, int pad_mode, int K1, int dilation2, fac_stream_t stream) {
+  return bwd_weight_split_impl(x, dy, dw, nullptr, ws, ws_bytes, B, C_in, T_in, C_out, T_out, K, stride, dilation, pad_left, pad_mode, K1,
+                               dilation2, stream);
+}
+
+extern "C" int fac_conv1d_bwd_weight_split_db(const float* x, const float* dy, float* dw, float* db, void* ws, int64_t ws_bytes, int B,
+                                              int C_in, int T_in, int C_out, int T_out, int K, int stride, int dilation,
+                                              int pad_left, int pad_mode, int K1, int dilation2, fac_stream_t stream) {
+  return bwd_weight_split_impl(x, dy, dw, db, ws, ws_bytes, B, C_in, T_in, C_out, T_out, K, stride, dilation, pad_left, pad_mode, K1,
+                               dilation2, stream);
+}
+
+static int bwd_weight_split_impl(const float* x, const float* dy, float* dw, float* db, void* ws, int64_t ws_bytes, int B, int C_in,
+                                 int T_in, int C_out, int T_out, int K, int stride, int dilation, int pad_left, int pad_mode, int K1,
+                                 int dilation2, fac_stream_t stream) {
   using namespace fac;
   FAC_REQUIRE(x && dy && dw && ws && B > 0 && C_in > 0 && C_out > 0 && T_in > 0 && T_out > 0 && K > 0 && stride > 0 &&
                   dilation > 0 && pad_left >= 0,
@@ -725,7 +803,8 @@ extern "C" int fac_conv1d_bwd_weight_split(const float* x, const float* dy, floa
     int S;
     if (wk_geometry(B, C_in, T_in, C_out, T_out, K, stride, dilation, K1, dilation2, &k, &S) == 0) {
       const long long part_bytes = ws_align((long long)S * C_out * k.NBk * 32 * 4);
-      FAC_REQUIRE(ws_bytes >= part_bytes + ws_align(3 * k.a_plane_bytes) + ws_align(3 * k.b_plane_bytes),
+      FAC_REQUIRE(ws_bytes >= part_bytes + ws_align(3 * k.a_plane_bytes) + ws_align(3 * k.b_plane_bytes) +
+                                  ws_align((long long)B * C_out * ((k.UA + 2047) / 2048) * 4),
                   "conv1d_bwd_weight_split: workspace too small");
       unsigned char* wsb = reinterpret_cast<unsigned char*>(ws);
       k.part = reinterpret_cast<float*>(ws);
@@ -742,8 +821,18 @@ extern "C" int fac_conv1d_bwd_weight_split(const float* x, const float* dy, floa
       const long long na = (long long)B * C_out * (k.UA / 8), nb = (long long)B * C_in * stride * (k.UB / 8);
       const int ga = (int)((na + 255) / 256 < 65535 * 16 ? (na + 255) / 256 : 65535 * 16);
       const int gb = (int)((nb + 255) / 256 < 65535 * 16 ? (nb + 255) / 256 : 65535 * 16);
-      hipLaunchKernelGGL(split_planes_kernel, dim3(ga), dim3(256), 0, st, dy, ap, (long long)B * C_out, T_out, T_out, T_out, 1, k.UA, 0,
-                         FAC_PAD_ZERO, k.a_plane_bytes);
+      if (db != nullptr && (long long)B * C_out <= 65535) {
+        const int n_chunks = (k.UA + 2047) / 2048;
+        float* rs = reinterpret_cast<float*>(bp + ws_align(3 * k.b_plane_bytes));
+        hipLaunchKernelGGL(split_planes_rowsum_kernel, dim3(n_chunks, B * C_out), dim3(256), 0, st, dy, ap, rs, T_out, k.UA, n_chunks,
+                           k.a_plane_bytes);
+        hipLaunchKernelGGL(bias_from_rowsums_kernel, dim3((C_out + 255) / 256), dim3(256), 0, st, rs, db, B, C_out, n_chunks);
+        db = nullptr;
+      } else {
+        hipLaunchKernelGGL(split_planes_kernel, dim3(ga), dim3(256), 0, st, dy, ap, (long long)B * C_out, T_out, T_out, T_out, 1, k.UA, 0,
+                           FAC_PAD_ZERO, k.a_plane_bytes);
+      }
+      FAC_REQUIRE(db == nullptr, "conv1d_bwd_weight_split_db: too many rows for the fused bias gradient (B * C_out > 65535)");
       hipLaunchKernelGGL(split_planes_kernel, dim3(gb), dim3(256), 0, st, x, bp, (long long)B * C_in, T_in, T_ext, T_pad, stride, k.UB,
                          pad_left, pad_mode, k.b_plane_bytes);
       static bool attr_set = false;
@@ -760,6 +849,7 @@ extern "C" int fac_conv1d_bwd_weight_split(const float* x, const float* dy, floa
       return check_launch("conv1d_bwd_weight_split(k-major)");
     }
   }
+  FAC_REQUIRE(db == nullptr, "conv1d_bwd_weight_split_db: the fused bias gradient needs the k-major kernel's shapes (>= 16 input channels)");
   WsArgs a;
   int S;
   size_t lds;

@@ -752,8 +752,10 @@ def conv1d_bwd_data(dy, v, g, t_in, stride=1, dilation=1, pad_mode=PAD_REFLECT, 
     return dx
 
 
-def conv1d_bwd_weight(x, dy, k, stride=1, dilation=1, pad_mode=PAD_REFLECT, causal=True, pad_left=None, k1=0, dilation2=0):
-    """dW (C_out, C_in, K) of SConv1d (or of a plain conv when pad_left is given explicitly; k1 / dilation2: two-level taps)."""
+def conv1d_bwd_weight(x, dy, k, stride=1, dilation=1, pad_mode=PAD_REFLECT, causal=True, pad_left=None, k1=0, dilation2=0,
+                      want_db=False):
+    """dW (C_out, C_in, K) of SConv1d (or of a plain conv when pad_left is given explicitly; k1 / dilation2: two-level taps).
+    want_db: also return the bias gradient sum_{b,t} dy -- folded into the split kernel's pass over dy where that kernel runs."""
     x, dy = _dev(x, "x"), _dev(dy, "dy")
     B, c_in, t_in = x.shape
     _, c_out, t_out = dy.shape
@@ -761,7 +763,10 @@ def conv1d_bwd_weight(x, dy, k, stride=1, dilation=1, pad_mode=PAD_REFLECT, caus
         _, padding_total, _ = conv_out_len(t_in, k, stride, dilation)
         pad_left = padding_total if causal else padding_total - padding_total // 2
     dw = torch.empty(c_out, c_in, k, device=x.device, dtype=torch.float32)
-    _bwd_weight_launch(x, dy, dw, B, c_in, t_in, c_out, t_out, k, stride, dilation, pad_left, pad_mode, k1, dilation2)
+    db = torch.empty(c_out, device=x.device, dtype=torch.float32) if want_db else None
+    fused = _bwd_weight_launch(x, dy, dw, B, c_in, t_in, c_out, t_out, k, stride, dilation, pad_left, pad_mode, k1, dilation2, db=db)
+    if want_db:
+        return dw, (db if fused else bias_grad(dy))
     return dw
 
 
@@ -782,9 +787,10 @@ def _wgrad_workspace(device, nbytes):
     return ws
 
 
-def _bwd_weight_launch(x, dy, dw, B, c_in, t_in, c_out, t_out, k, stride, dilation, pad_left, pad_mode, k1=0, dilation2=0):
+def _bwd_weight_launch(x, dy, dw, B, c_in, t_in, c_out, t_out, k, stride, dilation, pad_left, pad_mode, k1=0, dilation2=0, db=None):
     """dW on the bf16 matrix pipe with fp32-exact splitting (conv1d_wgrad_split.hip) when the shape qualifies and
-    FAC_BF16_SPLIT is on, else on the fp32 MFMA kernel."""
+    FAC_BF16_SPLIT is on, else on the fp32 MFMA kernel.  db: optional (C_out) buffer for the bias gradient; returns True when the
+    launch filled it."""
     lib = _lib.load()
     if _FLOPS is not None:
         _FLOPS.add("wgrad", 2.0 * B * c_out * c_in * k * t_out)
@@ -793,15 +799,21 @@ def _bwd_weight_launch(x, dy, dw, B, c_in, t_in, c_out, t_out, k, stride, dilati
         nbytes = -1
     if nbytes > 0:
         ws = _wgrad_workspace(x.device, nbytes)
+        if db is not None and lib.fac_conv1d_bwd_weight_split_db_ok(B, c_in, t_in, c_out, t_out, k, stride, dilation, k1, dilation2):
+            _lib.check(lib.fac_conv1d_bwd_weight_split_db(_ptr(x), _ptr(dy), _ptr(dw), _ptr(db), _ptr(ws), nbytes, B, c_in, t_in, c_out,
+                                                          t_out, k, stride, dilation, pad_left, pad_mode, k1, dilation2, _stream()),
+                       "fac_conv1d_bwd_weight_split_db")
+            return True
         _lib.check(lib.fac_conv1d_bwd_weight_split(_ptr(x), _ptr(dy), _ptr(dw), _ptr(ws), nbytes, B, c_in, t_in, c_out, t_out, k,
                                                    stride, dilation, pad_left, pad_mode, k1, dilation2, _stream()),
                    "fac_conv1d_bwd_weight_split")
-        return
+        return False
     kk1 = k1 if 0 < k1 < k else k                      # the fp32 kernel sees k / kk1 virtual channels per input channel
     nbytes = lib.fac_conv1d_bwd_weight_ws_bytes(B, c_in * (k // kk1), c_out, t_out, kk1)
     ws = torch.empty(nbytes // 4, device=x.device, dtype=torch.float32)
     _lib.check(lib.fac_conv1d_bwd_weight(_ptr(x), _ptr(dy), _ptr(dw), _ptr(ws), nbytes, B, c_in, t_in, c_out, t_out, k,
                                          stride, dilation, pad_left, pad_mode, k1, dilation2, _stream()), "fac_conv1d_bwd_weight")
+    return False
 
 
 def weight_norm_bwd(v, g, dw):

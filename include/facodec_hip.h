@@ -358,6 +358,13 @@ int64_t fac_conv1d_bwd_weight_split_ws_bytes(int B, int C_in, int T_in, int C_ou
 int fac_conv1d_bwd_weight_split(const float* x, const float* dy, float* dw, void* ws, int64_t ws_bytes, int B, int C_in, int T_in,
                                 int C_out, int T_out, int K, int stride, int dilation, int pad_left, int pad_mode, int K1,
                                 int dilation2, fac_stream_t stream);
+/* The same launch with the bias gradient db[co] = sum over (b, t) of dy folded into the dy operand's split pass (no separate
+ * pass over dy); k-major shapes only: C_in * K2 >= 16 and B * C_out <= 65535 (query: fac_conv1d_bwd_weight_split_db_ok). */
+int fac_conv1d_bwd_weight_split_db_ok(int B, int C_in, int T_in, int C_out, int T_out, int K, int stride, int dilation, int K1,
+                                      int dilation2);
+int fac_conv1d_bwd_weight_split_db(const float* x, const float* dy, float* dw, float* db, void* ws, int64_t ws_bytes, int B, int C_in,
+                                   int T_in, int C_out, int T_out, int K, int stride, int dilation, int pad_left, int pad_mode, int K1,
+                                   int dilation2, fac_stream_t stream);
 /* w = g*v/||v|| per row (n_rows x row_len): dv, dg from dW. */
 int fac_weight_norm_bwd(const float* v, const float* g, const float* dw, float* dv, float* dg, int n_rows, int row_len,
                         fac_stream_t stream);

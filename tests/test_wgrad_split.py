@@ -97,6 +97,15 @@ def test_wgrad_split_against_fp64(case, cuda):
     finally:
         ops.BF16_SPLIT = prev
     assert torch.equal(again, got)
+    # the bias gradient folded into the dy split pass (k-major shapes) or from fac_bias_grad (the others): same dW, db = sum dy
+    ops.BF16_SPLIT = True
+    try:
+        dw2, db = ops.conv1d_bwd_weight(x.to(cuda), dy.to(cuda), k, stride=stride, dilation=dil, pad_mode=mode, pad_left=pad_left, want_db=True)
+    finally:
+        ops.BF16_SPLIT = prev
+    assert torch.equal(dw2, got)
+    ref_db = dy.double().sum((0, 2))
+    assert float((db.cpu().double() - ref_db).abs().max()) <= 1e-5 * max(1.0, float(ref_db.abs().max()))
 
 
 def test_convtr_wgrad_on_split_kernel(cuda):
