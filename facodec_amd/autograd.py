@@ -22,6 +22,9 @@ from . import ops
 def _split_ok(c_out, c_in, k, stride, x):
     if k == 1 and stride == 1:          # 1x1 with many channels: split-bf16 GEMM (conv1d_gemm_split.hip)
         return ops.gemm_split_ok(c_out, c_in, 1, x.shape[0] * x.shape[-1])
+    if k in (3, 5):                     # WaveNet / style-encoder k = 5, encoder output conv k = 3: enough channels only
+        return (ops.BF16_SPLIT and stride == 1 and c_in % 16 == 0 and c_in >= 64 and c_out % 16 == 0 and c_out > 32
+                and x.shape[0] * x.shape[-1] > 640)
     return (ops.BF16_SPLIT and k == 7 and stride == 1 and c_in % 16 == 0 and c_out % 16 == 0 and c_out > 2
             and x.shape[0] * x.shape[-1] > 640)
 

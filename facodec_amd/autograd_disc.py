@@ -185,16 +185,14 @@ class Spectrogram(Function):
         _call("fac_pad_reflect", _p(wave.detach().contiguous()), _p(xp), B, T, pad, pad + right)
         nf = T1 // hop + 1 - 4
         frames = ops.stft_frames(xp, L, nf, hop, 0, 0)
-        with ops.flop_key("dft"):
-            spec = ops.conv1d(frames, scale.basis, 2 * scale.F, 1, pad_left=0, pad_mode=ops.PAD_ZERO, t_out=nf)
+        spec = scale.dft(frames, nf)
         ctx.cfg = (scale, B, T, T1, pad, nf)
         return spec
 
     @staticmethod
     def backward(ctx, dspec):
         scale, B, T, T1, pad, nf = ctx.cfg
-        with ops.flop_key("dft"):
-            dfr = ops.conv1d(dspec.contiguous(), scale.basis_bwd, scale.win, 1, pad_left=0, pad_mode=ops.PAD_ZERO, t_out=nf)
+        dfr = scale.dft_adjoint(dspec.contiguous(), nf)
         dxp = ops.stft_frames_bwd(dfr, T1, scale.hop, 0, 0)
         dx = torch.empty(B, 1, T, device=dspec.device)
         _lib.check(_lib.load().fac_pad_fold_bwd(_p(dxp), _p(dx), B, 1, T, T1, pad, ops.PAD_REFLECT, ops._stream()), "fac_pad_fold_bwd")

@@ -120,7 +120,7 @@ __global__ __launch_bounds__(512, 2) void conv1d_gemm_split_kernel(ConvArgs a) {
     n0 = tt * GS_COLS;
   }
   const int S = (K == 2 && a.stride > 1) ? a.stride : 1;      // input stride: S phase sub-signals as virtual channel chunks
-  const int n_chunks = (a.C_in / GS_CI) * S;
+  const int n_chunks = ((a.C_in + GS_CI - 1) / GS_CI) * S;   // a ragged last chunk multiplies the packed weights' zero padding
   const long long n_total = flat ? (long long)a.B * a.T_out : (long long)a.T_out;     // columns of this (clip | whole batch)
 
   if (wave >= 4) {
@@ -158,7 +158,7 @@ __global__ __launch_bounds__(512, 2) void conv1d_gemm_split_kernel(ConvArgs a) {
         off = c;                                             // strided: resolved per chunk (phase-dependent), see load_b
       }
       u_in[j] = in && u_ok[j];
-      u_off[j] = off + (S == 1 ? (long long)(g * 8) * a.x_cs : 0ll);
+      u_off[j] = off;                                        // batch / column part of the address; the channel is added per chunk
       u_g[j] = g;
     }
     auto issue_a = [&](int chunk, int buf) {
@@ -174,7 +174,6 @@ __global__ __launch_bounds__(512, 2) void conv1d_gemm_split_kernel(ConvArgs a) {
     // NBL loads per call, lanes without a real unit load a clamped address and are zeroed at the split
     auto load_b = [&](int chunk, float (&xr)[GS_NU][8], bool (&uin)[GS_NU]) {
       const int c32 = chunk / S, ph = chunk - c32 * S;
-      const float* xc = a.x + (long long)c32 * GS_CI * a.x_cs;
 #pragma unroll
       for (int j = 0; j < GS_NU; ++j) {
         long long o = u_off[j];
@@ -185,13 +184,17 @@ __global__ __launch_bounds__(512, 2) void conv1d_gemm_split_kernel(ConvArgs a) {
           if (a.pad_mode == FAC_PAD_REFLECT) idx = reflect_index(tin, a.T_in, a.T_ext);
           else idx = (tin >= 0 && tin < a.T_in) ? tin : -1;
           in = u_ok[j] && idx >= 0;
-          o = (long long)b * a.x_bs + (idx >= 0 ? idx : 0) + (long long)(u_g[j] * 8) * a.x_cs;
+          o = (long long)b * a.x_bs + (idx >= 0 ? idx : 0);
         }
         uin[j] = in;
-        const float* p = xc + (in ? o : 0ll);
+        const float* p = a.x + (in ? o : 0ll);
+        const int ch0 = c32 * GS_CI + u_g[j] * 8;
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
-          asm volatile("global_load_dword %0, %1, off" : "=v"(xr[j][i]) : "v"(p + (long long)i * a.x_cs) : "memory");
+        for (int i = 0; i < 8; ++i) {
+          // channels past C_in (ragged last chunk): their weights are zero, any finite value will do -- re-read the last channel
+          const int ch = ch0 + i < a.C_in ? ch0 + i : a.C_in - 1;
+          asm volatile("global_load_dword %0, %1, off" : "=v"(xr[j][i]) : "v"(p + (long long)ch * a.x_cs) : "memory");
+        }
       }
     };
     auto write_b = [&](int buf, float (&xr)[GS_NU][8], const bool (&uin)[GS_NU]) {
@@ -454,7 +457,7 @@ bool conv_gsplit_ok(const ConvArgs& a) {
   } else if (!(a.K == 1 || a.K == 2)) {
     return false;
   }
-  if (a.C_in % GS_CI != 0 || a.C_in < (strided ? 32 : 64)) return false;
+  if (a.C_in < (strided ? 32 : 64)) return false;
   if (!strided && a.K == 1 && (a.pad_left != 0 || a.T_in < a.T_out)) return false;
   if (!strided && a.K == 2 && (a.pad_mode != FAC_PAD_ZERO || a.pad_left > 1)) return false;
   const int rows = a.rp > 1 ? a.C_out_pad : a.C_out;

@@ -237,6 +237,30 @@ def _internal(t):
     return getattr(t, "_fac_internal", t)
 
 
+_DTARGETS = {}
+
+
+def gan_loss_d_batched(d_both):
+    """train.py:282-285 for ONE pass of the discriminators over [fake clips | real clips] (batch 2B, the fake half first):
+    loss_d = sum_k mean(D_k(fake)^2) + mean((1 - D_k(real))^2) = sum_k sum((logits - target)^2) / n_half with target 0 on the fake
+    half and 1 on the real half's data elements.  Half the launches of two separate passes and twice the tiles per launch."""
+    loss = None
+    for maps in d_both:
+        last = _internal(maps[-1])
+        mask, cnt_all = _row_mask(last)
+        key = (last.shape, getattr(last, "rows", None), last.device)
+        tgt = _DTARGETS.get(key)
+        if tgt is None:
+            tgt = (mask if mask is not None else torch.ones_like(last)).clone()
+            half = last.shape[-1] // 2
+            assert last.shape[-1] % 2 == 0 and cnt_all % 2 == 0
+            tgt[..., :half] = 0.0
+            _DTARGETS[key] = tgt
+        term = AD.PairMean.apply(last, tgt, 2, cnt_all // 2)
+        loss = term if loss is None else loss + term
+    return loss
+
+
 def gan_losses(d_fake, d_real):
     """train.py:282-285 and :304-312 -> (loss_d, loss_g, loss_feature) as autograd scalars, on the internal maps behind
     the views `Discriminator.forward` returns (plain tensors work too).  Means run over the data elements only (gap

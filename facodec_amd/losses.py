@@ -36,6 +36,10 @@ class _SpectralScale:
         basis_t = torch.from_numpy(basis).to(device).unsqueeze(-1)
         self.basis = ops.pack_conv_weight(basis_t)
         self.basis_bwd = ops.pack_conv_weight_bwd(basis_t)       # transposed GEMM of the backward pass
+        # the same two matrices as split-bf16 planes for the GEMM kernel (conv1d_gemm_split.hip; fp32-exact): the windowed-DFT
+        # GEMMs of the long windows are 1x1 convs with 256 .. 2048 "channels" and ran at 23 TFLOP/s on the fp32 tile
+        self.basis_t = basis_t
+        self._basis_split = self._basis_split_t = None
         self.n_mels = None
         if fbank is not None:            # (n_mels, F)
             fb = torch.as_tensor(fbank, dtype=torch.float32, device=device).contiguous()
@@ -43,13 +47,31 @@ class _SpectralScale:
             self.fb = ops.pack_conv_weight(fb.unsqueeze(-1))
             self.fb_bwd = ops.pack_conv_weight_bwd(fb.unsqueeze(-1))
 
+    def dft(self, frames, n_frames):
+        """frames (N, win, n_frames) -> (N, 2F, n_frames) [Re | Im]: the windowed-DFT GEMM."""
+        two_f = 2 * self.F
+        with ops.flop_key("dft"):
+            if ops.gemm_split_ok(two_f, self.win, 1, frames.shape[0] * n_frames):
+                if self._basis_split is None:
+                    self._basis_split = ops.pack_gemm_weight_split(self.basis_t)
+                return ops.conv1d(frames, None, two_f, 1, pad_left=0, pad_mode=ops.PAD_ZERO, t_out=n_frames, w_split=self._basis_split)
+            return ops.conv1d(frames, self.basis, two_f, 1, pad_left=0, pad_mode=ops.PAD_ZERO, t_out=n_frames)
+
+    def dft_adjoint(self, dspec, n_frames):
+        """dspec (N, 2F, n_frames) -> gradient of the frames (N, win, n_frames): the transposed GEMM."""
+        with ops.flop_key("dft"):
+            if ops.gemm_split_ok(self.win, 2 * self.F, 1, dspec.shape[0] * n_frames):
+                if self._basis_split_t is None:
+                    self._basis_split_t = ops.pack_gemm_weight_split_t(self.basis_t)
+                return ops.conv1d(dspec, None, self.win, 1, pad_left=0, pad_mode=ops.PAD_ZERO, t_out=n_frames, w_split=self._basis_split_t)
+            return ops.conv1d(dspec, self.basis_bwd, self.win, 1, pad_left=0, pad_mode=ops.PAD_ZERO, t_out=n_frames)
+
     def spectrum(self, waves, power):
         """waves (N, T) -> (N, F, frames) magnitude (power 1) or power (2) spectrogram."""
         N, T = waves.shape
         frames_n = 1 + T // self.hop
         fr = ops.stft_frames(waves, self.win, frames_n, self.hop, self.n_fft // 2, self.off)
-        with ops.flop_key("dft"):
-            spec = ops.conv1d(fr, self.basis, 2 * self.F, 1, pad_left=0, pad_mode=ops.PAD_ZERO, t_out=frames_n)
+        spec = self.dft(fr, frames_n)
         return ops.spec_power(spec, power)
 
     def mel(self, spec):
@@ -63,8 +85,7 @@ class _SpectralScale:
         N, T = waves.shape
         frames_n = 1 + T // self.hop
         fr = ops.stft_frames(waves, self.win, frames_n, self.hop, self.n_fft // 2, self.off)
-        with ops.flop_key("dft"):
-            spec = ops.conv1d(fr, self.basis, 2 * self.F, 1, pad_left=0, pad_mode=ops.PAD_ZERO, t_out=frames_n)
+        spec = self.dft(fr, frames_n)
         mag = ops.spec_power(spec, 1)
         feat = self.mel(mag) if use_mel else mag
         target = self._target
@@ -77,7 +98,7 @@ class _SpectralScale:
             else:
                 dmag = dfeat
             dspec = ops.spec_power_bwd(spec, dmag, 1)
-            dfr = ops.conv1d(dspec, self.basis_bwd, self.win, 1, pad_left=0, pad_mode=ops.PAD_ZERO, t_out=frames_n)
+        dfr = self.dft_adjoint(dspec, frames_n)
         return ops.stft_frames_bwd(dfr, T, self.hop, self.n_fft // 2, self.off)
 
 
@@ -250,8 +271,7 @@ def _reconstruction_grad(xs, gs, eps):
         frames_n = 1 + T // sc.hop
         mel_x = sc.mel(sc.spectrum(xs, 2))
         fr = ops.stft_frames(gs, sc.win, frames_n, sc.hop, sc.n_fft // 2, sc.off)
-        with ops.flop_key("dft"):
-            spec = ops.conv1d(fr, sc.basis, 2 * sc.F, 1, pad_left=0, pad_mode=ops.PAD_ZERO, t_out=frames_n)
+        spec = sc.dft(fr, frames_n)
         mel_g = sc.mel(ops.spec_power(spec, 2))
         dmel = torch.empty_like(mel_g)
         ops.pair_bwd(mel_g, mel_x, dmel, 0, 0.0, 1.0 / mel_g.numel(), accumulate=False)
@@ -259,7 +279,7 @@ def _reconstruction_grad(xs, gs, eps):
         with ops.flop_key("dft"):
             dpow = ops.conv1d(dmel, sc.fb_bwd, sc.F, 1, pad_left=0, pad_mode=ops.PAD_ZERO, t_out=frames_n)
             dspec = ops.spec_power_bwd(spec, dpow, 2)
-            dfr = ops.conv1d(dspec, sc.basis_bwd, sc.win, 1, pad_left=0, pad_mode=ops.PAD_ZERO, t_out=frames_n)
+        dfr = sc.dft_adjoint(dspec, frames_n)
         dg = ops.add(dg, ops.stft_frames_bwd(dfr, T, sc.hop, sc.n_fft // 2, sc.off))
     return dg
 

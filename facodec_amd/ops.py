@@ -114,7 +114,7 @@ def pack_convtr_weight_rows(v, g, stride, out=None):
 
 def convtr_split_ok(c_in, c_out, stride, batch, t_in, causal=True, alpha_in=None):
     """All-phases ConvTranspose1d on the split-bf16 GEMM kernel (conv1d_gemm_split.hip, K = 2): mirrors conv_gsplit_ok."""
-    return (BF16_SPLIT and GEMM_SPLIT and causal and alpha_in is None and 2 <= stride <= 16 and c_in % 32 == 0 and c_in >= 64
+    return (BF16_SPLIT and GEMM_SPLIT and causal and alpha_in is None and 2 <= stride <= 16 and c_in >= 64
             and t_in >= 256 and batch * t_in >= 1024 and c_out * stride >= 64)
 
 
@@ -268,7 +268,7 @@ def gemm_split_ok(c_out, c_in, k, n_cols, t_out=None):
     streaming kernel conv1d_pw.hip is the right tool), at least half a row tile, enough columns."""
     if not (BF16_SPLIT and GEMM_SPLIT and k in (1, 2)):
         return False
-    if c_in % 32 or c_in < GEMM_SPLIT_MIN_CIN or c_out < 64 or n_cols < 1024:
+    if c_in < GEMM_SPLIT_MIN_CIN or c_out < 64 or n_cols < 1024:
         return False
     return k == 1 or (t_out is not None and t_out >= 256)
 
@@ -276,7 +276,7 @@ def gemm_split_ok(c_out, c_in, k, n_cols, t_out=None):
 def gemm_split_strided_ok(c_out, c_in, k, stride, batch, t_out):
     """Strided conv with stride < k <= 2 * stride (the encoder's k = 2 s downsampling convs, the period discriminators' k = 5
     stride-3 convs) as a 2-tap split GEMM over the `stride` phase sub-signals: mirrors conv_gsplit_ok."""
-    return (BF16_SPLIT and GEMM_SPLIT and 1 < stride <= 16 and stride < k <= 2 * stride and c_in % 32 == 0 and c_in >= 32
+    return (BF16_SPLIT and GEMM_SPLIT and 1 < stride <= 16 and stride < k <= 2 * stride and c_in >= 32
             and c_out >= 64 and t_out >= 256 and batch * t_out >= 1024)
 
 
@@ -728,7 +728,8 @@ def conv1d_bwd_data(dy, v, g, t_in, stride=1, dilation=1, pad_mode=PAD_REFLECT, 
     pad_left = padding_total if causal else padding_total - padding_total // 2
     pad_right = (padding_total - pad_left) + extra
     tp = pad_left + t_in + pad_right
-    if stride == 1 and BF16_SPLIT and k == 7 and c_in % 16 == 0 and c_out % 16 == 0 and B * tp > 640:
+    if (stride == 1 and BF16_SPLIT and c_in % 16 == 0 and c_out % 16 == 0 and B * tp > 640
+            and (k == 7 or (k in (3, 5) and c_out >= 64 and c_in > 32))):
         # the flipped / transposed conv on the bf16 pipe too: materialise w = g v/||v||, swap channels, flip taps
         w = rows_fma(v, wn_scale(v, g)) if g is not None else v
         wt = w.permute(1, 0, 2).flip(2).contiguous()                       # (C_in, C_out, K) = weights of the bwd conv
@@ -864,7 +865,11 @@ def conv_transpose1d_bwd(x, dy, v, g, stride):
     B, c_in, t_in = x.shape
     c_out, k = v.shape[1], v.shape[2]
     assert k == 2 * stride and dy.shape == (B, c_out, t_in * stride)
-    dx = conv1d(dy, pack_conv_weight(v, g), c_in, k, stride=stride, pad_left=0, pad_mode=PAD_ZERO, t_out=t_in)
+    if gemm_split_strided_ok(c_in, c_out, k, stride, B, t_in):     # the strided conv of dy on the split GEMM kernel
+        dx = conv1d(dy, None, c_in, k, stride=stride, pad_left=0, pad_mode=PAD_ZERO, t_out=t_in,
+                    w_split=pack_gemm_weight_split(v, g, in_stride=stride))
+    else:
+        dx = conv1d(dy, pack_conv_weight(v, g), c_in, k, stride=stride, pad_left=0, pad_mode=PAD_ZERO, t_out=t_in)
     dw = torch.empty(c_in, c_out, k, device=x.device, dtype=torch.float32)
     _bwd_weight_launch(dy, x, dw, B, c_out, t_in * stride, c_in, t_in, k, stride, 1, 0, PAD_ZERO)
     return dx, dw

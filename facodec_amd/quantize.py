@@ -219,13 +219,16 @@ class LogMelFrontend(nn.Module):
         self.mel_scale = nn.Module()
         self.mel_scale.register_buffer("fb", torch.from_numpy(dsp.mel_fbank_htk(n_fft // 2 + 1, n_mels, sample_rate)))
         self._basis = None
+        self._basis_split = None
         self._fb_packed = None
 
     def _consts(self, device):
         if self._basis is None or self._basis.device != device:
             win = self.spectrogram.window.detach().cpu().numpy()
             basis, self._off = dsp.dft_basis(self.n_fft, self.win, win)
-            self._basis = ops.pack_conv_weight(torch.from_numpy(basis).to(device).unsqueeze(-1))
+            bt = torch.from_numpy(basis).to(device).unsqueeze(-1)
+            self._basis = ops.pack_conv_weight(bt)
+            self._basis_split = ops.pack_gemm_weight_split(bt) if ops.BF16_SPLIT and ops.GEMM_SPLIT else None
             fb = self.mel_scale.fb.detach().to(device).t().contiguous()  # (n_mels, F)
             self._fb_packed = ops.pack_conv_weight(fb.unsqueeze(-1))
         return self._basis, self._fb_packed, self._off
@@ -250,7 +253,10 @@ class LogMelFrontend(nn.Module):
         F_ = self.n_fft // 2 + 1
         frames = ops.stft_frames(w, self.win, n_frames, self.hop, self.n_fft // 2, off)
         with ops.flop_key("dft"):
-            spec = ops.conv1d(frames, basis, 2 * F_, 1, pad_left=0, pad_mode=ops.PAD_ZERO, t_out=n_frames)
+            if self._basis_split is not None and ops.gemm_split_ok(2 * F_, self.win, 1, B * n_frames):
+                spec = ops.conv1d(frames, None, 2 * F_, 1, pad_left=0, pad_mode=ops.PAD_ZERO, t_out=n_frames, w_split=self._basis_split)
+            else:
+                spec = ops.conv1d(frames, basis, 2 * F_, 1, pad_left=0, pad_mode=ops.PAD_ZERO, t_out=n_frames)
             power = ops.spec_power(spec, 2)
             return ops.conv1d(power, fbp, self.n_mels, 1, pad_left=0, pad_mode=ops.PAD_ZERO, t_out=n_frames,
                               act=ops.ACT_LOG_MEL)

@@ -131,6 +131,8 @@ class TrainStep(GeneratorStep):
         self._sync_start([self.opt[k] for k in ("discriminator", "fa_predictors") if k in self.opt])
         self.stft = losses.MultiScaleSTFTLoss()
         self.l1 = losses.L1Loss()
+        import os
+        self.batched_d_step = os.environ.get("FAC_BATCHED_D_STEP", "1") != "0"
 
     def predictor_losses(self, preds, rev, targets):
         """train.py:314-356 given the targets the reference takes from external models: f0 (B, F) normalised log-F0
@@ -184,8 +186,12 @@ class TrainStep(GeneratorStep):
             target = target[..., len_diff // 2:-len_diff // 2].contiguous()
         # ---- discriminator step (train.py:279-292)
         disc = m.discriminator
-        d_fake, d_real = disc.forward_internal(pred.detach()), disc.forward_internal(target)
-        loss_d, _, _ = gan_losses(d_fake, d_real)
+        if self.batched_d_step:      # one pass over [fake | real]: half the launches, twice the tiles per launch
+            from .discriminator import gan_loss_d_batched
+            loss_d = gan_loss_d_batched(disc.forward_internal(torch.cat([pred.detach(), target], 0)))
+        else:
+            d_fake, d_real = disc.forward_internal(pred.detach()), disc.forward_internal(target)
+            loss_d, _, _ = gan_losses(d_fake, d_real)
         loss_d.backward()
         opt["discriminator"].launch_all_reduce()                         # rides under the loss forwards below
         mel = self.mel(pred, target)

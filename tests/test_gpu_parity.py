@@ -803,7 +803,7 @@ def test_split_bf16_conv_matches_fp32_grade(B, C, T, d, mode, O, ops, cuda):
 
 
 @pytest.mark.parametrize("B,ci,co,T,act", [(8, 512, 512, 960, "none"), (32, 256, 512, 160, "mish"), (1, 1024, 4096, 2560, "none"),
-                                           (4, 320, 200, 333, "none"), (2, 768, 96, 1001, "none")])
+                                           (4, 320, 200, 333, "none"), (2, 768, 96, 1001, "none"), (2, 1200, 2050, 600, "none")])
 def test_gemm_split_1x1_matches_fp32_grade(B, ci, co, T, act, ops, cuda):
     """conv1d_gemm_split.hip, K = 1: many-channel 1x1 convs as a split-bf16 GEMM over the flattened (clip, time) columns --
     bias, activation, residual, second pre-activated output; row counts that do not fill a 128-row tile, T not a multiple of 4
