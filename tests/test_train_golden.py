@@ -14,7 +14,7 @@ from facodec_amd import synth
 pytestmark = pytest.mark.gpu
 
 LOSS_TOL = 1e-5          # north_star asks for 1e-4 relative; measured <= 2.2e-7
-PROBE_BAR = dict(discriminator=3e-3, encoder=1e-3, quantizer=1e-3, decoder=1e-3, fa_predictors=5e-5)
+PROBE_BAR = dict(discriminator=3e-3, encoder=5e-4, quantizer=5e-4, decoder=5e-4, fa_predictors=5e-5)
 
 
 def _model(cuda, keys=TR.KEYS):
@@ -72,8 +72,9 @@ def test_train_step_against_reference_golden(cuda, golden_dir):
     # (profiles/r02_train_golden_report*.json).  The conditioning experiment itself is a CPU test now
     # (tests/test_oracle_golden.py::test_gradient_probe_conditioning_justifies_the_gpu_bars, profiles/r03_gradient_conditioning_cpu.json:
     # a 1-ulp change of the waveforms moves discriminator probes by 1.08e-3, generator probes by <= 5.5e-5, predictor probes by
-    # 8e-7, losses by <= 2e-7).  Bars: 2e-4 on norms; probe values per key (PROBE_BAR): discriminator 3e-3, generator keys 1e-3
-    # (measured 6e-5 .. 4.4e-4 across tilings), predictor heads 5e-5 (measured 1e-6).
+    # 8e-7, losses by <= 2e-7).  Bars: 2e-4 on norms; probe values per key (PROBE_BAR): discriminator 3e-3, generator keys 5e-4
+    # (round 3, one autograd node per ResidualUnit: measured <= 1.4e-4; 6e-5 .. 5.9e-4 across the round-2 tilings), predictor heads
+    # 5e-5 (measured 1e-6).
     for k, e in report["grad_norm_rel"].items():
         assert e < 2e-4, (k, e)
     for k, w in report["worst_grad"].items():
