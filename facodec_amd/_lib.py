@@ -64,6 +64,8 @@ SIGNATURES = {
     "fac_conv1d_bwd_weight_split_db": (_i, [_p, _p, _p, _p, _p, _i64, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
     "fac_weight_norm_bwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _p]),
     "fac_snake_bwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
+    "fac_pack_lstm_whh_t": (_i, [_p, _p, _i, _p]),
+    "fac_lstm_layer_bwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
     "fac_snake_bwd_fused": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
     "fac_bias_grad": (_i, [_p, _p, _p, _i, _i, _i, _p]),
     "fac_pack_convtr_w": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),

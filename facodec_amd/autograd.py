@@ -19,6 +19,10 @@ from torch.autograd import Function
 from . import ops
 
 
+import os as _os
+_LSTM_BWD_FUSED = _os.environ.get("FAC_LSTM_BWD_FUSED", "1") != "0"
+
+
 def _split_ok(c_out, c_in, k, stride, x):
     if k == 1 and stride == 1:          # 1x1 with many channels: split-bf16 GEMM (conv1d_gemm_split.hip)
         return ops.gemm_split_ok(c_out, c_in, 1, x.shape[0] * x.shape[-1])
@@ -249,15 +253,18 @@ class _LSTM(Function):
         for l in reversed(range(L)):
             w_ih, w_hh, _, _ = (p.detach() for p in params[4 * l: 4 * l + 4])
             inp, yT, gates, cs = ctx.saved[l]
-            dgates = torch.empty(4 * H, T, BP, device=dy.device)
-            dc = torch.zeros(H, BP, device=dy.device)
-            whh_t = ops.pack_conv_weight(w_hh.t().contiguous().unsqueeze(-1))        # (H out, 4H in, 1)
-            rec = None
-            for t in reversed(range(T)):
-                ops.lstm_gate_bwd(d_out[:, t], rec, gates[:, t], cs[:, t], cs[:, t - 1] if t > 0 else None, dc,
-                                  dgates[:, t], H, BP, T * BP, first=(t == T - 1))
-                if t > 0:   # W_hh^T dgates_t feeds dh_{t-1}
-                    rec = ops.conv1d(dgates[:, t].unsqueeze(0), whh_t, H, 1, pad_left=0, pad_mode=ops.PAD_ZERO, t_out=BP)
+            if _LSTM_BWD_FUSED:       # whole recurrence of the layer in one C call, two launches per step (lstm.hip)
+                dgates = ops.lstm_layer_bwd(d_out.contiguous(), w_hh, gates, cs, H)
+            else:
+                dgates = torch.empty(4 * H, T, BP, device=dy.device)
+                dc = torch.zeros(H, BP, device=dy.device)
+                whh_t = ops.pack_conv_weight(w_hh.t().contiguous().unsqueeze(-1))        # (H out, 4H in, 1)
+                rec = None
+                for t in reversed(range(T)):
+                    ops.lstm_gate_bwd(d_out[:, t], rec, gates[:, t], cs[:, t], cs[:, t - 1] if t > 0 else None, dc,
+                                      dgates[:, t], H, BP, T * BP, first=(t == T - 1))
+                    if t > 0:   # W_hh^T dgates_t feeds dh_{t-1}
+                        rec = ops.conv1d(dgates[:, t].unsqueeze(0), whh_t, H, 1, pad_left=0, pad_mode=ops.PAD_ZERO, t_out=BP)
             dg_flat = dgates.view(1, 4 * H, T * BP)
             # dW_hh = sum_t dgates_t h_{t-1}^T  (h_{-1} = 0): pair dgates[:, 1:] with yT[:, :-1]
             if T > 1:

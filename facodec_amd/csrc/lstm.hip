@@ -157,6 +157,123 @@ __global__ void lstm_gate_bwd_kernel(const float* __restrict__ dy_t, const float
   }
 }
 
+// ---- back-propagation through time, one layer, driven from the host side of the library (fac_lstm_layer_bwd): per step
+//   rec partials:  W_hh^T dgates_{t+1}, as FOUR partial products (one per gate quarter of the 4H contraction) so that 4 x H/32
+//                  workgroups (192 at H = 1536) stream W_hh^T exactly like the forward step streams W_hh -- fragment-packed
+//                  weights and dgates, every load of the step issued before the first MFMA, 16 waves splitting K, LDS reduce;
+//   gate kernel:   dh = dy_t + sum of the four partials, gate derivatives, dc carry; writes dgates_t row-major (what the
+//                  weight-gradient GEMMs read) AND in MFMA-fragment order (what the next step's partial products read).
+// Two launches per step issued from one C call per layer (the Python loop with three ctypes launches per step was host-bound:
+// 1 920 dependent launches per layer pair), 4 x fewer VMEM instructions than the split-reduction conv kernel it replaces.
+template <int NW, int GPW>
+__global__ __launch_bounds__(NW * 64) void lstm_rec_bwd_kernel(const float* __restrict__ dg_frag,   // fragment-packed dgates_{t+1} (4H x BP)
+                                                               const float* __restrict__ whh_t,     // fac_pack_lstm_whh_t
+                                                               float* __restrict__ partial,         // (4, H, BP)
+                                                               int H, int BP) {
+  __shared__ float red[NW][32][33];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int l31 = lane & 31;
+  const int kq = lane >> 5;
+  const int ub = blockIdx.x, q = blockIdx.y, cb = blockIdx.z;
+  const int kgs = H / 8;                       // k-groups per quarter
+  const int per_wave = GPW > 0 ? GPW : kgs / NW;
+  const int kg0 = wave * per_wave;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  const float4* ap = reinterpret_cast<const float4*>(whh_t) + (((long long)q * (H / 32) + ub) * kgs + kg0) * 64 + lane;
+  const float4* bp = reinterpret_cast<const float4*>(dg_frag) + ((long long)cb * (4 * kgs) + (long long)q * kgs + kg0) * 64 + lane;
+  if constexpr (GPW > 0) {
+    float4 a4[GPW], b4[GPW];
+#pragma unroll
+    for (int g = 0; g < GPW; ++g) {
+      a4[g] = ap[(long long)g * 64];
+      b4[g] = bp[(long long)g * 64];
+    }
+#pragma unroll
+    for (int g = 0; g < GPW; ++g) {
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[g].x, b4[g].x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[g].y, b4[g].y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[g].z, b4[g].z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[g].w, b4[g].w, acc, 0, 0, 0);
+    }
+  } else {
+#pragma unroll 4
+    for (int g = 0; g < per_wave; ++g) {
+      const float4 a4 = ap[(long long)g * 64];
+      const float4 b4 = bp[(long long)g * 64];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4.x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4.y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, acc, 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = (r & 3) + 8 * (r >> 2) + 4 * kq;
+    red[wave][row][l31] = acc[r];
+  }
+  __syncthreads();
+  for (int o = tid; o < 32 * 32; o += NW * 64) {
+    const int row = o >> 5, col = o & 31;
+    float s = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) s += red[w][row][col];
+    partial[((long long)q * H + ub * 32 + row) * BP + cb * 32 + col] = s;
+  }
+}
+
+__global__ void lstm_gate_bwd2_kernel(const float* __restrict__ dy_t, const float* __restrict__ partial,   // (4, H, BP) or null
+                                      const float* __restrict__ gates_t, const float* __restrict__ c_t,
+                                      const float* __restrict__ c_prev, float* __restrict__ dc,
+                                      float* __restrict__ dgates_t, float* __restrict__ dg_frag, int H, int BP, long long rs, int first) {
+  const long long n = (long long)H * BP;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const int unit = (int)(i / BP), col = (int)(i - (long long)unit * BP);
+    const long long o = (long long)unit * rs + col;
+    const float ig = gates_t[o], fg = gates_t[(long long)H * rs + o], gg = gates_t[2ll * H * rs + o], og = gates_t[3ll * H * rs + o];
+    const float ct = c_t[o], cp = c_prev ? c_prev[o] : 0.f;
+    const float tc = tanhf(ct);
+    float dh = dy_t[o];
+    if (partial) dh += ((partial[i] + partial[n + i]) + (partial[2 * n + i] + partial[3 * n + i]));
+    const float d_o = dh * tc;
+    const float dcv = dh * og * (1.f - tc * tc) + (first ? 0.f : dc[i]);
+    dc[i] = dcv * fg;
+    float dg[4];
+    dg[0] = dcv * gg * ig * (1.f - ig);
+    dg[1] = dcv * cp * fg * (1.f - fg);
+    dg[2] = dcv * ig * (1.f - gg * gg);
+    dg[3] = d_o * og * (1.f - og);
+    const int cbk = col >> 5, c31 = col & 31;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      dgates_t[(long long)q * H * rs + o] = dg[q];
+      const int r = q * H + unit;          // row of the (4H x BP) matrix; fragment order as the forward's h state
+      dg_frag[((((long long)cbk * (4 * H >> 3) + (r >> 3)) * 2 + (r & 1)) * 32 + c31) * 4 + ((r & 7) >> 1)] = dg[q];
+    }
+  }
+}
+
+// W_hh (4H, H) -> transposed, fragment-packed per (gate quarter q, block of 32 hidden units): out[blk = q * H/32 + ub][kg][kq][32 units][4]
+// holds W_hh[q*H + kg*8 + 2*jj + kq][ub*32 + i]  (jj = float4 component) -- the A operand of lstm_rec_bwd_kernel.
+__global__ __launch_bounds__(256) void pack_whh_t_kernel(const float* __restrict__ w, float* __restrict__ out, int H) {
+  const long long n = (long long)4 * H * H;
+  const int kgs = H / 8, nub = H / 32;
+  for (long long o = (long long)blockIdx.x * 256 + threadIdx.x; o < n; o += (long long)gridDim.x * 256) {
+    const int jj = o & 3;
+    const int i = (o >> 2) & 31;
+    const int kq = (o >> 7) & 1;
+    const long long rest = o >> 8;
+    const int kg = (int)(rest % kgs);
+    const int blk = (int)(rest / kgs);
+    const int q = blk / nub, ub = blk - q * nub;
+    const long long row = (long long)q * H + kg * 8 + 2 * jj + kq;
+    out[o] = w[row * H + ub * 32 + i];
+  }
+}
+
 __global__ void tanh_bwd_kernel(const float* __restrict__ y, const float* __restrict__ dy, float* __restrict__ dx, long long n) {
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
     dx[i] = dy[i] * (1.f - y[i] * y[i]);
@@ -293,6 +410,49 @@ extern "C" int fac_lstm_gate_bwd(const float* dy_t, const float* rec, const floa
   hipLaunchKernelGGL(lstm_gate_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dy_t, rec, gates_t, c_t, c_prev,
                      dc, dgates_t, H, BP, (long long)rs, first);
   return check_launch("lstm_gate_bwd");
+}
+
+extern "C" int fac_pack_lstm_whh_t(const float* w_hh, float* packed, int H, fac_stream_t stream) {
+  using namespace fac;
+  FAC_REQUIRE(w_hh && packed && H > 0 && H % 64 == 0, "pack_lstm_whh_t: H must be a multiple of 64");
+  hipLaunchKernelGGL(pack_whh_t_kernel, dim3(2048), dim3(256), 0, (hipStream_t)stream, w_hh, packed, H);
+  return check_launch("pack_lstm_whh_t");
+}
+
+extern "C" int fac_lstm_layer_bwd(const float* dyT, const float* whh_t_packed, const float* gates, const float* cs, float* dgates,
+                                  float* scratch, int T, int H, int BP, fac_stream_t stream) {
+  using namespace fac;
+  FAC_REQUIRE(dyT && whh_t_packed && gates && cs && dgates && scratch, "lstm_layer_bwd: null pointer");
+  FAC_REQUIRE(T > 0 && H > 0 && H % 64 == 0 && BP > 0 && BP % 32 == 0, "lstm_layer_bwd: H must be a multiple of 64, BP of 32");
+  const long long rs = (long long)T * BP, n = (long long)H * BP;
+  // scratch = [dc (H*BP) | partial (4*H*BP) | dg_frag ping (4*H*BP) | dg_frag pong (4*H*BP)]
+  float* dc = scratch;
+  float* partial = scratch + n;
+  float* frag[2] = {scratch + 5 * n, scratch + 9 * n};
+  const int kgs = H / 8;
+  void (*rec)(const float*, const float*, float*, int, int);
+  int threads = 1024;
+  if (kgs % 16 == 0) {
+    switch (kgs / 16) {
+      case 12: rec = lstm_rec_bwd_kernel<16, 12>; break;
+      case 8: rec = lstm_rec_bwd_kernel<16, 8>; break;
+      default: rec = lstm_rec_bwd_kernel<16, 0>; break;
+    }
+  } else {
+    threads = 512;
+    rec = lstm_rec_bwd_kernel<8, 0>;
+  }
+  const int gblocks = (int)((n + 255) / 256);
+  for (int t = T - 1; t >= 0; --t) {
+    const bool first = t == T - 1;
+    if (!first)
+      hipLaunchKernelGGL(rec, dim3(H / 32, 4, BP / 32), dim3(threads), 0, (hipStream_t)stream, frag[(t + 1) & 1], whh_t_packed, partial, H, BP);
+    hipLaunchKernelGGL(lstm_gate_bwd2_kernel, dim3(gblocks), dim3(256), 0, (hipStream_t)stream, dyT + (long long)t * BP,
+                       first ? nullptr : partial, gates + (long long)t * BP, cs + (long long)t * BP,
+                       t > 0 ? cs + (long long)(t - 1) * BP : nullptr, dc, dgates + (long long)t * BP, frag[t & 1], H, BP, rs,
+                       first ? 1 : 0);
+  }
+  return check_launch("lstm_layer_bwd");
 }
 
 extern "C" int fac_tanh_bwd(const float* y, const float* dy, float* dx, int64_t n, fac_stream_t stream) {

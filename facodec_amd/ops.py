@@ -875,6 +875,19 @@ def conv_transpose1d_bwd(x, dy, v, g, stride):
     return dx, dw
 
 
+def lstm_layer_bwd(d_out, w_hh, gates, cs, H):
+    """BPTT of one layer (fac_lstm_layer_bwd): d_out (H, T, BP) gradient of the layer's h sequence -> dgates (4H, T, BP)."""
+    _, T, BP = d_out.shape
+    lib = _lib.load()
+    wt = torch.empty(4 * H * H, device=d_out.device, dtype=torch.float32)
+    _lib.check(lib.fac_pack_lstm_whh_t(_ptr(_dev(w_hh)), _ptr(wt), H, _stream()), "fac_pack_lstm_whh_t")
+    dgates = torch.empty(4 * H, T, BP, device=d_out.device, dtype=torch.float32)
+    scratch = torch.empty(13 * H * BP, device=d_out.device, dtype=torch.float32)
+    _lib.check(lib.fac_lstm_layer_bwd(_ptr(_dev(d_out)), _ptr(wt), _ptr(gates), _ptr(cs), _ptr(dgates), _ptr(scratch), T, H, BP,
+                                      _stream()), "fac_lstm_layer_bwd")
+    return dgates
+
+
 def lstm_gate_bwd(dy_t, rec, gates_t, c_t, c_prev, dc, dgates_t, H, BP, rs, first):
     """Views into (rows, T, BP) buffers at one time step (row stride rs); rec / dc dense (H, BP)."""
     _lib.check(_lib.load().fac_lstm_gate_bwd(_ptr(dy_t), _ptr(rec), _ptr(gates_t), _ptr(c_t), _ptr(c_prev), _ptr(dc),

@@ -221,6 +221,12 @@ int fac_lstm_layer_fwd_train(const float* pre, const float* whh_packed, float* y
  * derivatives from the saved activations -> dgates_t (rows of stride rs), carried dc (H, BP) (first = last time step). */
 int fac_lstm_gate_bwd(const float* dy_t, const float* rec, const float* gates_t, const float* c_t, const float* c_prev,
                       float* dc, float* dgates_t, int H, int BP, int64_t rs, int first, fac_stream_t stream);
+/* Back-propagation through time of one layer in ONE call: for t = T-1 .. 0 the recurrent product W_hh^T dgates_{t+1} (weights from
+ * fac_pack_lstm_whh_t, same element count as W_hh) and the gate derivatives.  dyT (H, T, BP): gradient w.r.t. the layer's h sequence;
+ * gates (4H, T, BP) / cs (H, T, BP): what fac_lstm_layer_fwd_train saved; dgates (4H, T, BP): out.  scratch: 13 * H * BP floats. */
+int fac_pack_lstm_whh_t(const float* w_hh, float* packed, int H, fac_stream_t stream);
+int fac_lstm_layer_bwd(const float* dyT, const float* whh_t_packed, const float* gates, const float* cs, float* dgates, float* scratch,
+                       int T, int H, int BP, fac_stream_t stream);
 /* dx = dy * (1 - y^2) */
 int fac_tanh_bwd(const float* y, const float* dy, float* dx, int64_t n, fac_stream_t stream);
 /* Backward of the spectral losses w.r.t. the estimate: da (+)= scale * d|a - b|/da (mode 0) or
