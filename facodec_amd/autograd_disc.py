@@ -72,24 +72,33 @@ class PlainConv(Function):
                 up = torch.empty(B, c_out, tu, device=dy.device)
                 _call("fac_zero_insert", _p(dy), _p(up), B * c_out, t_out, stride)
             if up is not None:
-                tp = up.shape[-1] + max_off        # full correlation: dxpad[i] = sum_k wflip[k] up[i - max_off + off'_k]
+                # dx[j] = dxpad[j + pad], dxpad[i] = sum_k wflip[k] up[i - max_off + off'_k]: the conv is launched with its left padding
+                # reduced by `pad` and exactly t_in outputs (columns past `up` read zeros), so no padded tensor is sliced or extended
+                pl = max_off - pad
+                if pl >= 0:
+                    tp, shift = t_in, pl
+                else:                     # (not reached by the model's layers: padding larger than the taps' span)
+                    tp, shift = up.shape[-1] + max_off, max_off
                 if ops.split2_ok(c_in, k, k1, 1, B * tp):
                     w = ops.rows_fma(vd, ops.wn_scale(vd, gd)) if gd is not None else vd
                     ws = ops.pack_conv_weight_split2(w.permute(1, 0, 2).flip(2).contiguous(), None, k1)
                     with ops.flop_scale(1.0 / stride):
-                        dxp = ops.conv1d(up, None, c_in, k, pad_left=max_off, pad_mode=ops.PAD_ZERO, t_out=tp, w_split=ws,
+                        dxp = ops.conv1d(up, None, c_in, k, pad_left=shift, pad_mode=ops.PAD_ZERO, t_out=tp, w_split=ws,
                                          k1=k1, dilation2=dil2)
                 elif not k1 and _split_ok(k, 1, c_out, c_in, B * tp):
                     w = ops.rows_fma(vd, ops.wn_scale(vd, gd)) if gd is not None else vd
                     ws = ops.pack_conv_weight_split(w.permute(1, 0, 2).flip(2).contiguous())
-                    dxp = ops.conv1d(up, None, c_in, k, pad_left=k - 1, pad_mode=ops.PAD_ZERO, t_out=tp, w_split=ws)
+                    dxp = ops.conv1d(up, None, c_in, k, pad_left=shift, pad_mode=ops.PAD_ZERO, t_out=tp, w_split=ws)
                 else:
                     with ops.flop_scale(1.0 / stride):        # zero-inserted columns (stride > 1) are not algorithmic work
-                        dxp = ops.conv1d(up, ops.pack_conv_weight_bwd(vd, gd), c_in, k, pad_left=max_off, pad_mode=ops.PAD_ZERO, t_out=tp,
+                        dxp = ops.conv1d(up, ops.pack_conv_weight_bwd(vd, gd), c_in, k, pad_left=shift, pad_mode=ops.PAD_ZERO, t_out=tp,
                                          k1=k1, dilation2=dil2)
-                if tp < pad + t_in:       # trailing inputs no window reads
-                    dxp = torch.cat([dxp, torch.zeros(B, c_in, pad + t_in - tp, device=dy.device)], dim=2)
-                dx = dxp[:, :, pad:pad + t_in].contiguous()
+                if pl >= 0:
+                    dx = dxp
+                else:
+                    if tp < pad + t_in:       # trailing inputs no window reads
+                        dxp = torch.cat([dxp, torch.zeros(B, c_in, pad + t_in - tp, device=dy.device)], dim=2)
+                    dx = dxp[:, :, pad:pad + t_in].contiguous()
         dv = dg = db = None
         want_db = bias is not None and ctx.needs_input_grad[3]
         if ctx.needs_input_grad[1]:       # frozen discriminator (generator step): no weight gradients
