@@ -43,12 +43,14 @@ class _Conv(Function):
     def forward(ctx, x, v, g, bias, cfg):
         k, stride, dilation, pad_mode, causal, act = cfg
         vd, gd = v.detach(), (g.detach() if g is not None else None)
+        sc = ops.wn_scale(vd, gd) if gd is not None else None          # g / ||v||: once per forward, re-used by the backward
         if stride > 1 and dilation == 1 and ops.gemm_split_strided_ok(v.shape[0], v.shape[1], k, stride, x.shape[0], -(-x.shape[-1] // stride)):
-            wp, ws = None, ops.pack_gemm_weight_split(vd, gd, in_stride=stride)     # downsampling conv on the split GEMM kernel
+            wp, ws = None, ops.pack_gemm_weight_split(vd, gd, in_stride=stride, scale=sc)     # downsampling conv on the split GEMM kernel
         elif _split_ok(v.shape[0], v.shape[1], k, stride, x):       # k = 7 / k = 1 convs: fp32-exact split on the bf16 pipe
-            wp, ws = None, ops.pack_conv_weight_split(vd, gd)
+            wp, ws = None, ops.pack_conv_weight_split(vd, gd, scale=sc)
         else:
-            wp, ws = ops.pack_conv_weight(vd, gd), None
+            wp, ws = ops.pack_conv_weight(vd, gd, scale=sc), None
+        ctx.scale = sc
         y = ops.conv1d(x.detach(), wp, v.shape[0], k, bias=bias.detach() if bias is not None else None,
                        stride=stride, dilation=dilation, pad_mode=pad_mode, causal=causal, act=act, w_split=ws)
         ctx.cfg = cfg
@@ -63,8 +65,8 @@ class _Conv(Function):
         if act == ops.ACT_TANH:
             dy = ops.tanh_bwd(y, dy)
         vd, gd = v.detach(), (g.detach() if g is not None else None)
-        dx = ops.conv1d_bwd_data(dy, vd, gd, x.shape[-1], stride=stride, dilation=dilation, pad_mode=pad_mode, causal=causal) \
-            if ctx.needs_input_grad[0] else None
+        dx = ops.conv1d_bwd_data(dy, vd, gd, x.shape[-1], stride=stride, dilation=dilation, pad_mode=pad_mode, causal=causal,
+                                 scale=ctx.scale) if ctx.needs_input_grad[0] else None
         db = None
         if bias is not None:
             dw, db = ops.conv1d_bwd_weight(x.detach(), dy, k, stride=stride, dilation=dilation, pad_mode=pad_mode, causal=causal, want_db=True)
@@ -152,19 +154,21 @@ class _ResUnit(Function):
         c = v7.shape[0]
         xd, xad = x.detach(), xa.detach()
         v7d, g7d, v1d, g1d = v7.detach(), g7.detach(), v1.detach(), g1.detach()
+        s7, s1 = ops.wn_scale(v7d, g7d), ops.wn_scale(v1d, g1d)      # once per forward, re-used by the backward
         if _split_ok(c, v7.shape[1], 7, 1, xad):
-            wp, ws = None, ops.pack_conv_weight_split(v7d, g7d)
+            wp, ws = None, ops.pack_conv_weight_split(v7d, g7d, scale=s7)
         else:
-            wp, ws = ops.pack_conv_weight(v7d, g7d), None
+            wp, ws = ops.pack_conv_weight(v7d, g7d, scale=s7), None
         h, ha = ops.conv1d(xad, wp, c, 7, bias=b7.detach(), dilation=dilation, pad_mode=pad_mode, causal=causal,
                            alpha_y2=a2.detach().reshape(-1), w_split=ws)
         if _split_ok(c, c, 1, 1, ha):
-            wp1, ws1 = None, ops.pack_conv_weight_split(v1d, g1d)
+            wp1, ws1 = None, ops.pack_conv_weight_split(v1d, g1d, scale=s1)
         else:
-            wp1, ws1 = ops.pack_conv_weight(v1d, g1d), None
+            wp1, ws1 = ops.pack_conv_weight(v1d, g1d, scale=s1), None
         y, ya = ops.conv1d(ha, wp1, c, 1, bias=b1.detach(), pad_mode=pad_mode, causal=causal, res=xd,
                            alpha_y2=a_next.detach().reshape(-1), w_split=ws1)
         ctx.cfg = cfg
+        ctx.scales = (s7, s1)
         ctx.save_for_backward(xa, h, ha, y, v7, g7, a2, v1, g1, a_next)
         return y, ya
 
@@ -181,10 +185,11 @@ class _ResUnit(Function):
             da_next = da_next.reshape(a_next.shape)
         else:
             dyt, da_next, db1 = dy.contiguous(), None, ops.bias_grad(dy.contiguous())
-        dha = ops.conv1d_bwd_data(dyt, v1d, g1d, T, pad_mode=pad_mode, causal=causal)
+        s7, s1 = ctx.scales
+        dha = ops.conv1d_bwd_data(dyt, v1d, g1d, T, pad_mode=pad_mode, causal=causal, scale=s1)
         dv1, dg1 = ops.weight_norm_bwd(v1d, g1d, ops.conv1d_bwd_weight(ha.detach(), dyt, 1, pad_mode=pad_mode, causal=causal))
         dh, da2, db7 = ops.snake_bwd_fused(h.detach(), a2.detach().reshape(-1), dha, want_bias=True)
-        dxa = ops.conv1d_bwd_data(dh, v7d, g7d, T, dilation=dilation, pad_mode=pad_mode, causal=causal)
+        dxa = ops.conv1d_bwd_data(dh, v7d, g7d, T, dilation=dilation, pad_mode=pad_mode, causal=causal, scale=s7)
         dv7, dg7 = ops.weight_norm_bwd(v7d, g7d, ops.conv1d_bwd_weight(xa.detach(), dh, 7, dilation=dilation, pad_mode=pad_mode,
                                                                        causal=causal))
         return dyt, dxa, dv7, dg7, db7, da2.reshape(a2.shape), dv1, dg1, db1, da_next, None

@@ -31,14 +31,16 @@ class PlainConv(Function):
         max_off = (k // k1 - 1) * dil2 + (k1 - 1) if k1 else k - 1
         t_out = (t_in + 2 * pad - max_off - 1) // stride + 1
         vd, gd = v.detach().contiguous(), (g.detach().contiguous() if g is not None else None)
+        sc = ops.wn_scale(vd, gd) if gd is not None else None           # once per forward, re-used by the backward
         if ops.split2_ok(v.shape[0], k, k1, stride, B * t_out):
-            wp, ws = None, ops.pack_conv_weight_split2(vd, gd, k1)      # 32-channel (3, 9) / (3, 3) stacks: conv1d_bsplit2.hip
+            wp, ws = None, ops.pack_conv_weight_split2(vd, gd, k1, scale=sc)      # 32-channel (3, 9) / (3, 3) stacks: conv1d_bsplit2.hip
         elif not k1 and stride > 1 and ops.gemm_split_strided_ok(v.shape[0], c_in, k, stride, B, t_out):
-            wp, ws = None, ops.pack_gemm_weight_split(vd, gd, in_stride=stride)     # (5, 1) stride-3 convs: split GEMM over 3 phases
+            wp, ws = None, ops.pack_gemm_weight_split(vd, gd, in_stride=stride, scale=sc)     # (5, 1) stride-3 convs: split GEMM over 3 phases
         elif not k1 and _split_ok(k, stride, c_in, v.shape[0], B * t_out):
-            wp, ws = None, ops.pack_conv_weight_split(vd, gd)
+            wp, ws = None, ops.pack_conv_weight_split(vd, gd, scale=sc)
         else:
-            wp, ws = ops.pack_conv_weight(vd, gd), None
+            wp, ws = ops.pack_conv_weight(vd, gd, scale=sc), None
+        ctx.scale = sc
         y = ops.conv1d(x.detach(), wp, v.shape[0], k, bias=bias.detach() if bias is not None else None,
                        stride=stride, pad_left=pad, pad_mode=ops.PAD_ZERO, t_out=t_out, w_split=ws, k1=k1, dilation2=dil2)
         ctx.cfg = (k, stride, pad, t_in, t_out, k1, dil2, max_off)
@@ -80,18 +82,16 @@ class PlainConv(Function):
                 else:                     # (not reached by the model's layers: padding larger than the taps' span)
                     tp, shift = up.shape[-1] + max_off, max_off
                 if ops.split2_ok(c_in, k, k1, 1, B * tp):
-                    w = ops.rows_fma(vd, ops.wn_scale(vd, gd)) if gd is not None else vd
-                    ws = ops.pack_conv_weight_split2(w.permute(1, 0, 2).flip(2).contiguous(), None, k1)
+                    ws = ops.pack_conv_weight_split2(ops.flipped_weight(vd, gd, ctx.scale), None, k1)
                     with ops.flop_scale(1.0 / stride):
                         dxp = ops.conv1d(up, None, c_in, k, pad_left=shift, pad_mode=ops.PAD_ZERO, t_out=tp, w_split=ws,
                                          k1=k1, dilation2=dil2)
                 elif not k1 and _split_ok(k, 1, c_out, c_in, B * tp):
-                    w = ops.rows_fma(vd, ops.wn_scale(vd, gd)) if gd is not None else vd
-                    ws = ops.pack_conv_weight_split(w.permute(1, 0, 2).flip(2).contiguous())
+                    ws = ops.pack_conv_weight_split(ops.flipped_weight(vd, gd, ctx.scale))
                     dxp = ops.conv1d(up, None, c_in, k, pad_left=shift, pad_mode=ops.PAD_ZERO, t_out=tp, w_split=ws)
                 else:
                     with ops.flop_scale(1.0 / stride):        # zero-inserted columns (stride > 1) are not algorithmic work
-                        dxp = ops.conv1d(up, ops.pack_conv_weight_bwd(vd, gd), c_in, k, pad_left=shift, pad_mode=ops.PAD_ZERO, t_out=tp,
+                        dxp = ops.conv1d(up, ops.pack_conv_weight_bwd(vd, gd, ctx.scale), c_in, k, pad_left=shift, pad_mode=ops.PAD_ZERO, t_out=tp,
                                          k1=k1, dilation2=dil2)
                 if pl >= 0:
                     dx = dxp

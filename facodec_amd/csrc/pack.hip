@@ -117,6 +117,21 @@ __global__ __launch_bounds__(256) void pack_convtr_rows_kernel(const float* __re
   }
 }
 
+// Weights of the data-gradient conv in one pass: out (C_in, C_out, K)[ci][co][k] = v (C_out, C_in, K)[co][ci][K-1-k] * scale[co]
+// (weight norm applied, channels swapped, taps flipped -- torch's rows_fma + permute + flip + contiguous as one launch).
+__global__ __launch_bounds__(256) void flip_transpose_w_kernel(const float* __restrict__ v, const float* __restrict__ scale,
+                                                               float* __restrict__ out, int C_out, int C_in, int K, long long n) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const int k = (int)(i % K);
+    const long long r = i / K;
+    const int co = (int)(r % C_out);
+    const int ci = (int)(r / C_out);
+    float w = v[((long long)co * C_in + ci) * K + (K - 1 - k)];
+    if (scale) w = __fmul_rn(w, scale[co]);
+    out[i] = w;
+  }
+}
+
 // W_hh (4H, H) -> packed[ublk][kg][kq][i][4]: for unit block ublk (8 hidden units) the 32 gate
 // rows i = gate*8 + u, k = kg*8 + 2*jj + kq  (jj = 0..3 is the float4 component).
 __global__ __launch_bounds__(256) void pack_whh_kernel(const float* __restrict__ w,
@@ -184,6 +199,15 @@ extern "C" int fac_pack_convtr_w_rows(const float* v, const float* scale, float*
   hipLaunchKernelGGL(pack_convtr_rows_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, v, scale, packed, C_in, C_out,
                      stride, R_pad, n);
   return check_launch("pack_convtr_w_rows");
+}
+
+extern "C" int fac_flip_transpose_w(const float* v, const float* scale, float* out, int C_out, int C_in, int K, fac_stream_t stream) {
+  using namespace fac;
+  FAC_REQUIRE(v && out && C_out > 0 && C_in > 0 && K > 0, "flip_transpose_w: bad arguments");
+  const long long n = (long long)C_out * C_in * K;
+  const int blocks = (int)((n + 255) / 256 < 65535 ? (n + 255) / 256 : 65535);
+  hipLaunchKernelGGL(flip_transpose_w_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, v, scale, out, C_out, C_in, K, n);
+  return check_launch("flip_transpose_w");
 }
 
 extern "C" int fac_pack_lstm_whh(const float* w_hh, float* packed, int H, fac_stream_t stream) {

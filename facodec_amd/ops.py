@@ -50,7 +50,7 @@ def wn_scale(v, g):
     return scale
 
 
-def pack_conv_weight(v, g=None, out=None):
+def pack_conv_weight(v, g=None, out=None, scale=None):
     """(C_out, C_in, K) [+ weight-norm gain g (C_out,1,1)] -> packed (cin_pad(C_in), K, pad32(C_out));
     the rows of the padding channels are written as zeros by the kernel (no separate fill)."""
     v = _dev(v, "weight")
@@ -58,7 +58,8 @@ def pack_conv_weight(v, g=None, out=None):
         v = v.unsqueeze(-1)
     c_out, c_in, k = v.shape
     cp = pad32(c_out)
-    scale = wn_scale(v, g) if g is not None else None
+    if scale is None and g is not None:
+        scale = wn_scale(v, g)
     if out is None:
         out = torch.empty(cin_pad(c_in), k, cp, device=v.device, dtype=torch.float32)
     _lib.check(_lib.load().fac_pack_conv_w(_ptr(v), _ptr(scale), _ptr(out), c_out, c_in, k, cp, _stream()),
@@ -280,7 +281,7 @@ def gemm_split_strided_ok(c_out, c_in, k, stride, batch, t_out):
             and c_out >= 64 and t_out >= 256 and batch * t_out >= 1024)
 
 
-def pack_gemm_weight_split(v, g=None, out=None, in_stride=1):
+def pack_gemm_weight_split(v, g=None, out=None, in_stride=1, scale=None):
     """(C_out, C_in, K) [weight-normed with g over dim 0] -> fac_pack_gemm_w_split layout (uint8 buffer); K <= 2, or a strided
     conv's taps (in_stride < K <= 2 * in_stride)."""
     v = _dev(v, "weight")
@@ -288,7 +289,8 @@ def pack_gemm_weight_split(v, g=None, out=None, in_stride=1):
         v = v.unsqueeze(-1)
     c_out, c_in, k = v.shape
     lib = _lib.load()
-    scale = wn_scale(v, g) if g is not None else None
+    if scale is None and g is not None:
+        scale = wn_scale(v, g)
     nbytes = lib.fac_gemm_w_split_bytes(c_out, c_in, k, in_stride)
     if out is None:
         out = torch.empty(nbytes, device=v.device, dtype=torch.uint8)
@@ -325,12 +327,13 @@ def split2_ok(c_out, k, k1, stride, n_cols):
             and n_cols >= 4096)
 
 
-def pack_conv_weight_split2(v, g=None, k1=0, out=None):
+def pack_conv_weight_split2(v, g=None, k1=0, out=None, scale=None):
     """(C_out <= 32, C_in, K) [weight-normed with g] -> fac_pack_conv_w_split2 layout (uint8 buffer); k1: taps per level."""
     v = _dev(v, "weight")
     c_out, c_in, k = v.shape
     lib = _lib.load()
-    scale = wn_scale(v, g) if g is not None else None
+    if scale is None and g is not None:
+        scale = wn_scale(v, g)
     nbytes = lib.fac_conv_w_split2_bytes(c_out, c_in, k, k1)
     if out is None:
         out = torch.empty(nbytes, device=v.device, dtype=torch.uint8)
@@ -354,15 +357,16 @@ def pack_convtr_weight_rows_split(v, g, stride, out=None):
     return out, R
 
 
-def pack_conv_weight_split(v, g=None, out=None):
+def pack_conv_weight_split(v, g=None, out=None, scale=None):
     """(C_out, C_in, K) [weight-normed with g] -> split-bf16 layout of fac_pack_conv_w_split (K = 5 / 7; uint8 buffer) or of
     fac_pack_gemm_w_split (K = 1 / 2)."""
     v = _dev(v, "weight")
     c_out, c_in, k = v.shape
     if k <= 2:
-        return pack_gemm_weight_split(v, g, out)
+        return pack_gemm_weight_split(v, g, out, scale=scale)
     lib = _lib.load()
-    scale = wn_scale(v, g) if g is not None else None
+    if scale is None and g is not None:
+        scale = wn_scale(v, g)
     nbytes = lib.fac_conv_w_split_bytes(c_out, c_in, k)
     if out is None:
         out = torch.empty(nbytes, device=v.device, dtype=torch.uint8)
@@ -707,20 +711,36 @@ def aa_snakebeta(x, alpha_log, beta_log, filter12):
 
 
 # --------------------------------------------------------------------------------- backward of the conv stack
-def pack_conv_weight_bwd(v, g=None):
+def flipped_weight(v, g=None, scale=None):
+    """(C_out, C_in, K) [weight-normed] -> (C_in, C_out, K) weights of the data-gradient conv (channels swapped, taps flipped),
+    one launch (fac_flip_transpose_w)."""
+    v = _dev(v, "weight")
+    c_out, c_in, k = v.shape
+    if scale is None and g is not None:
+        scale = wn_scale(v, g)
+    out = torch.empty(c_in, c_out, k, device=v.device, dtype=torch.float32)
+    _lib.check(_lib.load().fac_flip_transpose_w(_ptr(v), _ptr(scale), _ptr(out), c_out, c_in, k, _stream()), "fac_flip_transpose_w")
+    return out
+
+
+def pack_conv_weight_bwd(v, g=None, scale=None):
     """(C_out, C_in, K) [weight-normed] -> packed weights of the bwd-data conv (taps flipped, channels swapped)."""
     v = _dev(v, "weight")
     c_out, c_in, k = v.shape
     packed = torch.empty(cin_pad(c_out), k, pad32(c_in), device=v.device, dtype=torch.float32)
-    scale = wn_scale(v, g) if g is not None else None
+    if scale is None and g is not None:
+        scale = wn_scale(v, g)
     _lib.check(_lib.load().fac_pack_conv_w_bwd(_ptr(v), _ptr(scale), _ptr(packed), c_out, c_in, k, pad32(c_in), _stream()),
                "fac_pack_conv_w_bwd")
     return packed
 
 
-def conv1d_bwd_data(dy, v, g, t_in, stride=1, dilation=1, pad_mode=PAD_REFLECT, causal=True):
-    """Gradient w.r.t. the input of SConv1d (dac/model/encodec.py:212-228) given dy (B, C_out, T_out)."""
+def conv1d_bwd_data(dy, v, g, t_in, stride=1, dilation=1, pad_mode=PAD_REFLECT, causal=True, scale=None):
+    """Gradient w.r.t. the input of SConv1d (dac/model/encodec.py:212-228) given dy (B, C_out, T_out).
+    scale: the weight-norm scale g / ||v|| if the caller already has it (the forward computed it)."""
     dy = _dev(dy, "dy")
+    if scale is None and g is not None:
+        scale = wn_scale(v, g)
     c_out, c_in, k = v.shape
     B, _, t_out = dy.shape
     t_o, padding_total, extra = conv_out_len(t_in, k, stride, dilation)
@@ -731,15 +751,14 @@ def conv1d_bwd_data(dy, v, g, t_in, stride=1, dilation=1, pad_mode=PAD_REFLECT, 
     if (stride == 1 and BF16_SPLIT and c_in % 16 == 0 and c_out % 16 == 0 and B * tp > 640
             and (k == 7 or (k in (3, 5) and c_out >= 64 and c_in > 32))):
         # the flipped / transposed conv on the bf16 pipe too: materialise w = g v/||v||, swap channels, flip taps
-        w = rows_fma(v, wn_scale(v, g)) if g is not None else v
-        wt = w.permute(1, 0, 2).flip(2).contiguous()                       # (C_in, C_out, K) = weights of the bwd conv
+        wt = flipped_weight(v, g, scale)                                   # (C_in, C_out, K) = weights of the bwd conv
         dxpad = conv1d(dy, None, c_in, k, dilation=dilation, pad_left=(k - 1) * dilation, pad_mode=PAD_ZERO, t_out=tp,
                        w_split=pack_conv_weight_split(wt))
     elif stride == 1 and k == 1 and gemm_split_ok(c_in, c_out, 1, B * tp):
-        w = rows_fma(v, wn_scale(v, g)) if g is not None else v           # 1x1: the transposed GEMM on the bf16 pipe
+        w = rows_fma(v, scale) if g is not None else v                    # 1x1: the transposed GEMM on the bf16 pipe
         dxpad = conv1d(dy, None, c_in, 1, pad_left=0, pad_mode=PAD_ZERO, t_out=tp, w_split=pack_gemm_weight_split_t(w))
     elif stride == 1:
-        dxpad = conv1d(dy, pack_conv_weight_bwd(v, g), c_in, k, dilation=dilation, pad_left=(k - 1) * dilation,
+        dxpad = conv1d(dy, pack_conv_weight_bwd(v, g, scale), c_in, k, dilation=dilation, pad_left=(k - 1) * dilation,
                        pad_mode=PAD_ZERO, t_out=tp)
     else:
         if k != 2 * stride or dilation != 1:

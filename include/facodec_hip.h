@@ -333,6 +333,10 @@ int fac_crop_rows(const float* src, float* dst, const int64_t* start, int B, int
 int fac_stream_push(float* buf, const float* src, int64_t rows, int64_t cap, int hist, int n_prev, int n_new,
                     fac_stream_t stream);
 
+/* Weights of a conv's data-gradient conv for the split-bf16 kernels, materialised in one pass: out (C_in, C_out, K)[ci][co][k] =
+ * v (C_out, C_in, K)[co][ci][K-1-k] * scale[co] (scale: fac_wn_scale or NULL).  Pack the result with fac_pack_conv_w_split* . */
+int fac_flip_transpose_w(const float* v, const float* scale, float* out, int C_out, int C_in, int K, fac_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * Backward of the conv stack (first kernels of the training step; autograd semantics of
  * dac/model/encodec.py SConv1d / SConvTranspose1d, dac/nn/layers.py snake, weight_norm).
