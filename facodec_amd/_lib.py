@@ -67,6 +67,10 @@ SIGNATURES = {
     "fac_snake_bwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
     "fac_pack_lstm_whh_t": (_i, [_p, _p, _i, _p]),
     "fac_lstm_layer_bwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
+    "fac_lstm_persist_ok": (_i, [_i, _i]),
+    "fac_pack_lstm_whh16": (_i, [_p, _p, _i, _i, _p]),
+    "fac_lstm_layer_fwd_persist": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
+    "fac_lstm_layer_bwd_persist": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "fac_snake_bwd_fused": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
     "fac_bias_grad": (_i, [_p, _p, _p, _i, _i, _i, _p]),
     "fac_pack_convtr_w": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),

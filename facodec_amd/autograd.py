@@ -234,7 +234,10 @@ class _LSTM(Function):
                                  w_split=ops.pack_gemm_weight_split(w_ih) if use_split else None)
                 gates = torch.empty(4 * H, T, BP, device=x.device)
                 cs = torch.empty(H, T, BP, device=x.device)
-                yT = ops.lstm_layer(pre.view(4 * H, T, BP), ops.pack_lstm_whh(w_hh), H, save=(gates, cs))
+                if ops.lstm_persist_ok(H, B):      # whole layer in one launch, W_hh resident in registers
+                    yT = ops.lstm_layer_persist(pre.view(4 * H, T, BP), w_hh, H, B, save=(gates, cs))
+                else:
+                    yT = ops.lstm_layer(pre.view(4 * H, T, BP), ops.pack_lstm_whh(w_hh), H, save=(gates, cs))
             saved.append((inp, yT, gates, cs))
             inp = yT
         ctx.saved = saved
@@ -259,7 +262,7 @@ class _LSTM(Function):
             w_ih, w_hh, _, _ = (p.detach() for p in params[4 * l: 4 * l + 4])
             inp, yT, gates, cs = ctx.saved[l]
             if _LSTM_BWD_FUSED:       # whole recurrence of the layer in one C call, two launches per step (lstm.hip)
-                dgates = ops.lstm_layer_bwd(d_out.contiguous(), w_hh, gates, cs, H)
+                dgates = ops.lstm_layer_bwd(d_out.contiguous(), w_hh, gates, cs, H, batch=B)
             else:
                 dgates = torch.empty(4 * H, T, BP, device=dy.device)
                 dc = torch.zeros(H, BP, device=dy.device)

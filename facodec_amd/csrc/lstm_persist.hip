@@ -1,0 +1,500 @@
+// K5p: the SLSTM recurrence (dac/model/encodec.py:272-288, nn.LSTM gate order i,f,g,o, zero initial state) and its
+// back-propagation through time as ONE launch per layer.
+//
+// lstm.hip launches one kernel per time step; every step then re-streams its 128-192 KB slice of W_hh per workgroup
+// and pays a kernel boundary.  Here the H/8 workgroups of a layer (192 at H = 1536, 128 at H = 1024: fewer than the
+// 256 CUs, one workgroup of 16 waves per CU) stay resident for the whole sequence:
+//   * each lane keeps its 2 * H/64 weights of W_hh in registers for all T steps (the slice of a workgroup is exactly
+//     the register file of its waves: 48 VGPRs at H = 1536) -- W_hh is read from memory once per layer, not once per step;
+//   * the batch is handled in 16-column blocks on v_mfma_f32_16x16x4_f32 (B = 16 is one block; the per-step kernel's
+//     32x32x2 tile spends half its MFMA time on the padded columns 16..31);
+//   * the cell state lives in a register of the thread that owns the (unit, column);
+//   * steps are separated by a device-wide flag exchange instead of a kernel boundary: workgroup i publishes
+//     "finished step t" with one release store to flags[i]; a waiter reads all flags with ONE wave-wide load per poll
+//     (no read-modify-write, nothing serialises on a counter), then an agent-scope acquire makes h_{t} visible across
+//     the XCDs' L2s.  The flags hold epoch + step; the epoch advances by T per launch (last workgroup out), so a
+//     replayed hipGraph needs no host-side reset.  A waiter that sees no progress for ~4 s traps (loud launch failure)
+//     instead of hanging the queue.
+// Requirements (fac_lstm_persist_ok): H a multiple of 256 with H/64 in {8, 16, 24}, B <= 32, H/8 <= CUs of the device,
+// zero initial state.  Everything else (streaming sessions that carry state, larger batches) stays on lstm.hip.
+//
+// Operand layouts (v_mfma_f32_16x16x4_f32: A lane l = row l%16, k l/16; B lane l = k l/16, col l%16; D lane l, reg r =
+// row 4*(l/16)+r, col l%16).  Wave w of a workgroup contracts k in [w*H/16, (w+1)*H/16) in KS = H/64 MFMA steps:
+//   weights  packed[(blk*16 + w)*(KS/2) + j][lane] float4 = {A(s=2j, rb=0), A(2j, 1), A(2j+1, 0), A(2j+1, 1)},
+//            A(s, rb) = M[row(blk, rb*16 + l%16)][k0(blk) + w*H/16 + 4*s + l/16]            (fac_pack_lstm_whh16)
+//   state    frag[(cb*16 + w)*(KS/4) + j4][lane] float4 component jj = X[k = w*H/16 + 4*(4*j4+jj) + l/16][cb*16 + l%16]
+#include <stdlib.h>
+
+#include <mutex>
+#include <unordered_map>
+
+#include "common.h"
+
+namespace fac {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int LSTM_SYNC_SLOTS = 64;
+constexpr int LSTM_MAX_WG = 256;
+struct alignas(256) LstmSync {
+  unsigned epoch;                 // flags of finished launches are <= epoch
+  unsigned done;                  // workgroups that left the current launch
+  unsigned pad[62];
+  unsigned flags[LSTM_MAX_WG];    // flags[i] = epoch + n: workgroup i finished exchange point n of this launch
+  unsigned flags2[LSTM_MAX_WG];   // second exchange point of a BPTT step
+};
+__device__ LstmSync g_lstm_sync[LSTM_SYNC_SLOTS];
+
+constexpr long long LSTM_SPIN_LIMIT = 400000000ll;   // wall_clock64 ticks (100 MHz): 4 s without progress -> trap
+
+// wave 0: wait until flags[first .. first+count) have all reached `target`; then the workgroup passes a barrier and
+// every wave takes an agent-scope acquire (stale L1 / L2 lines of the exchanged buffers are dropped).
+// Exchange modes.  0: cache maintenance (buffer_wbl2 / buffer_inv) around plain accesses.  1: every exchanged word moves with
+// agent-scope (sc1) stores and loads, ordered by s_waitcnt only -- no L2 write-back / invalidate per step, but every
+// workgroup's copy of h_t comes from the memory side.  2: sc1 stores into a FRESH region per step, each workgroup writing
+// whole cache lines of its own; the consumers read with plain loads: no XCD can hold an older copy of a line that did
+// not exist before, so the first reader of an XCD misses to memory and the other 23 workgroups of that XCD hit its L2.
+__device__ __forceinline__ void wait_flags(const unsigned* flags, int first, int count, unsigned target, int mode) {
+  if ((threadIdx.x >> 6) == 0) {
+    const int lane = threadIdx.x & 63;
+    const long long t0 = wall_clock64();
+    for (unsigned it = 1;; ++it) {
+      bool behind;
+      if (count <= 64) {
+        const int i = lane < count ? lane : count - 1;
+        const unsigned f = __hip_atomic_load(flags + first + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        behind = (int)(f - target) < 0;
+      } else {   // all LSTM_MAX_WG flags in ONE wave-wide agent-scope load (first == 0; the array is 16-byte aligned)
+        u32x4 f;
+        asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(f) : "v"(flags + 4 * lane) : "memory");
+        behind = false;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) behind |= (4 * lane + c < count) && (int)(f[c] - target) < 0;
+      }
+      if (__ballot(behind) == 0ull) break;
+      __builtin_amdgcn_s_sleep(1);
+      if ((it & 1023u) == 0 && wall_clock64() - t0 > LSTM_SPIN_LIMIT) __builtin_trap();
+    }
+  }
+  __syncthreads();
+  if (mode == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+}
+
+__device__ __forceinline__ f32x4 load_agent_x4(const f32x4* p) {
+  f32x4 v;
+  asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
+  return v;
+}
+__device__ __forceinline__ void store_agent(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float load_agent(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// the stores of this workgroup (issued by threads tid < n_store, a multiple of 64) become visible device-wide, then flag
+__device__ __forceinline__ void publish_flag(unsigned* flag, unsigned value, int n_store, int mode) {
+  if (mode == 0) {
+    if ((int)threadIdx.x < n_store) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(flag, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the write-through (sc1) stores of this wave are acknowledged
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(flag, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+__device__ __forceinline__ unsigned launch_epoch(LstmSync* sync, unsigned* s_base) {
+  if (threadIdx.x == 0) *s_base = __hip_atomic_load(&sync->epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  return *s_base;
+}
+
+// last workgroup out advances the epoch past every flag value of this launch
+__device__ __forceinline__ void leave_launch(LstmSync* sync, unsigned base, unsigned advance, unsigned nwg) {
+  if (threadIdx.x == 0) {
+    const unsigned d = __hip_atomic_fetch_add(&sync->done, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    if (d == nwg - 1) {
+      __hip_atomic_store(&sync->done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&sync->epoch, base + advance, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
+// Contraction index <-> hidden unit.  Within every 16 units, unit 8p + e sits at k = 4*(e>>1) + 2p + (e&1): the 8 units a
+// workgroup produces per step then fill, for all 16 columns, the float4s of 32 consecutive lanes of one fragment block --
+// 512 contiguous bytes = four whole 128-byte lines that no other workgroup writes (mode 2 relies on this).
+__host__ __device__ __forceinline__ int k_of_unit(int unit) {
+  const int u16 = unit & 15, p = u16 >> 3, e = u16 & 7;
+  return (unit & ~15) + ((e >> 1) << 2) + 2 * p + (e & 1);
+}
+__host__ __device__ __forceinline__ int unit_of_k(int k) {
+  const int r = k & 15, jj = r >> 2, kq = r & 3;
+  return (k & ~15) + 8 * (kq >> 1) + 2 * jj + (kq & 1);
+}
+
+// position of X[unit][col] in the fragment-ordered exchange buffer (see the header of this file)
+__device__ __forceinline__ long long frag_index(int unit, int col, int H, int KS) {
+  const int k = k_of_unit(unit);
+  const int kw = H >> 4;                 // k per wave
+  const int w = k / kw, rem = k - w * kw;
+  const int s = rem >> 2, kq = rem & 3;
+  const int j4 = s >> 2, jj = s & 3;
+  const int cb = col >> 4, c16 = col & 15;
+  return ((((long long)(cb * 16 + w) * (KS >> 2) + j4) * 64 + kq * 16 + c16) << 2) + jj;
+}
+
+// One wave's share of  D(32 x NCB*16) += A(32 x H/16) * X(H/16 x NCB*16)  from its register-resident weights; the 16
+// partial results of the workgroup meet in `red`.
+template <int KS, int NCB>
+__device__ __forceinline__ void wave_product(const float4 (&a4)[KS / 2], const float* frag, int wave, int lane,
+                                             float (*red)[32][NCB * 16 + 1], int mode) {
+  f32x4 acc[2][NCB];
+#pragma unroll
+  for (int cb = 0; cb < NCB; ++cb) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      acc[0][cb][r] = 0.f;
+      acc[1][cb][r] = 0.f;
+    }
+  }
+#pragma unroll
+  for (int cb = 0; cb < NCB; ++cb) {
+    const f32x4* bp = reinterpret_cast<const f32x4*>(frag) + ((long long)(cb * 16 + wave) * (KS / 4)) * 64 + lane;
+    f32x4 b4[KS / 4];
+    if (mode != 1) {
+#pragma unroll
+      for (int j = 0; j < KS / 4; ++j) b4[j] = bp[(long long)j * 64];
+    } else {
+#pragma unroll
+      for (int j = 0; j < KS / 4; ++j) b4[j] = load_agent_x4(bp + (long long)j * 64);
+#pragma unroll
+      for (int j = 0; j < KS / 4; ++j) asm volatile("s_waitcnt vmcnt(0)" : "+v"(b4[j])::"memory");
+    }
+#pragma unroll
+    for (int j = 0; j < KS / 4; ++j) {
+      const float bv[4] = {b4[j][0], b4[j][1], b4[j][2], b4[j][3]};
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+        const int s = 4 * j + jj;
+        const float4 a = a4[s >> 1];
+        const float a0 = (s & 1) ? a.z : a.x;
+        const float a1 = (s & 1) ? a.w : a.y;
+        acc[0][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, bv[jj], acc[0][cb], 0, 0, 0);
+        acc[1][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, bv[jj], acc[1][cb], 0, 0, 0);
+      }
+    }
+  }
+  const int c16 = lane & 15, r0 = 4 * (lane >> 4);
+#pragma unroll
+  for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[wave][rb * 16 + r0 + r][cb * 16 + c16] = acc[rb][cb][r];
+}
+
+// ---------------------------------------------------------------------------------------------------------- forward
+// grid = H/8 workgroups of 1024 threads; workgroup ub owns hidden units ub*8 .. +8 (32 gate rows q*8+u).
+template <int KS, int NCB>
+__global__ __launch_bounds__(1024) void lstm_fwd_persist_kernel(const float* __restrict__ pre,     // (4H, T, BP)
+                                                                const float* __restrict__ whh16,   // fac_pack_lstm_whh16(.., 0)
+                                                                float* hfrag,                      // T x H*NC, fragment order
+                                                                float* __restrict__ yT,            // (H, T, BP)
+                                                                float* __restrict__ save_g,        // (4H, T, BP) or null
+                                                                float* __restrict__ save_c,        // (H, T, BP) or null
+                                                                int slot, int T, int H, int BP, int mode) {
+  constexpr int NC = NCB * 16;
+  __shared__ float red[16][32][NC + 1];
+  __shared__ unsigned s_base;
+  LstmSync* sync = &g_lstm_sync[slot];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ub = blockIdx.x, nwg = gridDim.x;
+  const long long rs = (long long)T * BP;
+
+  float4 a4[KS / 2];
+  {
+    const float4* ap = reinterpret_cast<const float4*>(whh16) + ((long long)(ub * 16 + wave) * (KS / 2)) * 64 + lane;
+#pragma unroll
+    for (int j = 0; j < KS / 2; ++j) a4[j] = ap[(long long)j * 64];
+  }
+  const unsigned base = launch_epoch(sync, &s_base);
+
+  const bool gate_thread = tid < 8 * NC;
+  const int u = tid / NC, col = tid - u * NC;
+  const int unit = ub * 8 + u;
+  float pre_v[4] = {0.f, 0.f, 0.f, 0.f};
+  float c_reg = 0.f;
+  if (gate_thread) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) pre_v[q] = pre[(long long)(q * H + unit) * rs + col];
+  }
+  const long long hpos = gate_thread ? frag_index(unit, col, H, KS) : 0;
+  const long long hbuf = (long long)H * NC;
+
+  for (int t = 0; t < T; ++t) {
+    float gate[4] = {pre_v[0], pre_v[1], pre_v[2], pre_v[3]};
+    if (t > 0) {
+      wait_flags(sync->flags, 0, nwg, base + (unsigned)t, mode);  // every workgroup has published h_{t-1}
+      wave_product<KS, NCB>(a4, hfrag + (mode == 2 ? t - 1 : (t - 1) & 1) * hbuf, wave, lane, red, mode);
+      __syncthreads();
+      if (gate_thread) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float s = 0.f;
+#pragma unroll
+          for (int w = 0; w < 16; ++w) s += red[w][q * 8 + u][col];
+          gate[q] += s;
+        }
+      }
+    }
+    if (gate_thread) {
+      const float ig = sigmoid_f(gate[0]);
+      const float fg = sigmoid_f(gate[1]);
+      const float gg = tanhf(gate[2]);
+      const float og = sigmoid_f(gate[3]);
+      const float c_new = __fadd_rn(__fmul_rn(fg, c_reg), __fmul_rn(ig, gg));
+      c_reg = c_new;
+      const float hv = __fmul_rn(og, tanhf(c_new));
+      if (t + 1 < T) store_agent(hfrag + (mode == 2 ? t : t & 1) * hbuf + hpos, hv);   // first: its write-through is the critical path
+      const long long o = (long long)unit * rs + (long long)t * BP + col;
+      yT[o] = hv;
+      if (save_g != nullptr) {
+        save_g[o] = ig;
+        save_g[(long long)H * rs + o] = fg;
+        save_g[2ll * H * rs + o] = gg;
+        save_g[3ll * H * rs + o] = og;
+        save_c[o] = c_new;
+      }
+    }
+    if (t + 1 < T) {
+      publish_flag(sync->flags + ub, base + (unsigned)t + 1u, 8 * NC, mode);
+      if (gate_thread) {      // next step's gate pre-activations arrive while the flags are polled
+#pragma unroll
+        for (int q = 0; q < 4; ++q) pre_v[q] = pre[(long long)(q * H + unit) * rs + (long long)(t + 1) * BP + col];
+      }
+    }
+  }
+  leave_launch(sync, base, (unsigned)T, (unsigned)nwg);
+}
+
+// --------------------------------------------------------------------------------------------------------- backward
+// grid = H/8 workgroups: workgroup (ub, q) = blockIdx.x / 4, blockIdx.x % 4 computes, for the 32 hidden units
+// ub*32 .. +32, the quarter-q part of  W_hh^T dgates_{t+1}  (contraction over the H gate rows q*H .. q*H+H) and then
+// the gate derivatives of the 8 units ub*32 + q*8 .. +8.  Two exchange points per step: the four quarter sums of a
+// unit block meet (4 flags), then dgates_t is published to everyone.
+template <int KS, int NCB>
+__global__ __launch_bounds__(1024) void lstm_bwd_persist_kernel(const float* __restrict__ dyT,     // (H, T, BP)
+                                                                const float* __restrict__ whh16t,  // fac_pack_lstm_whh16(.., 1)
+                                                                const float* __restrict__ gates,   // (4H, T, BP) saved
+                                                                const float* __restrict__ cs,      // (H, T, BP) saved
+                                                                float* __restrict__ dgates,        // (4H, T, BP) out
+                                                                float* partial,                    // (4, H, NC)
+                                                                float* dgfrag,                     // T x 4 x H*NC, fragment order
+                                                                int slot, int T, int H, int BP, int mode) {
+  constexpr int NC = NCB * 16;
+  __shared__ float red[16][32][NC + 1];
+  __shared__ unsigned s_base;
+  LstmSync* sync = &g_lstm_sync[slot];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wg = blockIdx.x, nwg = gridDim.x;
+  const int ub = wg >> 2, q = wg & 3;
+  const long long rs = (long long)T * BP;
+  const long long hbuf = (long long)H * NC;
+
+  float4 a4[KS / 2];
+  {
+    const float4* ap = reinterpret_cast<const float4*>(whh16t) + ((long long)(wg * 16 + wave) * (KS / 2)) * 64 + lane;
+#pragma unroll
+    for (int j = 0; j < KS / 2; ++j) a4[j] = ap[(long long)j * 64];
+  }
+  const unsigned base = launch_epoch(sync, &s_base);
+
+  const bool gate_thread = tid < 8 * NC;
+  const int u = tid / NC, col = tid - u * NC;
+  const int unit = ub * 32 + q * 8 + u;
+  const long long hpos = gate_thread ? frag_index(unit, col, H, KS) : 0;
+  float dc_reg = 0.f;
+
+  for (int n = 0; n < T; ++n) {
+    const int t = T - 1 - n;
+    // the saved activations do not depend on the exchange: fetch them first
+    float ig = 0.f, fg = 0.f, gg = 0.f, og = 0.f, ct = 0.f, cp = 0.f, dh = 0.f;
+    const long long o = (long long)unit * rs + (long long)t * BP + col;
+    if (gate_thread) {
+      ig = gates[o];
+      fg = gates[(long long)H * rs + o];
+      gg = gates[2ll * H * rs + o];
+      og = gates[3ll * H * rs + o];
+      ct = cs[o];
+      cp = t > 0 ? cs[o - BP] : 0.f;
+      dh = dyT[o];
+    }
+    if (n > 0) {
+      wait_flags(sync->flags2, 0, nwg, base + (unsigned)n, mode);   // dgates_{t+1} of every unit is published
+      wave_product<KS, NCB>(a4, dgfrag + (mode == 2 ? n - 1 : (n - 1) & 1) * 4 * hbuf + q * hbuf, wave, lane, red, mode);
+      __syncthreads();
+      for (int e = tid; e < 32 * NC; e += 1024) {
+        const int row = e / NC, c = e - row * NC;
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) s += red[w][row][c];
+        store_agent(partial + (long long)q * hbuf + (long long)(ub * 32 + row) * NC + c, s);
+      }
+      publish_flag(sync->flags + wg, base + (unsigned)n, 1024, mode);
+      wait_flags(sync->flags, ub * 4, 4, base + (unsigned)n, mode);   // the four quarter sums of this unit block
+      if (gate_thread) {
+        const float* pp = partial + (long long)unit * NC + col;
+        dh += ((load_agent(pp) + load_agent(pp + hbuf)) + (load_agent(pp + 2 * hbuf) + load_agent(pp + 3 * hbuf)));
+      }
+    }
+    if (gate_thread) {
+      const float tc = tanhf(ct);
+      const float d_o = dh * tc;
+      const float dcv = dh * og * (1.f - tc * tc) + dc_reg;
+      dc_reg = dcv * fg;
+      float dg[4];
+      dg[0] = dcv * gg * ig * (1.f - ig);
+      dg[1] = dcv * cp * fg * (1.f - fg);
+      dg[2] = dcv * ig * (1.f - gg * gg);
+      dg[3] = d_o * og * (1.f - og);
+      if (n + 1 < T) {      // first: their write-through is the critical path
+#pragma unroll
+        for (int g = 0; g < 4; ++g) store_agent(dgfrag + (mode == 2 ? n : n & 1) * 4 * hbuf + g * hbuf + hpos, dg[g]);
+      }
+#pragma unroll
+      for (int g = 0; g < 4; ++g) dgates[(long long)g * H * rs + o] = dg[g];
+    }
+    if (n + 1 < T) publish_flag(sync->flags2 + wg, base + (unsigned)n + 1u, 8 * NC, mode);
+  }
+  leave_launch(sync, base, (unsigned)T, (unsigned)nwg);
+}
+
+// W_hh (4H, H) -> register fragments of the persistent kernels.  transposed = 0 (forward): block = 8 hidden units,
+// row r32 = gate*8 + u of W_hh, k = hidden index.  transposed = 1 (BPTT): block = (32 hidden units, gate quarter q),
+// row r32 = unit within the block, k = the H gate rows of quarter q:  A = W_hh[q*H + k][unit].
+__global__ __launch_bounds__(256) void pack_whh16_kernel(const float* __restrict__ w, float* __restrict__ out, int H, int transposed) {
+  const long long n = (long long)4 * H * H;
+  const int KS = H >> 6, kw = H >> 4;
+  for (long long o = (long long)blockIdx.x * 256 + threadIdx.x; o < n; o += (long long)gridDim.x * 256) {
+    const int comp = (int)(o & 3);
+    const int lane = (int)((o >> 2) & 63);
+    long long rest = o >> 8;
+    const int j = (int)(rest % (KS >> 1));
+    rest /= (KS >> 1);
+    const int wv = (int)(rest & 15);
+    const int blk = (int)(rest >> 4);
+    const int s = 2 * j + (comp >> 1), rb = comp & 1;
+    const int r32 = rb * 16 + (lane & 15);
+    const int k = wv * kw + 4 * s + (lane >> 4);
+    float v;
+    if (!transposed) {
+      const int gate = r32 >> 3, uu = r32 & 7;
+      v = w[(long long)(gate * H + blk * 8 + uu) * H + unit_of_k(k)];
+    } else {
+      const int ubk = blk >> 2, qq = blk & 3;
+      v = w[(long long)(qq * H + unit_of_k(k)) * H + ubk * 32 + r32];
+    }
+    out[o] = v;
+  }
+}
+
+static int lstm_sync_slot(hipStream_t stream) {
+  static std::mutex mu;
+  static std::unordered_map<hipStream_t, int> slots;
+  std::lock_guard<std::mutex> lock(mu);
+  auto it = slots.find(stream);
+  if (it != slots.end()) return it->second;
+  if ((int)slots.size() >= LSTM_SYNC_SLOTS) return -1;
+  const int s = (int)slots.size();
+  slots.emplace(stream, s);
+  return s;
+}
+
+static int device_cus() {
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess) cus = v;
+  }
+  return cus;
+}
+
+// FAC_LSTM_EXCHANGE = fence (mode 0) | sc1 (mode 1) | fresh (mode 2, default)
+static int exchange_mode() {
+  static int mode = -1;
+  if (mode < 0) {
+    const char* e = getenv("FAC_LSTM_EXCHANGE");
+    mode = e == nullptr ? 2 : (e[0] == 'f' && e[1] == 'e') ? 0 : e[0] == 's' ? 1 : 2;
+  }
+  return mode;
+}
+
+static bool persist_shape_ok(int H, int B) {
+  if (H <= 0 || H % 256 != 0 || B <= 0 || B > 32) return false;
+  const int ks = H / 64;
+  if (ks != 8 && ks != 16 && ks != 24) return false;
+  const int wgs = H / 8;
+  return wgs <= LSTM_MAX_WG && wgs <= device_cus();
+}
+
+}  // namespace fac
+
+extern "C" int fac_lstm_persist_ok(int H, int B) { return fac::persist_shape_ok(H, B) ? 1 : 0; }
+
+extern "C" int fac_pack_lstm_whh16(const float* w_hh, float* packed, int H, int transposed, fac_stream_t stream) {
+  using namespace fac;
+  FAC_REQUIRE(w_hh && packed && H > 0 && H % 256 == 0, "pack_lstm_whh16: H must be a multiple of 256");
+  hipLaunchKernelGGL(pack_whh16_kernel, dim3(2048), dim3(256), 0, (hipStream_t)stream, w_hh, packed, H, transposed ? 1 : 0);
+  return check_launch("pack_lstm_whh16");
+}
+
+extern "C" int fac_lstm_layer_fwd_persist(const float* pre, const float* whh16, float* hfrag, float* yT, float* gates_save,
+                                          float* c_save, int T, int H, int B, int BP, fac_stream_t stream) {
+  using namespace fac;
+  FAC_REQUIRE(pre && whh16 && hfrag && yT, "lstm_layer_fwd_persist: null pointer");
+  FAC_REQUIRE((gates_save == nullptr) == (c_save == nullptr), "lstm_layer_fwd_persist: gates_save and c_save go together");
+  FAC_REQUIRE(T > 0 && BP >= B && BP % 32 == 0, "lstm_layer_fwd_persist: bad T / BP");
+  FAC_REQUIRE(persist_shape_ok(H, B), "lstm_layer_fwd_persist: H=%d B=%d is outside the resident kernel (fac_lstm_persist_ok)", H, B);
+  const int slot = lstm_sync_slot((hipStream_t)stream);
+  FAC_REQUIRE(slot >= 0, "lstm_layer_fwd_persist: more than %d streams in use", LSTM_SYNC_SLOTS);
+  const int ncb = (B + 15) / 16;
+  void (*kern)(const float*, const float*, float*, float*, float*, float*, int, int, int, int, int) = nullptr;
+  switch ((H / 64) * 10 + ncb) {
+    case 81: kern = lstm_fwd_persist_kernel<8, 1>; break;
+    case 82: kern = lstm_fwd_persist_kernel<8, 2>; break;
+    case 161: kern = lstm_fwd_persist_kernel<16, 1>; break;
+    case 162: kern = lstm_fwd_persist_kernel<16, 2>; break;
+    case 241: kern = lstm_fwd_persist_kernel<24, 1>; break;
+    case 242: kern = lstm_fwd_persist_kernel<24, 2>; break;
+  }
+  FAC_REQUIRE(kern != nullptr, "lstm_layer_fwd_persist: no kernel for H=%d", H);
+  hipLaunchKernelGGL(kern, dim3(H / 8), dim3(1024), 0, (hipStream_t)stream, pre, whh16, hfrag, yT, gates_save, c_save, slot, T, H, BP,
+                     exchange_mode());
+  return check_launch("lstm_layer_fwd_persist");
+}
+
+extern "C" int fac_lstm_layer_bwd_persist(const float* dyT, const float* whh16t, const float* gates, const float* cs, float* dgates,
+                                          float* scratch, int T, int H, int B, int BP, fac_stream_t stream) {
+  using namespace fac;
+  FAC_REQUIRE(dyT && whh16t && gates && cs && dgates && scratch, "lstm_layer_bwd_persist: null pointer");
+  FAC_REQUIRE(T > 0 && BP >= B && BP % 32 == 0, "lstm_layer_bwd_persist: bad T / BP");
+  FAC_REQUIRE(persist_shape_ok(H, B), "lstm_layer_bwd_persist: H=%d B=%d is outside the resident kernel (fac_lstm_persist_ok)", H, B);
+  const int slot = lstm_sync_slot((hipStream_t)stream);
+  FAC_REQUIRE(slot >= 0, "lstm_layer_bwd_persist: more than %d streams in use", LSTM_SYNC_SLOTS);
+  const int ncb = (B + 15) / 16;
+  const long long hbuf = (long long)H * ncb * 16;
+  float* partial = scratch;              // scratch = [partial 4*H*NC | dgates fragments T * 4*H*NC]
+  float* dgfrag = scratch + 4 * hbuf;
+  void (*kern)(const float*, const float*, const float*, const float*, float*, float*, float*, int, int, int, int, int) = nullptr;
+  switch ((H / 64) * 10 + ncb) {
+    case 81: kern = lstm_bwd_persist_kernel<8, 1>; break;
+    case 82: kern = lstm_bwd_persist_kernel<8, 2>; break;
+    case 161: kern = lstm_bwd_persist_kernel<16, 1>; break;
+    case 162: kern = lstm_bwd_persist_kernel<16, 2>; break;
+    case 241: kern = lstm_bwd_persist_kernel<24, 1>; break;
+    case 242: kern = lstm_bwd_persist_kernel<24, 2>; break;
+  }
+  FAC_REQUIRE(kern != nullptr, "lstm_layer_bwd_persist: no kernel for H=%d", H);
+  hipLaunchKernelGGL(kern, dim3(H / 8), dim3(1024), 0, (hipStream_t)stream, dyT, whh16t, gates, cs, dgates, partial, dgfrag, slot, T, H, BP,
+                     exchange_mode());
+  return check_launch("lstm_layer_bwd_persist");
+}

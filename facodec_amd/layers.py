@@ -204,7 +204,8 @@ class _LSTMParams(nn.Module):
 class SLSTM(nn.Module):
     """dac/model/encodec.py:272-288: multi-layer LSTM over time on (B, C, T) plus skip.
     Input projections run as ONE GEMM per layer on the MFMA conv kernel over the channel-major
-    (H, T*BP) work buffer; the recurrence is fac_lstm_layer_fwd (one launch per step)."""
+    (H, T*BP) work buffer; the recurrence is one resident launch per layer (fac_lstm_layer_fwd_persist) where it
+    applies, else fac_lstm_layer_fwd (one launch per step)."""
 
     def __init__(self, dimension, num_layers=2, skip=True):
         super().__init__()
@@ -223,11 +224,15 @@ class SLSTM(nn.Module):
             w_ih = None if use_split else ops.pack_conv_weight(w_raw)
             w_ih_split = ops.pack_gemm_weight_split(w_raw) if use_split else None
             bias = ops.add(getattr(p, f"bias_ih_l{l}").detach(), getattr(p, f"bias_hh_l{l}").detach())
-            whh = ops.pack_lstm_whh(getattr(p, f"weight_hh_l{l}").detach())
+            w_hh = getattr(p, f"weight_hh_l{l}").detach()
+            persist = ops.lstm_persist_ok(H, B)
             T_, BP = inp.shape[1], inp.shape[2]
             # one GEMM over every (t, b): the channel-major buffer is a (1, H, T*BP) "signal"
             with ops.flop_scale(B / BP):
                 pre = ops.conv1d(inp.view(1, H, T_ * BP), w_ih, 4 * H, 1, bias=bias, pad_left=0, t_out=T_ * BP,
                                  pad_mode=ops.PAD_ZERO, w_split=w_ih_split)
-                inp = ops.lstm_layer(pre.view(4 * H, T_, BP), whh, H)
+                if persist:     # whole layer in one launch, W_hh resident in registers (lstm_persist.hip)
+                    inp = ops.lstm_layer_persist(pre.view(4 * H, T_, BP), w_hh, H, B)
+                else:
+                    inp = ops.lstm_layer(pre.view(4 * H, T_, BP), ops.pack_lstm_whh(w_hh), H)
         return ops.lstm_from_time_major(inp, x if self.skip else None, B, alpha_out)

@@ -510,6 +510,51 @@ def pack_lstm_whh(w_hh, out=None):
     return out
 
 
+LSTM_PERSIST = os.environ.get("FAC_LSTM_PERSIST", "1") != "0"
+LSTM_PERSIST_MAX_BATCH = int(os.environ.get("FAC_LSTM_PERSIST_MAX_BATCH", "16"))
+
+
+def lstm_persist_ok(H, batch):
+    """True when the one-launch-per-layer recurrence (lstm_persist.hip) is used for an (H, batch) zero-initial-state
+    layer on this device: H in {512, 1024, 1536}, H/8 workgroups <= CUs, batch <= 16.  The kernels cover batch <= 32
+    (two 16-column blocks) but measure no faster than the per-step launches there (profiles/r03_lstm_bench.log)."""
+    return (LSTM_PERSIST and batch is not None and batch <= LSTM_PERSIST_MAX_BATCH
+            and bool(_lib.load().fac_lstm_persist_ok(int(H), int(batch))))
+
+
+def pack_lstm_whh16(w_hh, transposed=False):
+    """W_hh (4H, H) as the register fragments of the resident kernels (fac_pack_lstm_whh16)."""
+    w_hh = _dev(w_hh, "weight_hh")
+    out = torch.empty_like(w_hh)
+    _lib.check(_lib.load().fac_pack_lstm_whh16(_ptr(w_hh), _ptr(out), w_hh.shape[1], 1 if transposed else 0, _stream()),
+               "fac_pack_lstm_whh16")
+    return out
+
+
+def _zero_pad_cols(t, nc):
+    """Columns >= nc of a (rows, T, BP) work buffer are batch padding the resident kernels never touch."""
+    if nc < t.shape[-1]:
+        t[..., nc:].zero_()
+
+
+def lstm_layer_persist(pre, w_hh, H, batch, save=None):
+    """The whole layer in ONE launch (fac_lstm_layer_fwd_persist): pre (4H, T, BP), raw W_hh (4H, H) -> yT (H, T, BP)."""
+    _, T, BP = pre.shape
+    nc = 16 * ((batch + 15) // 16)
+    if _FLOPS is not None:
+        _FLOPS.add("lstm", 2.0 * 4 * H * H * T * BP)
+    yT = torch.empty(H, T, BP, device=pre.device, dtype=torch.float32)
+    _zero_pad_cols(yT, nc)
+    sg, sc = save if save is not None else (None, None)
+    if save is not None:
+        _zero_pad_cols(sg, nc)
+        _zero_pad_cols(sc, nc)
+    hfrag = torch.empty(T * H * nc, device=pre.device, dtype=torch.float32)       # one fresh exchange region per step
+    _lib.check(_lib.load().fac_lstm_layer_fwd_persist(_ptr(pre), _ptr(pack_lstm_whh16(w_hh)), _ptr(hfrag), _ptr(yT), _ptr(sg),
+                                                      _ptr(sc), T, H, batch, BP, _stream()), "fac_lstm_layer_fwd_persist")
+    return yT
+
+
 def lstm_layer(pre, whh_packed, H, state=None, step0=0, save=None):
     """pre (4H, T, BP) -> yT (H, T, BP).  state (3, H, BP): carried cell / hidden buffers of a streaming
     session with `step0` steps already taken (None: fresh zero state).  save = (gates (4H,T,BP), c (H,T,BP)):
@@ -894,10 +939,20 @@ def conv_transpose1d_bwd(x, dy, v, g, stride):
     return dx, dw
 
 
-def lstm_layer_bwd(d_out, w_hh, gates, cs, H):
-    """BPTT of one layer (fac_lstm_layer_bwd): d_out (H, T, BP) gradient of the layer's h sequence -> dgates (4H, T, BP)."""
+def lstm_layer_bwd(d_out, w_hh, gates, cs, H, batch=None):
+    """BPTT of one layer (fac_lstm_layer_bwd): d_out (H, T, BP) gradient of the layer's h sequence -> dgates (4H, T, BP).
+    batch: number of real columns; with it the resident kernel (fac_lstm_layer_bwd_persist) runs where it applies."""
     _, T, BP = d_out.shape
     lib = _lib.load()
+    if lstm_persist_ok(H, batch):
+        dgates = torch.empty(4 * H, T, BP, device=d_out.device, dtype=torch.float32)
+        nc = 16 * ((batch + 15) // 16)
+        _zero_pad_cols(dgates, nc)
+        scratch = torch.empty((4 + 4 * T) * H * nc, device=d_out.device, dtype=torch.float32)
+        _lib.check(lib.fac_lstm_layer_bwd_persist(_ptr(_dev(d_out)), _ptr(pack_lstm_whh16(w_hh, transposed=True)), _ptr(gates),
+                                                  _ptr(cs), _ptr(dgates), _ptr(scratch), T, H, batch, BP, _stream()),
+                   "fac_lstm_layer_bwd_persist")
+        return dgates
     wt = torch.empty(4 * H * H, device=d_out.device, dtype=torch.float32)
     _lib.check(lib.fac_pack_lstm_whh_t(_ptr(_dev(w_hh)), _ptr(wt), H, _stream()), "fac_pack_lstm_whh_t")
     dgates = torch.empty(4 * H, T, BP, device=d_out.device, dtype=torch.float32)

@@ -227,6 +227,20 @@ int fac_lstm_gate_bwd(const float* dy_t, const float* rec, const float* gates_t,
 int fac_pack_lstm_whh_t(const float* w_hh, float* packed, int H, fac_stream_t stream);
 int fac_lstm_layer_bwd(const float* dyT, const float* whh_t_packed, const float* gates, const float* cs, float* dgates, float* scratch,
                        int T, int H, int BP, fac_stream_t stream);
+
+/* The same recurrence and its BPTT as ONE launch per layer (lstm_persist.hip): the H/8 workgroups stay resident for all T steps
+ * with their slice of W_hh in registers and exchange h_t (dgates_t) through device-wide flags.  Covers zero-initial-state layers
+ * with fac_lstm_persist_ok(H, B) != 0 (H in {512, 1024, 1536}, B <= 32, H/8 <= CUs); B = number of real batch columns, only the
+ * column blocks ceil(B/16)*16 are computed and written (the caller zero-fills the padded columns of yT / saves / dgates).
+ * whh16: fac_pack_lstm_whh16(W_hh, out (4H*H floats), H, transposed = 0 forward / 1 BPTT).  With NC = 16 * ceil(B/16): hfrag is
+ * T * H * NC floats of scratch, fac_lstm_layer_bwd_persist's scratch (4 + 4 * T) * H * NC floats (one fresh exchange region per
+ * step).  One resident layer per stream at a time (stream order guarantees it). */
+int fac_lstm_persist_ok(int H, int B);
+int fac_pack_lstm_whh16(const float* w_hh, float* packed, int H, int transposed, fac_stream_t stream);
+int fac_lstm_layer_fwd_persist(const float* pre, const float* whh16, float* hfrag, float* yT, float* gates_save, float* c_save,
+                               int T, int H, int B, int BP, fac_stream_t stream);
+int fac_lstm_layer_bwd_persist(const float* dyT, const float* whh16t, const float* gates, const float* cs, float* dgates,
+                               float* scratch, int T, int H, int B, int BP, fac_stream_t stream);
 /* dx = dy * (1 - y^2) */
 int fac_tanh_bwd(const float* y, const float* dy, float* dx, int64_t n, fac_stream_t stream);
 /* Backward of the spectral losses w.r.t. the estimate: da (+)= scale * d|a - b|/da (mode 0) or
