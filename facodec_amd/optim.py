@@ -59,12 +59,14 @@ class FlatAdamW:
         self.norm = torch.zeros(2, device=dev, dtype=torch.float32)
         off = 0
         self.slices = []
+        self._views = []                                      # the arena views `p.grad` is bound to
         self._touched = [False] * P
         for i, p in enumerate(self.params):
             k = p.numel()
             self.p[off:off + k].copy_(p.data.reshape(-1))
             p.data = self.p[off:off + k].view_as(p)          # the module now reads its weights from the arena
-            p.grad = self.g[off:off + k].view_as(p)          # ... and autograd accumulates into the arena
+            self._views.append(self.g[off:off + k].view_as(p))
+            p.grad = self._views[i]                          # ... and autograd accumulates into the arena
             p.register_post_accumulate_grad_hook(self._mark(i))
             self.slices.append((off, k))
             off += k
@@ -111,31 +113,49 @@ class FlatAdamW:
         if self._work is not None:
             self.wait_all_reduce()
 
-    def zero_grad(self, set_to_none=False):
+    def zero_grad(self, set_to_none=False, unbind=False):
         """One memset of the gradient arena (+ flags); the `.grad` views stay bound (set_to_none is accepted and ignored:
-        unbinding would only force a re-bind)."""
+        unbinding would only force a re-bind).
+        unbind=True (what TrainStep uses): `.grad` is left None for the coming backward, so autograd's AccumulateGrad
+        keeps ("steals") each produced gradient tensor instead of launching one add-into-the-view kernel per parameter
+        (~800 small launches per step); `launch_all_reduce` / `step` then fold all of them into the arena with one
+        multi-tensor copy and bind the views again."""
         self._drain()
         self._rebind()
         self._gx.zero_()
         self._touched = [False] * len(self.params)
         self._flags_final = False
+        if unbind:
+            for p in self.params:
+                p.grad = None
 
     def _rebind(self):
         """`p.grad` must be the arena view (someone may have set it to None or to a foreign tensor), `p.data` must still
-        live in the parameter arena (a later module.to()/.float() would silently detach the optimiser from the model)."""
+        live in the parameter arena (a later module.to()/.float() would silently detach the optimiser from the model).
+        Foreign gradient tensors are folded into the arena -- all of them in one multi-tensor copy -- and marked."""
         base_p, base_g = self.p.data_ptr(), self.g.data_ptr()
+        src, dst = [], []
         for i, (p, (off, k)) in enumerate(zip(self.params, self.slices)):
             if p.data_ptr() != base_p + 4 * off:
                 raise RuntimeError("FlatAdamW: a parameter no longer lives in the optimiser's arena (was the module moved or cast after "
                                    "the optimiser was built?); build FlatAdamW after the model is on its final device")
-            if p.grad is None:
-                p.grad = self.g[off:off + k].view_as(p)
-            elif p.grad.data_ptr() != base_g + 4 * off:       # foreign gradient tensor: fold it in once, then rebind
-                self._drain()
-                self.g[off:off + k].copy_(p.grad.reshape(-1))
-                p.grad = self.g[off:off + k].view_as(p)
+            g = p.grad
+            if g is None:
+                p.grad = self._views[i]
+            elif g.data_ptr() != base_g + 4 * off:            # foreign gradient tensor: fold it in once, then rebind
+                src.append(g.detach())
+                dst.append(self._views[i])
+                p.grad = self._views[i]
                 self._touched[i] = True
-                self._flags_final = False
+        if src:
+            self._drain()
+            self._flags_final = False
+            same = all(a.dtype == b.dtype and a.device == b.device and a.is_contiguous() for a, b in zip(src, dst))
+            if same and hasattr(torch, "_foreach_copy_"):
+                torch._foreach_copy_(dst, src)
+            else:
+                for a, b in zip(src, dst):
+                    b.copy_(a)
 
     def gather_grads(self, mark_all=False):
         """Compatibility with callers that assign `.grad` tensors by hand: folds them into the arena (no-op for views).
@@ -176,11 +196,12 @@ class FlatAdamW:
         `backward_complete()`."""
         if self._work is not None or self._flags_final or not _dist_on():
             return
+        if only_if_complete and not self.backward_complete():
+            return
+        self._rebind()                                         # gradients autograd kept outside the arena (zero_grad(unbind=True))
         # a single rank has nothing to exchange; FAC_FORCE_ALLREDUCE=1 still issues the collective (smoke-tests the RCCL path --
         # AVG op, async work handle, stream hand-over -- on a one-GPU box: the mean over one rank is the identity)
         if dist.get_world_size() == 1 and os.environ.get("FAC_FORCE_ALLREDUCE") != "1":
-            return
-        if only_if_complete and not self.backward_complete():
             return
         self._upload_flags()
         self._flags_final = True

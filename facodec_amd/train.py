@@ -12,6 +12,8 @@ Data parallel: one asynchronous all-reduce(mean) of each key's gradient arena, l
 gradients are final (decoder: from a hook on the decoder input's gradient, i.e. under the quantizer / encoder
 backward; discriminator: under the mel-loss forward of the generator half), waited for in the key's optimiser step.
 """
+import os
+
 import torch
 
 from . import losses, optim
@@ -35,6 +37,9 @@ def crop_segments(waves, mel_input_length, max_frame_len=80, hop=300, starts=Non
     wav_seg = AD.CropRows.apply(waves.reshape(B, 1, -1), starts, seg * hop, hop)
     out_extra = [AD.CropRows.apply(e if e.dim() == 3 else e.reshape(B, 1, -1), starts, seg, 1).reshape(*e.shape[:-1], seg) for e in extra]
     return wav_seg, starts, out_extra
+
+
+UNBIND_GRADS = os.environ.get("FAC_UNBIND_GRADS", "1") != "0"
 
 
 class GeneratorStep:
@@ -69,7 +74,6 @@ class GeneratorStep:
         double-checks against the previous step's usage pattern; a key that is not complete simply launches after backward.
         Every rank issues the collectives in the same order because the usage pattern of this model is static
         (FAC_EARLY_EXCHANGE=0 switches the hooks off)."""
-        import os
         if os.environ.get("FAC_EARLY_EXCHANGE", "1") == "0":
             return
         opt = self.opt
@@ -89,8 +93,11 @@ class GeneratorStep:
                 for k, o in self.opt.items()}
 
     def _zero(self, keys):
+        """Gradient arenas cleared; `.grad` left unbound so that autograd hands over its gradient tensors and the
+        optimiser folds them in with one multi-tensor copy (FlatAdamW.zero_grad).  Under a DistributedDataParallel
+        wrapper (data_parallel=False) the reducer owns `.grad`: the views stay bound."""
         for k in keys:
-            self.opt[k].zero_grad()
+            self.opt[k].zero_grad(unbind=UNBIND_GRADS and self.opt[k].data_parallel)
 
     def forward_backward(self, wave, masks=None, full_waves=None, wave_lens=None):
         m = self.model
@@ -131,7 +138,6 @@ class TrainStep(GeneratorStep):
         self._sync_start([self.opt[k] for k in ("discriminator", "fa_predictors") if k in self.opt])
         self.stft = losses.MultiScaleSTFTLoss()
         self.l1 = losses.L1Loss()
-        import os
         self.batched_d_step = os.environ.get("FAC_BATCHED_D_STEP", "1") != "0"
 
     def predictor_losses(self, preds, rev, targets):

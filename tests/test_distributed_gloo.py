@@ -225,3 +225,32 @@ def test_two_rank_touched_flags_travel_with_the_gradients():
     assert torch.allclose(o0["arena"][2][6:10], torch.full((4,), 1.5))                          # (3 + 0) / 2 on BOTH ranks
     assert torch.allclose(o1["ddp_wrapped"][2][6:10], torch.zeros(4))                           # no arena exchange in DDP mode
     assert hid0 == [False, False, False] and mk0 == [False, False, True]
+
+
+def test_unbound_gradients_are_folded_in_one_copy():
+    """FlatAdamW.zero_grad(unbind=True): autograd keeps its gradient tensors (`.grad` is None during backward, no
+    add-into-the-view launch per parameter); `gather_grads` / `launch_all_reduce` / `step` fold them into the arena, mark the
+    parameters and bind the views again.  Same arena contents as the bound mode."""
+    sys.path.insert(0, REPO)
+    from facodec_amd.optim import FlatAdamW
+    torch.manual_seed(3)
+    shapes = [(4, 3), (5,), (2, 2, 2), (6,)]
+
+    def run(unbind):
+        torch.manual_seed(4)
+        params = [torch.nn.Parameter(torch.randn(*s)) for s in shapes]
+        opt = FlatAdamW(params)
+        opt.zero_grad(unbind=unbind)
+        assert all((p.grad is None) == unbind for p in params)
+        loss = sum((p * float(i + 1)).pow(2).sum() for i, p in enumerate(params[:3]))      # params[3] is not reached
+        loss = loss + params[0].sum()                                                        # two contributions to params[0]
+        loss.backward()
+        if unbind:
+            assert params[0].grad.data_ptr() != opt.g.data_ptr()                             # autograd's own tensor
+            assert params[3].grad is None
+        opt.gather_grads()
+        assert all(p.grad.data_ptr() == opt.g.data_ptr() + 4 * off for p, (off, _) in zip(params, opt.slices))
+        assert opt.params_without_grad() == [3]
+        return opt.g.clone()
+
+    assert torch.equal(run(True), run(False))
