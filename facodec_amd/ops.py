@@ -229,12 +229,33 @@ _CONV_WS = {}
 CONV_WS_BYTES = 32 << 20
 
 
+_CONV_WS_SLOT = 0
+
+
+class conv_workspace_slot:
+    """Launches issued inside the block use scratch buffer `slot` instead of buffer 0: for a second chain of launches that
+    runs on another stream at the same time (streaming.py: quantizer + decoder beside the encoder)."""
+
+    def __init__(self, slot):
+        self.slot = slot
+
+    def __enter__(self):
+        global _CONV_WS_SLOT
+        self.prev, _CONV_WS_SLOT = _CONV_WS_SLOT, self.slot
+
+    def __exit__(self, *exc):
+        global _CONV_WS_SLOT
+        _CONV_WS_SLOT = self.prev
+
+
 def _conv_workspace(device):
-    """Zero-filled scratch handed to every conv launch (fac_conv_desc.ws): one per device, used by the
-    split-reduction kernel for launches with few output columns.  All launches go to torch's current stream."""
-    ws = _CONV_WS.get(device)
+    """Zero-filled scratch handed to every conv launch (fac_conv_desc.ws), used by the split-reduction kernel for launches
+    with few output columns: the partial sums live there between the two kernels of a launch, so it belongs to ONE stream
+    at a time -- one buffer per (device, conv_workspace_slot)."""
+    key = (device, _CONV_WS_SLOT)
+    ws = _CONV_WS.get(key)
     if ws is None:
-        ws = _CONV_WS[device] = torch.zeros(CONV_WS_BYTES // 4, device=device, dtype=torch.float32)
+        ws = _CONV_WS[key] = torch.zeros(CONV_WS_BYTES // 4, device=device, dtype=torch.float32)
     return ws
 
 

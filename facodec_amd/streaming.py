@@ -24,6 +24,8 @@ How the offline arithmetic is reproduced incrementally
   * `finish()` flushes the frames that were waiting for look-ahead, with the reflect padding of the END of the
     signal the offline front-end applies.
 """
+import os
+
 import torch
 
 from . import ops
@@ -293,15 +295,28 @@ class _QuantizerStream:
         if z_new is not None:
             self.z_fifo.push(z_new)
 
-    def run(self, n_c, final=False):
-        """Quantizes the frames whose look-ahead is complete -> (outs, [codes_p, codes_c, codes_r]) or None."""
+    def take_latents(self, final=False):
+        """The latents of the frames whose look-ahead is complete, copied out of the FIFO -- or None when some of them are
+        still to be produced by the encoder call of this very step (prime(), finish()).  In a steady-state hop they all come
+        from earlier hops (the prosody front-end lags 1 024 samples, a hop brings 480), so the quantizer + decoder half of
+        the hop does not depend on the encoder half and the two can run on two streams."""
+        f0 = self.c[0]
+        n = self.frames_ready(self.wave.c[0], final) - f0
+        if n <= 0 or f0 + n > self.z_fifo.c[0]:
+            return None
+        return self.z_fifo.window(f0, n).contiguous()
+
+    def run(self, n_c, final=False, x=None):
+        """Quantizes the frames whose look-ahead is complete -> (outs, [codes_p, codes_c, codes_r]) or None.
+        x: their latents if `take_latents` already copied them out."""
         q = self.q
         f0 = self.c[0]
         n = self.frames_ready(self.wave.c[0], final) - f0
         if n <= 0:
             return None
         mel = self._mel(f0, n, final)
-        x = self.z_fifo.window(f0, n).contiguous()
+        if x is None:
+            x = self.z_fifo.window(f0, n).contiguous()
         h = ops.conv1d(mel[:, :20], q.melspec_linear.w.packed(), 256, 1, bias=q.melspec_linear.w.bias, pad_left=0,
                        pad_mode=ops.PAD_ZERO, t_out=n)
         wn = q.melspec_encoder
@@ -349,16 +364,34 @@ class StreamingCodec:
         self.n_samples = 0
         self.hops = 0
         self.use_graphs = use_graphs
+        self.two_streams = os.environ.get("FAC_STREAM_TWO_STREAMS", "1") != "0"
+        self._side = torch.cuda.Stream(device=self.device) if self.device.type == "cuda" else None
         self._graphs = {}
         self._snap = {}
         self._hop_in = torch.zeros(B, 1, HOP, device=self.device)
 
     # ------------------------------------------------------------------------------------------ steps
     def _step(self, wave_new, final=False):
-        if wave_new is not None:
+        first = self.qs.c[0]
+        if wave_new is not None and self.two_streams and self._side is not None:
+            # steady-state hop: [encoder -> latent FIFO] and [quantizer -> decoder] touch disjoint state once the samples are in
+            # the STFT history and the due latents are copied out -- two chains of ~100 latency-bound launches side by side
+            self.qs.push(wave_new, None)
+            x = self.qs.take_latents(final)
+            if x is not None:
+                main = torch.cuda.current_stream(self.device)
+                self._side.wait_stream(main)
+                with torch.cuda.stream(self._side), ops.conv_workspace_slot(1):
+                    outs, codes = self.qs.run(self.n_c, final, x=x)
+                    wave = self.dec.run(outs)
+                self.qs.push(None, self.enc.run(wave_new))
+                # join: everything later on the caller's stream (reading the outputs, the next hop's fork) is ordered behind both
+                main.wait_stream(self._side)
+                return dict(frame0=first, codes=codes, wave=wave)
+            self.qs.push(None, self.enc.run(wave_new))
+        elif wave_new is not None:
             z = self.enc.run(wave_new)
             self.qs.push(wave_new, z)
-        first = self.qs.c[0]
         r = self.qs.run(self.n_c, final)
         if r is None:
             return dict(frame0=first, codes=None, wave=None)
