@@ -12,11 +12,13 @@ feature maps shaped (B, C, L, period) for MPD and (B, C, T, F) for MRD, so train
 `F.l1_loss` over them) runs unchanged.  Each returned tensor is a zero-copy strided VIEW of the internal map (autograd
 flows through it) and carries the internal tensor as `._fac_internal`; `gan_losses()` -- the fused path TrainStep uses --
 reads that attribute and never touches the views."""
+import os
+
 import torch
 from torch import nn
 
 from . import autograd_disc as AD
-from . import losses
+from . import losses, ops
 
 BANDS = ((0.0, 0.1), (0.1, 0.25), (0.25, 0.5), (0.5, 0.75), (0.75, 1.0))
 
@@ -169,15 +171,41 @@ class Discriminator(nn.Module):
     def preprocess(self, y):
         return AD.Preprocess.apply(y)
 
+    def _run_all(self, x):
+        """The 8 sub-discriminators are independent chains of launches with 200-800 tiles each on 256 CUs (one workgroup per
+        CU): run side by side on N_STREAMS streams, one chain's last, partly filled round of workgroups overlaps another
+        chain's kernels.  autograd runs every node's backward on the stream of its forward, so the backward passes overlap
+        the same way; the streams fork from and join the caller's stream here."""
+        n = min(N_STREAMS, len(self.discriminators))
+        if n <= 1 or not x.is_cuda:
+            return [d(x) for d in self.discriminators]
+        main = torch.cuda.current_stream(x.device)
+        key = (x.device, n)
+        if key not in _STREAMS:
+            _STREAMS[key] = [torch.cuda.Stream(device=x.device) for _ in range(n)]
+            for st in _STREAMS[key]:
+                ops.register_stream_slot(st)                 # own split-reduction scratch (few-column layers of short clips)
+        streams = _STREAMS[key]
+        for st in streams:
+            st.wait_stream(main)
+        outs = [None] * len(self.discriminators)
+        # heaviest chains first (the spectrogram discriminators, then the period discriminators), round robin over the streams
+        order = sorted(range(len(outs)), key=lambda i: not isinstance(self.discriminators[i], MRD))
+        for j, i in enumerate(order):
+            with torch.cuda.stream(streams[j % n]):
+                outs[i] = self.discriminators[i](x)
+        for st in streams:
+            main.wait_stream(st)
+        return outs
+
     def forward_internal(self, x):
         """The 8 lists of internal-layout maps (row-concatenated MPD signals, (B*T, C, F) MRD rows)."""
-        x = self.preprocess(x)
-        return [d(x) for d in self.discriminators]
+        return self._run_all(self.preprocess(x))
 
     def forward(self, x):
         B = x.shape[0]
-        x = self.preprocess(x)
-        return [[_reference_view(d, m, B) for m in d(x)] for d in self.discriminators]
+        maps = self._run_all(self.preprocess(x))
+        return [[_reference_view(d, m, B) for m in dm] for d, dm in zip(self.discriminators, maps)]
 
 
 def _reference_view(d, m, batch):
@@ -216,6 +244,8 @@ def reference_layout(disc, fmaps, batch):
 
 
 _MASKS = {}
+_STREAMS = {}
+N_STREAMS = int(os.environ.get("FAC_DISC_STREAMS", "3"))
 
 
 def _row_mask(t):

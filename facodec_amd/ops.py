@@ -229,30 +229,25 @@ _CONV_WS = {}
 CONV_WS_BYTES = 32 << 20
 
 
-_CONV_WS_SLOT = 0
+_STREAM_SLOTS = {}
 
 
-class conv_workspace_slot:
-    """Launches issued inside the block use scratch buffer `slot` instead of buffer 0: for a second chain of launches that
-    runs on another stream at the same time (streaming.py: quantizer + decoder beside the encoder)."""
-
-    def __init__(self, slot):
-        self.slot = slot
-
-    def __enter__(self):
-        global _CONV_WS_SLOT
-        self.prev, _CONV_WS_SLOT = _CONV_WS_SLOT, self.slot
-
-    def __exit__(self, *exc):
-        global _CONV_WS_SLOT
-        _CONV_WS_SLOT = self.prev
+def register_stream_slot(stream):
+    """Gives `stream` (a torch.cuda.Stream that will carry launches concurrently with other streams: the streaming session's
+    second chain, the discriminators' side streams) its own conv scratch buffer; returns the slot.  Unregistered streams --
+    the caller's stream, a graph-capture stream -- share slot 0, so nothing is allocated inside a capture."""
+    key = stream.cuda_stream
+    if key not in _STREAM_SLOTS:
+        _STREAM_SLOTS[key] = len(_STREAM_SLOTS) + 1
+    return _STREAM_SLOTS[key]
 
 
 def _conv_workspace(device):
     """Zero-filled scratch handed to every conv launch (fac_conv_desc.ws), used by the split-reduction kernel for launches
     with few output columns: the partial sums live there between the two kernels of a launch, so it belongs to ONE stream
-    at a time -- one buffer per (device, conv_workspace_slot)."""
-    key = (device, _CONV_WS_SLOT)
+    at a time -- one buffer per (device, registered stream)."""
+    slot = _STREAM_SLOTS.get(torch.cuda.current_stream(device).cuda_stream, 0) if _STREAM_SLOTS else 0
+    key = (device, slot)
     ws = _CONV_WS.get(key)
     if ws is None:
         ws = _CONV_WS[key] = torch.zeros(CONV_WS_BYTES // 4, device=device, dtype=torch.float32)
@@ -864,12 +859,15 @@ WGRAD_WS_CAP = int(float(os.environ.get("FAC_WGRAD_WS_GB", "6")) * (1 << 30))
 
 
 def _wgrad_workspace(device, nbytes):
-    ws = _WGRAD_WS.get(device)
+    """One grow-only buffer per (device, stream): the discriminators' backward passes run on several streams at once
+    (discriminator.py), and a launch's operand planes / partial sums must not be overwritten by another stream's launch."""
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    ws = _WGRAD_WS.get(key)
     if ws is None or ws.numel() * 4 < nbytes:
         if ws is not None:
-            del _WGRAD_WS[device]
+            del _WGRAD_WS[key]
             ws = None
-        ws = _WGRAD_WS[device] = torch.empty((nbytes + (64 << 20)) // 4, device=device, dtype=torch.float32)
+        ws = _WGRAD_WS[key] = torch.empty((nbytes + (64 << 20)) // 4, device=device, dtype=torch.float32)
     return ws
 
 

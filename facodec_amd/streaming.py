@@ -366,6 +366,8 @@ class StreamingCodec:
         self.use_graphs = use_graphs
         self.two_streams = os.environ.get("FAC_STREAM_TWO_STREAMS", "1") != "0"
         self._side = torch.cuda.Stream(device=self.device) if self.device.type == "cuda" else None
+        if self._side is not None:
+            ops.register_stream_slot(self._side)            # its own split-reduction scratch
         self._graphs = {}
         self._snap = {}
         self._hop_in = torch.zeros(B, 1, HOP, device=self.device)
@@ -381,7 +383,7 @@ class StreamingCodec:
             if x is not None:
                 main = torch.cuda.current_stream(self.device)
                 self._side.wait_stream(main)
-                with torch.cuda.stream(self._side), ops.conv_workspace_slot(1):
+                with torch.cuda.stream(self._side):
                     outs, codes = self.qs.run(self.n_c, final, x=x)
                     wave = self.dec.run(outs)
                 self.qs.push(None, self.enc.run(wave_new))

@@ -115,3 +115,40 @@ def test_modules_under_distributed_data_parallel(cuda):
     rep = json.loads(line[-1])
     assert rep["ok_all_ranks"], rep
     assert r.returncode == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("T", [4800, 24000])
+def test_discriminators_on_side_streams_match_one_stream(cuda, T):
+    """The eight sub-discriminators run as concurrent chains on FAC_DISC_STREAMS side streams (forward and, through autograd,
+    backward): same feature maps bit for bit and the same gradients as one chain after the other -- short clips included,
+    whose deep layers take the split-reduction kernel with its per-stream scratch."""
+    from facodec_amd import discriminator as D
+    from facodec_amd import synth
+    disc = D.Discriminator(sample_rate=24000)
+    synth.load_synthetic(disc, seed=0, prefix="discriminator.")
+    disc.to(cuda)
+    x, xr = synth.synth_clips(3, T, seed=5).to(cuda), synth.synth_clips(3, T, seed=6).to(cuda)
+
+    def run(n):
+        old, D.N_STREAMS = D.N_STREAMS, n
+        try:
+            for p in disc.parameters():
+                p.grad = None
+            xf = x.clone().requires_grad_()
+            d_fake, d_real = disc.forward_internal(xf), disc.forward_internal(xr)
+            loss_d, loss_g, loss_f = D.gan_losses(d_fake, d_real)
+            (loss_d + 0.5 * loss_g + 0.25 * loss_f).backward()
+            torch.cuda.synchronize()
+            maps = [m.detach().clone() for dm in d_fake for m in dm]
+            return maps, xf.grad.clone(), {k: p.grad.clone() for k, p in disc.named_parameters()}
+        finally:
+            D.N_STREAMS = old
+
+    for trial in range(3):            # a race would not show every time
+        m1, g1, p1 = run(1)
+        m3, g3, p3 = run(3)
+        assert all(torch.equal(a, b) for a, b in zip(m1, m3))
+        assert float((g1 - g3).abs().max() / g1.abs().max()) < 1e-6          # fan-in order of the eight input gradients may differ
+        for k in p1:
+            assert torch.equal(p1[k], p3[k]), k
