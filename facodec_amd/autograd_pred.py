@@ -2,6 +2,8 @@
 gradient_reversal.py) with HIP forward and backward.  The heads' LOSSES need external targets (phonemes from a CTC
 model, F0 / UV, speaker ids: train.py:314-356) and are not part of this build; what is here are the differentiable
 heads themselves, so a caller that has targets can train them."""
+import os
+
 import torch
 from torch.autograd import Function
 
@@ -77,13 +79,13 @@ def cnnlstm(m, x):
     return outs
 
 
+PRED_STREAMS = int(os.environ.get("FAC_PRED_STREAMS", "3"))
+
+
 def predictors(m, quantized, timbre):
     """FApredictors.forward_v2 (modules/quantize.py:564-606), timbre_norm configuration."""
     prosody, content, residual = quantized
     rev = lambda t: _GradReverse.apply(t, 1.0)   # noqa: E731
-    content_pred = cnnlstm(m.phone_predictor, content)[0]
-    spk_pred = A.linear(m.timbre_predictor, timbre)
-    f0_pred, uv_pred = cnnlstm(m.f0_predictor, prosody)
 
     def total(parts, like):
         acc = None
@@ -91,13 +93,21 @@ def predictors(m, quantized, timbre):
             acc = p if acc is None else A.add(acc, p)
         return acc if acc is not None else torch.zeros_like(like)
 
-    rin = total(([content] if m.use_gr_content_f0 else []) + ([residual] if m.use_gr_residual_f0 else []), prosody)
-    rev_f0_pred, rev_uv_pred = cnnlstm(m.rev_f0_predictor[1], rev(rin))
-    rin = total(([prosody] if m.use_gr_prosody_phone else []) + ([residual] if m.use_gr_residual_phone else []), content)
-    rev_content_pred = cnnlstm(m.rev_content_predictor[1], rev(rin))[0]
-    x_spk_pred = None
+    rin_f0 = total(([content] if m.use_gr_content_f0 else []) + ([residual] if m.use_gr_residual_f0 else []), prosody)
+    rin_ph = total(([prosody] if m.use_gr_prosody_phone else []) + ([residual] if m.use_gr_residual_phone else []), content)
+    # four (five) independent heads, 1 024 channels x (B x 160) columns each: 160 workgroups per launch on 256 CUs -- run them
+    # side by side (ops.run_chains; FAC_PRED_STREAMS=1: one after the other)
+    chains = [lambda: cnnlstm(m.phone_predictor, content), lambda: cnnlstm(m.f0_predictor, prosody),
+              lambda: cnnlstm(m.rev_f0_predictor[1], rev(rin_f0)), lambda: cnnlstm(m.rev_content_predictor[1], rev(rin_ph))]
     if m.use_gr_x_timbre:
-        x_spk_pred = cnnlstm(m.rev_timbre_predictor[1], rev(A.add(A.add(prosody, content), residual)))[0]
+        chains.append(lambda: cnnlstm(m.rev_timbre_predictor[1], rev(A.add(A.add(prosody, content), residual))))
+    res = ops.run_chains(chains, content.device, PRED_STREAMS)
+    content_pred = res[0][0]
+    f0_pred, uv_pred = res[1]
+    rev_f0_pred, rev_uv_pred = res[2]
+    rev_content_pred = res[3][0]
+    x_spk_pred = res[4][0] if m.use_gr_x_timbre else None
+    spk_pred = A.linear(m.timbre_predictor, timbre)
     preds = {"f0": f0_pred, "uv": uv_pred, "content": content_pred, "timbre": spk_pred}
     rev_preds = {"rev_f0": rev_f0_pred, "rev_uv": rev_uv_pred, "rev_content": rev_content_pred, "x_timbre": x_spk_pred}
     return preds, rev_preds

@@ -176,26 +176,14 @@ class Discriminator(nn.Module):
         CU): run side by side on N_STREAMS streams, one chain's last, partly filled round of workgroups overlaps another
         chain's kernels.  autograd runs every node's backward on the stream of its forward, so the backward passes overlap
         the same way; the streams fork from and join the caller's stream here."""
-        n = min(N_STREAMS, len(self.discriminators))
-        if n <= 1 or not x.is_cuda:
+        if N_STREAMS <= 1 or not x.is_cuda:
             return [d(x) for d in self.discriminators]
-        main = torch.cuda.current_stream(x.device)
-        key = (x.device, n)
-        if key not in _STREAMS:
-            _STREAMS[key] = [torch.cuda.Stream(device=x.device) for _ in range(n)]
-            for st in _STREAMS[key]:
-                ops.register_stream_slot(st)                 # own split-reduction scratch (few-column layers of short clips)
-        streams = _STREAMS[key]
-        for st in streams:
-            st.wait_stream(main)
-        outs = [None] * len(self.discriminators)
         # heaviest chains first (the spectrogram discriminators, then the period discriminators), round robin over the streams
-        order = sorted(range(len(outs)), key=lambda i: not isinstance(self.discriminators[i], MRD))
-        for j, i in enumerate(order):
-            with torch.cuda.stream(streams[j % n]):
-                outs[i] = self.discriminators[i](x)
-        for st in streams:
-            main.wait_stream(st)
+        order = sorted(range(len(self.discriminators)), key=lambda i: not isinstance(self.discriminators[i], MRD))
+        res = ops.run_chains([lambda d=self.discriminators[i]: d(x) for i in order], x.device, N_STREAMS)
+        outs = [None] * len(order)
+        for i, r in zip(order, res):
+            outs[i] = r
         return outs
 
     def forward_internal(self, x):
@@ -244,7 +232,6 @@ def reference_layout(disc, fmaps, batch):
 
 
 _MASKS = {}
-_STREAMS = {}
 N_STREAMS = int(os.environ.get("FAC_DISC_STREAMS", "3"))
 
 

@@ -242,6 +242,40 @@ def register_stream_slot(stream):
     return _STREAM_SLOTS[key]
 
 
+_SIDE_STREAMS = {}
+
+
+def side_streams(device, n):
+    """n cached side streams of `device`, each with its own conv scratch (register_stream_slot)."""
+    key = (device, n)
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = [torch.cuda.Stream(device=device) for _ in range(n)]
+        for st in _SIDE_STREAMS[key]:
+            register_stream_slot(st)
+    return _SIDE_STREAMS[key]
+
+
+def run_chains(chains, device, n_streams):
+    """Independent chains of launches (callables) side by side on up to n_streams side streams that fork from and join the
+    caller's stream; returns their results in order.  Kernels with fewer workgroups than CUs (or a partly filled last round)
+    then overlap with another chain's kernels; autograd replays every node's backward on the stream of its forward, so the
+    backward passes of the chains overlap the same way."""
+    n = min(n_streams, len(chains))
+    if n <= 1 or device.type != "cuda":
+        return [c() for c in chains]
+    main = torch.cuda.current_stream(device)
+    streams = side_streams(device, n)
+    for st in streams:
+        st.wait_stream(main)
+    outs = []
+    for j, c in enumerate(chains):
+        with torch.cuda.stream(streams[j % n]):
+            outs.append(c())
+    for st in streams:
+        main.wait_stream(st)
+    return outs
+
+
 def _conv_workspace(device):
     """Zero-filled scratch handed to every conv launch (fac_conv_desc.ws), used by the split-reduction kernel for launches
     with few output columns: the partial sums live there between the two kernels of a launch, so it belongs to ONE stream
