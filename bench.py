@@ -159,6 +159,9 @@ def train_leg(model, device, rank, world, steps, warmup):
                     "feature-matching), 7-scale mel loss, commitment + codebook + F0 / UV / content(focal) / speaker losses with "
                     "synthetic targets, 5 x (clip + AdamW + ExponentialLR)",
         "with_predictors": True,
+        "concurrent_chains": {"discriminator_streams": _disc_streams(), "predictor_streams": _pred_streams(),
+                              "note": "independent sub-networks (8 discriminators, 4 predictor heads) run side by side on side streams of the "
+                                      "one GPU, forward and backward; FAC_DISC_STREAMS=1 FAC_PRED_STREAMS=1 runs them one after the other"},
         "parallelism": f"dp{world}: one all-reduce(mean) per model key over RCCL, launched asynchronously under backward",
         "allreduce_bytes_per_step": ar_bytes, "allreduce_ms_standalone": None if ar_ms is None else round(ar_ms, 2),
         "allreduce_overlap": {"launched_early": [k for k, e in exchange.items() if e["launched"] == "hook"],
@@ -180,6 +183,16 @@ def train_leg(model, device, rank, world, steps, warmup):
                      "basis": "whole step, per GPU: audio-s/s x COUNTED TFLOP per audio-second against the fp32 MFMA peak; "
                               "per-kernel numbers in profiles/"},
     }
+
+
+def _disc_streams():
+    from facodec_amd import discriminator
+    return discriminator.N_STREAMS
+
+
+def _pred_streams():
+    from facodec_amd import autograd_pred
+    return autograd_pred.PRED_STREAMS
 
 
 def streaming_leg(model, device, hops=2000):
@@ -207,7 +220,8 @@ def streaming_leg(model, device, hops=2000):
         wall = time.perf_counter() - t_all
     steady = sorted(lat[10:])
     q = lambda p: round(1e3 * steady[min(len(steady) - 1, int(p * len(steady)))], 4)  # noqa: E731
-    return {"workload": f"configs[4] (short): {hops} hops of {HOP} samples, one stream, carried conv / LSTM state, HIP-graph replay",
+    return {"workload": f"configs[4] (short): {hops} hops of {HOP} samples, one stream, carried conv / LSTM state, HIP-graph replay, "
+                        "encoder and quantizer+decoder halves of a hop as two concurrent chains",
             "hops": hops, "p50_ms": q(0.5), "p99_ms": q(0.99), "rtf": round(wall / (hops * HOP / SAMPLE_RATE), 5)}
 
 
