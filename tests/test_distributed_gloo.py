@@ -254,3 +254,56 @@ def test_unbound_gradients_are_folded_in_one_copy():
         return opt.g.clone()
 
     assert torch.equal(run(True), run(False))
+
+
+def _unbound_worker(rank, world, port, q):
+    sys.path.insert(0, REPO)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from facodec_amd import benchutil
+    from facodec_amd.optim import FlatAdamW
+    benchutil.init_distributed("gloo")
+    torch.manual_seed(0)
+    params = [torch.nn.Parameter(torch.randn(4, 3)), torch.nn.Parameter(torch.randn(5)), torch.nn.Parameter(torch.randn(6))]
+    opt = FlatAdamW(params)
+    log = []
+    for it in range(2):
+        opt.zero_grad(unbind=True)                       # what TrainStep does: autograd hands its gradient tensors over
+        assert all(p.grad is None for p in params)
+        (params[0] * float(rank + 1)).sum().backward()
+        if it == 0:
+            opt.launch_all_reduce(only_if_complete=True)  # usage pattern unknown yet: a hook-time launch declines
+            assert opt._work is None
+        if rank == 0:                                    # params[1] is reached on rank 0 only; params[2] on no rank
+            (params[1] * 3.0).sum().backward()
+        opt.launch_all_reduce()                          # folds the stolen tensors into the arena, then ONE collective
+        opt.wait_all_reduce()
+        assert all(p.grad.data_ptr() == opt.g.data_ptr() + 4 * off for p, (off, _) in zip(params, opt.slices))   # bound again
+        log.append((opt.g.clone(), opt._flags.clone()))
+        opt._expected = tuple(opt._touched)
+        opt._flags_final = False
+    q.put((rank, log))
+    torch.distributed.destroy_process_group()
+
+
+def test_two_rank_unbound_gradients_fold_and_exchange():
+    """zero_grad(unbind=True) under two ranks: the gradients autograd kept are folded into the arena by launch_all_reduce, the
+    exchange averages them, the per-parameter flags say which parameters ANY rank reached, and the views are bound again."""
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_unbound_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((r, log) for r, log in (q.get(timeout=120) for _ in range(world)))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for it in range(2):
+        (g0, f0), (g1, f1) = res[0][1][it], res[1][1][it]
+        assert torch.equal(g0, g1) and torch.equal(f0, f1)
+        assert torch.allclose(g0[:12], torch.full((12,), 1.5))                  # mean of 1 and 2
+        assert torch.allclose(g0[12:17], torch.full((5,), 1.5))                 # 3 on rank 0, nothing on rank 1 -> mean 1.5
+        assert torch.equal(g0[17:], torch.zeros(6))
+        assert (f0[:2] > 0).all() and f0[2] == 0
