@@ -72,8 +72,12 @@ class GeneratorStep:
         quantizer (side branches included: they were created after the encoder) are done: the decoder's 342 MB ride under
         the quantizer + encoder backward, the quantizer's / predictors' under the encoder backward.  `only_if_complete`
         double-checks against the previous step's usage pattern; a key that is not complete simply launches after backward.
-        Every rank issues the collectives in the same order because the usage pattern of this model is static
-        (FAC_EARLY_EXCHANGE=0 switches the hooks off)."""
+        Order of the collectives across ranks: a rank launches a key from its hook iff every parameter the key reached in the
+        previous step has been reached again, so all ranks take the same decision as long as WHICH parameters receive a gradient
+        does not depend on the rank -- true for this model: the half of every batch that quantizer dropout leaves alone uses
+        every codebook (dac/nn/quantize.py:163-168), so every parameter is reached on every rank in every step.  A configuration
+        that breaks this (quantizer_dropout = 1.0 with a few clips per rank) must run with FAC_EARLY_EXCHANGE=0: all keys then
+        launch after backward in one fixed order."""
         if os.environ.get("FAC_EARLY_EXCHANGE", "1") == "0":
             return
         opt = self.opt
