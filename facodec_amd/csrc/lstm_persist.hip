@@ -9,12 +9,14 @@
 //   * the batch is handled in 16-column blocks on v_mfma_f32_16x16x4_f32 (B = 16 is one block; the per-step kernel's
 //     32x32x2 tile spends half its MFMA time on the padded columns 16..31);
 //   * the cell state lives in a register of the thread that owns the (unit, column);
-//   * steps are separated by a device-wide flag exchange instead of a kernel boundary: workgroup i publishes
-//     "finished step t" with one release store to flags[i]; a waiter reads all flags with ONE wave-wide load per poll
-//     (no read-modify-write, nothing serialises on a counter), then an agent-scope acquire makes h_{t} visible across
-//     the XCDs' L2s.  The flags hold epoch + step; the epoch advances by T per launch (last workgroup out), so a
-//     replayed hipGraph needs no host-side reset.  A waiter that sees no progress for ~4 s traps (loud launch failure)
-//     instead of hanging the queue.
+//   * steps are separated by a device-wide flag exchange instead of a kernel boundary: workgroup i writes h_t with
+//     write-through (agent-scope, sc1) stores into a FRESH region per step, waits for their acknowledgement and stores
+//     "finished step t" into flags[i]; a waiter reads all flags with ONE wave-wide sc1 load per poll (no read-modify-write,
+//     nothing serialises on a counter) and then reads h_t with plain loads -- no XCD can hold an older copy of lines that
+//     did not exist before.  No buffer_wbl2 / buffer_inv on the step path: the memory-model fences of a textbook grid
+//     barrier measured 25-92 us per step on this part (exchange modes below).  The flags hold epoch + step;
+//     the epoch advances by T per launch (last workgroup out), so a replayed hipGraph needs no host-side reset.  A
+//     waiter that sees no progress for ~4 s traps (loud launch failure) instead of hanging the queue.
 // Requirements (fac_lstm_persist_ok): H a multiple of 256 with H/64 in {8, 16, 24}, B <= 32, H/8 <= CUs of the device,
 // zero initial state.  Everything else (streaming sessions that carry state, larger batches) stays on lstm.hip.
 //
@@ -23,6 +25,8 @@
 //   weights  packed[(blk*16 + w)*(KS/2) + j][lane] float4 = {A(s=2j, rb=0), A(2j, 1), A(2j+1, 0), A(2j+1, 1)},
 //            A(s, rb) = M[row(blk, rb*16 + l%16)][k0(blk) + w*H/16 + 4*s + l/16]            (fac_pack_lstm_whh16)
 //   state    frag[(cb*16 + w)*(KS/4) + j4][lane] float4 component jj = X[k = w*H/16 + 4*(4*j4+jj) + l/16][cb*16 + l%16]
+//   k <-> hidden unit: permuted inside every group of 16 units (k_of_unit) so that a workgroup's 8 units x 16 columns are
+//   four whole 128-byte lines of the state buffer; the weights are packed with the same permutation (unit_of_k).
 #include <stdlib.h>
 
 #include <mutex>
@@ -48,8 +52,8 @@ __device__ LstmSync g_lstm_sync[LSTM_SYNC_SLOTS];
 
 constexpr long long LSTM_SPIN_LIMIT = 400000000ll;   // wall_clock64 ticks (100 MHz): 4 s without progress -> trap
 
-// wave 0: wait until flags[first .. first+count) have all reached `target`; then the workgroup passes a barrier and
-// every wave takes an agent-scope acquire (stale L1 / L2 lines of the exchanged buffers are dropped).
+// wave 0: wait until flags[first .. first+count) have all reached `target`; then the workgroup passes a barrier (mode 0
+// only: and every wave takes an agent-scope acquire that drops stale L1 / L2 lines of the exchanged buffers).
 // Exchange modes.  0: cache maintenance (buffer_wbl2 / buffer_inv) around plain accesses.  1: every exchanged word moves with
 // agent-scope (sc1) stores and loads, ordered by s_waitcnt only -- no L2 write-back / invalidate per step, but every
 // workgroup's copy of h_t comes from the memory side.  2: sc1 stores into a FRESH region per step, each workgroup writing
