@@ -18,6 +18,45 @@ def _free_port():
     return p
 
 
+def _portable(x):
+    """Tensors cross the result queue BY VALUE (numpy bytes): torch's default reduction hands over a shared-memory file
+    descriptor through a socket to the producing process, and a worker that has already exited resets that connection
+    (the suite's one flaky failure: ConnectionResetError in q.get)."""
+    if torch.is_tensor(x):
+        return ("__tensor__", x.detach().cpu().numpy().copy())
+    if isinstance(x, dict):
+        return {k: _portable(v) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return type(x)(_portable(v) for v in x)
+    return x
+
+
+def _restore(x):
+    if isinstance(x, tuple) and len(x) == 2 and isinstance(x[0], str) and x[0] == "__tensor__":
+        return torch.from_numpy(x[1])
+    if isinstance(x, dict):
+        return {k: _restore(v) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return type(x)(_restore(v) for v in x)
+    return x
+
+
+def _run_ranks(worker, world=2, *args):
+    """Spawns `world` gloo ranks of `worker(rank, world, port, q, *args)`; returns their results ordered by rank (each worker
+    puts ONE tuple whose first element is its rank)."""
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=worker, args=(r, world, port, q) + args) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((_restore(q.get(timeout=180)) for _ in range(world)), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    return res
+
+
 def _worker(rank, world, port, q):
     sys.path.insert(0, REPO)
     os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
@@ -35,22 +74,12 @@ def _worker(rank, world, port, q):
 
     dt = benchutil.timed_steps(step, steps=3, warmup=1, sync_fn=lambda: None)
     units = benchutil.aggregate_units((hi - lo) * 3)
-    q.put((r, lo, hi, len(calls), dt, units, float(clips.abs().max())))
+    q.put(_portable((r, lo, hi, len(calls), dt, units, float(clips.abs().max()))))
     torch.distributed.destroy_process_group()
 
 
 def test_two_rank_gloo_scaffold():
-    world = 2
-    port = _free_port()
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
-    for p in procs:
-        p.start()
-    res = sorted(q.get(timeout=120) for _ in range(world))
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
+    res = _run_ranks(_worker)
     (r0, lo0, hi0, c0, dt0, u0, m0), (r1, lo1, hi1, c1, dt1, u1, m1) = res
     assert (lo0, hi0, lo1, hi1) == (0, 4, 4, 7)          # disjoint cover of the 7 clips
     assert c0 == c1 == 4                                  # 1 warm-up + exactly 3 timed steps
@@ -83,24 +112,14 @@ def _grad_worker(rank, world, port, q):
     # params[2] has no gradient on any rank: counts as zeros
     opt.gather_grads()
     opt.all_reduce_mean()                                           # ONE collective over the whole arena
-    q.put((rank, opt.g.clone()))
+    q.put(_portable((rank, opt.g.clone())))
     torch.distributed.destroy_process_group()
 
 
 def test_two_rank_gradient_arena_all_reduce():
     """Data-parallel exchange of the training step (facodec_amd/optim.py): every rank ends with the mean gradient,
     one all-reduce per model key, unused parameters as zeros."""
-    world = 2
-    port = _free_port()
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    procs = [ctx.Process(target=_grad_worker, args=(r, world, port, q)) for r in range(world)]
-    for p in procs:
-        p.start()
-    res = sorted((r, g) for r, g in (q.get(timeout=120) for _ in range(world)))
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
+    res = _run_ranks(_grad_worker)
     g0, g1 = res[0][1], res[1][1]
     assert torch.equal(g0, g1)
     assert torch.allclose(g0[:15], torch.full((15,), 1.5))
@@ -145,7 +164,7 @@ def _overlap_worker(rank, world, port, q):
     keys["decoder"].launch_all_reduce(only_if_complete=True)
     late = keys["decoder"]._work is not None
     keys["decoder"].wait_all_reduce()
-    q.put((rank, res, early, late, keys["decoder"].g.clone()))
+    q.put(_portable((rank, res, early, late, keys["decoder"].g.clone())))
     torch.distributed.destroy_process_group()
 
 
@@ -153,17 +172,7 @@ def test_two_rank_async_exchange_order_and_empty_key():
     """One asynchronous all-reduce per model key: gradients live in the arena (views), keys launch in a fixed order and are
     waited for in another, a key whose parameters get no gradient still takes part (zeros) so the collectives stay matched,
     and a launch from inside backward only happens once the key's gradients are complete."""
-    world = 2
-    port = _free_port()
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    procs = [ctx.Process(target=_overlap_worker, args=(r, world, port, q)) for r in range(world)]
-    for p in procs:
-        p.start()
-    res = sorted((q.get(timeout=120) for _ in range(world)), key=lambda t: t[0])
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
+    res = _run_ranks(_overlap_worker)
     (_, g0, e0, l0, d0), (_, g1, e1, l1, d1) = res
     for k in g0:
         assert torch.equal(g0[k], g1[k])
@@ -197,7 +206,7 @@ def _flag_worker(rank, world, port, q):
     params[2].grad.add_(1.0)
     hidden = list(opt._touched)
     opt.mark_grads([params[2]])
-    q.put((rank, out, hidden, list(opt._touched)))
+    q.put(_portable((rank, out, hidden, list(opt._touched))))
     torch.distributed.destroy_process_group()
 
 
@@ -205,17 +214,7 @@ def test_two_rank_touched_flags_travel_with_the_gradients():
     """which parameters are stepped must be the UNION over ranks -- a parameter reached on rank 0 only
     receives the averaged gradient on both ranks and must be stepped on both.  The flags ride at the tail of the arena
     through the same all-reduce (or, for DDP-wrapped modules whose gradients DDP averages, through a MAX of the flags)."""
-    world = 2
-    port = _free_port()
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    procs = [ctx.Process(target=_flag_worker, args=(r, world, port, q)) for r in range(world)]
-    for p in procs:
-        p.start()
-    res = sorted((q.get(timeout=120) for _ in range(world)), key=lambda t: t[0])
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
+    res = _run_ranks(_flag_worker)
     (_, o0, hid0, mk0), (_, o1, _, _) = res
     assert o0["arena"][0] == [True, True, False] and o1["arena"][0] == [True, False, False]      # local views differ
     for mode in ("arena", "ddp_wrapped"):
@@ -282,24 +281,14 @@ def _unbound_worker(rank, world, port, q):
         log.append((opt.g.clone(), opt._flags.clone()))
         opt._expected = tuple(opt._touched)
         opt._flags_final = False
-    q.put((rank, log))
+    q.put(_portable((rank, log)))
     torch.distributed.destroy_process_group()
 
 
 def test_two_rank_unbound_gradients_fold_and_exchange():
     """zero_grad(unbind=True) under two ranks: the gradients autograd kept are folded into the arena by launch_all_reduce, the
     exchange averages them, the per-parameter flags say which parameters ANY rank reached, and the views are bound again."""
-    world = 2
-    port = _free_port()
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    procs = [ctx.Process(target=_unbound_worker, args=(r, world, port, q)) for r in range(world)]
-    for p in procs:
-        p.start()
-    res = sorted((r, log) for r, log in (q.get(timeout=120) for _ in range(world)))
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
+    res = _run_ranks(_unbound_worker)
     for it in range(2):
         (g0, f0), (g1, f1) = res[0][1][it], res[1][1][it]
         assert torch.equal(g0, g1) and torch.equal(f0, f1)
