@@ -94,6 +94,34 @@ def check_codes(model, device):
     return total == 0
 
 
+def check_codes_b32(model, wave, rank):
+    """configs[1] at its own size: the six code streams of the TIMED batch (rank 0's 32 clips = synth.synth_clips(32, 48000,
+    seed=0)) against the REAL reference's run on the same 32 clips (tests/golden/codec_b32.npz, made by
+    tests/golden/make_golden_bench.py).  Same triage as check_codes.  Returns None when the batch is not that batch."""
+    import hashlib
+    import numpy as np
+    from facodec_amd.diagnostics import LatentCapture, classify_code_mismatches
+    path = os.path.join(REPO, "tests", "golden", "codec_b32.npz")
+    if rank != 0 or tuple(wave.shape) != (32, 1, 48000) or not os.path.exists(path):
+        return None
+    gold = np.load(path)
+    with LatentCapture(model.quantizer) as cap:
+        _, codes = make_step(model, wave)()
+    rvqs, report, lo = dict(cap.rvqs), {}, 0
+    for (name, _), c in zip(cap.rvqs, codes):                      # prosody (1), content (2), residual (3) streams
+        n = c.shape[1]
+        report[name] = classify_code_mismatches(rvqs[name], cap.latents[name], c, gold["codes"][:, lo:lo + n])
+        lo += n
+    if sum(r["genuine"] for r in report.values()):
+        raise SystemExit(f"[bench] code-index mismatch on the timed 32-clip batch against the reference: {report}")
+    allc = torch.cat(codes, 1).cpu().numpy().astype(np.int16)
+    flips = sum(r["mismatches"] for r in report.values())
+    return {"clips": 32, "codes": int(allc.size), "mismatches": flips,
+            "near_tie_flips_and_cascades": {k: {kk: r[kk] for kk in ("near_tie", "cascade", "worst_gap")} for k, r in report.items()} if flips else {},
+            "sha256_equal": hashlib.sha256(allc.tobytes()).hexdigest() == str(gold["codes_sha256"]),
+            "fixture": "tests/golden/codec_b32.npz (real reference, CPU, this batch)"}
+
+
 def synthetic_predictor_targets(batch, frames, device, seed=3):
     """What train.py:214-262 obtains from the external pitch extractor / CTC phoneme model / speaker model, as synthetic
     tensors of the same shapes and ranges (tests/golden/make_golden_train.py uses the same recipe): normalised log-F0 with
@@ -239,29 +267,82 @@ def respawn_under_launcher(n):
     raise SystemExit(subprocess.run(cmd, env=env).returncode)
 
 
-def cpu_baseline(batch=4, passes=5):
-    """The CPU oracle (port of the reference algorithm, pinned to it by tests/golden) timed on this
-    host's cores over a bounded sample of the same workload."""
+def cpu_baseline(batch=4, passes=5, warmups=2, with_train=True):
+    """The CPU oracle (port of the reference algorithm, pinned to it by tests/golden) timed on this host's cores over a
+    bounded sample of the same workload (B = 4 clips of 2 s, median of 5 passes after 2 warm-ups).
+    `value` = (A) the eval forward; `train` = (B) the train-mode iteration (forward + backward of encoder / quantizer /
+    predictors / decoder, 7-scale mel loss, both discriminator passes and its AdamW step: oracle/train_iteration.py), with
+    fewer passes when one pass is long (said in `sample`)."""
+    import statistics
     from oracle import facodec_oracle as O
     model = build_model(default_model_params())
-    sds = {k: synth.synth_state_dict(synth.param_shapes(model[k]), 0, k + ".") for k in ("encoder", "quantizer", "decoder")}
+    keys = ("encoder", "quantizer", "decoder", "discriminator", "fa_predictors") if with_train else ("encoder", "quantizer", "decoder")
+    sds = {k: synth.synth_state_dict(synth.param_shapes(model[k]), 0, k + ".") for k in keys}
+    names = {k: {n for n, _ in model[k].named_parameters()} for k in keys}
     del model
-    wave = synth.synth_clips(batch, int(CLIP_SECONDS * SAMPLE_RATE), seed=0)
-    # thread sweep on the GPU box's host (tests/tools/cpu_thread_sweep.py: 8/16/32/64/128 threads ->
-    # 1.91/2.14/1.79/1.21/0.48 audio-s/s): 16 threads is the oracle's best case, so that is the baseline
+    n_samples = int(CLIP_SECONDS * SAMPLE_RATE)
+    wave = synth.synth_clips(batch, n_samples, seed=0)
+    # thread sweep on the GPU box's host (tests/tools/cpu_thread_sweep.py, output in profiles/r04_cpu_thread_sweep.log):
+    # 16 threads is the oracle's best case on the 256-logical-core host, so that is the baseline
     prev_threads = torch.get_num_threads()
     threads = min(16, os.cpu_count() or 1)
     torch.set_num_threads(threads)
+    times = []
     with torch.no_grad():
-        O.codec_forward(sds, wave[:1], n_c=2)  # warm-up (page-in, oneDNN primitive cache)
-        t0 = time.perf_counter()
-        for _ in range(passes):
+        O.codec_forward(sds, wave[:1], n_c=2)  # page-in, oneDNN primitive cache
+        for i in range(warmups + passes):
+            t0 = time.perf_counter()
             O.codec_forward(sds, wave, n_c=2)
-        dt = time.perf_counter() - t0
+            times.append(time.perf_counter() - t0)
+    med = statistics.median(times[warmups:])
+    out = dict(value=round(batch * CLIP_SECONDS / med, 3), unit="audio-s/s", cores=threads, kind="port",
+               sample=f"median of {passes} passes after {warmups} warm-ups, {batch} clips x 2 s each (oracle/facodec_oracle.py "
+                      f"codec_forward, torch-CPU fp32, {threads} threads, {os.cpu_count()} logical cores on host), "
+                      f"{sum(times):.1f} s of CPU work")
+    if with_train:
+        from oracle.train_iteration import oracle_iteration
+        frames = n_samples // 300
+        tg = synthetic_predictor_targets(batch, frames, "cpu", seed=3)
+        ones = lambda n: torch.ones(n, batch)  # noqa: E731
+        t = dict(wav_seg=wave, waves=wave.squeeze(1), wave_lens=torch.full((batch,), n_samples, dtype=torch.int64),
+                 targets=dict(f0=tg["f0"], uv=tg["uv"], phones=tg["phones"], speaker=tg["speaker"]),
+                 masks=dict(p=ones(1), c=ones(2), r=ones(3), res=torch.ones(batch), dropout=False))
+        tt = []
+        t0 = time.perf_counter()
+        oracle_iteration(sds, names, t)
+        first = time.perf_counter() - t0
+        tw, tp = (2, 5) if first * 7 < 90 else (1, 3)          # keep the default bench.py run within a few minutes
+        for i in range(tw - 1 + tp):
+            t0 = time.perf_counter()
+            oracle_iteration(sds, names, t)
+            tt.append(time.perf_counter() - t0)
+        medt = statistics.median(tt[tw - 1:])
+        out["train"] = dict(value=round(batch * CLIP_SECONDS / medt, 3), unit="audio-s/s", ms_per_step=round(1e3 * medt, 1), cores=threads,
+                            kind="port",
+                            sample=f"median of {tp} iterations after {tw} warm-up(s), {batch} clips x 2 s: train.py:265-374 through "
+                                   f"oracle/train_iteration.py + torch autograd (encoder / quantizer / predictors / decoder forward + "
+                                   f"backward, 7-scale mel loss, discriminator step + generator step), {threads} threads, "
+                                   f"{first + sum(tt):.1f} s of CPU work")
     torch.set_num_threads(prev_threads)
-    return dict(value=round(batch * CLIP_SECONDS * passes / dt, 3), unit="audio-s/s", cores=threads, kind="port",
-                sample=f"{passes} passes of {batch} clips x 2 s (oracle/facodec_oracle.py codec_forward, torch-CPU fp32, "
-                       f"{threads} threads, {os.cpu_count()} logical cores on host), {dt:.1f} s of CPU work")
+    return out
+
+
+def latest_pmc_traffic():
+    """The HBM-traffic counters are collected by separate rocprofv3 --pmc passes (tools/pmc_traffic.py; MI355X_MICROARCH.md HBM
+    section), not inside this run: returns (per-kernel dict, source description) of the newest committed profiles/rNN_pmc_traffic.json."""
+    import glob
+    import re
+    best = None
+    for f in glob.glob(os.path.join(REPO, "profiles", "r*_pmc_traffic.json")):
+        m = re.match(r"r(\d+)_pmc_traffic\.json", os.path.basename(f))
+        if m and (best is None or int(m.group(1)) > best[0]):
+            best = (int(m.group(1)), f)
+    if best is None:
+        return {}, None
+    d = json.load(open(best[1]))
+    src = dict(d.get("_source", {}), file=os.path.relpath(best[1], REPO),
+               note="separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) over bench.py, per launch; not measured inside this timed run")
+    return d, src
 
 
 def main():
@@ -293,6 +374,7 @@ def main():
     n_samples = int(CLIP_SECONDS * SAMPLE_RATE)
     codes_match = check_codes(model, device)
     wave = synth.synth_clips(args.batch, n_samples, seed=0, rank=rank).to(device)   # resident in HBM
+    codes_b32 = check_codes_b32(model, wave, rank)
     step = make_step(model, wave)
     sync = torch.cuda.synchronize
 
@@ -343,10 +425,11 @@ def main():
         "metric": "24kHz audio sec encoded+decoded per wall-sec",
         "value": round(value, 2), "unit": "audio-s/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic", "codes_match": codes_match,
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic", "codes_match": codes_match, "codes_match_timed_batch": codes_b32,
         "arithmetic": ("fp32 tensors and fp32 accumulation everywhere; the k=7 ResidualUnit convs form each fp32 product from "
-                       "three-way exact bf16 splits of both operands on the bf16 matrix pipe (error vs fp64 <= the fp32 MFMA's, "
-                       "tests/test_gpu_parity.py::test_split_bf16_conv_matches_fp32_grade)" if ops.BF16_SPLIT else "fp32 MFMA"),
+                       "three-way exact bf16 splits of both operands on the bf16 matrix pipe, six of the nine cross products kept "
+                       "(tested bars, tests/test_gpu_parity.py::test_split_bf16_conv_matches_fp32_grade: 1e-5 of the oracle like the fp32 "
+                       "kernel, and error vs fp64 < 1.5 x the fp32-MFMA kernel's + 1e-7; codes bit-exact vs the reference)" if ops.BF16_SPLIT else "fp32 MFMA"),
         "config": {"workload": f"configs[1]: batch={args.batch}/GPU x 2 s @ 24 kHz, forward encoder->FVQ(6 codebooks)->decoder, "
                                "FAcodec configs/config.yml model (137.7 M params), weights formula-generated, "
                                "weight-norm re-materialised every step", "clips_per_gpu": args.batch,
@@ -357,15 +440,13 @@ def main():
         name, best = max(summ.items(), key=lambda kv: kv[1]["ms"])
         tot_ms = sum(v["ms"] for v in summ.values())
         achieved = best["flops"] / (best["ms"] * 1e-3) / 1e12
-        traffic = None
-        pmc = os.path.join(REPO, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc):
-            traffic = json.load(open(pmc)).get(name.split(" ")[0])
+        pmc, pmc_src = latest_pmc_traffic()
+        traffic = pmc.get(name.split(" ")[0])
         is_split = "bsplit" in name
         peak = SPLIT_PEAK_TFLOPS if is_split else FP32_MFMA_PEAK_TFLOPS
         out["roofline"] = {
             "bound": "mfma", "kernel": name, "achieved": round(achieved, 2), "peak": round(peak, 1),
-            "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,
+            "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": pmc_src if traffic is not None else None,
             "peak_basis": ("bf16 MFMA dense peak 2516.6 / 6 MFMAs per fp32-equivalent K step (fp32-exact operand splitting); "
                            "achieved = algorithmic fp32 FLOPs / time" if is_split else "fp32 MFMA dense peak"),
             "launches_per_step": best["launches"] // args.steps,
@@ -378,9 +459,12 @@ def main():
             "conv_ms_per_step": round(tot_ms / args.steps, 3),
             "whole_step_tflops": round(value / world * FLOP_PER_AUDIO_S / 1e12, 2),
             "whole_step_frac_of_fp32_mfma_peak": round(value / world * FLOP_PER_AUDIO_S / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
-            "note": "SURVEY.md 8d prices the whole forward against the fp32 MFMA peak (157.3): that fraction is "
-                    "whole_step_frac_of_fp32_mfma_peak.  The bf16 pipe sustains 1913 TFLOP/s on random operands on this part "
-                    "(tools/microbench), so the practical ceiling of the split kernel is ~319 fp32-equivalent TFLOP/s, not 419.",
+            "whole_step_frac_of_split_peak": round(value / world * FLOP_PER_AUDIO_S / 1e12 / SPLIT_PEAK_TFLOPS, 4),
+            "note": "SURVEY.md 8d prices the whole forward against the fp32 MFMA peak (157.3): whole_step_frac_of_fp32_mfma_peak.  That is "
+                    "flattering here, because most of the step's FLOPs run on the bf16 pipe as six exact products each: "
+                    "whole_step_frac_of_split_peak prices the same step against that pipe (2516.6 / 6 = 419.4 fp32-equivalent TFLOP/s). "
+                    "The bf16 pipe sustains 1913 TFLOP/s on random operands on this part (tools/microbench), so the practical ceiling of the "
+                    "split kernels is ~319 fp32-equivalent TFLOP/s.",
         }
     if train is not None:
         out["train_step"] = train

@@ -351,7 +351,7 @@ class _RVQ(Function):
     Returns z_q, commitment (scalar), codebook loss (scalar); codes via the `codes` buffer (B, n, T)."""
 
     @staticmethod
-    def forward(ctx, z, mask, codes, *params):
+    def forward(ctx, z, mask, codes, latents, *params):
         n = len(params) // 7
         B, D, T = z.shape
         zd = z.detach()
@@ -369,6 +369,8 @@ class _RVQ(Function):
                         codes[:, i], residual=nxt, zq_acc=z_q, mask=mask[i].contiguous(), z_e=z_e, loss_part=lp[i])
             # the fused kernel writes nxt = src - z_q_i (reading src = z_in): keep src untouched for the backward
             z_es.append(z_e)
+            if latents is not None:
+                latents[:, 8 * i: 8 * (i + 1)] = z_e
             src = nxt
         per = lp.sum(2) / float(8 * T)                 # (n, B): mse per sample; commitment == codebook loss in value
         loss = (per * mask).mean(1).sum()
@@ -408,12 +410,13 @@ class _RVQ(Function):
             grads[7 * i], grads[7 * i + 1] = ops.weight_norm_bwd(v_in, g_in, dw_in)
             grads[7 * i + 2] = ops.bias_grad(d_ze)
             d_res = d_in if d_res is None else ops.add(d_res, d_in)
-        return (d_res, None, None, *grads)
+        return (d_res, None, None, None, *grads)
 
 
-def rvq(m, z, mask=None):
+def rvq(m, z, mask=None, latents=None):
     """ResidualVectorQuantize module `m` in training mode -> (z_q, codes, commitment, codebook_loss).
-    mask (n, B) float 0/1 (quantizer dropout); None = every quantizer active for every sample."""
+    mask (n, B) float 0/1 (quantizer dropout); None = every quantizer active for every sample.
+    latents: optional (B, 8 n, T) buffer that receives the projected latents z_e_i (dac/nn/quantize.py:195; no gradient)."""
     n = m.n_codebooks
     B, _, T = z.shape
     if mask is None:
@@ -423,7 +426,7 @@ def rvq(m, z, mask=None):
     for q in m.quantizers:
         flat += [q.in_proj.weight_v, q.in_proj.weight_g, q.in_proj.bias, q.codebook.weight,
                  q.out_proj.weight_v, q.out_proj.weight_g, q.out_proj.bias]
-    z_q, commit, cbl = _RVQ.apply(z, mask, codes, *flat)
+    z_q, commit, cbl = _RVQ.apply(z, mask, codes, latents, *flat)
     return z_q, codes, commit, cbl
 
 

@@ -151,25 +151,38 @@ __global__ __launch_bounds__((NMW + NSW) * 64, (NMW + NSW) / 4) void conv1d_bspl
       else idx = (tin >= 0 && tin < a.T_in) ? tin : -1;
       u_idx[j] = u_c[j] >= 0 ? idx : -1;
     }
-    auto stage_w = [&](int chunk, int buf) {   // weights: one contiguous slab, 16 B per lane
+    // Weights: one contiguous slab per stage, 16 B per lane by LDS-DMA.  Every staging wave issues exactly ND DMA instructions
+    // (the block index is clamped: a wave short of one block re-copies the last block -- same bytes to the same place), so the
+    // position of a stage's loads in the wave's in-order load queue is a compile-time constant (see `landed`).
+    constexpr int NBLK = W_STAGE / 1024;               // 1 KiB blocks per weight stage
+    constexpr int ND = (NBLK + NSW - 1) / NSW;         // DMA instructions per staging wave and stage
+    constexpr int NX = BS_XU * 8;                      // input loads per staging wave and stage
+    static_assert(W_STAGE % 1024 == 0 && ND + NX <= 63, "vmcnt is a 6-bit counter");
+    auto stage_w = [&](int chunk, int buf) {
 #if !defined(FAC_ABL_NOSTAGE) && !defined(FAC_ABL_NOSTAGE_W)
-      constexpr int N16 = W_STAGE / 16;
       const unsigned char* src = wsrc + (long long)chunk * W_STAGE;
       unsigned char* dst = Wbuf + buf * W_STAGE;
-      for (int i = lw; i * 64 < N16; i += NSW) {
-        const int q = i * 64 + lane;
-        if (q < N16)
-          __builtin_amdgcn_global_load_lds((glb_void_t*)(src + (long long)q * 16), (lds_void_t*)(dst + i * 1024), 16, 0, 0);
+#pragma unroll
+      for (int j = 0; j < ND; ++j) {
+        const int i = min(lw + NSW * j, NBLK - 1);
+        __builtin_amdgcn_global_load_lds((glb_void_t*)(src + (long long)i * 1024 + lane * 16), (lds_void_t*)(dst + i * 1024), 16, 0, 0);
       }
 #endif
     };
-    // Every instruction of the staging waves costs the SIMD's MFMA wave issue time (measured: a stage takes 3.0 us with the
-    // staging work removed, 4.7 us with it), so the loads are kept to one instruction each: the channel row is a uniform
-    // (scalar) base, the column a per-lane 32-bit offset resolved once per tile; lanes on padding read a clamped column and
-    // are zeroed by a select (no exec-mask branches), and C_in % (8 G) == 0 (dispatcher) makes every channel of a stage real.
-    int u_off[BS_XU];
+    // Every instruction of the staging waves costs the SIMD's MFMA wave issue time, so the loads are kept to one instruction
+    // each: the channel row is a uniform (scalar) base, the column a per-lane 32-bit byte offset resolved once per tile; lanes on
+    // padding read a clamped column and are zeroed at the split (no exec-mask branches), and C_in % (8 G) == 0 (dispatcher)
+    // makes every channel of a stage real.
+    //
+    // The loads are INLINE ASM: hipcc's own s_waitcnt placement waits for a plain C++ load at its first use -- and the padding
+    // select is a use -- so the "register double buffer" of rounds 1-3 was waited for with vmcnt(0) right behind the last load
+    // of the same stage (and again in front of every barrier, together with the weight DMA issued a moment earlier): each
+    // stage paid a full memory round trip on the staging waves' critical path (found in the ISA in round 4).  Invisible to the
+    // compiler, the loads of chunk c + 2 now stay in flight across the barrier, and `landed(n)` = `s_waitcnt vmcnt(n)` on the
+    // in-order queue waits for exactly the loads a step needs.
+    unsigned u_boff[BS_XU];
 #pragma unroll
-    for (int j = 0; j < BS_XU; ++j) u_off[j] = u_idx[j] >= 0 ? u_idx[j] : 0;
+    for (int j = 0; j < BS_XU; ++j) u_boff[j] = (unsigned)(u_idx[j] >= 0 ? u_idx[j] : 0) * 4u;
     auto load_x = [&](int chunk, float (&xr)[BS_XU][8]) {
 #if !defined(FAC_ABL_NOSTAGE) && !defined(FAC_ABL_NOSTAGE_X)
 #pragma unroll
@@ -177,11 +190,19 @@ __global__ __launch_bounds__((NMW + NSW) * 64, (NMW + NSW) / 4) void conv1d_bspl
         const float* grp = xg + (long long)((chunk * G + u_g[j]) * 8) * xcs;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-          const float v = (grp + (long long)i * xcs)[u_off[j]];
-          xr[j][i] = u_idx[j] >= 0 ? v : 0.f;
+          const float* row = grp + (long long)i * xcs;
+          asm volatile("global_load_dword %0, %1, %2" : "=v"(xr[j][i]) : "v"(u_boff[j]), "s"(row) : "memory");
         }
       }
 #endif
+    };
+    // `landed<n>`: everything but the youngest n loads of this wave has landed (loads return in order); the register set is
+    // named as an in/out operand so that no use of it moves above the wait
+    auto pin = [&](float (&xr)[BS_XU][8]) {
+#pragma unroll
+      for (int j = 0; j < BS_XU; ++j)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) asm volatile("" : "+v"(xr[j][i]) : : "memory");
     };
     auto write_x = [&](int buf, const float (&xr)[BS_XU][8]) {
 #if !defined(FAC_ABL_NOSTAGE) && !defined(FAC_ABL_NOSTAGE_X)
@@ -193,7 +214,7 @@ __global__ __launch_bounds__((NMW + NSW) * 64, (NMW + NSW) / 4) void conv1d_bspl
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
           __bf16 p0, p1, p2;
-          split3(xr[j][i], p0, p1, p2);
+          split3(u_idx[j] >= 0 ? xr[j][i] : 0.f, p0, p1, p2);
           h[i] = p0; m[i] = p1; l[i] = p2;
         }
         *reinterpret_cast<bf16x8*>(xd + ((0 * G + u_g[j]) * XW + u_c[j]) * 16) = h;
@@ -202,28 +223,51 @@ __global__ __launch_bounds__((NMW + NSW) * 64, (NMW + NSW) / 4) void conv1d_bspl
       }
 #endif
     };
-    // The fp32 inputs of chunk c+2 are requested one whole stage before they are split and written
-    // (register double buffer, static indices): their HBM/L2 latency hides behind the MFMAs of chunk c.
+    // Chunk c + 1 is staged while the MFMA waves multiply chunk c; the fp32 inputs of chunk c + 2 are requested a whole stage
+    // before they are split and written (two register sets: xa holds even chunks, xb odd ones).  In-order load queue of a wave
+    // inside iteration c: [inputs of c + 1 (NX)] [weight DMA of c + 1 (ND)], then -- the inputs of c + 1 have landed --
+    // [weight DMA of c + 1 (ND)] [inputs of c + 2 (NX)].
     float xa[BS_XU][8], xb[BS_XU][8];
+    // steady state (c + 2 < n_chunks): `cur` holds chunk c + 1 (requested a whole stage ago), `nxt` receives chunk c + 2.
+    // At most ND + NX loads are in flight (vmcnt is a 6-bit counter).
+    auto steady = [&](int c, int buf_next, float (&nxt)[BS_XU][8], float (&cur)[BS_XU][8]) {
+      stage_w(c + 1, buf_next);                                  // that buffer was read during chunk c - 1
+      asm volatile("s_waitcnt vmcnt(%0)" : : "n"(ND) : "memory");                  // inputs of c + 1 (older than the DMA)
+      pin(cur);
+      load_x(c + 2, nxt);
+      write_x(buf_next, cur);
+      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" : : "n"(NX) : "memory");       // weights of c + 1 landed, LDS writes done
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+    };
+    auto last = [&](int c, int buf_next, float (&cur)[BS_XU][8]) {                 // c + 2 == n_chunks: nothing further to request
+      stage_w(c + 1, buf_next);
+      asm volatile("s_waitcnt vmcnt(%0)" : : "n"(ND) : "memory");
+      pin(cur);
+      write_x(buf_next, cur);
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+    };
     load_x(0, xa);
     stage_w(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                               // inputs and weights of chunk 0
+    pin(xa);
     if (n_chunks > 1) load_x(1, xb);
     write_x(0, xa);
-    __syncthreads();
-    for (int chunk = 0; chunk < n_chunks; chunk += 2) {
-      if (chunk + 1 < n_chunks) {
-        stage_w(chunk + 1, 1);
-        if (chunk + 2 < n_chunks) load_x(chunk + 2, xa);
-        write_x(1, xb);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    for (int c = 0; c < n_chunks; ++c) {
+      const bool odd = c & 1;
+      if (c + 2 < n_chunks) {
+        if (!odd) steady(c, 1, xa, xb); else steady(c, 0, xb, xa);
+      } else if (c + 1 < n_chunks) {
+        if (!odd) last(c, 1, xb); else last(c, 0, xa);
+      } else {
+        __builtin_amdgcn_s_barrier();                            // pairs with the MFMA waves' barrier behind the last chunk
+        asm volatile("" ::: "memory");
       }
-      __syncthreads();
-      if (chunk + 1 >= n_chunks) break;
-      if (chunk + 2 < n_chunks) {
-        stage_w(chunk + 2, 0);
-        if (chunk + 3 < n_chunks) load_x(chunk + 3, xb);
-        write_x(0, xa);
-      }
-      __syncthreads();
     }
     __builtin_amdgcn_s_setprio(0);
   } else {

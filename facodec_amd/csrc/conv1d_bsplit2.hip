@@ -117,35 +117,55 @@ __global__ __launch_bounds__(512, 2) void conv1d_bsplit2_kernel(ConvArgs a) {
       u_pos[j] = ((c % S) * XWh + c / S) * 16;
     }
     const int tin0 = t0 * S - a.pad_left;
-    auto stage_w = [&](int chunk, int buf) {   // weights: one contiguous slab, 16 B per lane
-      constexpr int N16 = W_STAGE / 16;
+    // Weights: one contiguous slab per stage, 16 B per lane by LDS-DMA; every staging wave issues exactly ND instructions (a wave
+    // short of one block re-copies the last block), so `s_waitcnt vmcnt(n)` on the in-order load queue can name what it waits for.
+    constexpr int NBLK = W_STAGE / 1024;
+    constexpr int ND = (NBLK + 3) / 4;
+    constexpr int NX = XU * 8;
+    static_assert(W_STAGE % 1024 == 0 && ND + NX <= 63, "vmcnt is a 6-bit counter");
+    auto stage_w = [&](int chunk, int buf) {
       const unsigned char* src = wsrc + (long long)chunk * W_STAGE;
       unsigned char* dst = Wbuf + buf * W_STAGE;
-      for (int i = lw; i * 64 < N16; i += 4) {
-        const int q = i * 64 + lane;
-        if (q < N16)
-          __builtin_amdgcn_global_load_lds((glb_void_t*)(src + (long long)q * 16), (lds_void_t*)(dst + i * 1024), 16, 0, 0);
+#pragma unroll
+      for (int j = 0; j < ND; ++j) {
+        const int i = min(lw + 4 * j, NBLK - 1);
+        __builtin_amdgcn_global_load_lds((glb_void_t*)(src + (long long)i * 1024 + lane * 16), (lds_void_t*)(dst + i * 1024), 16, 0, 0);
       }
     };
+    // which (virtual channel i of the chunk, unit j) elements are real samples (the others are the conv's zero padding)
+    auto in_range = [&](int chunk, int i, int j, int& tin) {
+      const int v = chunk * 8 + i;
+      const bool vok = v < a.CV;
+      const int vv = vok ? v : 0;
+      const int k2 = vv % K2v;
+      tin = tin0 + k2 * dil2 + u_c[j];
+      return vok && u_c[j] >= 0 && tin >= 0 && tin < a.T_in;
+    };
+    // Loads by INLINE ASM (see conv1d_bsplit.hip: hipcc waits for a C++ load at its first use -- the padding select -- i.e. with
+    // vmcnt(0) right behind the loads of the same stage, and again before every barrier; rounds 1-3 paid a memory round trip per
+    // stage on the staging waves' critical path).  Scalar row base + per-lane byte offset, one instruction per element.
     auto load_x = [&](int chunk, float (&xr)[XU][8]) {
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         int v = chunk * 8 + i;                              // uniform: (real channel, second-level tap) of virtual channel v
-        const bool vok = v < a.CV;
-        v = vok ? v : 0;
-        const int ci = v / K2v, k2 = v - ci * K2v;
-        const float* row = xg + (long long)ci * xcs;
-        const int sh = tin0 + k2 * dil2;
+        v = v < a.CV ? v : 0;
+        const float* row = xg + (long long)(v / K2v) * xcs;
 #pragma unroll
         for (int j = 0; j < XU; ++j) {
-          const int tin = sh + u_c[j];
-          const bool ok = vok && u_c[j] >= 0 && tin >= 0 && tin < a.T_in;
-          const float val = row[ok ? tin : 0];
-          xr[j][i] = ok ? val : 0.f;
+          int tin;
+          const bool ok = in_range(chunk, i, j, tin);
+          const unsigned off = ok ? (unsigned)tin * 4u : 0u;
+          asm volatile("global_load_dword %0, %1, %2" : "=v"(xr[j][i]) : "v"(off), "s"(row) : "memory");
         }
       }
     };
-    auto write_x = [&](int buf, const float (&xr)[XU][8]) {
+    auto pin = [&](float (&xr)[XU][8]) {
+#pragma unroll
+      for (int j = 0; j < XU; ++j)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) asm volatile("" : "+v"(xr[j][i]) : : "memory");
+    };
+    auto write_x = [&](int chunk, int buf, const float (&xr)[XU][8]) {
       unsigned char* xd = Xbuf + buf * X_STAGE;
 #pragma unroll
       for (int j = 0; j < XU; ++j) {
@@ -153,8 +173,10 @@ __global__ __launch_bounds__(512, 2) void conv1d_bsplit2_kernel(ConvArgs a) {
         bf16x8 h, m, l;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
+          int tin;
+          const bool ok = in_range(chunk, i, j, tin);
           __bf16 p0, p1, p2;
-          b2_split3(xr[j][i], p0, p1, p2);
+          b2_split3(ok ? xr[j][i] : 0.f, p0, p1, p2);
           h[i] = p0; m[i] = p1; l[i] = p2;
         }
         *reinterpret_cast<bf16x8*>(xd + u_pos[j]) = h;
@@ -162,27 +184,47 @@ __global__ __launch_bounds__(512, 2) void conv1d_bsplit2_kernel(ConvArgs a) {
         *reinterpret_cast<bf16x8*>(xd + 2 * XWT * 16 + u_pos[j]) = l;
       }
     };
-    // fp32 inputs of chunk c + 2 are requested a whole stage before they are split (register double buffer)
+    // Chunk c + 1 is staged while the MFMA waves multiply chunk c; the fp32 inputs of chunk c + 2 are requested a whole stage
+    // before they are split (two register sets: xa even chunks, xb odd ones); at most ND + NX loads in flight.
     float xa[XU][8], xb[XU][8];
+    auto steady = [&](int c, int buf_next, float (&nxt)[XU][8], float (&cur)[XU][8]) {
+      stage_w(c + 1, buf_next);
+      asm volatile("s_waitcnt vmcnt(%0)" : : "n"(ND) : "memory");                  // inputs of c + 1 (older than the DMA)
+      pin(cur);
+      load_x(c + 2, nxt);
+      write_x(c + 1, buf_next, cur);
+      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" : : "n"(NX) : "memory");       // weights of c + 1 landed, LDS writes done
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+    };
+    auto last = [&](int c, int buf_next, float (&cur)[XU][8]) {
+      stage_w(c + 1, buf_next);
+      asm volatile("s_waitcnt vmcnt(%0)" : : "n"(ND) : "memory");
+      pin(cur);
+      write_x(c + 1, buf_next, cur);
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+    };
     load_x(0, xa);
     stage_w(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    pin(xa);
     if (n_chunks > 1) load_x(1, xb);
-    write_x(0, xa);
-    __syncthreads();
-    for (int chunk = 0; chunk < n_chunks; chunk += 2) {
-      if (chunk + 1 < n_chunks) {
-        stage_w(chunk + 1, 1);
-        if (chunk + 2 < n_chunks) load_x(chunk + 2, xa);
-        write_x(1, xb);
+    write_x(0, 0, xa);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    for (int c = 0; c < n_chunks; ++c) {
+      const bool odd = c & 1;
+      if (c + 2 < n_chunks) {
+        if (!odd) steady(c, 1, xa, xb); else steady(c, 0, xb, xa);
+      } else if (c + 1 < n_chunks) {
+        if (!odd) last(c, 1, xb); else last(c, 0, xa);
+      } else {
+        __builtin_amdgcn_s_barrier();                            // pairs with the MFMA waves' barrier behind the last chunk
+        asm volatile("" ::: "memory");
       }
-      __syncthreads();
-      if (chunk + 1 >= n_chunks) break;
-      if (chunk + 2 < n_chunks) {
-        stage_w(chunk + 2, 0);
-        if (chunk + 3 < n_chunks) load_x(chunk + 3, xb);
-        write_x(0, xa);
-      }
-      __syncthreads();
     }
     __builtin_amdgcn_s_setprio(0);
   } else {

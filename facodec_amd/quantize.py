@@ -62,7 +62,11 @@ class VectorQuantize(nn.Module):
 
 
 class ResidualVectorQuantize(nn.Module):
-    """dac/nn/quantize.py:97-198 (eval-mode forward: no quantizer dropout)."""
+    """dac/nn/quantize.py:97-198.  eval: `n_quantizers` codebooks for every sample.  train (:163-168): the first
+    int(B * quantizer_dropout) samples keep only `torch.randint(1, n_codebooks + 1)` codebooks (drawn on the CPU's default
+    generator exactly like the reference, or handed in as `masks` (n, B) of 0/1), forward and backward on the HIP path
+    (`autograd.rvq`: straight-through estimator, commitment / codebook losses with the reference's detach placements);
+    `latents` carry no gradient."""
 
     def __init__(self, input_dim=512, n_codebooks=9, codebook_size=1024, codebook_dim=8, quantizer_dropout=0.0):
         super().__init__()
@@ -70,9 +74,15 @@ class ResidualVectorQuantize(nn.Module):
         self.quantizers = nn.ModuleList([VectorQuantize(input_dim, codebook_size, codebook_dim) for _ in range(n_codebooks)])
         self.quantizer_dropout = quantizer_dropout
 
-    def forward(self, z, n_quantizers=None):
+    def forward(self, z, n_quantizers=None, masks=None):
         if self.training:
-            raise NotImplementedError("train-mode RVQ (quantizer dropout + backward) is not built yet")
+            from . import autograd as A
+            B, _, T = z.shape
+            if masks is None:
+                masks = A.draw_quantizer_masks(self.n_codebooks, B, self.quantizer_dropout)
+            latents = torch.empty(B, 8 * self.n_codebooks, T, device=z.device, dtype=torch.float32)
+            z_q, codes, commit, cbl = A.rvq(self, z, masks.to(z.device, torch.float32), latents=latents)
+            return z_q, codes, latents, commit, cbl
         n = self.n_codebooks if n_quantizers is None else min(int(n_quantizers), self.n_codebooks)
         B, D, T = z.shape
         dev = z.device

@@ -222,21 +222,25 @@ def vq_forward_train(z, sd, p):
     return out, commit, cbl, idx, z_e
 
 
-def rvq_forward_train(z, sd, p, n_codebooks, mask):
+def rvq_forward_train(z, sd, p, n_codebooks, mask, return_latents=False):
     """ResidualVectorQuantize.forward in training mode (dac/nn/quantize.py:171-196) with the per-sample quantizer
-    masks (n, B) given instead of drawn (:163-168)."""
+    masks (n, B) given instead of drawn (:163-168).  return_latents: also the concatenated z_e_i of :195 (5-tuple like the
+    reference's return)."""
     z_q = torch.zeros_like(z)
     residual = z
     commit = torch.zeros(())
     cbl = torch.zeros(())
-    codes = []
+    codes, latents = [], []
     for i in range(n_codebooks):
-        out, c_i, cb_i, idx, _ = vq_forward_train(residual, sd, f"{p}quantizers.{i}.")
+        out, c_i, cb_i, idx, z_e_i = vq_forward_train(residual, sd, f"{p}quantizers.{i}.")
+        latents.append(z_e_i)
         z_q = z_q + out * mask[i][:, None, None]
         residual = residual - out
         commit = commit + (c_i * mask[i]).mean()
         cbl = cbl + (cb_i * mask[i]).mean()
         codes.append(idx)
+    if return_latents:
+        return z_q, torch.stack(codes, 1), torch.cat(latents, 1), commit, cbl
     return z_q, torch.stack(codes, 1), commit, cbl
 
 
@@ -265,17 +269,46 @@ def rvq_forward(z, sd, p, n_codebooks, n_quantizers=None):
 
 def fvq_forward(z, sd, p, training=False, commitment=0.15):
     """FactorizedVectorQuantize.forward quantize/fvq.py:36-86: weight-normed nn.Linear projections
-    around the same search; returns (z_q, indices, commit_loss) with the loss zero in eval."""
+    around the same search; returns (z_q, indices, commit_loss (B,)) with the loss zero in eval.  Differentiable with
+    the reference's detach placements (:67-71 commitment against z_q.detach(), codebook loss against z_e.detach(); :76-78
+    straight-through estimator), so torch autograd on this function gives the reference's gradients."""
     zt = z.transpose(1, 2)
     z_e = F.linear(zt, conv_weight(sd, p + "in_proj."), sd[p + "in_proj.bias"]).transpose(1, 2)
     z_q, idx = vq_nearest(z_e, sd[p + "_codebook.weight"])
     if training:
-        loss = (z_e - z_q).pow(2).mean([1, 2]) * commitment + (z_q - z_e).pow(2).mean([1, 2])
+        loss = (z_e - z_q.detach()).pow(2).mean([1, 2]) * commitment + (z_q - z_e.detach()).pow(2).mean([1, 2])
     else:
         loss = torch.zeros(z.shape[0])
-    z_q = z_e + (z_q - z_e)
+    z_q = z_e + (z_q - z_e).detach()
     out = F.linear(z_q.transpose(1, 2), conv_weight(sd, p + "out_proj."), sd[p + "out_proj.bias"]).transpose(1, 2)
     return out, idx, loss
+
+
+def residual_vq_forward(x, sd, p, num_quantizers, training=False, n_quantizers=None, dropout=None, quantizer_dropout=0.0,
+                        commitment=0.15):
+    """ResidualVQ.forward quantize/rvq.py:27-73.  `dropout`: the (B,) draw the reference takes from torch.randint at :38-44
+    (already 2 ** draw for dropout_type 'exp'); the first int(B * quantizer_dropout) samples keep only that many
+    quantizers.  Returns (quantized_out, all_indices (N, B, T), all_losses (N,), all_quantized (N, B, D, T))."""
+    B = x.shape[0]
+    if n_quantizers is None:
+        n_quantizers = num_quantizers
+    if training:
+        n_quantizers = torch.ones(B) * num_quantizers + 1
+        n_drop = int(B * quantizer_dropout)
+        n_quantizers[:n_drop] = torch.as_tensor(dropout)[:n_drop].to(n_quantizers.dtype)
+    quantized_out, residual = 0.0, x
+    losses, idxs, quants = [], [], []
+    for i in range(num_quantizers):
+        if not training and i >= n_quantizers:
+            break
+        q, idx, loss = fvq_forward(residual, sd, f"{p}layers.{i}.", training=training, commitment=commitment)
+        mask = torch.full((B,), float(i)) < n_quantizers
+        residual = residual - q
+        quantized_out = quantized_out + q * mask[:, None, None]
+        losses.append((loss * mask).mean())
+        idxs.append(idx)
+        quants.append(q)
+    return quantized_out, torch.stack(idxs), torch.stack(losses), torch.stack(quants)
 
 
 # ---------------------------------------------------------------------------------------------

@@ -62,7 +62,7 @@ def grad_probes(model, key, names):
     return out
 
 
-def masks_from_draws(n_codebooks, draws, quantizer_dropout=0.5):
+def masks_from_draws(n_codebooks, draws, quantizer_dropout=0.5, B=B):
     """dac/nn/quantize.py:163-183: n_quantizers = n_codebooks + 1, first int(B * p) samples take the draw."""
     nq = torch.ones(B) * n_codebooks + 1
     nd = int(B * quantizer_dropout)
@@ -70,9 +70,7 @@ def masks_from_draws(n_codebooks, draws, quantizer_dropout=0.5):
     return torch.stack([(torch.full((B,), float(i)) < nq).float() for i in range(n_codebooks)])
 
 
-def main():
-    torch.manual_seed(0)
-    torch.set_num_threads(os.cpu_count())
+def build_reference_in_train_mode():
     build_model, recursive_munch = MG.ref_imports()
     model = build_model(recursive_munch(MG.model_params()))
     sds = {}
@@ -82,15 +80,25 @@ def main():
         for m in model[k].modules():
             if isinstance(m, torch.nn.Dropout):
                 m.p = 0.0
-    out = {}
-    report = {}
+    return model, sds
 
+
+DEFAULT_CFG = dict(B=B, SEG_FRAMES=SEG_FRAMES, T_FULL=T_FULL, WAVE_LENS=WAVE_LENS, CROP_START=CROP_START, DROPOUT_DRAWS=DROPOUT_DRAWS,
+                   RES_MASK=RES_MASK, wave_seed=23, target_seed=99, probes=True)
+
+
+def iteration(model, cfg):
+    """One train.py:188-374 iteration of the real reference on the inputs `cfg` describes.  Returns (out: what goes into the
+    .npz, aux: live tensors for the oracle pinning in main())."""
+    B, SEG_FRAMES, T_FULL, WAVE_LENS, CROP_START = cfg["B"], cfg["SEG_FRAMES"], cfg["T_FULL"], cfg["WAVE_LENS"], cfg["CROP_START"]
+    DROPOUT_DRAWS, RES_MASK = cfg["DROPOUT_DRAWS"], cfg["RES_MASK"]
+    out = {}
     # ------------------------------------------------------------------ inputs (train.py:176-212)
-    waves = synth.synth_clips(B, T_FULL, seed=23).squeeze(1)                 # (B, T_full) padded batch
+    waves = synth.synth_clips(B, T_FULL, seed=cfg["wave_seed"]).squeeze(1)   # (B, T_full) padded batch
     wave_lengths = torch.tensor(WAVE_LENS)
     for b, n in enumerate(WAVE_LENS):
         waves[b, n:] = 0.0
-    g = torch.Generator().manual_seed(99)
+    g = torch.Generator().manual_seed(cfg["target_seed"])
     f0_targets = torch.randn(B, SEG_FRAMES, generator=g)
     f0_targets[torch.rand(B, SEG_FRAMES, generator=g) < 0.3] = -10.0          # unvoiced frames (train.py:241)
     real_norm = torch.randn(B, SEG_FRAMES, generator=g)
@@ -128,7 +136,7 @@ def main():
     assert calls["randint"] == 3
     wav_seg_target = wav_seg
     assert wav_seg_target.size(-1) == pred_wave.size(-1)
-    masks = {k: masks_from_draws(n, DROPOUT_DRAWS[k]) for k, n in (("p", 1), ("c", 2), ("r", 3))}
+    masks = {k: masks_from_draws(n, DROPOUT_DRAWS[k], B=B) for k, n in (("p", 1), ("c", 2), ("r", 3))}
     out.update(mask_p=masks["p"].numpy(), mask_c=masks["c"].numpy(), mask_r=masks["r"].numpy(),
                mask_res=np.array(RES_MASK, np.float32))
 
@@ -146,14 +154,15 @@ def main():
                         if n.startswith(("discriminators.0.convs.0.", "discriminators.4.convs.3.0.weight_v", "discriminators.2.conv_post.",
                                          "discriminators.5.band_convs.0.0.", "discriminators.7.band_convs.4.3.0.weight_g",
                                          "discriminators.6.conv_post."))]
-    out.update(grad_probes(model, "discriminator", disc_probe_names))
+    if cfg["probes"]:
+        out.update(grad_probes(model, "discriminator", disc_probe_names))
     out["grad_norm64_discriminator"] = np.float64(torch.sqrt(sum(p.grad.double().pow(2).sum() for p in model.discriminator.parameters())))
     gn_d = torch.nn.utils.clip_grad_norm_(model.discriminator.parameters(), 10.0)
     opt_d = torch.optim.AdamW(model.discriminator.parameters(), lr=1e-4, betas=(0.9, 0.98), eps=1e-9, weight_decay=0.1)  # optimizers.py:91-97
     opt_d.step()
     out.update(loss_d=np.float64(loss_d.detach()), grad_norm_discriminator=np.float64(gn_d))
     pd = dict(model.discriminator.named_parameters())
-    for n in disc_probe_names[:4]:
+    for n in disc_probe_names[:4] if cfg["probes"] else []:
         flat = pd[n].detach().reshape(-1)
         out[f"param_after.discriminator.{n}.probe"] = flat[probe_index(flat.numel())].numpy().copy()
 
@@ -223,7 +232,8 @@ def main():
         have = dict(model[k].named_parameters())
         missing = [n for n in names if n not in have]
         assert not missing, (k, missing, list(have)[:40])
-        out.update(grad_probes(model, k, names))
+        if cfg["probes"]:
+            out.update(grad_probes(model, k, names))
     # parameters that must receive no gradient in the reference (so the optimiser skips them)
     no_grad = {k: [n for n, p in model[k].named_parameters() if p.grad is None] for k in KEYS if k != "discriminator"}
     out["params_without_grad"] = np.array(json.dumps(no_grad))
@@ -238,6 +248,21 @@ def main():
     out.update({f"grad_norm_{k}": np.float64(v) for k, v in gn.items()})
     out.update(pred_wave_probe=pred_wave.detach()[:, 0, ::13].numpy(), timbre=timbre.detach().numpy(),
                zq_probe=zq.detach()[:, ::8, :].numpy(), z_probe=z.detach()[:, ::8, :].numpy())
+    aux = dict(wav_seg=wav_seg, z=z, zq=zq, masks=masks, waves=waves, wave_lengths=wave_lengths, commitment_loss=commitment_loss,
+               codebook_loss=codebook_loss, timbre=timbre, preds=preds, n=n, tgt=tgt, content_loss=content_loss)
+    return out, aux
+
+
+def main():
+    torch.manual_seed(0)
+    torch.set_num_threads(os.cpu_count())
+    model, sds = build_reference_in_train_mode()
+    report = {}
+    out, aux = iteration(model, DEFAULT_CFG)
+    wav_seg, z, zq, masks, waves, wave_lengths = (aux[k] for k in ("wav_seg", "z", "zq", "masks", "waves", "wave_lengths"))
+    commitment_loss, codebook_loss, timbre, preds, n, tgt, content_loss = (aux[k] for k in (
+        "commitment_loss", "codebook_loss", "timbre", "preds", "n", "tgt", "content_loss"))
+    from losses import FocalLoss, reconstruction_loss
 
     # -------------------------------------------------------------- oracle pinning of the train-mode restatement
     with torch.no_grad():

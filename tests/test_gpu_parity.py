@@ -465,6 +465,94 @@ def test_named_fvq_variant_against_oracle(O, cuda):
     assert torch.equal(ai.cpu(), torch.stack(idxs)) and rel(qo, acc) < OP_TOL and aq.shape == (2, 2, 256, 130)
 
 
+def _fvq_upstream(shape, seed):
+    """The fixed upstream-gradient weights of tests/golden/make_golden_fvq_train.py."""
+    n = int(np.prod(shape))
+    k = torch.arange(n, dtype=torch.float64)
+    return torch.sin(0.37 * k + seed).reshape(tuple(shape)).float() / float(np.sqrt(n))
+
+
+def test_fvq_train_mode_against_reference_golden(cuda, golden_dir):
+    """Row a11 in TRAIN mode on the HIP path against the REAL reference's forward values AND autograd gradients
+    (tests/golden/fvq_train.npz, made by make_golden_fvq_train.py from quantize/fvq.py + quantize/rvq.py): one
+    FactorizedVectorQuantize (commitment + codebook loss with the reference's detach placements, straight-through estimator),
+    then ResidualVQ with 'linear' and 'exp' quantizer dropout (the reference's recorded torch.randint draw handed in).
+    Indices bit-exact; values and every parameter / input gradient at 1e-4 (measured ~1e-6)."""
+    from facodec_amd.fvq import FactorizedVectorQuantize, ResidualVQ
+    d = np.load(os.path.join(golden_dir, "fvq_train.npz"))
+    vq = FactorizedVectorQuantize(dim=64, codebook_size=1024, codebook_dim=8, commitment=0.15)
+    synth.load_synthetic(vq, seed=4, prefix="fvq.")
+    vq.to(cuda).train()
+    z = torch.from_numpy(d["fvq_z"]).to(cuda).requires_grad_()
+    zq, idx, loss = vq(z)
+    assert torch.equal(idx.cpu(), torch.from_numpy(d["fvq_idx"].astype(np.int64)))
+    assert rel(zq, d["fvq_zq"]) < OP_TOL and float((loss.detach().cpu() - torch.from_numpy(d["fvq_loss"])).abs().max()) < 1e-6
+    ((zq * _fvq_upstream(zq.shape, 1).to(cuda)).sum() + (loss * _fvq_upstream(loss.shape, 2).to(cuda)).sum()).backward()
+    worst = {"dz": rel(z.grad, d["fvq_dz"])}
+    for n, p in vq.named_parameters():
+        worst[n] = rel(p.grad, d["fvq_grad." + n])
+    assert max(worst.values()) < E2E_TOL, worst
+    # eval mode of the same module object still returns the zero loss (fvq.py:73-74), no autograd node
+    with torch.no_grad():
+        assert float(vq.eval()(z.detach())[2].abs().max()) == 0.0
+    for kind, nq in (("linear", 3), ("exp", 4)):
+        rv = ResidualVQ(num_quantizers=nq, codebook_size=10, dim=64, codebook_dim=8, commitment=0.15, quantizer_dropout=0.75, dropout_type=kind)
+        synth.load_synthetic(rv, seed=6, prefix="rvq.")
+        rv.to(cuda).train()
+        pre = f"rvq_{kind}_"
+        x = torch.from_numpy(d[pre + "x"]).to(cuda).requires_grad_()
+        draw = torch.from_numpy(d[pre + "draw"])
+        draw = torch.pow(2, draw) if kind == "exp" else draw                # rvq.py:44
+        q_out, all_idx, all_loss, all_q = rv(x, dropout=draw)
+        assert torch.equal(all_idx.cpu(), torch.from_numpy(d[pre + "idx"].astype(np.int64))), kind
+        assert rel(q_out, d[pre + "out"]) < OP_TOL and rel(all_q[:, :, ::4, ::5], d[pre + "quantized_probe"]) < OP_TOL
+        assert float((all_loss.detach().cpu() - torch.from_numpy(d[pre + "losses"])).abs().max()) < 1e-6
+        ((q_out * _fvq_upstream(q_out.shape, 3).to(cuda)).sum() + (all_loss * _fvq_upstream(all_loss.shape, 4).to(cuda)).sum()
+         + (all_q * _fvq_upstream(all_q.shape, 5).to(cuda)).sum()).backward()
+        worst = {"dx": rel(x.grad, d[pre + "dx"])}
+        for n, p in rv.named_parameters():
+            worst[n] = rel(p.grad, d[pre + "grad." + n])
+        assert max(worst.values()) < E2E_TOL, (kind, worst)
+    # the reference's own draw: same torch.randint call on the CPU generator -> same n_quantizers for the same seed
+    torch.manual_seed(123)
+    want = torch.randint(1, 3 + 1, (4,))
+    torch.manual_seed(123)
+    rv3 = ResidualVQ(num_quantizers=3, codebook_size=10, dim=64, codebook_dim=8, commitment=0.15, quantizer_dropout=0.75, dropout_type="linear")
+    assert torch.equal(rv3._draw_n_quantizers(4, None), torch.tensor([float(want[0]), float(want[1]), float(want[2]), 4.0]))
+    with pytest.raises(UnboundLocalError):            # rvq.py:45 with dropout_type=None
+        ResidualVQ(num_quantizers=2, codebook_size=10, dim=64, codebook_dim=8, commitment=0.15).train()._draw_n_quantizers(4, None)
+
+
+def test_standalone_rvq_train_mode_against_oracle(O, cuda):
+    """dac/nn/quantize.py:127-198 called directly in .train() (what `model.quantizer.content_quantizer(z)` does for a caller with the
+    reference's habits): masks drawn like :163-168 or handed in; z_q / codes / latents / both losses and the gradients of the input
+    and of every parameter against torch autograd through the oracle."""
+    from facodec_amd.quantize import ResidualVectorQuantize
+    m = ResidualVectorQuantize(256, 3, 1024, 8, quantizer_dropout=0.5)
+    sd = synth.load_synthetic(m, seed=9)
+    m.to(cuda).train()
+    B, T = 4, 90
+    z = torch.randn(B, 256, T, generator=_g(21))
+    masks = torch.tensor([[1, 1, 1, 1], [0, 1, 1, 1], [0, 0, 1, 1]], dtype=torch.float32)     # draws (1, 2) for the first two samples
+    leaves = {k: v.clone().requires_grad_() for k, v in sd.items()}
+    zc = z.clone().requires_grad_()
+    zq_o, codes_o, lat_o, cm_o, cb_o = O.rvq_forward_train(zc, leaves, "", 3, masks, return_latents=True)
+    up = _fvq_upstream(zq_o.shape, 7)
+    ((zq_o * up).sum() + 0.25 * cm_o + cb_o).backward()
+    zg = z.to(cuda).requires_grad_()
+    zq, codes, lat, cm, cb = m(zg, masks=masks)
+    assert torch.equal(codes.cpu(), codes_o) and rel(zq, zq_o) < OP_TOL and rel(lat, lat_o) < OP_TOL
+    assert abs(float(cm) - float(cm_o)) / float(cm_o) < OP_TOL and abs(float(cb) - float(cb_o)) / float(cb_o) < OP_TOL
+    ((zq * up.to(cuda)).sum() + 0.25 * cm + cb).backward()
+    worst = {"dz": rel(zg.grad, zc.grad)}
+    for n, p in m.named_parameters():
+        worst[n] = rel(p.grad, leaves[n].grad)
+    assert max(worst.values()) < E2E_TOL, worst
+    torch.manual_seed(5)                      # default path: the module draws its own masks, shapes as the reference returns them
+    out = m(z.to(cuda))
+    assert out[0].shape == (B, 256, T) and out[1].shape == (B, 3, T) and out[2].shape == (B, 24, T) and out[3].dim() == 0
+
+
 def test_spectral_losses_against_oracle(O, cuda):
     """MelSpectrogramLoss (train.py:155-163 arguments), MultiScaleSTFTLoss, L1Loss, reconstruction_loss on
     2 s clips; bar 1e-4 relative.  Third-party STFT/mel semantics restated on both sides: parity unpinned."""

@@ -103,6 +103,45 @@ def test_filterbanks_against_transformers():
     assert np.abs(sl.numpy().T - ref2).max() < 1e-6
 
 
+def test_stft_mel_pipelines_against_transformers_spectrogram():
+    """Whole-pipeline cross-check of the parity-UNPINNED rows (a15-a18, the log-mel front-end) that does not route through the
+    oracle on the checking side: `transformers.audio_utils.spectrogram` (numpy framing + rfft, periodic Hann,
+    center / reflect) with its own `mel_filter_bank` against (i) O.logmel_frontend (torchaudio MelSpectrogram semantics: power
+    2, HTK mel, 1 200-sample window centred in a 2 048-point FFT), (ii) one scale of MelSpectrogramLoss (audiotools / librosa
+    semantics: magnitude, Slaney mel with Slaney norm, window = FFT length, hop = window / 4), (iii) one scale of
+    MultiScaleSTFTLoss.  Still not the third-party packages themselves (absent here): an independent implementation of the
+    same published semantics agreeing to fp32 rounding."""
+    from transformers.audio_utils import mel_filter_bank, spectrogram, window_function
+    wave = synth.synth_clips(2, 12000, seed=17)
+    est = (0.7 * wave + 0.05 * synth.synth_clips(2, 12000, seed=18)).contiguous()
+    # (i) log-mel front-end
+    win = window_function(1200, "hann", periodic=True, frame_length=2048, center=True)
+    fb_htk = mel_filter_bank(1025, 80, 0.0, 12000.0, 24000, norm=None, mel_scale="htk")
+    got = O.logmel_frontend(wave, 80)
+    for b in range(2):
+        mel = spectrogram(wave[b, 0].numpy().astype(np.float64), win, 2048, 300, fft_length=2048, power=2.0, center=True, pad_mode="reflect",
+                          mel_filters=fb_htk, mel_floor=0.0, dtype=np.float64)
+        ref = (np.log(1e-5 + mel) + 4.0) / 4.0
+        assert np.abs(got[b].numpy() - ref[:, :got.shape[-1]]).max() < 2e-4 * np.abs(ref).max()
+    # (ii) / (iii) one loss scale each, computed entirely from transformers' spectrogram
+    w = 512
+    win_w = window_function(w, "hann", periodic=True)
+    fb_sl = mel_filter_bank(w // 2 + 1, 80, 0.0, 12000.0, 24000, norm="slaney", mel_scale="slaney")
+
+    def mags(x, **kw):
+        return np.stack([spectrogram(x[b, 0].numpy().astype(np.float64), win_w, w, w // 4, fft_length=w, power=1.0, center=True,
+                                     pad_mode="reflect", dtype=np.float64, **kw) for b in range(x.shape[0])])
+
+    xm, ym = mags(est, mel_filters=fb_sl, mel_floor=0.0), mags(wave, mel_filters=fb_sl, mel_floor=0.0)
+    mel_ref = np.abs(np.log10(np.maximum(xm, 1e-5)) - np.log10(np.maximum(ym, 1e-5))).mean()
+    mel_got = float(O.mel_spectrogram_loss(est, wave, n_mels=(80,), window_lengths=(w,)))
+    assert abs(mel_got - mel_ref) / mel_ref < 1e-4, (mel_got, mel_ref)
+    xs, ys = mags(est), mags(wave)
+    stft_ref = np.abs(np.log10(np.maximum(xs, 1e-5) ** 2) - np.log10(np.maximum(ys, 1e-5) ** 2)).mean() + np.abs(xs - ys).mean()
+    stft_got = float(O.multiscale_stft_loss(est, wave, window_lengths=(w,)))
+    assert abs(stft_got - stft_ref) / stft_ref < 1e-4, (stft_got, stft_ref)
+
+
 def test_product_dsp_tables_equal_oracle_tables():
     from facodec_amd import dsp
     assert np.array_equal(dsp.mel_fbank_htk(1025, 80, 24000), O.mel_filterbank_htk(1025, 80, 24000).numpy())
@@ -205,6 +244,46 @@ def test_fvq_and_rvq_against_reference(golden_dir):
         assert rel(q[:, ::4, ::5], d["rvq_quantized_probe"][i]) < 1e-5
         residual, total = residual - q, total + q
     assert rel(total, d["rvq_out"]) < 1e-5
+
+
+def _fvq_upstream(shape, seed):
+    """The fixed upstream-gradient weights of tests/golden/make_golden_fvq_train.py."""
+    n = int(np.prod(shape))
+    k = torch.arange(n, dtype=torch.float64)
+    return torch.sin(0.37 * k + seed).reshape(tuple(shape)).float() / float(np.sqrt(n))
+
+
+def test_fvq_and_rvq_train_gradients_against_reference(golden_dir):
+    """Row a11 in TRAIN mode (quantize/fvq.py:66-78 detach placements + straight-through; quantize/rvq.py:36-64 quantizer dropout,
+    'linear' and 'exp'): the oracle's values and torch-autograd gradients against those of the real classes (fvq_train.npz)."""
+    d = np.load(os.path.join(golden_dir, "fvq_train.npz"))
+    from facodec_amd.fvq import FactorizedVectorQuantize, ResidualVQ   # parameter shapes only (CPU, no forward)
+    vq = FactorizedVectorQuantize(dim=64, codebook_size=1024, codebook_dim=8, commitment=0.15)
+    sd = {k: v.requires_grad_() for k, v in synth.synth_state_dict(synth.param_shapes(vq), 4, "fvq.").items()}
+    z = torch.from_numpy(d["fvq_z"]).requires_grad_()
+    zq, idx, loss = O.fvq_forward(z, sd, "", training=True)
+    assert torch.equal(idx, torch.from_numpy(d["fvq_idx"].astype(np.int64)))
+    assert rel(zq.detach(), d["fvq_zq"]) < 1e-5 and float((loss.detach() - torch.from_numpy(d["fvq_loss"])).abs().max()) < 1e-6
+    ((zq * _fvq_upstream(zq.shape, 1)).sum() + (loss * _fvq_upstream(loss.shape, 2)).sum()).backward()
+    assert rel(z.grad, d["fvq_dz"]) < 1e-5
+    for n, v in sd.items():
+        assert rel(v.grad, d["fvq_grad." + n]) < 1e-5, n
+    for kind, nq in (("linear", 3), ("exp", 4)):
+        rv = ResidualVQ(num_quantizers=nq, codebook_size=10, dim=64, codebook_dim=8, commitment=0.15, quantizer_dropout=0.75, dropout_type=kind)
+        sdr = {k: v.requires_grad_() for k, v in synth.synth_state_dict(synth.param_shapes(rv), 6, "rvq.").items()}
+        p = f"rvq_{kind}_"
+        x = torch.from_numpy(d[p + "x"]).requires_grad_()
+        draw = torch.from_numpy(d[p + "draw"])
+        draw = torch.pow(2, draw) if kind == "exp" else draw                    # rvq.py:44
+        q_out, all_idx, all_loss, all_q = O.residual_vq_forward(x, sdr, "", nq, training=True, dropout=draw, quantizer_dropout=0.75)
+        assert torch.equal(all_idx, torch.from_numpy(d[p + "idx"].astype(np.int64)))
+        assert rel(q_out.detach(), d[p + "out"]) < 1e-5 and rel(all_q.detach()[:, :, ::4, ::5], d[p + "quantized_probe"]) < 1e-5
+        assert float((all_loss.detach() - torch.from_numpy(d[p + "losses"])).abs().max()) < 1e-6
+        ((q_out * _fvq_upstream(q_out.shape, 3)).sum() + (all_loss * _fvq_upstream(all_loss.shape, 4)).sum()
+         + (all_q * _fvq_upstream(all_q.shape, 5)).sum()).backward()
+        assert rel(x.grad, d[p + "dx"]) < 1e-5
+        for n, v in sdr.items():
+            assert rel(v.grad, d[p + "grad." + n]) < 2e-5, (kind, n)
 
 
 def test_focal_recon_meldataset_against_reference(golden_dir):
