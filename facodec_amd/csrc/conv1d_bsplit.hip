@@ -24,6 +24,7 @@
 // (8-channel stages with tap pairs: 80 KB; a single stage of 73 KB with the co-resident workgroup as the
 // second pipeline stage) ran at 100-120 TFLOP/s-equivalent against 125-180 for this layout.
 #include "conv1d_mfma.h"
+#include "inflight_regs.h"
 
 namespace fac {
 
@@ -153,11 +154,11 @@ __global__ __launch_bounds__((NMW + NSW) * 64, (NMW + NSW) / 4) void conv1d_bspl
     }
     // Weights: one contiguous slab per stage, 16 B per lane by LDS-DMA.  Every staging wave issues exactly ND DMA instructions
     // (the block index is clamped: a wave short of one block re-copies the last block -- same bytes to the same place), so the
-    // position of a stage's loads in the wave's in-order load queue is a compile-time constant (see `landed`).
+    // position of a stage's loads in the wave's in-order load queue is a compile-time constant.
     constexpr int NBLK = W_STAGE / 1024;               // 1 KiB blocks per weight stage
     constexpr int ND = (NBLK + NSW - 1) / NSW;         // DMA instructions per staging wave and stage
     constexpr int NX = BS_XU * 8;                      // input loads per staging wave and stage
-    static_assert(W_STAGE % 1024 == 0 && ND + NX <= 63, "vmcnt is a 6-bit counter");
+    static_assert(W_STAGE % 1024 == 0 && ND + NX <= 63 && NX == 24, "vmcnt is a 6-bit counter; FAC_XREGS24_* list 24 registers per set");
     auto stage_w = [&](int chunk, int buf) {
 #if !defined(FAC_ABL_NOSTAGE) && !defined(FAC_ABL_NOSTAGE_W)
       const unsigned char* src = wsrc + (long long)chunk * W_STAGE;
@@ -169,42 +170,7 @@ __global__ __launch_bounds__((NMW + NSW) * 64, (NMW + NSW) / 4) void conv1d_bspl
       }
 #endif
     };
-    // Every instruction of the staging waves costs the SIMD's MFMA wave issue time, so the loads are kept to one instruction
-    // each: the channel row is a uniform (scalar) base, the column a per-lane 32-bit byte offset resolved once per tile; lanes on
-    // padding read a clamped column and are zeroed at the split (no exec-mask branches), and C_in % (8 G) == 0 (dispatcher)
-    // makes every channel of a stage real.
-    //
-    // The loads are INLINE ASM: hipcc's own s_waitcnt placement waits for a plain C++ load at its first use -- and the padding
-    // select is a use -- so the "register double buffer" of rounds 1-3 was waited for with vmcnt(0) right behind the last load
-    // of the same stage (and again in front of every barrier, together with the weight DMA issued a moment earlier): each
-    // stage paid a full memory round trip on the staging waves' critical path (found in the ISA in round 4).  Invisible to the
-    // compiler, the loads of chunk c + 2 now stay in flight across the barrier, and `landed(n)` = `s_waitcnt vmcnt(n)` on the
-    // in-order queue waits for exactly the loads a step needs.
-    unsigned u_boff[BS_XU];
-#pragma unroll
-    for (int j = 0; j < BS_XU; ++j) u_boff[j] = (unsigned)(u_idx[j] >= 0 ? u_idx[j] : 0) * 4u;
-    auto load_x = [&](int chunk, float (&xr)[BS_XU][8]) {
-#if !defined(FAC_ABL_NOSTAGE) && !defined(FAC_ABL_NOSTAGE_X)
-#pragma unroll
-      for (int j = 0; j < BS_XU; ++j) {
-        const float* grp = xg + (long long)((chunk * G + u_g[j]) * 8) * xcs;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          const float* row = grp + (long long)i * xcs;
-          asm volatile("global_load_dword %0, %1, %2" : "=v"(xr[j][i]) : "v"(u_boff[j]), "s"(row) : "memory");
-        }
-      }
-#endif
-    };
-    // `landed<n>`: everything but the youngest n loads of this wave has landed (loads return in order); the register set is
-    // named as an in/out operand so that no use of it moves above the wait
-    auto pin = [&](float (&xr)[BS_XU][8]) {
-#pragma unroll
-      for (int j = 0; j < BS_XU; ++j)
-#pragma unroll
-        for (int i = 0; i < 8; ++i) asm volatile("" : "+v"(xr[j][i]) : : "memory");
-    };
-    auto write_x = [&](int buf, const float (&xr)[BS_XU][8]) {
+    auto write_x = [&](int buf, const float (&xr)[BS_XU][8]) {       // xr: landed samples, padding lanes already zero
 #if !defined(FAC_ABL_NOSTAGE) && !defined(FAC_ABL_NOSTAGE_X)
       unsigned char* xd = Xbuf + buf * X_STAGE;
 #pragma unroll
@@ -214,7 +180,7 @@ __global__ __launch_bounds__((NMW + NSW) * 64, (NMW + NSW) / 4) void conv1d_bspl
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
           __bf16 p0, p1, p2;
-          split3(u_idx[j] >= 0 ? xr[j][i] : 0.f, p0, p1, p2);
+          split3(xr[j][i], p0, p1, p2);
           h[i] = p0; m[i] = p1; l[i] = p2;
         }
         *reinterpret_cast<bf16x8*>(xd + ((0 * G + u_g[j]) * XW + u_c[j]) * 16) = h;
@@ -223,50 +189,119 @@ __global__ __launch_bounds__((NMW + NSW) * 64, (NMW + NSW) / 4) void conv1d_bspl
       }
 #endif
     };
-    // Chunk c + 1 is staged while the MFMA waves multiply chunk c; the fp32 inputs of chunk c + 2 are requested a whole stage
-    // before they are split and written (two register sets: xa holds even chunks, xb odd ones).  In-order load queue of a wave
-    // inside iteration c: [inputs of c + 1 (NX)] [weight DMA of c + 1 (ND)], then -- the inputs of c + 1 have landed --
-    // [weight DMA of c + 1 (ND)] [inputs of c + 2 (NX)].
-    float xa[BS_XU][8], xb[BS_XU][8];
-    // steady state (c + 2 < n_chunks): `cur` holds chunk c + 1 (requested a whole stage ago), `nxt` receives chunk c + 2.
-    // At most ND + NX loads are in flight (vmcnt is a 6-bit counter).
-    auto steady = [&](int c, int buf_next, float (&nxt)[BS_XU][8], float (&cur)[BS_XU][8]) {
-      stage_w(c + 1, buf_next);                                  // that buffer was read during chunk c - 1
-      asm volatile("s_waitcnt vmcnt(%0)" : : "n"(ND) : "memory");                  // inputs of c + 1 (older than the DMA)
-      pin(cur);
-      load_x(c + 2, nxt);
-      write_x(buf_next, cur);
-      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" : : "n"(NX) : "memory");       // weights of c + 1 landed, LDS writes done
-      __builtin_amdgcn_s_barrier();
-      asm volatile("" ::: "memory");
-    };
-    auto last = [&](int c, int buf_next, float (&cur)[BS_XU][8]) {                 // c + 2 == n_chunks: nothing further to request
-      stage_w(c + 1, buf_next);
-      asm volatile("s_waitcnt vmcnt(%0)" : : "n"(ND) : "memory");
-      pin(cur);
-      write_x(buf_next, cur);
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      asm volatile("" ::: "memory");
-    };
-    load_x(0, xa);
-    stage_w(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                               // inputs and weights of chunk 0
-    pin(xa);
-    if (n_chunks > 1) load_x(1, xb);
-    write_x(0, xa);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    for (int c = 0; c < n_chunks; ++c) {
-      const bool odd = c & 1;
-      if (c + 2 < n_chunks) {
-        if (!odd) steady(c, 1, xa, xb); else steady(c, 0, xb, xa);
-      } else if (c + 1 < n_chunks) {
-        if (!odd) last(c, 1, xb); else last(c, 0, xa);
-      } else {
-        __builtin_amdgcn_s_barrier();                            // pairs with the MFMA waves' barrier behind the last chunk
-        asm volatile("" ::: "memory");
+    // Every instruction of the staging waves costs the SIMD's MFMA wave issue time, so the loads are kept to one instruction
+    // each: the channel row is a uniform (scalar) base, the column a per-lane 32-bit byte offset resolved once per tile; lanes on
+    // padding read a clamped column and are zeroed when the value is taken out of its landing register, and C_in % (8 G) == 0
+    // (dispatcher) makes every channel of a stage real.
+    if constexpr (G == 2) {
+      // ---- wide shape: the inputs of chunk c + 2 stay IN FLIGHT across the barrier -----------------------------------------
+      // Rounds 1-3 wrote this as a "register double buffer" of plain C++ loads; hipcc waits for such a load at its first use --
+      // and the padding select is a use -- so it placed s_waitcnt vmcnt(0) right behind the last load of the same stage (and again
+      // in front of every barrier, together with the weight DMA issued a moment earlier): every stage paid a full memory round
+      // trip on the staging waves' critical path, which is what kept the matrix pipe at 48 % busy (found in the ISA in round 4).
+      // Loads that stay in flight cannot be compiler-visible values: hipcc does not know that the destination of an inline-asm
+      // load is invalid until the matching s_waitcnt, and it did copy such registers at control-flow joins (right at B = 2,
+      // wrong codes at B = 32 when the memory system is loaded).  So the landing registers are NAMED PHYSICAL REGISTERS that the
+      // compiler never sees as values: set A = v208..v231 (even chunks), set B = v232..v255 (odd chunks), written by
+      // `global_load_dword vNNN` and read back -- after `s_waitcnt vmcnt(n)` on the in-order load queue -- by the v_cndmask that
+      // zeroes the padding lanes anyway.  hipcc allocates registers from v0 upwards and this kernel needs ~120, far from v208;
+      // tools/check_inflight_regs.py (tests/test_isa_inflight.py) verifies on the ISA that nothing else touches v208..v255.
+#define BS_LD(n, R)                                                                                                          \
+  asm volatile("global_load_dword v" #R ", %0, %1" : : "v"(u_boff[(n) / 8]), "s"(grp[(n) / 8] + (long long)((n) % 8) * xcs) : "memory", "v" #R);
+#define BS_RD(n, R) asm volatile("v_cndmask_b32_e64 %0, 0, v" #R ", %1" : "=v"(xr[(n) / 8][(n) % 8]) : "s"(u_mask[(n) / 8]) : "memory");
+      unsigned u_boff[BS_XU];
+      unsigned long long u_mask[BS_XU];                               // lanes of unit j that hold a real sample
+#pragma unroll
+      for (int j = 0; j < BS_XU; ++j) {
+        u_boff[j] = (unsigned)(u_idx[j] >= 0 ? u_idx[j] : 0) * 4u;
+        u_mask[j] = __builtin_amdgcn_ballot_w64(u_idx[j] >= 0);
+      }
+      auto rows_of = [&](int chunk, const float* (&grp)[BS_XU]) {
+#pragma unroll
+        for (int j = 0; j < BS_XU; ++j) grp[j] = xg + (long long)((chunk * G + u_g[j]) * 8) * xcs;
+      };
+      auto load_a = [&](int chunk) {
+#if !defined(FAC_ABL_NOSTAGE) && !defined(FAC_ABL_NOSTAGE_X)
+        const float* grp[BS_XU];
+        rows_of(chunk, grp);
+        FAC_XREGS24_A(BS_LD)
+#endif
+      };
+      auto load_b = [&](int chunk) {
+#if !defined(FAC_ABL_NOSTAGE) && !defined(FAC_ABL_NOSTAGE_X)
+        const float* grp[BS_XU];
+        rows_of(chunk, grp);
+        FAC_XREGS24_B(BS_LD)
+#endif
+      };
+      auto take_a = [&](float (&xr)[BS_XU][8]) { FAC_XREGS24_A(BS_RD) };
+      auto take_b = [&](float (&xr)[BS_XU][8]) { FAC_XREGS24_B(BS_RD) };
+      // ONE software-pipelined loop from c = -2: step(c) = { weight DMA of chunk c + 1 into stage (c + 1) & 1; wait for the inputs
+      // of c + 1 (requested by step(c - 1), older than that DMA: vmcnt(ND)); request the inputs of c + 2; take c + 1 out of its
+      // landing registers, split, write; wait for the DMA (vmcnt(NX): the inputs of c + 2 stay in flight); barrier }, each part
+      // skipped where its chunk does not exist.  At most ND + NX loads are in flight.
+      for (int base = -2; base < n_chunks; base += 2) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {                                // c + 1 has parity 1 - i: its stage and its register set
+          const int c = base + i;
+          if (c >= n_chunks) break;
+          const bool has_next = c + 1 >= 0 && c + 1 < n_chunks, has_next2 = c + 2 < n_chunks;
+          float xr[BS_XU][8];
+          if (has_next) {
+            stage_w(c + 1, 1 - i);                                   // that stage was read during chunk c - 1
+            asm volatile("s_waitcnt vmcnt(%0)" : : "n"(ND) : "memory");
+            if (i == 0) take_b(xr); else take_a(xr);
+          }
+          if (has_next2) {
+            if (i == 0) load_a(c + 2); else load_b(c + 2);
+          }
+          if (has_next) write_x(1 - i, xr);
+          if (c >= -1) {
+            if (has_next2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" : : "n"(NX) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();      // c = -1: chunk 0 staged; later: pairs with the MFMA waves' barrier behind chunk c
+            asm volatile("" ::: "memory");
+          }
+        }
+      }
+#undef BS_LD
+#undef BS_RD
+    } else {
+      // ---- narrow shape (32 / 48 input channels, three waves per SIMD: no registers to spare for named landing sets): plain
+      // loads, which hipcc waits for within the stage
+      auto load_x = [&](int chunk, float (&xr)[BS_XU][8]) {
+#if !defined(FAC_ABL_NOSTAGE) && !defined(FAC_ABL_NOSTAGE_X)
+#pragma unroll
+        for (int j = 0; j < BS_XU; ++j) {
+          const float* grp = xg + (long long)((chunk * G + u_g[j]) * 8) * xcs;
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            const float v = (grp + (long long)i * xcs)[u_idx[j] >= 0 ? u_idx[j] : 0];
+            xr[j][i] = u_idx[j] >= 0 ? v : 0.f;
+          }
+        }
+#endif
+      };
+      float xa[BS_XU][8], xb[BS_XU][8];
+      load_x(0, xa);
+      stage_w(0, 0);
+      if (n_chunks > 1) load_x(1, xb);
+      write_x(0, xa);
+      __syncthreads();
+      for (int chunk = 0; chunk < n_chunks; chunk += 2) {
+        if (chunk + 1 < n_chunks) {
+          stage_w(chunk + 1, 1);
+          if (chunk + 2 < n_chunks) load_x(chunk + 2, xa);
+          write_x(1, xb);
+        }
+        __syncthreads();
+        if (chunk + 1 >= n_chunks) break;
+        if (chunk + 2 < n_chunks) {
+          stage_w(chunk + 2, 0);
+          if (chunk + 3 < n_chunks) load_x(chunk + 3, xb);
+          write_x(0, xa);
+        }
+        __syncthreads();
       }
     }
     __builtin_amdgcn_s_setprio(0);

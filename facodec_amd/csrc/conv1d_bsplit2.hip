@@ -18,6 +18,7 @@
 //            carries its padding as zero gaps);
 //   epilogue by all eight waves from an fp32 tile in LDS (bias, activation, residual), 16-byte stores.
 #include "conv1d_mfma.h"
+#include "inflight_regs.h"
 
 namespace fac {
 
@@ -141,31 +142,44 @@ __global__ __launch_bounds__(512, 2) void conv1d_bsplit2_kernel(ConvArgs a) {
       tin = tin0 + k2 * dil2 + u_c[j];
       return vok && u_c[j] >= 0 && tin >= 0 && tin < a.T_in;
     };
-    // Loads by INLINE ASM (see conv1d_bsplit.hip: hipcc waits for a C++ load at its first use -- the padding select -- i.e. with
-    // vmcnt(0) right behind the loads of the same stage, and again before every barrier; rounds 1-3 paid a memory round trip per
-    // stage on the staging waves' critical path).  Scalar row base + per-lane byte offset, one instruction per element.
-    auto load_x = [&](int chunk, float (&xr)[XU][8]) {
+    // The inputs of chunk c + 2 stay in flight across the barrier, landing in NAMED physical registers (inflight_regs.h; see
+    // conv1d_bsplit.hip for why neither plain C++ loads nor compiler-allocated asm destinations work): element n = 8 j + i of a set
+    // = (unit j, virtual channel i of the chunk); scalar row base + per-lane byte offset, one instruction per element; lanes on
+    // padding read offset 0 and are zeroed by the v_cndmask that takes the value out of its landing register.
+#define B2_LD(n, R)                                                                                                      \
+  {                                                                                                                      \
+    int tin;                                                                                                             \
+    const bool ok = in_range(chunk, (n) % 8, (n) / 8, tin);                                                              \
+    asm volatile("global_load_dword v" #R ", %0, %1" : : "v"(ok ? (unsigned)tin * 4u : 0u), "s"(row[(n) % 8]) : "memory", "v" #R); \
+  }
+#define B2_RD(n, R)                                                                                                      \
+  {                                                                                                                      \
+    int tin;                                                                                                             \
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(in_range(chunk, (n) % 8, (n) / 8, tin));                    \
+    asm volatile("v_cndmask_b32_e64 %0, 0, v" #R ", %1" : "=v"(xr[(n) / 8][(n) % 8]) : "s"(m) : "memory");              \
+  }
+    auto load_x = [&](int chunk, int set) {
+      const float* row[8];
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         int v = chunk * 8 + i;                              // uniform: (real channel, second-level tap) of virtual channel v
         v = v < a.CV ? v : 0;
-        const float* row = xg + (long long)(v / K2v) * xcs;
-#pragma unroll
-        for (int j = 0; j < XU; ++j) {
-          int tin;
-          const bool ok = in_range(chunk, i, j, tin);
-          const unsigned off = ok ? (unsigned)tin * 4u : 0u;
-          asm volatile("global_load_dword %0, %1, %2" : "=v"(xr[j][i]) : "v"(off), "s"(row) : "memory");
-        }
+        row[i] = xg + (long long)(v / K2v) * xcs;
+      }
+      if constexpr (XU == 5) {
+        if (set == 0) { FAC_XREGS40_A(B2_LD) } else { FAC_XREGS40_B(B2_LD) }
+      } else {
+        if (set == 0) { FAC_XREGS24_A(B2_LD) } else { FAC_XREGS24_B(B2_LD) }
       }
     };
-    auto pin = [&](float (&xr)[XU][8]) {
-#pragma unroll
-      for (int j = 0; j < XU; ++j)
-#pragma unroll
-        for (int i = 0; i < 8; ++i) asm volatile("" : "+v"(xr[j][i]) : : "memory");
+    auto take_x = [&](int chunk, int set, float (&xr)[XU][8]) {      // after the s_waitcnt that covers the set's loads
+      if constexpr (XU == 5) {
+        if (set == 0) { FAC_XREGS40_A(B2_RD) } else { FAC_XREGS40_B(B2_RD) }
+      } else {
+        if (set == 0) { FAC_XREGS24_A(B2_RD) } else { FAC_XREGS24_B(B2_RD) }
+      }
     };
-    auto write_x = [&](int chunk, int buf, const float (&xr)[XU][8]) {
+    auto write_x = [&](int buf, const float (&xr)[XU][8]) {           // xr: landed samples, padding already zero
       unsigned char* xd = Xbuf + buf * X_STAGE;
 #pragma unroll
       for (int j = 0; j < XU; ++j) {
@@ -173,10 +187,8 @@ __global__ __launch_bounds__(512, 2) void conv1d_bsplit2_kernel(ConvArgs a) {
         bf16x8 h, m, l;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-          int tin;
-          const bool ok = in_range(chunk, i, j, tin);
           __bf16 p0, p1, p2;
-          b2_split3(ok ? xr[j][i] : 0.f, p0, p1, p2);
+          b2_split3(xr[j][i], p0, p1, p2);
           h[i] = p0; m[i] = p1; l[i] = p2;
         }
         *reinterpret_cast<bf16x8*>(xd + u_pos[j]) = h;
@@ -184,48 +196,33 @@ __global__ __launch_bounds__(512, 2) void conv1d_bsplit2_kernel(ConvArgs a) {
         *reinterpret_cast<bf16x8*>(xd + 2 * XWT * 16 + u_pos[j]) = l;
       }
     };
-    // Chunk c + 1 is staged while the MFMA waves multiply chunk c; the fp32 inputs of chunk c + 2 are requested a whole stage
-    // before they are split (two register sets: xa even chunks, xb odd ones); at most ND + NX loads in flight.
-    float xa[XU][8], xb[XU][8];
-    auto steady = [&](int c, int buf_next, float (&nxt)[XU][8], float (&cur)[XU][8]) {
-      stage_w(c + 1, buf_next);
-      asm volatile("s_waitcnt vmcnt(%0)" : : "n"(ND) : "memory");                  // inputs of c + 1 (older than the DMA)
-      pin(cur);
-      load_x(c + 2, nxt);
-      write_x(c + 1, buf_next, cur);
-      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" : : "n"(NX) : "memory");       // weights of c + 1 landed, LDS writes done
-      __builtin_amdgcn_s_barrier();
-      asm volatile("" ::: "memory");
-    };
-    auto last = [&](int c, int buf_next, float (&cur)[XU][8]) {
-      stage_w(c + 1, buf_next);
-      asm volatile("s_waitcnt vmcnt(%0)" : : "n"(ND) : "memory");
-      pin(cur);
-      write_x(c + 1, buf_next, cur);
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      asm volatile("" ::: "memory");
-    };
-    load_x(0, xa);
-    stage_w(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    pin(xa);
-    if (n_chunks > 1) load_x(1, xb);
-    write_x(0, 0, xa);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    for (int c = 0; c < n_chunks; ++c) {
-      const bool odd = c & 1;
-      if (c + 2 < n_chunks) {
-        if (!odd) steady(c, 1, xa, xb); else steady(c, 0, xb, xa);
-      } else if (c + 1 < n_chunks) {
-        if (!odd) last(c, 1, xb); else last(c, 0, xa);
-      } else {
-        __builtin_amdgcn_s_barrier();                            // pairs with the MFMA waves' barrier behind the last chunk
-        asm volatile("" ::: "memory");
+    // ONE software-pipelined loop from c = -2: step(c) = { weight DMA of chunk c + 1; wait for the inputs of c + 1 (requested by
+    // step(c - 1), older than that DMA: vmcnt(ND)); request the inputs of c + 2; take c + 1 out of its landing registers, split,
+    // write; wait for the DMA (vmcnt(NX)); barrier }.  Chunk parity = LDS stage = register set.  At most ND + NX loads in flight.
+    for (int base = -2; base < n_chunks; base += 2) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int c = base + i;
+        if (c >= n_chunks) break;
+        const bool has_next = c + 1 >= 0 && c + 1 < n_chunks, has_next2 = c + 2 < n_chunks;
+        float xr[XU][8];
+        if (has_next) {
+          stage_w(c + 1, 1 - i);
+          asm volatile("s_waitcnt vmcnt(%0)" : : "n"(ND) : "memory");
+          take_x(c + 1, 1 - i, xr);
+        }
+        if (has_next2) load_x(c + 2, i);
+        if (has_next) write_x(1 - i, xr);
+        if (c >= -1) {
+          if (has_next2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" : : "n"(NX) : "memory");
+          else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_s_barrier();
+          asm volatile("" ::: "memory");
+        }
       }
     }
+#undef B2_LD
+#undef B2_RD
     __builtin_amdgcn_s_setprio(0);
   } else {
     // ========================= MFMA waves: 32 rows x 128 columns each

@@ -138,13 +138,14 @@ class _MaskedAcc(Function):
     @staticmethod
     def forward(ctx, acc, q, mask):
         ctx.save_for_backward(mask)
+        ctx.has_acc = acc is not None
         return ops.rows_fma(q.detach().contiguous(), mask, None if acc is None else acc.detach())
 
     @staticmethod
     def backward(ctx, d):
         (mask,) = ctx.saved_tensors
         d = d.contiguous()
-        return d, ops.rows_fma(d, mask), None
+        return (d if ctx.has_acc else None), ops.rows_fma(d, mask), None
 
 
 class ResidualVQ(nn.Module):

@@ -1,0 +1,24 @@
+"""Build-time check of the kernels that keep loads in flight across barriers in NAMED physical registers (csrc/inflight_regs.h,
+conv1d_bsplit.hip, conv1d_bsplit2.hip): no compiler-generated instruction of those kernels may touch the reserved registers --
+otherwise a value would be overwritten by, or read before, a load that has not landed.  Runs hipcc (gfx950 cross-compile), no
+GPU needed."""
+import os
+import shutil
+import sys
+
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(REPO, "tools"))
+
+
+@pytest.mark.skipif(not (os.path.exists("/opt/rocm/bin/hipcc") or shutil.which("hipcc")), reason="needs hipcc")
+@pytest.mark.parametrize("src,n_kernels", [("conv1d_bsplit.hip", 3), ("conv1d_bsplit2.hip", 3)])
+def test_named_landing_registers_are_left_alone(src, n_kernels):
+    import check_inflight_regs as C
+    asm = C.compile_to_asm(os.path.join(REPO, "facodec_amd", "csrc", src))
+    res = C.reserved_violations(asm)
+    assert len(res) == n_kernels, sorted(res)          # every wide k = 7 / 5 / 3 kernel, every (K1, stride) of the 32-row kernel
+    for name, (lo, bad) in res.items():
+        assert lo in (176, 208), (name, lo)
+        assert not bad, (name, bad[:5])
