@@ -75,16 +75,13 @@ def check_codes(model, device):
     (facodec_amd/diagnostics.py): a flip between two codes whose distances to the latent differ by <= 1e-5, and the later
     residual stages it drags along, is reported; anything else raises."""
     import numpy as np
-    from facodec_amd.diagnostics import LatentCapture, classify_code_mismatches
+    from facodec_amd.diagnostics import LatentCapture, classify_faquantizer_codes
     gold = np.load(os.path.join(REPO, "tests", "golden", "codec_e2e.npz"))
     wave = synth.synth_clips(2, int(CLIP_SECONDS * SAMPLE_RATE), seed=0).to(device)
     with LatentCapture(model.quantizer) as cap:
         _, codes = make_step(model, wave)()
-    report = {}
-    rvqs = dict(cap.rvqs)
     # FAquantizer.forward_v2 (modules/quantize.py:398-437) runs prosody, content and residual quantizers in this order
-    for (name, _), c, k in zip(cap.rvqs, codes, ("codes_p", "codes_c", "codes_r")):
-        report[k] = classify_code_mismatches(rvqs[name], cap.latents[name], c, gold[k])
+    report = classify_faquantizer_codes(cap, codes, [gold[k] for k in ("codes_p", "codes_c", "codes_r")])
     genuine = sum(r["genuine"] for r in report.values())
     total = sum(r["mismatches"] for r in report.values())
     if genuine:
@@ -100,18 +97,14 @@ def check_codes_b32(model, wave, rank):
     tests/golden/make_golden_bench.py).  Same triage as check_codes.  Returns None when the batch is not that batch."""
     import hashlib
     import numpy as np
-    from facodec_amd.diagnostics import LatentCapture, classify_code_mismatches
+    from facodec_amd.diagnostics import LatentCapture, classify_faquantizer_codes
     path = os.path.join(REPO, "tests", "golden", "codec_b32.npz")
     if rank != 0 or tuple(wave.shape) != (32, 1, 48000) or not os.path.exists(path):
         return None
     gold = np.load(path)
     with LatentCapture(model.quantizer) as cap:
         _, codes = make_step(model, wave)()
-    rvqs, report, lo = dict(cap.rvqs), {}, 0
-    for (name, _), c in zip(cap.rvqs, codes):                      # prosody (1), content (2), residual (3) streams
-        n = c.shape[1]
-        report[name] = classify_code_mismatches(rvqs[name], cap.latents[name], c, gold["codes"][:, lo:lo + n])
-        lo += n
+    report = classify_faquantizer_codes(cap, codes, [gold["codes"][:, lo:hi] for lo, hi in ((0, 1), (1, 3), (3, 6))])   # prosody | content | residual
     if sum(r["genuine"] for r in report.values()):
         raise SystemExit(f"[bench] code-index mismatch on the timed 32-clip batch against the reference: {report}")
     allc = torch.cat(codes, 1).cpu().numpy().astype(np.int16)

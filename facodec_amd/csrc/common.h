@@ -93,3 +93,13 @@ __device__ __forceinline__ int reflect_index(int t, int T, int Text) {
 }
 
 }  // namespace fac
+
+// Issue priorities (s_setprio) of the two wave roles of the split-bf16 kernels (conv1d_bsplit / bsplit2 / gemm_split / wgrad k-major):
+// MFMA waves and staging waves share a SIMD; the arbiter picks the higher priority when both have an instruction ready.
+#ifndef FAC_PRIO_STAGE
+#define FAC_PRIO_STAGE 3
+#endif
+#ifndef FAC_PRIO_MFMA
+#define FAC_PRIO_MFMA 0
+#endif
+

@@ -133,7 +133,7 @@ __global__ __launch_bounds__((NMW + NSW) * 64, (NMW + NSW) / 4) void conv1d_bspl
   if (wave >= NMW) {
     // ===================== staging waves
     const int lw = wave - NMW;
-    __builtin_amdgcn_s_setprio(3);
+    __builtin_amdgcn_s_setprio(FAC_PRIO_STAGE);
     const float* xg = a.x + (long long)b * a.x_bs;
     const int xcs = (int)a.x_cs;     // one clip's rows stay far below 2^31 elements (checked by the dispatcher)
     const unsigned char* wsrc = reinterpret_cast<const unsigned char*>(a.w) + (long long)(co0 / BS_CO) * n_chunks * W_STAGE;
@@ -310,6 +310,7 @@ __global__ __launch_bounds__((NMW + NSW) * 64, (NMW + NSW) / 4) void conv1d_bspl
 #ifdef FAC_PROF
   const unsigned long long tp0 = wall_clock64();
 #endif
+  __builtin_amdgcn_s_setprio(FAC_PRIO_MFMA);
   const int l31 = lane & 31;
   const int kq = lane >> 5;
   const int n0 = wave * 64;
@@ -338,7 +339,11 @@ __global__ __launch_bounds__((NMW + NSW) * 64, (NMW + NSW) / 4) void conv1d_bspl
     // A fragments are requested one step ahead (register double buffer); B fragments at the start of their
     // step, in the order the six terms consume them (the compiler waits per fragment, and the second workgroup
     // on the CU covers what latency remains) -- keeps the kernel under the 170 VGPRs of 3 waves per SIMD.
-    bf16x8 A[2][MB][3], Bf[NB][3];
+#ifndef FAC_BS_BDBL
+#define FAC_BS_BDBL 1
+#endif
+    constexpr bool BDBL = FAC_BS_BDBL && NMW == 4;     // B fragments requested one step ahead as well (two register sets)
+    bf16x8 A[2][MB][3], Bf[BDBL ? 2 : 1][NB][3];
     auto ldA = [&](int st, bf16x8 (&Ad)[MB][3]) {
 #ifdef FAC_ABL_NOLDS
       if (st > 1) return;
@@ -349,7 +354,7 @@ __global__ __launch_bounds__((NMW + NSW) * 64, (NMW + NSW) / 4) void conv1d_bspl
         for (int m = 0; m < MB; ++m)
           Ad[m][p] = *reinterpret_cast<const bf16x8*>(Wb + ((p * H + 2 * st) * BS_CO + m * 32) * 16);
     };
-    auto ldB = [&](int st) {
+    auto ldB = [&](int st, bf16x8 (&Bd)[NB][3]) {
 #ifdef FAC_ABL_NOLDS
       if (st > 0) return;
 #endif
@@ -359,15 +364,20 @@ __global__ __launch_bounds__((NMW + NSW) * 64, (NMW + NSW) / 4) void conv1d_bspl
       for (int pi = 0; pi < 3; ++pi)
 #pragma unroll
         for (int n = 0; n < NB; ++n)
-          Bf[n][PO[pi]] = *reinterpret_cast<const bf16x8*>(Xb + xo + (PO[pi] * G * XW + n * 32) * 16);
+          Bd[n][PO[pi]] = *reinterpret_cast<const bf16x8*>(Xb + xo + (PO[pi] * G * XW + n * 32) * 16);
     };
     // 8 MFMA waves (2 per SIMD, 3 waves per SIMD in all -> 170 VGPRs): the sibling wave hides the LDS latency,
     // so A is fetched at the start of its step too and only one A buffer is kept
     constexpr bool ADBL = NMW == 4;
     if (ADBL) ldA(0, A[0]);
+    if (BDBL) ldB(0, Bf[0]);
 #pragma unroll
     for (int st = 0; st < H / 2; ++st) {
-      ldB(st);
+      if (BDBL) {
+        if (st + 1 < H / 2) ldB(st + 1, Bf[(st + 1) & 1]);
+      } else {
+        ldB(st, Bf[0]);
+      }
       if (ADBL) {
         if (st + 1 < H / 2) ldA(st + 1, A[(st + 1) & 1]);
       } else {
@@ -375,6 +385,7 @@ __global__ __launch_bounds__((NMW + NSW) * 64, (NMW + NSW) / 4) void conv1d_bspl
       }
       __builtin_amdgcn_sched_barrier(0);
       const int s = ADBL ? (st & 1) : 0;
+      const int sb = BDBL ? (st & 1) : 0;
       // smallest terms first: mid*mid, lo*hi, hi*lo, mid*hi, hi*mid, hi*hi.  The term loop is OUTSIDE the
       // block loops so that consecutive MFMAs write different accumulators (no back-to-back dependency).
       constexpr int TA[6] = {1, 2, 0, 1, 0, 0}, TB[6] = {1, 0, 2, 0, 1, 0};
@@ -385,12 +396,12 @@ __global__ __launch_bounds__((NMW + NSW) * 64, (NMW + NSW) / 4) void conv1d_bspl
         for (int m = 0; m < MB; ++m)
 #pragma unroll
           for (int n = 0; n < NB; ++n)
-            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[s][m][TA[q]], Bf[n][TB[q]], acc[m][n], 0, 0, 0);
+            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[s][m][TA[q]], Bf[sb][n][TB[q]], acc[m][n], 0, 0, 0);
 #else
 #pragma unroll
       for (int m = 0; m < MB; ++m)
 #pragma unroll
-        for (int n = 0; n < NB; ++n) acc[m][n][st & 15] += (float)A[s][m][0][0] * (float)Bf[n][1][1] + (float)A[s][m][2][3] + (float)Bf[n][2][5] + (float)A[s][m][1][7] * (float)Bf[n][0][2];
+        for (int n = 0; n < NB; ++n) acc[m][n][st & 15] += (float)A[s][m][0][0] * (float)Bf[sb][n][1][1] + (float)A[s][m][2][3] + (float)Bf[sb][n][2][5] + (float)A[s][m][1][7] * (float)Bf[sb][n][0][2];
 #endif
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -401,6 +412,7 @@ __global__ __launch_bounds__((NMW + NSW) * 64, (NMW + NSW) / 4) void conv1d_bspl
   const unsigned long long tp2 = wall_clock64();
   pf0 = tp0; pf1 = tp1; pf2 = tp2;
 #endif
+  __builtin_amdgcn_s_setprio(0);
   // ---- accumulators -> LDS (both stage buffers are free now): tile[co][t] fp32, row pitch BS_TT + 4 floats.
   // C/D layout of the 32x32 block: register r <-> row (r & 3) + 8 (r >> 2) + 4 kq, column l31.
   {

@@ -104,7 +104,7 @@ __global__ __launch_bounds__(512, 2) void conv1d_bsplit2_kernel(ConvArgs a) {
   if (wave >= 4) {
     // ===================== staging waves
     const int lw = wave - 4;
-    __builtin_amdgcn_s_setprio(3);
+    __builtin_amdgcn_s_setprio(FAC_PRIO_STAGE);
     const float* xg = a.x + (long long)b * a.x_bs;
     const int xcs = (int)a.x_cs;
     const unsigned char* wsrc = reinterpret_cast<const unsigned char*>(a.w) + (long long)(co0 / B2_CO) * n_chunks * W_STAGE;
@@ -226,6 +226,7 @@ __global__ __launch_bounds__(512, 2) void conv1d_bsplit2_kernel(ConvArgs a) {
     __builtin_amdgcn_s_setprio(0);
   } else {
     // ========================= MFMA waves: 32 rows x 128 columns each
+    __builtin_amdgcn_s_setprio(FAC_PRIO_MFMA);
     const int l31 = lane & 31;
     const int kq = lane >> 5;
     const int n0 = wave * (32 * B2_NB);
@@ -277,6 +278,7 @@ __global__ __launch_bounds__(512, 2) void conv1d_bsplit2_kernel(ConvArgs a) {
       }
       __syncthreads();
     }
+    __builtin_amdgcn_s_setprio(0);
     // accumulators -> fp32 tile in LDS (both stage buffers are free now)
     float* tile = reinterpret_cast<float*>(sm);
     constexpr int EP = B2_TT + 4;

@@ -127,7 +127,7 @@ __global__ __launch_bounds__(512, 2) void conv1d_gemm_split_kernel(ConvArgs a) {
     // ===================================================================== staging waves
     const int lw = wave - 4;
     const int sl = tid - 256;
-    __builtin_amdgcn_s_setprio(3);
+    __builtin_amdgcn_s_setprio(FAC_PRIO_STAGE);
     const unsigned char* wsrc = reinterpret_cast<const unsigned char*>(a.w) + (long long)(row0 / GS_ROWS) * n_chunks * A_BYTES;
     // input units of this lane: column c of the staged window (row c of the B planes), 8-channel group g
     long long u_off[GS_NU];
@@ -265,6 +265,7 @@ __global__ __launch_bounds__(512, 2) void conv1d_gemm_split_kernel(ConvArgs a) {
     __builtin_amdgcn_s_setprio(0);
   } else {
     // ========================================================================= MFMA waves: 64 x 64 each (2 x 2 blocks)
+    __builtin_amdgcn_s_setprio(FAC_PRIO_MFMA);
     const int l31 = lane & 31, kq = lane >> 5;
     const int mh = wave >> 1, nh = wave & 1;
     const int swa = (l31 >> 2) & 3;
@@ -332,6 +333,7 @@ __global__ __launch_bounds__(512, 2) void conv1d_gemm_split_kernel(ConvArgs a) {
         }
       }
     }
+    __builtin_amdgcn_s_setprio(0);
     // accumulators -> fp32 tile in LDS (every stage buffer is free: nothing is in flight after the last barrier)
     float* tile = reinterpret_cast<float*>(sm);
     constexpr int EP = GS_COLS + 4;

@@ -36,9 +36,30 @@ def _distances(lat, codebook):
     return e.pow(2).sum(1, keepdim=True) - 2 * e @ c.t() + c.pow(2).sum(1, keepdim=True).t()
 
 
-def classify_code_mismatches(rvq, latents, got, expected, tie_tol=1e-5):
+def flipped_frames(got, expected):
+    """(B, n, T) codes -> (B, T) bool: frames at which any stage differs."""
+    return (got.cpu().long() != torch.as_tensor(expected).long()).any(1)
+
+
+def classify_faquantizer_codes(capture, codes, expected_list, tie_tol=1e-5):
+    """The three code streams FAquantizer.forward_v2 returns (prosody, content, residual: modules/quantize.py:398-437) against
+    the reference's; a frame whose prosody or content code flipped feeds the residual quantizer a different input, so its
+    residual mismatches are counted as that flip's cascade.  capture: the LatentCapture the forward ran under.
+    -> {quantizer name: classify_code_mismatches result}."""
+    rvqs, report, upstream = dict(capture.rvqs), {}, None
+    for (name, _), c, e in zip(capture.rvqs, codes, expected_list):
+        is_residual = name.startswith("residual")
+        report[name] = classify_code_mismatches(rvqs[name], capture.latents[name], c, e, tie_tol, upstream if is_residual else None)
+        f = flipped_frames(c, e)
+        upstream = f if upstream is None else (upstream | f)
+    return report
+
+
+def classify_code_mismatches(rvq, latents, got, expected, tie_tol=1e-5, upstream_flips=None):
     """rvq: the ResidualVectorQuantize that produced `got` (B, n, T) with projected latents (B, 8 n, T); expected: the
-    reference's codes, same shape.  -> dict(mismatches, near_tie, cascade, genuine, worst_gap)."""
+    reference's codes, same shape.  upstream_flips: optional (B, T) bool -- frames at which a quantizer FEEDING this one already
+    differs (modules/quantize.py:411: the residual quantizer's input is x - z_p - z_c, frame by frame), whose mismatches here are
+    that flip's cascade (`flipped_frames`).  -> dict(mismatches, near_tie, cascade, genuine, worst_gap)."""
     got, expected = got.cpu().long(), torch.as_tensor(expected).long()
     assert got.shape == expected.shape, (got.shape, expected.shape)
     diff = got != expected
@@ -49,6 +70,9 @@ def classify_code_mismatches(rvq, latents, got, expected, tie_tol=1e-5):
     B, n, T = got.shape
     for b, t in diff.any(1).nonzero().tolist():
         stages = diff[b, :, t].nonzero().flatten().tolist()
+        if upstream_flips is not None and bool(upstream_flips[b, t]):
+            out["cascade"] += len(stages)
+            continue
         i = stages[0]
         d = _distances(lat[b, 8 * i: 8 * i + 8, t][None], rvq.quantizers[i].codebook.weight.detach().cpu())[0]
         gap = float(d[expected[b, i, t]] - d[got[b, i, t]])

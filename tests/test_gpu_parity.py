@@ -514,10 +514,10 @@ def test_fvq_train_mode_against_reference_golden(cuda, golden_dir):
             worst[n] = rel(p.grad, d[pre + "grad." + n])
         assert max(worst.values()) < E2E_TOL, (kind, worst)
     # the reference's own draw: same torch.randint call on the CPU generator -> same n_quantizers for the same seed
+    rv3 = ResidualVQ(num_quantizers=3, codebook_size=10, dim=64, codebook_dim=8, commitment=0.15, quantizer_dropout=0.75, dropout_type="linear")
     torch.manual_seed(123)
     want = torch.randint(1, 3 + 1, (4,))
     torch.manual_seed(123)
-    rv3 = ResidualVQ(num_quantizers=3, codebook_size=10, dim=64, codebook_dim=8, commitment=0.15, quantizer_dropout=0.75, dropout_type="linear")
     assert torch.equal(rv3._draw_n_quantizers(4, None), torch.tensor([float(want[0]), float(want[1]), float(want[2]), 4.0]))
     with pytest.raises(UnboundLocalError):            # rvq.py:45 with dropout_type=None
         ResidualVQ(num_quantizers=2, codebook_size=10, dim=64, codebook_dim=8, commitment=0.15).train()._draw_n_quantizers(4, None)

@@ -97,7 +97,7 @@ def test_batch32_codes_against_reference_golden(cuda, golden_dir):
     x 2 s that bench.py times): all 32 x 6 x 160 code indices (a flip between two codes whose distances differ by <= 1e-5, and the
     residual stages it drags along, is triaged and reported by bench.py; here none is allowed beyond that triage and the
     count is asserted small), latent / quantizer-output / waveform / timbre probes of four clips at 1e-4."""
-    from facodec_amd.diagnostics import LatentCapture, classify_code_mismatches
+    from facodec_amd.diagnostics import LatentCapture, classify_faquantizer_codes
     d = np.load(os.path.join(golden_dir, "codec_b32.npz"))
     model = _model(cuda, ("encoder", "quantizer", "decoder"))
     for k in ("encoder", "quantizer", "decoder"):
@@ -107,12 +107,8 @@ def test_batch32_codes_against_reference_golden(cuda, golden_dir):
         z = model.encoder(wave)
         outs, _, commit, cbl, timbre, codes = model.quantizer(z, wave, n_c=2, return_codes=True)
         y = model.decoder(outs)
-    rvqs, lo, report = dict(cap.rvqs), 0, {}
-    for (name, _), c in zip(cap.rvqs, codes):
-        n = c.shape[1]
-        report[name] = classify_code_mismatches(rvqs[name], cap.latents[name], c, d["codes"][:, lo:lo + n])
-        lo += n
-    assert lo == 6 and sum(r["genuine"] for r in report.values()) == 0, report
+    report = classify_faquantizer_codes(cap, codes, [d["codes"][:, lo:hi] for lo, hi in ((0, 1), (1, 3), (3, 6))])
+    assert sum(c.shape[1] for c in codes) == 6 and sum(r["genuine"] for r in report.values()) == 0, report
     assert sum(r["mismatches"] for r in report.values()) <= 6, report           # measured: 0 of 30 720
     pc = d["probe_clips"].tolist()
     rel = lambda a, b, scale: float(np.abs(a.detach().cpu().numpy() - b).max()) / float(scale)   # noqa: E731
