@@ -270,7 +270,10 @@ def cpu_baseline(batch=4, passes=5, warmups=2, with_train=True):
     from oracle import facodec_oracle as O
     model = build_model(default_model_params())
     keys = ("encoder", "quantizer", "decoder", "discriminator", "fa_predictors") if with_train else ("encoder", "quantizer", "decoder")
-    sds = {k: synth.synth_state_dict(synth.param_shapes(model[k]), 0, k + ".") for k in keys}
+    sds = {}
+    for k in keys:       # parameters by formula, buffers (anti-aliasing filters, mel tables) as the modules build them
+        synth.load_synthetic(model[k], seed=0, prefix=k + ".")
+        sds[k] = {n: v.detach().clone() for n, v in model[k].state_dict().items()}
     names = {k: {n for n, _ in model[k].named_parameters()} for k in keys}
     del model
     n_samples = int(CLIP_SECONDS * SAMPLE_RATE)
@@ -304,7 +307,11 @@ def cpu_baseline(batch=4, passes=5, warmups=2, with_train=True):
         t0 = time.perf_counter()
         oracle_iteration(sds, names, t)
         first = time.perf_counter() - t0
-        tw, tp = (2, 5) if first * 7 < 90 else (1, 3)          # keep the default bench.py run within a few minutes
+        # BASELINE.md 3 asks for the median of 5 after 2 warm-ups; one iteration of this port takes tens of seconds at B = 4, so
+        # the number of timed iterations is cut to what ~100 s of CPU allow (said in `sample`): the default bench.py run must
+        # still finish within a few minutes
+        tp = max(1, min(5, int(100.0 / max(first, 1e-3)) - 1))
+        tw = 2 if tp == 5 else 1
         for i in range(tw - 1 + tp):
             t0 = time.perf_counter()
             oracle_iteration(sds, names, t)
