@@ -68,6 +68,7 @@ SIGNATURES = {
     "fac_pack_lstm_whh_t": (_i, [_p, _p, _i, _p]),
     "fac_lstm_layer_bwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
     "fac_lstm_persist_ok": (_i, [_i, _i]),
+    "fac_lstm_persist_stream_ok": (_i, [_p]),
     "fac_pack_lstm_whh16": (_i, [_p, _p, _i, _i, _p]),
     "fac_lstm_layer_fwd_persist": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "fac_lstm_layer_bwd_persist": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),

@@ -166,7 +166,11 @@ __global__ __launch_bounds__((NMW + NSW) * 64, (NMW + NSW) / 4) void conv1d_bspl
 #pragma unroll
       for (int j = 0; j < ND; ++j) {
         const int i = min(lw + NSW * j, NBLK - 1);
+#ifdef FAC_ABL_WSRC_SAME   // tuning: every DMA block reads the same 1 KiB (cache-resident) -- same LDS write volume, no L2 fetch volume
+        __builtin_amdgcn_global_load_lds((glb_void_t*)(wsrc + lane * 16), (lds_void_t*)(dst + i * 1024), 16, 0, 0);
+#else
         __builtin_amdgcn_global_load_lds((glb_void_t*)(src + (long long)i * 1024 + lane * 16), (lds_void_t*)(dst + i * 1024), 16, 0, 0);
+#endif
       }
 #endif
     };

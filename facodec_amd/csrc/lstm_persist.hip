@@ -401,25 +401,69 @@ __global__ __launch_bounds__(256) void pack_whh16_kernel(const float* __restrict
   }
 }
 
+// Exchange-flag slots are handed out per (device, stream) for the life of the process; a process that has used them all
+// gets -1 and the caller runs the per-step kernels (lstm.hip) on that stream instead (fac_lstm_persist_stream_ok).
 static int lstm_sync_slot(hipStream_t stream) {
   static std::mutex mu;
-  static std::unordered_map<hipStream_t, int> slots;
+  static std::unordered_map<unsigned long long, int> slots;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const unsigned long long key = (reinterpret_cast<unsigned long long>(stream) << 4) ^ (unsigned long long)dev;
   std::lock_guard<std::mutex> lock(mu);
-  auto it = slots.find(stream);
+  auto it = slots.find(key);
   if (it != slots.end()) return it->second;
   if ((int)slots.size() >= LSTM_SYNC_SLOTS) return -1;
   const int s = (int)slots.size();
-  slots.emplace(stream, s);
+  slots.emplace(key, s);
   return s;
 }
 
+constexpr int LSTM_MAX_DEV = 16;
+
 static int device_cus() {
-  static int cus = 0;
-  if (cus == 0) {
-    int dev = 0, v = 0;
-    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess) cus = v;
+  static int cus[LSTM_MAX_DEV] = {0};
+  int dev = 0, v = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= LSTM_MAX_DEV) return 0;
+  if (cus[dev] == 0 && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess) cus[dev] = v;
+  return cus[dev];
+}
+
+// The resident kernels spin on flags written by the OTHER workgroups of their grid, so the whole grid must be resident at once
+// (ADVICE r3).  Two guards, both on the host:
+//  * the runtime's own occupancy figure for the kernel x the device's CUs must cover the grid (a workgroup is 1024 threads + ~35 KB
+//    of LDS, i.e. one per CU; a build that needs more registers would silently stop fitting);
+//  * resident launches of one process are SERIALISED on the device, whatever streams or threads they come from: every launch
+//    waits for the event recorded behind the previous one (two half-resident grids would wait for each other's CUs for ever).
+//    Launches issued during stream capture skip the event (an un-captured event cannot be waited for inside a capture): a graph's
+//    own launches are ordered by the graph, and replaying such a graph next to other resident launches is the caller's to order.
+//  Several PROCESSES sharing one device cannot be ordered from here: facodec_amd.ops.lstm_persist_ok refuses the resident path
+//  when ranks share a device.
+static bool grid_fits(const void* kern, int grid) {
+  int per_cu = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 1024, 0) != hipSuccess) return false;
+  return (long long)per_cu * device_cus() >= grid;
+}
+
+struct PersistOrder {
+  std::mutex mu;
+  hipEvent_t ev[LSTM_MAX_DEV] = {};
+  bool have[LSTM_MAX_DEV] = {};
+};
+static PersistOrder g_order;
+
+// before == true: make `stream` wait for the previous resident launch of this process on this device; false: record behind this one
+static void order_resident_launch(hipStream_t stream, bool before) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= LSTM_MAX_DEV) return;
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(stream, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return;
+  std::lock_guard<std::mutex> lock(g_order.mu);
+  if (before) {
+    if (g_order.have[dev]) (void)hipStreamWaitEvent(stream, g_order.ev[dev], 0);
+  } else {
+    if (!g_order.ev[dev] && hipEventCreateWithFlags(&g_order.ev[dev], hipEventDisableTiming) != hipSuccess) return;
+    g_order.have[dev] = hipEventRecord(g_order.ev[dev], stream) == hipSuccess;
   }
-  return cus;
 }
 
 // FAC_LSTM_EXCHANGE = fence (mode 0) | sc1 (mode 1) | fresh (mode 2, default)
@@ -443,6 +487,8 @@ static bool persist_shape_ok(int H, int B) {
 }  // namespace fac
 
 extern "C" int fac_lstm_persist_ok(int H, int B) { return fac::persist_shape_ok(H, B) ? 1 : 0; }
+
+extern "C" int fac_lstm_persist_stream_ok(fac_stream_t stream) { return fac::lstm_sync_slot((hipStream_t)stream) >= 0 ? 1 : 0; }
 
 extern "C" int fac_pack_lstm_whh16(const float* w_hh, float* packed, int H, int transposed, fac_stream_t stream) {
   using namespace fac;
@@ -471,9 +517,13 @@ extern "C" int fac_lstm_layer_fwd_persist(const float* pre, const float* whh16, 
     case 242: kern = lstm_fwd_persist_kernel<24, 2>; break;
   }
   FAC_REQUIRE(kern != nullptr, "lstm_layer_fwd_persist: no kernel for H=%d", H);
+  FAC_REQUIRE(grid_fits(reinterpret_cast<const void*>(kern), H / 8), "lstm_layer_fwd_persist: %d workgroups are not co-resident on this device", H / 8);
+  order_resident_launch((hipStream_t)stream, true);
   hipLaunchKernelGGL(kern, dim3(H / 8), dim3(1024), 0, (hipStream_t)stream, pre, whh16, hfrag, yT, gates_save, c_save, slot, T, H, BP,
                      exchange_mode());
-  return check_launch("lstm_layer_fwd_persist");
+  const int rc = check_launch("lstm_layer_fwd_persist");
+  order_resident_launch((hipStream_t)stream, false);
+  return rc;
 }
 
 extern "C" int fac_lstm_layer_bwd_persist(const float* dyT, const float* whh16t, const float* gates, const float* cs, float* dgates,
@@ -498,7 +548,11 @@ extern "C" int fac_lstm_layer_bwd_persist(const float* dyT, const float* whh16t,
     case 242: kern = lstm_bwd_persist_kernel<24, 2>; break;
   }
   FAC_REQUIRE(kern != nullptr, "lstm_layer_bwd_persist: no kernel for H=%d", H);
+  FAC_REQUIRE(grid_fits(reinterpret_cast<const void*>(kern), H / 8), "lstm_layer_bwd_persist: %d workgroups are not co-resident on this device", H / 8);
+  order_resident_launch((hipStream_t)stream, true);
   hipLaunchKernelGGL(kern, dim3(H / 8), dim3(1024), 0, (hipStream_t)stream, dyT, whh16t, gates, cs, dgates, partial, dgfrag, slot, T, H, BP,
                      exchange_mode());
-  return check_launch("lstm_layer_bwd_persist");
+  const int rc = check_launch("lstm_layer_bwd_persist");
+  order_resident_launch((hipStream_t)stream, false);
+  return rc;
 }

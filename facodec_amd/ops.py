@@ -568,8 +568,20 @@ def lstm_persist_ok(H, batch):
     """True when the one-launch-per-layer recurrence (lstm_persist.hip) is used for an (H, batch) zero-initial-state
     layer on this device: H in {512, 1024, 1536}, H/8 workgroups <= CUs, batch <= 16.  The kernels cover batch <= 32
     (two 16-column blocks) but measure no faster than the per-step launches there (profiles/r03_lstm_bench.log)."""
-    return (LSTM_PERSIST and batch is not None and batch <= LSTM_PERSIST_MAX_BATCH
-            and bool(_lib.load().fac_lstm_persist_ok(int(H), int(batch))))
+    return (LSTM_PERSIST and batch is not None and batch <= LSTM_PERSIST_MAX_BATCH and not _ranks_share_a_device()
+            and bool(_lib.load().fac_lstm_persist_ok(int(H), int(batch)))
+            and bool(_lib.load().fac_lstm_persist_stream_ok(_stream())))
+
+
+def _ranks_share_a_device():
+    """The resident LSTM grids of two PROCESSES on one GPU could each hold part of the CUs and spin on workgroups that never get
+    one (launches are only serialised inside a process, lstm_persist.hip): with more local ranks than visible devices (the
+    two-ranks-on-one-GPU smoke mode of tools/ddp_smoke.py) the per-step kernels are used instead."""
+    try:
+        local_world = int(os.environ.get("LOCAL_WORLD_SIZE", "1"))
+    except ValueError:
+        local_world = 1
+    return local_world > max(1, torch.cuda.device_count())
 
 
 def pack_lstm_whh16(w_hh, transposed=False):

@@ -236,6 +236,10 @@ int fac_lstm_layer_bwd(const float* dyT, const float* whh_t_packed, const float*
  * T * H * NC floats of scratch, fac_lstm_layer_bwd_persist's scratch (4 + 4 * T) * H * NC floats (one fresh exchange region per
  * step).  One resident layer per stream at a time (stream order guarantees it). */
 int fac_lstm_persist_ok(int H, int B);
+/* 1 when `stream` has (or can still get) one of the process's 64 exchange-flag slots; 0 -> run the per-step kernels on it.
+ * The resident launches of one process are serialised on the device (an event chain across streams) and refuse to launch when
+ * the runtime's occupancy figure says the H/8 workgroups would not be co-resident. */
+int fac_lstm_persist_stream_ok(fac_stream_t stream);
 int fac_pack_lstm_whh16(const float* w_hh, float* packed, int H, int transposed, fac_stream_t stream);
 int fac_lstm_layer_fwd_persist(const float* pre, const float* whh16, float* hfrag, float* yT, float* gates_save, float* c_save,
                                int T, int H, int B, int BP, fac_stream_t stream);
