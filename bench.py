@@ -188,8 +188,10 @@ def train_leg(model, device, rank, world, steps, warmup):
         "allreduce_overlap": {"launched_early": [k for k, e in exchange.items() if e["launched"] == "hook"],
                               "launched_after_backward": [k for k, e in exchange.items() if e["launched"] == "end"],
                               "wait_ms": {k: (None if e["wait_ms"] is None else round(e["wait_ms"], 3)) for k, e in exchange.items()},
-                              "note": "launched_early = the key's collective was issued from a gradient hook inside backward; wait_ms = "
-                                      "stall of the compute stream at the key's optimiser step (what the overlap failed to hide)"},
+                              "buckets": {k: {"n": e["n_buckets"], "launches": ["%s:%s" % (b, w) for b, w in e["buckets"]]} for k, e in exchange.items()},
+                              "note": "each key's gradient arena leaves in <= 64 MB buckets, end of the arena first; launched_early = the "
+                                      "key's first bucket was issued from a gradient hook inside backward (bucket:where lists every launch); "
+                                      "wait_ms = stall of the compute stream at the key's optimiser step (what the overlap failed to hide)"},
         "losses_finite": finite, "loss": round(float(last["loss"]), 4), "mel": round(float(last["mel"]), 4),
         "peak_mem_GB": round(peak_mem / 2 ** 30, 1),
         "counted_flops": {"per_step_TFLOP": round(fc.total / 1e12, 3), "per_audio_s_TFLOP": round(flop_per_audio_s / 1e12, 4),

@@ -126,6 +126,7 @@ class Encoder(nn.Module):
         layers += [Snake1d(d_model), SConv1d(d_model, d_latent, kernel_size=3, causal=causal, norm="weight_norm")]
         self.block = nn.Sequential(*layers)
         self.enc_dim = d_model
+        self.boundary_hook = None          # training only: callable(child module, activation entering it), see train.GeneratorStep
 
     def _forward_train(self, x):
         """Training mode: one autograd node per ResidualUnit (A.res_unit), every Snake but the one after the LSTM fused into a
@@ -133,6 +134,8 @@ class Encoder(nn.Module):
         mods = list(self.block)
         x = A.conv(mods[0], x)
         for m in mods[1:-2]:
+            if self.boundary_hook is not None:
+                self.boundary_hook(m, x)            # x enters top-level child m (train.py: progressive gradient exchange)
             if isinstance(m, EncoderBlock):
                 b = m.block
                 x, xa = A.snake_dual(x, b[0].block[0].alpha)
@@ -206,6 +209,7 @@ class Decoder(nn.Module):
         layers += [Snake1d(out_dim), SConv1d(out_dim, d_out, kernel_size=7, causal=causal, norm="weight_norm"),
                    nn.Tanh()]
         self.model = nn.Sequential(*layers)
+        self.boundary_hook = None
 
     def _forward_train(self, x):
         """Training mode: see Encoder._forward_train.  The last ResidualUnit of a block emits the copy pre-activated with the
@@ -215,6 +219,8 @@ class Decoder(nn.Module):
         x = A.conv(mods[0], x)
         xa = None
         for m in mods[1:-3]:
+            if self.boundary_hook is not None:
+                self.boundary_hook(m, x)            # x enters top-level child m (for a block after the first: together with xa)
             if isinstance(m, DecoderBlock):
                 b = m.block
                 if xa is None:

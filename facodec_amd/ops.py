@@ -273,7 +273,24 @@ def run_chains(chains, device, n_streams):
             outs.append(c())
     for st in streams:
         main.wait_stream(st)
+    # The results live in the side streams' allocator pools but are consumed (and saved for backward) by nodes of the caller's
+    # stream: tell the caching allocator, or a block freed on the host while the main-stream reader is still queued could be
+    # handed to another chain's side-stream kernel (the forward is covered by the fork / join above, backward frees
+    # are not).
+    _record_stream(outs, main)
     return outs
+
+
+def _record_stream(obj, stream):
+    if torch.is_tensor(obj):
+        if obj.is_cuda:
+            obj.record_stream(stream)
+    elif isinstance(obj, (list, tuple)):
+        for o in obj:
+            _record_stream(o, stream)
+    elif isinstance(obj, dict):
+        for o in obj.values():
+            _record_stream(o, stream)
 
 
 def _conv_workspace(device):

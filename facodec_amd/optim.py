@@ -6,12 +6,14 @@ ExponentialLR(gamma 0.999996) per model key, wrapped in `MultiOptimizer` :11-70;
 Per model key there are four contiguous arenas (parameters, gradients, first / second moments):
   * every `p.data` is a view of the parameter arena and every `p.grad` a view of the gradient arena, so autograd
     accumulates straight into the arena -- there is no bucket-assembly copy;
-  * the data-parallel exchange is ONE all-reduce(mean) of the gradient arena per key (145 / 64 / 342 / 170 MB:
-    few, large collectives for the point-to-point xGMI links), launched asynchronously (`launch_all_reduce`) as soon
-    as that key's backward is complete and waited for only in `step` -- RCCL runs it on its own stream under the
-    rest of the backward pass;
+  * the data-parallel exchange is an all-reduce(mean) of the gradient arena itself, cut into BUCKETS of <= 64 MB on parameter
+    boundaries, counted from the END of the arena (the parameters backward reaches first): few, large collectives for the
+    point-to-point xGMI links, and what is still outstanding when backward ends is at most the first bucket -- the remainder --
+    not a 145 - 777 MB key.  Buckets are launched asynchronously in that fixed order (`launch_all_reduce(from_param=...)`), from
+    gradient hooks at points of the graph where the bucket is final BY CONSTRUCTION (train.py), never from a per-rank guess;
+    `step` launches whatever is left and waits.  A gradient that shows up after its bucket was launched is a hard error;
   * WHICH parameters are stepped is decided on the device.  One flag per parameter ("autograd produced a gradient for
-    it on this rank") rides at the tail of the gradient arena through the same all-reduce, so after the exchange a
+    it on this rank") is exchanged by one more small collective behind the key's last bucket, so after the exchange a
     flag is > 0 iff ANY rank reached the parameter; `fac_adamw_step_masked` steps exactly those on every rank (their
     slice holds the averaged gradient everywhere) with a per-parameter step count kept on the device, and leaves the
     others alone -- no weight decay, no moment update -- like torch's AdamW skips `grad is None`.  Ranks therefore
@@ -37,9 +39,10 @@ def _dist_on():
 
 class FlatAdamW:
     def __init__(self, params, lr=1e-4, betas=(0.9, 0.98), eps=1e-9, weight_decay=0.1, gamma=0.999996, max_norm=1000.0,
-                 data_parallel=True):
+                 data_parallel=True, bucket_bytes=None):
         """data_parallel=False: the gradients are averaged by somebody else (the modules are wrapped in torch's
-        DistributedDataParallel as train.py:110-111 does) -- no arena all-reduce, only the tiny flag exchange."""
+        DistributedDataParallel as train.py:110-111 does) -- no arena all-reduce, only the tiny flag exchange.
+        bucket_bytes: size of the exchange buckets (default FAC_BUCKET_MB or 64 MB; 0 = the whole arena as one)."""
         self.params = [p for p in params if p.requires_grad]
         if not self.params:
             raise ValueError("no trainable parameters")
@@ -74,13 +77,24 @@ class FlatAdamW:
         self.lr, self.base_lr = lr, lr
         self.betas, self.eps, self.wd, self.gamma, self.max_norm = betas, eps, weight_decay, gamma, max_norm
         self.lr_epochs = 0                                    # ExponentialLR.last_epoch
-        self._work = None
+        if bucket_bytes is None:
+            bucket_bytes = int(float(os.environ.get("FAC_BUCKET_MB", "64")) * 2 ** 20)
+        # buckets = parameter index ranges [lo, hi), built from the END of the arena backwards; buckets[0] is launched first
+        self.buckets, hi, size = [], P, 0
+        for i in reversed(range(P)):
+            size += 4 * self.slices[i][1]
+            if i == 0 or (bucket_bytes > 0 and size >= bucket_bytes):
+                self.buckets.append((i, hi))
+                hi, size = i, 0
+        self._works = []                                      # pending asynchronous collectives of this step, in launch order
+        self._next_bucket = 0                                 # buckets [0, _next_bucket) have been launched this step
+        self._at_launch = [False] * P                         # `_touched` of a bucket's parameters when it was launched
         self._need_scale = False
         self._flags_final = False                             # flags uploaded (and exchanged) for the pending step
         self._flags_pat, self._flags_cache = None, None
-        self._expected = None                                 # parameters the previous step's backward reached
-        self.exchange_log = []                                # per step: "hook" (launched from inside backward) | "end" | "none"
-        self._launched_from = "none"
+        self._expected = None                                 # parameters the previous step's backward reached (reporting only)
+        self.exchange_log = []                                # per step: [(bucket, "hook" | "end"), ...]  ([] = nothing exchanged)
+        self._launch_log = []
         self.time_exchange, self._wait_events = False, None
 
     def _mark(self, i):
@@ -108,9 +122,14 @@ class FlatAdamW:
         return max(self.param_steps)
 
     # ------------------------------------------------------------------------------------------ gradients
+    @property
+    def _work(self):
+        """The pending collectives of this step (None when nothing is in flight)."""
+        return self._works[-1] if self._works else None
+
     def _drain(self):
         """A pending asynchronous exchange must finish before anybody writes into the arena."""
-        if self._work is not None:
+        if self._works:
             self.wait_all_reduce()
 
     def zero_grad(self, set_to_none=False, unbind=False):
@@ -125,17 +144,24 @@ class FlatAdamW:
         self._gx.zero_()
         self._touched = [False] * len(self.params)
         self._flags_final = False
+        self._next_bucket = 0
+        self._launch_log = []
         if unbind:
             for p in self.params:
                 p.grad = None
 
-    def _rebind(self):
+    def _rebind(self, lo=0, hi=None):
         """`p.grad` must be the arena view (someone may have set it to None or to a foreign tensor), `p.data` must still
         live in the parameter arena (a later module.to()/.float() would silently detach the optimiser from the model).
-        Foreign gradient tensors are folded into the arena -- all of them in one multi-tensor copy -- and marked."""
+        Foreign gradient tensors are folded into the arena -- all of them in one multi-tensor copy -- and marked.
+        [lo, hi): only these parameters (a bucket about to be launched).  A foreign gradient on a parameter whose bucket is
+        ALREADY in flight means the bucket was launched before its gradients were final: that is an error, not a fold."""
         base_p, base_g = self.p.data_ptr(), self.g.data_ptr()
         src, dst = [], []
-        for i, (p, (off, k)) in enumerate(zip(self.params, self.slices)):
+        hi = len(self.params) if hi is None else hi
+        launched_from = self.buckets[self._next_bucket - 1][0] if self._next_bucket else len(self.params)
+        for i in range(lo, hi):
+            p, (off, k) = self.params[i], self.slices[i]
             if p.data_ptr() != base_p + 4 * off:
                 raise RuntimeError("FlatAdamW: a parameter no longer lives in the optimiser's arena (was the module moved or cast after "
                                    "the optimiser was built?); build FlatAdamW after the model is on its final device")
@@ -143,13 +169,14 @@ class FlatAdamW:
             if g is None:
                 p.grad = self._views[i]
             elif g.data_ptr() != base_g + 4 * off:            # foreign gradient tensor: fold it in once, then rebind
+                if i >= launched_from and (self._works or self._flags_final):
+                    raise RuntimeError(f"FlatAdamW: the gradient of parameter {i} arrived after the exchange of its bucket was launched "
+                                       "(the launch point is too early for this graph; FAC_EARLY_EXCHANGE=0 launches after backward)")
                 src.append(g.detach())
                 dst.append(self._views[i])
                 p.grad = self._views[i]
                 self._touched[i] = True
         if src:
-            self._drain()
-            self._flags_final = False
             same = all(a.dtype == b.dtype and a.device == b.device and a.is_contiguous() for a, b in zip(src, dst))
             if same and hasattr(torch, "_foreach_copy_"):
                 torch._foreach_copy_(dst, src)
@@ -176,12 +203,12 @@ class FlatAdamW:
         self._flags_final = False
 
     def backward_complete(self):
-        """True once every parameter the previous step's backward reached has been reached again (the usage pattern of
-        the model is static, so all ranks agree): the arena is final and may be handed to the collective early."""
+        """True once every parameter the previous step's backward reached has been reached again (reporting / tests; launch
+        decisions do not depend on it)."""
         return self._expected is not None and all(t or not e for t, e in zip(self._touched, self._expected))
 
     def _upload_flags(self):
-        """Local flags -> tail of the gradient arena.  The usage pattern of the model is static after the first step, so the
+        """Local flags -> the flag tail of the arena.  The usage pattern of the model is static after the first step, so the
         pattern is kept as a device tensor and re-used (a device-to-device copy, no host transfer in the steady state)."""
         pat = tuple(self._touched)
         if pat != self._flags_pat:
@@ -189,39 +216,66 @@ class FlatAdamW:
             self._flags_pat = pat
         self._flags.copy_(self._flags_cache)
 
-    def launch_all_reduce(self, only_if_complete=False):
-        """Data-parallel exchange: one asynchronous all-reduce(mean) of the whole arena, flags included (RCCL over xGMI
-        under backend 'nccl'; it runs on the process group's stream, after everything already queued on the current
-        stream).  only_if_complete: called from inside backward (gradient hooks) -- launch only when
-        `backward_complete()`."""
-        if self._work is not None or self._flags_final or not _dist_on():
+    def _exchanging(self):
+        # a single rank has nothing to exchange; FAC_FORCE_ALLREDUCE=1 still issues the collectives (smoke-tests the RCCL path --
+        # AVG op, async work handles, stream hand-over -- on a one-GPU box: the mean over one rank is the identity)
+        return _dist_on() and (dist.get_world_size() > 1 or os.environ.get("FAC_FORCE_ALLREDUCE") == "1")
+
+    def launch_all_reduce(self, from_param=0, from_hook=False, only_if_complete=False):
+        """Data-parallel exchange (RCCL over xGMI under backend 'nccl'; the collectives run on the process group's stream, after
+        everything already queued on the current stream).  Launches, in the fixed end-of-arena-first order, every bucket not yet
+        launched whose parameters all have index >= from_param, each as one asynchronous all-reduce(mean) of its slice of the
+        gradient arena; behind the key's last bucket one small collective carries the per-parameter flags.
+
+        from_param > 0 is for calls from inside backward (gradient hooks): the caller asserts that the parameters from there on are
+        FINAL at this point of the graph on every rank (train.py derives that from the order autograd runs the nodes in, not from
+        which parameters happened to receive a gradient on this rank), so every rank issues the same collectives in the same order.
+        `only_if_complete` is accepted for older callers and ignored."""
+        if self._flags_final or not self._exchanging():
             return
-        if only_if_complete and not self.backward_complete():
+        where = "hook" if from_hook else "end"
+        if not self.data_parallel:          # gradients already averaged by a DDP wrapper: only the flags travel (MAX: any rank)
+            if from_param > 0:
+                return
+            self._rebind()
+            self._upload_flags()
+            self._flags_final = True
+            self._launch_log.append(("flags", where))
+            self._works.append(dist.all_reduce(self._flags, op=dist.ReduceOp.MAX, async_op=True))
             return
-        self._rebind()                                         # gradients autograd kept outside the arena (zero_grad(unbind=True))
-        # a single rank has nothing to exchange; FAC_FORCE_ALLREDUCE=1 still issues the collective (smoke-tests the RCCL path --
-        # AVG op, async work handle, stream hand-over -- on a one-GPU box: the mean over one rank is the identity)
-        if dist.get_world_size() == 1 and os.environ.get("FAC_FORCE_ALLREDUCE") != "1":
-            return
-        self._upload_flags()
-        self._flags_final = True
-        self._launched_from = "hook" if only_if_complete else "end"
-        if not self.data_parallel:     # gradients already averaged by a DDP wrapper: only the flags travel (MAX: any rank)
-            self._work = dist.all_reduce(self._flags, op=dist.ReduceOp.MAX, async_op=True)
-        elif dist.get_backend() == "nccl":          # RCCL: the mean is part of the collective
-            self._work = dist.all_reduce(self._gx, op=dist.ReduceOp.AVG, async_op=True)
-        else:   # gloo (CPU test scaffold, or two ranks sharing one GPU in a smoke run) has no AVG
-            self._work = dist.all_reduce(self._gx, op=dist.ReduceOp.SUM, async_op=True)
-            self._need_scale = True
+        nccl = dist.get_backend() == "nccl"         # RCCL: the mean is part of the collective; gloo (CPU scaffold) has no AVG
+        op = dist.ReduceOp.AVG if nccl else dist.ReduceOp.SUM
+        while self._next_bucket < len(self.buckets) and self.buckets[self._next_bucket][0] >= from_param:
+            lo, hi = self.buckets[self._next_bucket]
+            self._rebind(lo, hi)                    # gradients autograd kept outside the arena (zero_grad(unbind=True))
+            self._at_launch[lo:hi] = self._touched[lo:hi]
+            e_lo, e_hi = self.slices[lo][0], self.slices[hi - 1][0] + self.slices[hi - 1][1]
+            self._works.append(dist.all_reduce(self.g[e_lo:e_hi], op=op, async_op=True))
+            self._launch_log.append((self._next_bucket, where))
+            self._next_bucket += 1
+            self._need_scale = self._need_scale or not nccl
+        if self._next_bucket == len(self.buckets):
+            self._upload_flags()
+            self._flags_final = True
+            self._works.append(dist.all_reduce(self._flags, op=op, async_op=True))
+
+    def _late_gradients(self):
+        """Parameters of already launched buckets that were marked after the launch (in-place accumulation into the bound views
+        while the collective may be reading them)."""
+        if not self._next_bucket:
+            return []
+        lo = self.buckets[self._next_bucket - 1][0]
+        return [i for i in range(lo, len(self.params)) if self._touched[i] and not self._at_launch[i]]
 
     def wait_all_reduce(self):
-        if self._work is not None:
-            work, self._work = self._work, None               # cleared first: an exception in wait() must not wedge the next step
+        if self._works:
+            works, self._works = self._works, []              # cleared first: an exception in wait() must not wedge the next step
             timed = self.time_exchange and self._gx.is_cuda
-            if timed:                                         # how long the compute stream stalls for the collective: what the
+            if timed:                                         # how long the compute stream stalls for the collectives: what the
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)   # overlap failed to hide
                 e0.record()
-            work.wait()                                       # makes the current stream wait for the collective
+            for w in works:
+                w.wait()                                      # makes the current stream wait for the collective
             if timed:
                 e1.record()
                 self._wait_events = (e0, e1)
@@ -251,9 +305,12 @@ class FlatAdamW:
     def step(self, zero_grad=True, advance_lr=True):
         lib = _lib.load()
         st = ops._stream()
-        self._drain()                                          # nothing may write into the arena under a running collective
-        self._rebind()
-        self.all_reduce_mean()
+        late = self._late_gradients() if self._exchanging() else []
+        if late:
+            raise RuntimeError(f"FlatAdamW: parameters {late[:8]} received a gradient after the exchange of their bucket was launched "
+                               "(the launch point is too early for this graph; FAC_EARLY_EXCHANGE=0 launches after backward)")
+        self._rebind()                                         # raises as well if a stolen gradient belongs to a launched bucket
+        self.all_reduce_mean()                                 # whatever has not been launched yet, then wait for everything
         if not self._flags_final:                              # single rank (or no process group): local flags
             self._upload_flags()
         clip = None
@@ -266,8 +323,7 @@ class FlatAdamW:
                                              ops._ptr(self._bc), self.lr, self.betas[0], self.betas[1], self.eps, self.wd,
                                              ops._ptr(clip), st), "fac_adamw_step_masked")
         self._expected = tuple(self._touched)
-        self.exchange_log.append(self._launched_from)
-        self._launched_from = "none"
+        self.exchange_log.append(list(self._launch_log))
         if len(self.exchange_log) > 64:
             del self.exchange_log[:-64]
         self._flags_final = False

@@ -50,10 +50,10 @@ def test_multi_optimizer_surface_of_the_reference_loop():
     class _Work:
         def wait(self):
             raise RuntimeError("collective failed")
-    opt._work = _Work()
+    opt._works.append(_Work())
     with pytest.raises(RuntimeError):
         opt.zero_grad()
-    assert opt._work is None
+    assert opt._work is None and opt._works == []
     opt.zero_grad()
 
 

@@ -143,9 +143,9 @@ def _overlap_worker(rank, world, port, q):
         (p * float(rank + 1) * (i + 1)).sum().backward()
     assert keys["decoder"].params[0].grad.data_ptr() == keys["decoder"].g.data_ptr()      # views, no gather copy
     assert keys["decoder"].params_without_grad() == [] and keys["unused"].params_without_grad() == [0]
-    # first step: nothing is known about the usage pattern yet -> a hook-time launch must decline
-    keys["decoder"].launch_all_reduce(only_if_complete=True)
-    assert keys["decoder"]._work is None
+    # the decoder's exchange leaves from "inside backward" (a hook): no knowledge of earlier steps is needed or used
+    keys["decoder"].launch_all_reduce(from_hook=True)
+    early_first_step = keys["decoder"]._work is not None
     (keys["encoder"].params[0] * float(rank + 1)).sum().backward()
     # end of backward: every key launches in the same fixed order on every rank, including the key without any gradient
     for k in ("decoder", "unused", "encoder"):
@@ -153,33 +153,110 @@ def _overlap_worker(rank, world, port, q):
     for k in ("encoder", "decoder", "unused"):          # waited for in a different order (the optimiser-step order)
         keys[k].wait_all_reduce()
     res = {k: o.g.clone() for k, o in keys.items()}
-    # second iteration with the usage pattern known: the decoder's exchange may start from inside backward
+    logs = {k: list(o._launch_log) for k, o in keys.items()}
+    # second iteration: the ranks reach DIFFERENT parameter sets (rank 0 only parameter 0, rank 1 only parameter 1) and both
+    # launch from the hook: same collectives in the same order, unreached parameters count as zeros
     for o in keys.values():
-        o._expected = tuple(o._touched)
         o.zero_grad()
-    (keys["decoder"].params[0] * 2.0).sum().backward()
-    keys["decoder"].launch_all_reduce(only_if_complete=True)
-    early = keys["decoder"]._work is not None           # still incomplete: parameter 1 not reached yet
-    (keys["decoder"].params[1] * 2.0).sum().backward()
-    keys["decoder"].launch_all_reduce(only_if_complete=True)
-    late = keys["decoder"]._work is not None
+    (keys["decoder"].params[rank] * 2.0).sum().backward()
+    keys["decoder"].launch_all_reduce(from_hook=True)
     keys["decoder"].wait_all_reduce()
-    q.put(_portable((rank, res, early, late, keys["decoder"].g.clone())))
+    q.put(_portable((rank, res, early_first_step, logs, keys["decoder"].g.clone(), keys["decoder"]._flags.clone())))
     torch.distributed.destroy_process_group()
 
 
 def test_two_rank_async_exchange_order_and_empty_key():
-    """One asynchronous all-reduce per model key: gradients live in the arena (views), keys launch in a fixed order and are
-    waited for in another, a key whose parameters get no gradient still takes part (zeros) so the collectives stay matched,
-    and a launch from inside backward only happens once the key's gradients are complete."""
+    """Asynchronous exchange per model key: gradients live in the arena (views), keys launch in a fixed order and are waited for
+    in another, a key whose parameters get no gradient still takes part (zeros) so the collectives stay matched, a launch from
+    inside backward needs no history, and two ranks that reach DIFFERENT parameters neither deadlock nor drift: every rank ends
+    with the mean (zeros for the rank that did not reach a parameter) and with the union of the flags."""
     res = _run_ranks(_overlap_worker)
-    (_, g0, e0, l0, d0), (_, g1, e1, l1, d1) = res
+    (_, g0, e0, log0, d0, f0), (_, g1, e1, log1, d1, f1) = res
     for k in g0:
         assert torch.equal(g0[k], g1[k])
     assert torch.allclose(g0["decoder"][:12], torch.full((12,), 1.5)) and torch.allclose(g0["decoder"][12:], torch.full((5,), 3.0))
     assert torch.equal(g0["unused"], torch.zeros(6)) and torch.allclose(g0["encoder"], torch.full((4,), 1.5))
-    assert (e0, l0, e1, l1) == (False, True, False, True)
-    assert torch.allclose(d0, torch.full((17,), 2.0)) and torch.equal(d0, d1)
+    assert e0 and e1 and log0 == log1
+    assert log0["decoder"] == [(0, "hook")] and log0["unused"] == [(0, "end")]
+    assert torch.equal(d0, d1) and torch.allclose(d0, torch.full((17,), 1.0))          # (2 + 0) / 2 for both parameters
+    assert torch.equal(f0 > 0, torch.tensor([True, True])) and torch.equal(f0, f1)
+
+
+class _Chain(torch.nn.Module):
+    """Four 'blocks' in a chain, like the encoder / decoder: x -> b0 -> b1 -> b2 -> b3."""
+
+    def __init__(self):
+        super().__init__()
+        self.blocks = torch.nn.ModuleList([torch.nn.Linear(8, 8) for _ in range(4)])
+
+    def forward(self, x, hook=None):
+        for k, b in enumerate(self.blocks):
+            if hook is not None:
+                hook(k, x)
+            x = torch.tanh(b(x))
+        return x
+
+
+def _bucket_worker(rank, world, port, q):
+    sys.path.insert(0, REPO)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from facodec_amd import benchutil
+    from facodec_amd.optim import FlatAdamW
+    benchutil.init_distributed("gloo")
+    out = {}
+    for mode in ("one_bucket", "progressive"):
+        torch.manual_seed(0)
+        net = _Chain()
+        # 72 floats per block (64 weights + 8 biases): 300-byte buckets hold one block each, counted from the end
+        opt = FlatAdamW(net.parameters(), bucket_bytes=0 if mode == "one_bucket" else 280)
+        first = [2 * k for k in range(4)]                   # index of block k's first parameter (weight, bias per block)
+        events = []
+
+        def hook(k, x, opt=opt, events=events):             # gradient of the activation entering block k: blocks k + 1 .. are final
+            if x.requires_grad and k + 1 < 4:
+                def fire(g, k=k):
+                    opt.launch_all_reduce(from_param=first[k + 1], from_hook=True)
+                    events.append((k, opt._next_bucket))
+                x.register_hook(fire)
+
+        opt.zero_grad(unbind=True)
+        x = torch.randn(5, 8, generator=torch.Generator().manual_seed(10 + rank)).requires_grad_()   # a different batch per rank
+        net(x, hook if mode == "progressive" else None).pow(2).sum().backward()
+        in_flight_at_end = len(opt._works)
+        opt.launch_all_reduce()
+        opt.wait_all_reduce()
+        out[mode] = (opt.g.clone(), list(opt._launch_log), events, in_flight_at_end, len(opt.buckets))
+    # a gradient that shows up after its bucket has left is an error, not a silent skip
+    opt.zero_grad(unbind=True)
+    net(torch.randn(2, 8)).sum().backward()
+    opt.launch_all_reduce(from_param=first[3], from_hook=True)
+    net.blocks[3].weight.grad = torch.ones(8, 8)            # "late": a new tensor on a parameter of the launched bucket
+    try:
+        opt.gather_grads()
+        late_raises = False
+    except RuntimeError:
+        late_raises = True
+    opt._works, opt._flags_final = [], False                # (the other rank raised at the same point: nothing left to match)
+    q.put(_portable((rank, out, late_raises)))
+    torch.distributed.destroy_process_group()
+
+
+def test_two_rank_bucketed_progressive_exchange():
+    """The arena leaves in buckets counted from its end; buckets whose parameters are final are launched from activation-gradient
+    hooks while backward is still running (what train.py installs at the encoder / decoder block boundaries).  Same averaged
+    gradients as one collective over the whole arena, same launch sequence on both ranks although their batches differ, only the
+    first bucket (the remainder) is left for the end, and a late gradient raises."""
+    res = _run_ranks(_bucket_worker)
+    (_, o0, late0), (_, o1, late1) = res
+    for o in (o0, o1):
+        assert torch.allclose(o["one_bucket"][0], o["progressive"][0], atol=1e-7)
+        assert o["one_bucket"][4] == 1 and o["progressive"][4] == 4
+        assert o["progressive"][1] == [(0, "hook"), (1, "hook"), (2, "hook"), (3, "end")]
+        assert o["progressive"][2] == [(2, 1), (1, 2), (0, 3)]         # boundary of block k fires -> buckets of blocks k + 1 .. are out
+        assert o["progressive"][3] == 3                                # three collectives already in flight when backward ends
+    assert torch.equal(o0["progressive"][0], o1["progressive"][0]) and o0["progressive"][1] == o1["progressive"][1]
+    assert late0 and late1
 
 
 def _flag_worker(rank, world, port, q):
@@ -270,9 +347,6 @@ def _unbound_worker(rank, world, port, q):
         opt.zero_grad(unbind=True)                       # what TrainStep does: autograd hands its gradient tensors over
         assert all(p.grad is None for p in params)
         (params[0] * float(rank + 1)).sum().backward()
-        if it == 0:
-            opt.launch_all_reduce(only_if_complete=True)  # usage pattern unknown yet: a hook-time launch declines
-            assert opt._work is None
         if rank == 0:                                    # params[1] is reached on rank 0 only; params[2] on no rank
             (params[1] * 3.0).sum().backward()
         opt.launch_all_reduce()                          # folds the stolen tensors into the arena, then ONE collective

@@ -38,11 +38,14 @@ def test_one_rank_rccl_exchange_is_the_identity():
     assert forced["losses"] == plain["losses"]
     assert forced["param_sums"] == plain["param_sums"]
     assert all(v == "none" for rep in plain["exchange_launched_from"] for v in rep.values())
-    first, last = forced["exchange_launched_from"][0], forced["exchange_launched_from"][-1]
-    assert all(v == "end" for v in first.values())                       # nothing is known about the usage pattern yet
-    # from the second iteration on the decoder's and the quantizer's collectives start inside backward (hooks on the decoder
-    # input's / the latent's gradient), the encoder's and the discriminator's after their backward
-    assert last["decoder"] == "hook" and last["quantizer"] == "hook"
-    assert last["encoder"] == "end" and last["discriminator"] == "end"
+    # every iteration, the first one included (launch points are fixed by the graph, not learnt from a previous step): the decoder's
+    # and the quantizer's buckets leave from the hooks on the decoder input's / the latent's gradient, the encoder's later buckets
+    # from its block-boundary hooks; the discriminator's after its own backward
+    for rep in forced["exchange_launched_from"]:
+        assert rep["decoder"] == "hook" and rep["quantizer"] == "hook" and rep["encoder"] == "hook" and rep["discriminator"] == "end", rep
+    last = forced["bucket_launches"][-1]
+    assert len(last["decoder"]) >= 5 and all(w == "hook" for _, w in last["decoder"])           # 342 MB in <= 64 MB buckets
+    assert [b for b, _ in last["encoder"]] == list(range(len(last["encoder"])))                  # fixed order, end of the arena first
+    assert last["encoder"][-1][1] == "end" and last["encoder"][0][1] == "hook"                  # only the remainder waits for the end
     os.makedirs(os.path.join(REPO, "gpurun_out"), exist_ok=True)
     json.dump(dict(plain=plain, forced=forced), open(os.path.join(REPO, "gpurun_out", "rccl_one_rank.json"), "w"), indent=1)

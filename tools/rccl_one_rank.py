@@ -32,16 +32,17 @@ def main():
     B, T = 2, 12000
     masks = dict(p=torch.ones(1, B), c=torch.ones(2, B), r=torch.ones(3, B), res=torch.ones(B), dropout=False)
     masks = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in masks.items()}
-    losses, reports = [], []
+    losses, reports, buckets = [], [], []
     for it in range(3):
         out = step(synth.synth_clips(B, T, seed=it).to(dev), masks=masks)
         losses.append({k: float(out[k]) for k in ("loss", "loss_d", "mel", "feature")})
         reports.append({k: v["launched"] for k, v in step.exchange_report().items()})
+        buckets.append({k: [list(b) for b in v["buckets"]] for k, v in step.exchange_report().items()})
     torch.cuda.synchronize()
     sums = {k: float(step.opt[k].p.double().sum()) for k in sorted(step.opt)}
     import torch.distributed as dist
     print(json.dumps({"process_group": dist.is_initialized() and dist.get_backend(), "world": world, "losses": losses,
-                      "param_sums": sums, "exchange_launched_from": reports,
+                      "param_sums": sums, "exchange_launched_from": reports, "bucket_launches": buckets,
                       "wait_ms": {k: v["wait_ms"] for k, v in step.exchange_report().items()}}))
     if dist.is_initialized():
         dist.destroy_process_group()
