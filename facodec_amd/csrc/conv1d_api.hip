@@ -22,7 +22,7 @@ static int select_variant(const fac_conv_desc* d) {
   return wide ? 5 : 4;
 }
 
-#ifdef FAC_PROF
+#if defined(FAC_PROF) || defined(FAC_PROF2)
 unsigned long long* g_conv_dbg = nullptr;
 #endif
 
@@ -36,7 +36,7 @@ static bool narrow_ok(const fac_conv_desc* d) {
 
 }  // namespace fac
 
-#ifdef FAC_PROF
+#if defined(FAC_PROF) || defined(FAC_PROF2)
 extern "C" void fac_debug_set_buffer(void* p) { fac::g_conv_dbg = (unsigned long long*)p; }
 #endif
 

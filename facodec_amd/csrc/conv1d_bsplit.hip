@@ -244,6 +244,9 @@ __global__ __launch_bounds__((NMW + NSW) * 64, (NMW + NSW) / 4) void conv1d_bspl
       // of c + 1 (requested by step(c - 1), older than that DMA: vmcnt(ND)); request the inputs of c + 2; take c + 1 out of its
       // landing registers, split, write; wait for the DMA (vmcnt(NX): the inputs of c + 2 stay in flight); barrier }, each part
       // skipped where its chunk does not exist.  At most ND + NX loads are in flight.
+#ifdef FAC_PROF2
+      long long pq[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
       for (int base = -2; base < n_chunks; base += 2) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {                                // c + 1 has parity 1 - i: its stage and its register set
@@ -251,6 +254,77 @@ __global__ __launch_bounds__((NMW + NSW) * 64, (NMW + NSW) / 4) void conv1d_bspl
           if (c >= n_chunks) break;
           const bool has_next = c + 1 >= 0 && c + 1 < n_chunks, has_next2 = c + 2 < n_chunks;
           float xr[BS_XU][8];
+#ifndef FAC_BS_W_VGPR
+#define FAC_BS_W_VGPR 1
+#endif
+#if FAC_BS_W_VGPR
+          // The weight slab goes through registers (global_load_dwordx4 -> ds_write_b128, requested before the input work of the
+          // stage, written behind it -- no value crosses a barrier, plain compiler-allocated registers) instead of LDS-DMA:
+          // measured +2 .. 4 % (C = 192 .. 768).  Ablations of round 4 (profiles/r04_bsplit_ablation.log): what the weight
+          // stage costs the MFMA waves is its LDS WRITE traffic, whichever way it arrives (a DMA that reads one cache-resident
+          // KiB over and over costs the same as the real one), not the L2 fetch.  FAC_BS_W_VGPR=0: LDS-DMA.
+          typedef float wv4 __attribute__((ext_vector_type(4)));
+          wv4 wv[ND];
+#ifdef FAC_PROF2
+          const long long q0 = clock64();
+          long long q1 = q0, q2 = q0, q3 = q0, q4 = q0, q5 = q0, q6 = q0;
+#endif
+          if (has_next) {
+            const unsigned char* src = wsrc + (long long)(c + 1) * W_STAGE;
+#pragma unroll
+            for (int j = 0; j < ND; ++j) {
+              const int bi = min(lw + NSW * j, NBLK - 1);
+              asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(wv[j]) : "v"((unsigned)(bi * 1024 + lane * 16)), "s"(src) : "memory");
+            }
+            asm volatile("s_waitcnt vmcnt(%0)" : : "n"(ND) : "memory");
+#ifdef FAC_PROF2
+            q1 = clock64();
+#endif
+            if (i == 0) take_b(xr); else take_a(xr);
+#ifdef FAC_PROF2
+            q2 = clock64();
+#endif
+          }
+          if (has_next2) {
+            if (i == 0) load_a(c + 2); else load_b(c + 2);
+          }
+#ifdef FAC_PROF2
+          q3 = clock64();
+#endif
+          if (has_next) {
+            write_x(1 - i, xr);
+#ifdef FAC_PROF2
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            q4 = clock64();
+#endif
+            if (has_next2) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(NX) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef FAC_PROF2
+            q5 = clock64();
+#endif
+            unsigned char* dst = Wbuf + (1 - i) * W_STAGE;
+#pragma unroll
+            for (int j = 0; j < ND; ++j) {
+              asm volatile("" : "+v"(wv[j]) : : "memory");
+              const int bi = min(lw + NSW * j, NBLK - 1);
+              *reinterpret_cast<wv4*>(dst + bi * 1024 + lane * 16) = wv[j];
+            }
+          }
+          if (c >= -1) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#ifdef FAC_PROF2
+            q6 = clock64();
+#endif
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+#ifdef FAC_PROF2
+            if (c >= 0 && has_next2) {      // steady-state iterations only
+              pq[0] += q1 - q0; pq[1] += q2 - q1; pq[2] += q3 - q2; pq[3] += q4 - q3; pq[4] += q5 - q4; pq[5] += q6 - q5;
+              pq[6] += clock64() - q6; pq[7] += 1;
+            }
+#endif
+          }
+#else
           if (has_next) {
             stage_w(c + 1, 1 - i);                                   // that stage was read during chunk c - 1
             asm volatile("s_waitcnt vmcnt(%0)" : : "n"(ND) : "memory");
@@ -266,8 +340,15 @@ __global__ __launch_bounds__((NMW + NSW) * 64, (NMW + NSW) / 4) void conv1d_bspl
             __builtin_amdgcn_s_barrier();      // c = -1: chunk 0 staged; later: pairs with the MFMA waves' barrier behind chunk c
             asm volatile("" ::: "memory");
           }
+#endif
         }
       }
+#ifdef FAC_PROF2
+      if (a.dbg && lw == 0 && lane == 0) {
+        unsigned long long* d = a.dbg + (long long)blockIdx.x * 16 + 8;
+        for (int k = 0; k < 8; ++k) d[k] = (unsigned long long)pq[k];
+      }
+#endif
 #undef BS_LD
 #undef BS_RD
     } else {
@@ -336,7 +417,13 @@ __global__ __launch_bounds__((NMW + NSW) * 64, (NMW + NSW) / 4) void conv1d_bspl
 #ifdef FAC_PROF
   const unsigned long long tp1 = wall_clock64();
 #endif
+#ifdef FAC_PROF2
+  long long pm[3] = {0, 0, 0};
+#endif
   for (int chunk = 0; chunk < n_chunks; ++chunk) {
+#ifdef FAC_PROF2
+    const long long m0 = clock64();
+#endif
     const int buf = chunk & 1;
     const unsigned char* Wb = Wbuf + buf * W_STAGE + (kq * BS_CO + l31) * 16;          // half slot 2s + kq
     const unsigned char* Xb = Xbuf + buf * X_STAGE + (n0 + l31) * 16 + x_lane;
@@ -409,8 +496,20 @@ __global__ __launch_bounds__((NMW + NSW) * 64, (NMW + NSW) / 4) void conv1d_bspl
 #endif
       __builtin_amdgcn_sched_barrier(0);
     }
+#ifdef FAC_PROF2
+    const long long m1 = clock64();
+#endif
     __syncthreads();
+#ifdef FAC_PROF2
+    pm[0] += m1 - m0; pm[1] += clock64() - m1; pm[2] += 1;
+#endif
   }
+#ifdef FAC_PROF2
+  if (a.dbg && wave == 0 && lane == 0) {
+    unsigned long long* d = a.dbg + (long long)blockIdx.x * 16;
+    d[0] = (unsigned long long)pm[0]; d[1] = (unsigned long long)pm[1]; d[2] = (unsigned long long)pm[2];
+  }
+#endif
 
 #ifdef FAC_PROF
   const unsigned long long tp2 = wall_clock64();
@@ -537,7 +636,7 @@ static int bsplit_launch(ConvArgs& a, hipStream_t s) {
     set_error("conv1d: too many workgroups (%lld)", n_wg);
     return FAC_ERR_ARG;
   }
-#ifdef FAC_PROF
+#if defined(FAC_PROF) || defined(FAC_PROF2)
   a.dbg = g_conv_dbg;
 #endif
   hipLaunchKernelGGL(kern, dim3((unsigned)n_wg), dim3((NMW + NSW) * 64), lds, s, a);

@@ -61,7 +61,7 @@ struct ConvArgs {
   int XB;   // 64-wide column blocks per staged row = ceil(XW/64)
   int XQ, XR;  // 4 / XB, 4 % XB: (row, block) advance of one wave per staging iteration
   int n_t_tiles;
-#ifdef FAC_PROF
+#if defined(FAC_PROF) || defined(FAC_PROF2)
   unsigned long long* dbg;   // per-workgroup cycle counters (tuning builds only)
 #endif
   int x_off;   // columns staged to the left of the receptive field so that the slab starts 16-B aligned
@@ -709,7 +709,7 @@ __global__ __launch_bounds__((WM * WN + 4) * 64, (WM * WN == 4 ? FAC_CONV_WPE : 
   }
 }
 
-#ifdef FAC_PROF
+#if defined(FAC_PROF) || defined(FAC_PROF2)
 extern unsigned long long* g_conv_dbg;
 #endif
 

@@ -65,8 +65,12 @@ def main():
 
     with torch.no_grad():
         if check_frames:        # the offline pass comes first: the session is conditioned on ITS timbre vector (as in the parity test)
+            # timbre from a 2 s enrolment clip handed in as the "full utterance" (modules/quantize.py:378-383): the style encoder's
+            # attention over all frames of a 5-minute signal is outside its kernel's tile, and a session is enrolled this way anyway
+            enrol = loop[:, 0, :48000].contiguous()
+            lens = torch.full((a.streams,), 48000, dtype=torch.int64, device=dev)
             z = model.encoder(loop)
-            outs, _, _, _, timbre, codes = model.quantizer(z, loop, n_c=2, return_codes=True)
+            outs, _, _, _, timbre, codes = model.quantizer(z, loop, n_c=2, return_codes=True, full_waves=enrol, wave_lens=lens)
             ref_codes = torch.cat(codes, 1)[:, :, :check_frames].clone()
             ref_y = model.decoder(outs)[:, :, :check_frames * 300].clone()
             del z, outs, codes
