@@ -29,6 +29,7 @@ class ConvDesc(C.Structure):
         ("act", C.c_int32),
         ("w_batched", C.c_int32), ("w_bs", _i64), ("ws", _p), ("ws_bytes", _i64), ("w_split", _p),
         ("K1", C.c_int32), ("dilation2", C.c_int32), ("row_phases", C.c_int32),
+        ("x_p8", _p), ("x_p8_plane_bytes", _i64), ("y2_p8", _p), ("y2_p8_plane_bytes", _i64),
     ]
 
 
@@ -67,6 +68,7 @@ SIGNATURES = {
     "fac_snake_bwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
     "fac_pack_lstm_whh_t": (_i, [_p, _p, _i, _p]),
     "fac_lstm_layer_bwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
+    "fac_to_p8": (_i, [_p, _p, _p, _i, _i, _i, _p]),
     "fac_lstm_persist_ok": (_i, [_i, _i]),
     "fac_lstm_persist_stream_ok": (_i, [_p]),
     "fac_pack_lstm_whh16": (_i, [_p, _p, _i, _i, _p]),

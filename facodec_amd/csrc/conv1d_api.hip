@@ -42,7 +42,7 @@ extern "C" void fac_debug_set_buffer(void* p) { fac::g_conv_dbg = (unsigned long
 
 extern "C" int fac_conv1d_fwd(const fac_conv_desc* d, fac_stream_t stream) {
   using namespace fac;
-  FAC_REQUIRE(d && d->x && (d->w || d->w_split) && (d->y || d->y2), "conv1d: null pointer");
+  FAC_REQUIRE(d && (d->x || d->x_p8) && (d->w || d->w_split) && (d->y || d->y2 || d->y2_p8), "conv1d: null pointer");
   FAC_REQUIRE(!d->y2 || d->alpha_y2, "conv1d: y2 needs alpha_y2");
   FAC_REQUIRE(d->B > 0 && d->C_in > 0 && d->C_out > 0 && d->T_in > 0 && d->T_out > 0,
               "conv1d: bad shape B=%d C_in=%d C_out=%d T_in=%d T_out=%d", d->B, d->C_in, d->C_out,
@@ -56,6 +56,9 @@ extern "C" int fac_conv1d_fwd(const fac_conv_desc* d, fac_stream_t stream) {
   a.x = d->x; a.w = d->w; a.bias = d->bias; a.alpha_in = d->alpha_in; a.alpha_out = d->alpha_out;
   a.res = d->res; a.y = d->y; a.y2 = d->y2; a.alpha2 = d->alpha_y2;
   a.w1 = d->w_k1; a.bias1 = d->bias_k1;
+  a.x_p8 = reinterpret_cast<const unsigned char*>(d->x_p8); a.x_p8_ps = d->x_p8_plane_bytes;
+  a.y2_p8 = reinterpret_cast<unsigned char*>(d->y2_p8); a.y2_p8_ps = d->y2_p8_plane_bytes;
+  FAC_REQUIRE(!d->y2_p8 || d->alpha_y2, "conv1d: y2_p8 needs alpha_y2");
   if (d->w_k1) {
     FAC_REQUIRE(d->C_in == d->C_out && d->C_out_pad == d->C_out && d->n_phase == 1 && d->stride == 1 &&
                     d->alpha_out && d->act == FAC_ACT_NONE && !d->w_batched,
@@ -87,6 +90,11 @@ extern "C" int fac_conv1d_fwd(const fac_conv_desc* d, fac_stream_t stream) {
     a.T_ext = d->T_in > max_pad ? d->T_in : max_pad + 1;
   }
   hipStream_t s = (hipStream_t)stream;
+  if (d->x_p8 || d->y2_p8) {      // P8 operands exist only in the kernels listed at fac_conv_desc.x_p8: no silent fp32 detour
+    const bool ok = d->w_split && !conv_two_level(a) && conv_bsplit_p8_ok(a) && !conv_cin1_ok(a) && !d->y2_p8;
+    FAC_REQUIRE(ok, "conv1d: P8 operands given but the launch does not run on a kernel that takes them (K=%d stride=%d C_in=%d columns=%lld)",
+                d->K, d->stride, d->C_in, (long long)d->B * d->T_out);
+  }
   if (d->w_k1) return conv_dispatch_fused_ru(a, s);
   a.gflat = 0;
   // few-output-channel 9- / 3-tap convs (two-level taps included) with split weights of fac_pack_conv_w_split2

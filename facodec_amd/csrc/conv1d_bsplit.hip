@@ -197,7 +197,59 @@ __global__ __launch_bounds__((NMW + NSW) * 64, (NMW + NSW) / 4) void conv1d_bspl
     // each: the channel row is a uniform (scalar) base, the column a per-lane 32-bit byte offset resolved once per tile; lanes on
     // padding read a clamped column and are zeroed when the value is taken out of its landing register, and C_in % (8 G) == 0
     // (dispatcher) makes every channel of a stage real.
-    if constexpr (G == 2) {
+    if (G == 2 && a.x_p8 != nullptr) {
+      // ---- P8 input (fac_conv_desc.x_p8): the producer wrote the three bf16 planes, 8 channels x 16 B per time step -- exactly
+      // a column of this kernel's input stage.  A unit (channel group, column) is three 16-byte loads and three ds_write_b128: NO
+      // vector-ALU work at all (the fp32 path below spends ~170 VALU instructions per staging wave and stage on the split, and
+      // VALU instructions do not overlap the MFMAs of the same SIMD: profiles/r04_bsplit_stage_phases.log).  Everything is
+      // requested at the start of the step and written at its end; nothing stays in flight across a barrier.
+      typedef float wv4 __attribute__((ext_vector_type(4)));
+      const unsigned char* xp = a.x_p8 + (long long)b * (a.C_in / 8) * a.T_in * 16;      // plane 0 of this clip
+      const long long grp_bytes = (long long)a.T_in * 16;
+      unsigned u_poff[BS_XU];
+      bool any_pad = false;
+#pragma unroll
+      for (int j = 0; j < BS_XU; ++j) {
+        u_poff[j] = (unsigned)(u_idx[j] >= 0 ? u_idx[j] : 0) * 16u;
+        any_pad = any_pad || __builtin_amdgcn_ballot_w64(u_c[j] >= 0 && u_idx[j] < 0) != 0;
+      }
+      for (int c = -1; c < n_chunks; ++c) {                          // step(c): chunk c + 1 -> stage (c + 1) & 1
+        if (c + 1 < n_chunks) {
+          const int buf = (c + 1) & 1;
+          wv4 wv[ND], xv[BS_XU][3];
+          const unsigned char* src = wsrc + (long long)(c + 1) * W_STAGE;
+#pragma unroll
+          for (int j = 0; j < ND; ++j) {
+            const int bi = min(lw + NSW * j, NBLK - 1);
+            wv[j] = *reinterpret_cast<const wv4*>(src + bi * 1024 + lane * 16);
+          }
+#pragma unroll
+          for (int j = 0; j < BS_XU; ++j) {
+            const unsigned char* grp = xp + (long long)((c + 1) * G + u_g[j]) * grp_bytes;      // uniform
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) xv[j][pl] = *reinterpret_cast<const wv4*>(grp + pl * a.x_p8_ps + u_poff[j]);
+          }
+          unsigned char* xd = Xbuf + buf * X_STAGE;
+#pragma unroll
+          for (int j = 0; j < BS_XU; ++j) {
+            if (u_c[j] < 0) continue;
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+              wv4 v = xv[j][pl];
+              if (any_pad && u_idx[j] < 0) v = wv4{0.f, 0.f, 0.f, 0.f};            // edge tiles only (wave-uniform guard)
+              *reinterpret_cast<wv4*>(xd + ((pl * G + u_g[j]) * XW + u_c[j]) * 16) = v;
+            }
+          }
+          unsigned char* dst = Wbuf + buf * W_STAGE;
+#pragma unroll
+          for (int j = 0; j < ND; ++j) {
+            const int bi = min(lw + NSW * j, NBLK - 1);
+            *reinterpret_cast<wv4*>(dst + bi * 1024 + lane * 16) = wv[j];
+          }
+        }
+        __syncthreads();       // c = -1: chunk 0 staged; later: pairs with the MFMA waves' barrier behind chunk c
+      }
+    } else if constexpr (G == 2) {
       // ---- wide shape: the inputs of chunk c + 2 stay IN FLIGHT across the barrier -----------------------------------------
       // Rounds 1-3 wrote this as a "register double buffer" of plain C++ loads; hipcc waits for such a load at its first use --
       // and the padding select is a use -- so it placed s_waitcnt vmcnt(0) right behind the last load of the same stage (and again
@@ -611,6 +663,10 @@ bool conv_bsplit_ok(const ConvArgs& a) {
   const int kp = G == 2 ? a.K - 1 : ((a.K + 1) & ~1) - 1;                        // G = 1 also reads the zero tap
   return a.C_in % (8 * G) == 0 && G * ((tt + kp * a.dil + 63) / 64) <= BS_NSW * BS_XU &&
          a.x_cs * (long long)a.C_in < (1ll << 31);
+}
+
+bool conv_bsplit_p8_ok(const ConvArgs& a) {
+  return conv_bsplit_ok(a) && bs_group(a.C_in) == 2 && (long long)a.T_in * 16 < (1ll << 32);
 }
 
 template <int KT, int G, int NMW, int NSW>

@@ -66,6 +66,10 @@ struct ConvArgs {
 #endif
   int x_off;   // columns staged to the left of the receptive field so that the slab starts 16-B aligned
   int gflat;   // conv1d_gemm_split.hip: columns are the flattened (clip, time) index (K = 1)
+  const unsigned char* x_p8;   // input as P8 planes (fac_conv_desc.x_p8) or NULL
+  long long x_p8_ps;           // bytes between planes
+  unsigned char* y2_p8;        // second output as P8 planes or NULL
+  long long y2_p8_ps;
   int rp;      // > 1: output rows are (channel, phase) pairs, phase fastest, CO_TILE / rp channels per tile (all-phases
                // ConvTranspose1d, fac_conv_desc.row_phases); the all-waves epilogue interleaves them into contiguous runs
 };
@@ -809,6 +813,7 @@ int conv_dispatch_bsplit2(ConvArgs& a, hipStream_t s);
 bool conv_gsplit_ok(const ConvArgs& a);
 int conv_dispatch_gsplit(ConvArgs& a, hipStream_t s);
 bool conv_bsplit_ok(const ConvArgs& a);
+bool conv_bsplit_p8_ok(const ConvArgs& a);   // ... and the launch takes a P8 input (wide shape: C_in >= 64, C_in % 16 == 0)
 int conv_dispatch_bsplit(ConvArgs& a, hipStream_t s);
 bool conv_skinny_ok(const ConvArgs& a, const void* ws, long long ws_bytes);
 int conv_dispatch_skinny(ConvArgs& a, void* ws, long long ws_bytes, hipStream_t s);

@@ -825,3 +825,46 @@ extern "C" int fac_stft_frames_bwd(const float* dframes, float* dwave, int B, in
   EW_LAUNCH(stft_frames_bwd_kernel, n, dframes, dwave, T, n_win, n_frames, hop, pad, n_off, n);
   return check_launch("stft_frames_bwd");
 }
+
+
+// ---------------------------------------------------------------------------------------- fp32 (B, C, T) -> P8 planes
+// One thread = one (clip, 8-channel group, time step): 8 coalesced fp32 loads (rows T apart), optional Snake, the exact
+// round-to-nearest three-way bf16 split, three 16-byte stores (one per plane).  HBM-bound: 4 B read + 6 B written per element.
+namespace fac {
+typedef __bf16 p8_bf16x8 __attribute__((ext_vector_type(8)));
+__global__ __launch_bounds__(256) void to_p8_kernel(const float* __restrict__ x, const float* __restrict__ alpha, p8_bf16x8* __restrict__ out,
+                                                    int C8, int T, long long n, long long plane_units) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const int t = (int)(i % T);
+    const long long bg = i / T;                 // b * C8 + g
+    const int g = (int)(bg % C8);
+    const float* row = x + (bg * 8) * T + t;
+    p8_bf16x8 h, m, l;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      float v = row[(long long)k * T];
+      if (alpha != nullptr) {
+        const float al = alpha[g * 8 + k];
+        v = snake_apply(v, al, snake_inv(al));
+      }
+      const __bf16 a = (__bf16)v;
+      const float r1 = v - (float)a;
+      const __bf16 b2 = (__bf16)r1;
+      const __bf16 c = (__bf16)(r1 - (float)b2);
+      h[k] = a; m[k] = b2; l[k] = c;
+    }
+    out[i] = h;
+    out[plane_units + i] = m;
+    out[2 * plane_units + i] = l;
+  }
+}
+}  // namespace fac
+
+extern "C" int fac_to_p8(const float* x, const float* alpha, void* out, int B, int C, int T, fac_stream_t stream) {
+  using namespace fac;
+  FAC_REQUIRE(x && out && B > 0 && C > 0 && C % 8 == 0 && T > 0, "to_p8: bad arguments (C must be a multiple of 8)");
+  const long long n = (long long)B * (C / 8) * T;
+  const int blocks = (int)((n + 255) / 256 < 262144 ? (n + 255) / 256 : 262144);
+  hipLaunchKernelGGL(to_p8_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, alpha, reinterpret_cast<p8_bf16x8*>(out), C / 8, T, n, n);
+  return check_launch("to_p8");
+}

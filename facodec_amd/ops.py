@@ -453,6 +453,34 @@ def conv_out_len(t_in, k, stride, dilation):
     return t_out, padding_total, extra
 
 
+class P8:
+    """An activation tensor (B, C, T) as three bf16 planes hi / mid / lo (hi + mid + lo == value exactly), each laid out
+    [b][c / 8][t][8] -- the operand format of the split-bf16 kernels' LDS stages (fac_conv_desc.x_p8): `planes` is a (3, B, C / 8, T, 8)
+    bfloat16 tensor."""
+
+    def __init__(self, planes, shape):
+        self.planes, self.shape = planes, tuple(shape)
+
+    @property
+    def plane_bytes(self):
+        return self.planes.stride(0) * 2
+
+    def to_float(self):
+        """The fp32 tensor the planes add up to (tests)."""
+        B, C, T = self.shape
+        v = self.planes.float().sum(0)                     # (B, C/8, T, 8): exact, three addends of disjoint significance
+        return v.permute(0, 1, 3, 2).reshape(B, C, T).contiguous()
+
+
+def to_p8(x, alpha=None):
+    """fp32 (B, C, T) [-> snake(x, alpha)] -> P8 (fac_to_p8)."""
+    x = _dev(x, "x")
+    B, C, T = x.shape
+    planes = torch.empty(3, B, C // 8, T, 8, device=x.device, dtype=torch.bfloat16)
+    _lib.check(_lib.load().fac_to_p8(_ptr(x), _ptr(alpha), _ptr(planes), B, C, T, _stream()), "fac_to_p8")
+    return P8(planes, (B, C, T))
+
+
 def conv1d(x, w_packed, c_out, k, bias=None, stride=1, dilation=1, pad_left=None, pad_mode=PAD_REFLECT,
            t_out=None, alpha_in=None, alpha_out=None, res=None, act=ACT_NONE, out=None, causal=True,
            alpha_y2=None, want_y=True, w_k1=None, bias_k1=None, w_split=None, k1=0, dilation2=0):
@@ -461,9 +489,14 @@ def conv1d(x, w_packed, c_out, k, bias=None, stride=1, dilation=1, pad_left=None
     k1 / dilation2: two-level taps (tap k = k2 * k1 + k1' reads offset k2 * dilation2 + k1' * dilation), see fac_conv_desc.
     alpha_y2: also produce y2 = snake(y, alpha_y2) (returned as (y, y2); y is None if not want_y).
     w_k1 / bias_k1: fused ResidualUnit tail -- y = w_k1 * snake(conv + bias, alpha_out) + bias_k1 + res."""
-    if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 3 and x.stride(2) == 1):
-        x = _dev(x, "x")     # channel-sliced views (time contiguous) are consumed in place
-    B, c_in, t_in = x.shape
+    x_p8 = x if isinstance(x, P8) else None
+    if x_p8 is not None:
+        B, c_in, t_in = x_p8.shape
+    else:
+        if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 3 and x.stride(2) == 1):
+            x = _dev(x, "x")     # channel-sliced views (time contiguous) are consumed in place
+        B, c_in, t_in = x.shape
+    dev_ = x_p8.planes.device if x_p8 is not None else x.device
     if pad_left is None:
         t_o, padding_total, _ = conv_out_len(t_in, k, stride, dilation)
         pad_left = padding_total if causal else padding_total - padding_total // 2
@@ -473,11 +506,15 @@ def conv1d(x, w_packed, c_out, k, bias=None, stride=1, dilation=1, pad_left=None
         raise ValueError("t_out required with explicit pad_left")
     cp = w_packed.shape[-1] if w_packed is not None else pad32(c_out)
     if out is None and want_y:
-        out = torch.empty(B, c_out, t_out, device=x.device, dtype=torch.float32)
-    y2 = torch.empty(B, c_out, t_out, device=x.device, dtype=torch.float32) if alpha_y2 is not None else None
+        out = torch.empty(B, c_out, t_out, device=dev_, dtype=torch.float32)
+    y2 = torch.empty(B, c_out, t_out, device=dev_, dtype=torch.float32) if alpha_y2 is not None else None
     res = _dev(res, "res")
     d = ConvDesc()
-    d.x, d.bias = x.data_ptr(), (bias.data_ptr() if bias is not None else None)
+    d.bias = bias.data_ptr() if bias is not None else None
+    if x_p8 is not None:
+        d.x, d.x_p8, d.x_p8_plane_bytes = None, x_p8.planes.data_ptr(), x_p8.plane_bytes
+    else:
+        d.x = x.data_ptr()
     d.w = w_packed.data_ptr() if w_packed is not None else w_split.data_ptr()   # split-only launch: see fac_conv_desc.w_split
     d.alpha_in = alpha_in.data_ptr() if alpha_in is not None else None
     d.alpha_out = alpha_out.data_ptr() if alpha_out is not None else None
@@ -488,7 +525,7 @@ def conv1d(x, w_packed, c_out, k, bias=None, stride=1, dilation=1, pad_left=None
     d.w_k1 = w_k1.data_ptr() if w_k1 is not None else None
     d.bias_k1 = bias_k1.data_ptr() if bias_k1 is not None else None
     d.w_split = w_split.data_ptr() if w_split is not None else None
-    d.x_bs, d.x_cs = x.stride(0), x.stride(1)
+    d.x_bs, d.x_cs = (x.stride(0), x.stride(1)) if x_p8 is None else (c_in * t_in, t_in)
     d.y_bs, d.y_cs = c_out * t_out, t_out
     d.B, d.C_in, d.T_in, d.C_out, d.C_out_pad, d.T_out = B, c_in, t_in, c_out, cp, t_out
     d.K, d.stride, d.dilation, d.pad_left, d.pad_mode = k, stride, dilation, pad_left, pad_mode

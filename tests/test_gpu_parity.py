@@ -553,6 +553,29 @@ def test_standalone_rvq_train_mode_against_oracle(O, cuda):
     assert out[0].shape == (B, 256, T) and out[1].shape == (B, 3, T) and out[2].shape == (B, 24, T) and out[3].dim() == 0
 
 
+@pytest.mark.parametrize("B,C,T,k,d,pad", [(2, 64, 1000, 7, 1, "reflect"), (1, 192, 777, 7, 9, "reflect"), (2, 128, 300, 5, 1, "zero"),
+                                            (1, 768, 520, 7, 3, "reflect"), (1, 64, 20, 7, 9, "reflect"), (1, 1024, 700, 3, 1, "reflect")])
+def test_split_conv_takes_p8_input_bit_identically(ops, cuda, B, C, T, k, d, pad):
+    """fac_conv_desc.x_p8: the split k = 3 / 5 / 7 kernel fed with the pre-split planes (fac_to_p8: exact round-to-nearest
+    three-way bf16 split, [b][c/8][t][8]) multiplies the same bf16 operands in the same order as when it splits the fp32 tensor
+    itself, so the outputs must be IDENTICAL -- interior tiles, reflect / zero edges, an input shorter than the pad; and the planes
+    must add back up to the fp32 tensor exactly (with and without the Snake prologue of the producer)."""
+    g = _g(90 + C)
+    x = torch.randn(B, C, T, generator=g).to(cuda)
+    w = (torch.randn(C, C, k, generator=g) / (C * k) ** 0.5).to(cuda)
+    bias = torch.randn(C, generator=g).to(cuda)
+    al = (1 + 0.3 * torch.rand(C, generator=g)).to(cuda)
+    ws = ops.pack_conv_weight_split(w)
+    pm = ops.PAD_REFLECT if pad == "reflect" else ops.PAD_ZERO
+    p8 = ops.to_p8(x)
+    assert torch.equal(p8.to_float(), x)
+    y_ref = ops.conv1d(x, None, C, k, bias=bias, dilation=d, alpha_out=al, pad_mode=pm, w_split=ws)
+    y_p8 = ops.conv1d(p8, None, C, k, bias=bias, dilation=d, alpha_out=al, pad_mode=pm, w_split=ws)
+    assert torch.equal(y_p8, y_ref)
+    xs = ops.snake(x, al)
+    assert torch.equal(ops.to_p8(x, al).to_float(), xs)
+
+
 def test_spectral_losses_against_oracle(O, cuda):
     """MelSpectrogramLoss (train.py:155-163 arguments), MultiScaleSTFTLoss, L1Loss, reconstruction_loss on
     2 s clips; bar 1e-4 relative.  Third-party STFT/mel semantics restated on both sides: parity unpinned."""

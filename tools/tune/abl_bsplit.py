@@ -24,5 +24,18 @@ for (C, T, d) in ((96, 48000, 1), (192, 24000, 3), (768, 960, 1)):
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / 20
-    out.append(f"C={C}: {ms:.3f} ms {2.0 * B * C * C * 7 * T / ms / 1e9:6.1f} TF")
+    txt = f"C={C}: {ms:.3f} ms {2.0 * B * C * C * 7 * T / ms / 1e9:6.1f} TF"
+    if hasattr(ops, "to_p8") and os.environ.get("FAC_ABL_P8", "1") != "0":
+        p8 = ops.to_p8(x)
+        for _ in range(3):
+            ops.conv1d(p8, None, C, 7, dilation=d, bias=bias, alpha_out=al, w_split=ws)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(20):
+            ops.conv1d(p8, None, C, 7, dilation=d, bias=bias, alpha_out=al, w_split=ws)
+        e1.record()
+        torch.cuda.synchronize()
+        ms8 = e0.elapsed_time(e1) / 20
+        txt += f" | P8 input {ms8:.3f} ms {2.0 * B * C * C * 7 * T / ms8 / 1e9:6.1f} TF"
+    out.append(txt)
 print(os.path.basename(os.environ.get("FAC_LIB_PATH", "default")), " | ".join(out))
