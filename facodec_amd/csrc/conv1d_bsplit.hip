@@ -159,18 +159,16 @@ __global__ __launch_bounds__((NMW + NSW) * 64, (NMW + NSW) / 4) void conv1d_bspl
     constexpr int ND = (NBLK + NSW - 1) / NSW;         // DMA instructions per staging wave and stage
     constexpr int NX = BS_XU * 8;                      // input loads per staging wave and stage
     static_assert(W_STAGE % 1024 == 0 && ND + NX <= 63 && NX == 24, "vmcnt is a 6-bit counter; FAC_XREGS24_* list 24 registers per set");
+    // (used by the narrow shape; a fully unrolled version with clamped block indices made hipcc spill 443 registers there)
     auto stage_w = [&](int chunk, int buf) {
 #if !defined(FAC_ABL_NOSTAGE) && !defined(FAC_ABL_NOSTAGE_W)
+      constexpr int N16 = W_STAGE / 16;
       const unsigned char* src = wsrc + (long long)chunk * W_STAGE;
       unsigned char* dst = Wbuf + buf * W_STAGE;
-#pragma unroll
-      for (int j = 0; j < ND; ++j) {
-        const int i = min(lw + NSW * j, NBLK - 1);
-#ifdef FAC_ABL_WSRC_SAME   // tuning: every DMA block reads the same 1 KiB (cache-resident) -- same LDS write volume, no L2 fetch volume
-        __builtin_amdgcn_global_load_lds((glb_void_t*)(wsrc + lane * 16), (lds_void_t*)(dst + i * 1024), 16, 0, 0);
-#else
-        __builtin_amdgcn_global_load_lds((glb_void_t*)(src + (long long)i * 1024 + lane * 16), (lds_void_t*)(dst + i * 1024), 16, 0, 0);
-#endif
+      for (int i = lw; i * 64 < N16; i += NSW) {
+        const int q = i * 64 + lane;
+        if (q < N16)
+          __builtin_amdgcn_global_load_lds((glb_void_t*)(src + (long long)q * 16), (lds_void_t*)(dst + i * 1024), 16, 0, 0);
       }
 #endif
     };
@@ -290,6 +288,16 @@ __global__ __launch_bounds__((NMW + NSW) * 64, (NMW + NSW) / 4) void conv1d_bspl
         FAC_XREGS24_B(BS_LD)
 #endif
       };
+      auto stage_w_fixed = [&](int chunk, int buf) {       // FAC_BS_W_VGPR=0: exactly ND LDS-DMA instructions per wave
+        const unsigned char* src = wsrc + (long long)chunk * W_STAGE;
+        unsigned char* dst = Wbuf + buf * W_STAGE;
+#pragma unroll
+        for (int j = 0; j < ND; ++j) {
+          const int i = min(lw + NSW * j, NBLK - 1);
+          __builtin_amdgcn_global_load_lds((glb_void_t*)(src + (long long)i * 1024 + lane * 16), (lds_void_t*)(dst + i * 1024), 16, 0, 0);
+        }
+      };
+      (void)stage_w_fixed;
       auto take_a = [&](float (&xr)[BS_XU][8]) { FAC_XREGS24_A(BS_RD) };
       auto take_b = [&](float (&xr)[BS_XU][8]) { FAC_XREGS24_B(BS_RD) };
       // ONE software-pipelined loop from c = -2: step(c) = { weight DMA of chunk c + 1 into stage (c + 1) & 1; wait for the inputs
@@ -378,7 +386,7 @@ __global__ __launch_bounds__((NMW + NSW) * 64, (NMW + NSW) / 4) void conv1d_bspl
           }
 #else
           if (has_next) {
-            stage_w(c + 1, 1 - i);                                   // that stage was read during chunk c - 1
+            stage_w_fixed(c + 1, 1 - i);                             // that stage was read during chunk c - 1
             asm volatile("s_waitcnt vmcnt(%0)" : : "n"(ND) : "memory");
             if (i == 0) take_b(xr); else take_a(xr);
           }
@@ -406,6 +414,9 @@ __global__ __launch_bounds__((NMW + NSW) * 64, (NMW + NSW) / 4) void conv1d_bspl
     } else {
       // ---- narrow shape (32 / 48 input channels, three waves per SIMD: no registers to spare for named landing sets): plain
       // loads, which hipcc waits for within the stage
+      int u_off[BS_XU];
+#pragma unroll
+      for (int j = 0; j < BS_XU; ++j) u_off[j] = u_idx[j] >= 0 ? u_idx[j] : 0;
       auto load_x = [&](int chunk, float (&xr)[BS_XU][8]) {
 #if !defined(FAC_ABL_NOSTAGE) && !defined(FAC_ABL_NOSTAGE_X)
 #pragma unroll
@@ -413,7 +424,7 @@ __global__ __launch_bounds__((NMW + NSW) * 64, (NMW + NSW) / 4) void conv1d_bspl
           const float* grp = xg + (long long)((chunk * G + u_g[j]) * 8) * xcs;
 #pragma unroll
           for (int i = 0; i < 8; ++i) {
-            const float v = (grp + (long long)i * xcs)[u_idx[j] >= 0 ? u_idx[j] : 0];
+            const float v = (grp + (long long)i * xcs)[u_off[j]];
             xr[j][i] = u_idx[j] >= 0 ? v : 0.f;
           }
         }
@@ -469,6 +480,84 @@ __global__ __launch_bounds__((NMW + NSW) * 64, (NMW + NSW) / 4) void conv1d_bspl
 #ifdef FAC_PROF
   const unsigned long long tp1 = wall_clock64();
 #endif
+#ifndef FAC_BS_PIPE
+#define FAC_BS_PIPE 1
+#endif
+  if constexpr (NMW == 4 && FAC_BS_PIPE) {
+    // ---- wide shape, round 4: the fragment pipeline runs ACROSS the stage barrier.
+    // A stage is H / 2 steps of 24 MFMAs; the fragments of step s + 1 are requested while step s multiplies (two register sets).
+    //  * The 12 ds_read_b128 of the next step are interleaved with the MFMAs of the current one (sched_group_barrier: 2 MFMAs,
+    //    1 read, ...) instead of being issued in a burst in front of them: a wave issues in order, so the burst kept the matrix
+    //    pipe idle for the issue time of twelve LDS instructions once per step.
+    //  * The stage barrier sits in front of the LAST step's MFMAs, not behind them: by then every fragment of the stage is in
+    //    registers (s_waitcnt lgkmcnt(0)), so the staging waves may overwrite the buffer, and the first fragments of the NEXT stage
+    //    -- staged long ago -- are requested right behind the barrier and arrive under the last step's 24 MFMAs.  With the barrier
+    //    at the end, every stage started with an exposed LDS round trip and a drained matrix pipe.
+    // H / 2 is odd (7, 5, 3 steps), so the register-set parity flips from stage to stage: the loop body covers two stages.
+    constexpr int S = H / 2;
+    bf16x8 A[2][MB][3], Bf[2][NB][3];
+    auto ld = [&](int buf, int st, bf16x8 (&Ad)[MB][3], bf16x8 (&Bd)[NB][3]) {
+      const unsigned char* Wb = Wbuf + buf * W_STAGE + (kq * BS_CO + l31) * 16;          // half slot 2 st + kq
+      const unsigned char* Xb = Xbuf + buf * X_STAGE + (n0 + l31) * 16 + x_lane + st * x_step;
+      constexpr int PO[3] = {1, 0, 2};   // planes in order of first use: mid, hi, lo
+#pragma unroll
+      for (int pi = 0; pi < 3; ++pi) {
+#pragma unroll
+        for (int n = 0; n < NB; ++n) Bd[n][PO[pi]] = *reinterpret_cast<const bf16x8*>(Xb + (PO[pi] * G * XW + n * 32) * 16);
+#pragma unroll
+        for (int m = 0; m < MB; ++m) Ad[m][PO[pi]] = *reinterpret_cast<const bf16x8*>(Wb + ((PO[pi] * H + 2 * st) * BS_CO + m * 32) * 16);
+      }
+    };
+    auto mma = [&](const bf16x8 (&Ac)[MB][3], const bf16x8 (&Bc)[NB][3]) {
+      // smallest terms first: mid*mid, lo*hi, hi*lo, mid*hi, hi*mid, hi*hi; the term loop is OUTSIDE the block loops so that
+      // consecutive MFMAs write different accumulators
+      constexpr int TA[6] = {1, 2, 0, 1, 0, 0}, TB[6] = {1, 0, 2, 0, 1, 0};
+#pragma unroll
+      for (int q = 0; q < 6; ++q)
+#pragma unroll
+        for (int m = 0; m < MB; ++m)
+#pragma unroll
+          for (int n = 0; n < NB; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ac[m][TA[q]], Bc[n][TB[q]], acc[m][n], 0, 0, 0);
+    };
+    auto interleave = [&]() {            // 24 MFMAs and 12 LDS reads in the region: M M R  M M R ...
+#pragma unroll
+      for (int i = 0; i < 3 * (MB + NB); ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
+    };
+    ld(0, 0, A[0], Bf[0]);
+    for (int base = 0; base < n_chunks; base += 2) {
+#pragma unroll
+      for (int cc = 0; cc < 2; ++cc) {
+        const int chunk = base + cc;
+        if (chunk >= n_chunks) break;
+        const int buf = cc;                                     // chunk & 1 (base is even)
+#pragma unroll
+        for (int st = 0; st < S; ++st) {
+          const int cur = (cc * S + st) & 1;                   // compile-time after unrolling
+          if (st + 1 < S) {
+            if (cur == 0) ld(buf, st + 1, A[1], Bf[1]); else ld(buf, st + 1, A[0], Bf[0]);
+            if (cur == 0) mma(A[0], Bf[0]); else mma(A[1], Bf[1]);
+            interleave();
+            __builtin_amdgcn_sched_barrier(0);
+          } else {
+            // last step of the stage: its fragments were requested a step ago; once they are in, the buffer is free
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            if (chunk + 1 < n_chunks) {
+              if (cur == 0) ld(buf ^ 1, 0, A[1], Bf[1]); else ld(buf ^ 1, 0, A[0], Bf[0]);
+            }
+            if (cur == 0) mma(A[0], Bf[0]); else mma(A[1], Bf[1]);
+            if (chunk + 1 < n_chunks) interleave();
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+      }
+    }
+  } else {
 #ifdef FAC_PROF2
   long long pm[3] = {0, 0, 0};
 #endif
@@ -563,6 +652,7 @@ __global__ __launch_bounds__((NMW + NSW) * 64, (NMW + NSW) / 4) void conv1d_bspl
   }
 #endif
 
+  }
 #ifdef FAC_PROF
   const unsigned long long tp2 = wall_clock64();
   pf0 = tp0; pf1 = tp1; pf2 = tp2;

@@ -202,6 +202,19 @@ def reserved_violations(asm_path):
     return out
 
 
+def spill_counts(asm_path):
+    """{kernel: vgpr_spill_count} from the kernel metadata of the assembly."""
+    out, name = {}, None
+    for line in open(asm_path):
+        m = re.match(r"\s*\.name:\s+(\S+)", line)
+        if m:
+            name = m.group(1)
+        m = re.match(r"\s*\.vgpr_spill_count:\s+(\d+)", line)
+        if m and name:
+            out[name] = int(m.group(1))
+    return out
+
+
 def main():
     rc = 0
     for src in sys.argv[1:]:
@@ -209,6 +222,10 @@ def main():
         rep, bad = check(asm)
         res = reserved_violations(asm)
         print(os.path.basename(src))
+        spills = {k: v for k, v in spill_counts(asm).items() if v > 32}
+        for k, v in spills.items():
+            print(f"   REGISTER SPILLS: {k[:70]} spills {v} VGPRs to scratch")
+            rc = 1
         for k, (lo, viol) in res.items():
             print(f"   {k[:70]}: landing registers v{lo}..v255 named in inline asm, {len(viol)} other instruction(s) touch them")
             for ins in viol[:10]:
