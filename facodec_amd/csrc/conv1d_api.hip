@@ -91,7 +91,9 @@ extern "C" int fac_conv1d_fwd(const fac_conv_desc* d, fac_stream_t stream) {
   }
   hipStream_t s = (hipStream_t)stream;
   if (d->x_p8 || d->y2_p8) {      // P8 operands exist only in the kernels listed at fac_conv_desc.x_p8: no silent fp32 detour
-    const bool ok = d->w_split && !conv_two_level(a) && conv_bsplit_p8_ok(a) && !conv_cin1_ok(a) && !d->y2_p8;
+    const bool gs = d->w_split && (d->K <= 2 || (d->stride > 1 && d->K <= 2 * d->stride)) && conv_gsplit_ok(a) &&
+                    !conv_skinny_ok(a, d->ws, d->ws_bytes) && d->C_in % 8 == 0 && d->x_p8_plane_bytes < (1ll << 32);
+    const bool ok = !d->y2_p8 && (gs || (d->w_split && !conv_two_level(a) && conv_bsplit_p8_ok(a) && !conv_cin1_ok(a)));
     FAC_REQUIRE(ok, "conv1d: P8 operands given but the launch does not run on a kernel that takes them (K=%d stride=%d C_in=%d columns=%lld)",
                 d->K, d->stride, d->C_in, (long long)d->B * d->T_out);
   }

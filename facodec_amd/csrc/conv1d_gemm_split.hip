@@ -129,6 +129,97 @@ __global__ __launch_bounds__(512, 2) void conv1d_gemm_split_kernel(ConvArgs a) {
     const int sl = tid - 256;
     __builtin_amdgcn_s_setprio(FAC_PRIO_STAGE);
     const unsigned char* wsrc = reinterpret_cast<const unsigned char*>(a.w) + (long long)(row0 / GS_ROWS) * n_chunks * A_BYTES;
+    if (a.x_p8 != nullptr) {
+      // ------------------------------------------------------------------- P8 input: BOTH operands by LDS-DMA
+      // The input arrives as the bf16 planes themselves, 16 bytes per (8-channel group, time step) (fac_conv_desc.x_p8): that is
+      // one slot of a B row, so a staging lane copies it straight into its fixed slot -- lane l of a 1 KiB block owns (row
+      // blk * 16 + l / 4, slot l % 4) and fetches the piece the XOR swizzle puts there.  No registers, no vector-ALU work per
+      // stage (in the fp32 path below the split costs the staging waves ~100 VALU instructions per stage, which do not overlap
+      // the MFMAs of their SIMD: the stage of 48 MFMAs then lasts twice its matrix-pipe time).  Columns outside the signal read
+      // the zero unit that closes every plane.  Inputs are requested NST - 1 stages ahead, like the weights.
+      constexpr int XROWS = GS_COLS + K - 1;
+      constexpr int NBB = (XROWS * GS_RB + 1023) / 1024;          // 1 KiB blocks per input plane (the last one partly beyond XROWS)
+      constexpr int NB = (3 * NBB + 3) / 4;                       // input DMA instructions per staging wave and stage
+      constexpr int LPT = NA + NB;
+      const int C8 = a.C_in / 8;
+      const unsigned zero_off = (unsigned)(((long long)a.B * C8 * a.T_in) * 16);      // the plane's trailing zero unit
+      // per DMA slot j: (plane, row, piece) of this lane; the unit offset inside a plane for channel group 0 of the chunk
+      int b_plane[NB], b_row[NB], b_piece[NB], b_lds[NB];
+      unsigned b_off[NB];
+      bool b_live[NB];
+#pragma unroll
+      for (int j = 0; j < NB; ++j) {
+        const int id = min(j * 4 + lw, 3 * NBB - 1);
+        const int plane = id / NBB, blk = id - plane * NBB;
+        const int row = blk * 16 + (lane >> 2);
+        b_plane[j] = plane;
+        b_row[j] = row;
+        b_piece[j] = (lane & 3) ^ ((row >> 2) & 3);
+        b_lds[j] = A_BYTES + plane * GS_BPL + blk * 1024;
+        b_live[j] = row < GS_XR;                                   // rows past the plane's LDS allocation must not be written
+        unsigned off = zero_off;
+        if (flat) {
+          const long long nn = (long long)n0 + row;
+          if (nn < n_total && row < XROWS) {
+            const long long bb = nn / a.T_out;
+            off = (unsigned)(((bb * C8) * a.T_in + (nn - bb * a.T_out)) * 16);
+          }
+        } else if (S == 1) {
+          const int tin = n0 - a.pad_left + row;
+          if (tin >= 0 && tin < a.T_in && row < XROWS) off = (unsigned)((((long long)b * C8) * a.T_in + tin) * 16);
+        }
+        b_off[j] = off;
+      }
+      const unsigned grp_bytes = (unsigned)a.T_in * 16u;            // one 8-channel group of one clip
+      auto issue = [&](int chunk, int buf) {
+        const int ch = chunk < n_chunks ? chunk : n_chunks - 1;     // past the end: re-request the last chunk (keeps LPT constant)
+        const unsigned char* asrc = wsrc + (long long)ch * A_BYTES;
+        unsigned char* dst = sm + buf * STAGE;
+#pragma unroll
+        for (int j = 0; j < NA; ++j) {
+          const int blk = j * 4 + lw;
+          __builtin_amdgcn_global_load_lds((glb_void_t*)(asrc + blk * 1024 + lane * 16), (lds_void_t*)(dst + blk * 1024), 16, 0, 0);
+        }
+        const int c32 = ch / S, ph = ch - c32 * S;
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+          int g8 = c32 * 4 + b_piece[j];
+          g8 = g8 < C8 ? g8 : C8 - 1;                               // ragged last chunk: zero weights, any finite input will do
+          unsigned off = b_off[j];
+          if (S > 1) {       // column r of the window <-> sample (n0 + r) * S + phase - pad_left of the padded signal
+            const int tin = (n0 + b_row[j]) * S + ph - a.pad_left;
+            int idx;
+            if (a.pad_mode == FAC_PAD_REFLECT) idx = reflect_index(tin, a.T_in, a.T_ext);
+            else idx = (tin >= 0 && tin < a.T_in) ? tin : -1;
+            off = (idx >= 0 && b_row[j] < XROWS) ? (unsigned)((((long long)b * C8) * a.T_in + idx) * 16) : zero_off;
+          }
+          const unsigned goff = off == zero_off ? zero_off : off + (unsigned)g8 * grp_bytes;
+          const unsigned char* bsrc = a.x_p8 + (long long)b_plane[j] * a.x_p8_ps;
+          if (b_live[j]) __builtin_amdgcn_global_load_lds((glb_void_t*)(bsrc + goff), (lds_void_t*)(dst + b_lds[j]), 16, 0, 0);
+        }
+      };
+      auto landed = [&](bool younger_in_flight) {                   // everything but the youngest stage's requests has landed
+        if (younger_in_flight) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(LPT) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      };
+      issue(0, 0);
+      if (NST == 3) issue(1, 1);
+      if (NST == 3) landed(true); else landed(false);
+      gs_barrier();                                                 // stage 0 visible to the MFMA waves
+      for (int base = 0; base < n_chunks; base += NST) {
+#pragma unroll
+        for (int i = 0; i < NST; ++i) {
+          const int c = base + i;
+          if (c < n_chunks) {
+            // stage (c + NST - 1) % NST was read during iteration c - 1, which every wave has left
+            if (c + NST - 1 < n_chunks) issue(c + NST - 1, (i + NST - 1) % NST);
+            if (c + 1 < n_chunks) landed(NST == 3 && c + 2 < n_chunks);
+            gs_barrier();
+          }
+        }
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
     // input units of this lane: column c of the staged window (row c of the B planes), 8-channel group g
     long long u_off[GS_NU];
     int u_lds[GS_NU], u_g[GS_NU];
@@ -262,6 +353,7 @@ __global__ __launch_bounds__(512, 2) void conv1d_gemm_split_kernel(ConvArgs a) {
       }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     __builtin_amdgcn_s_setprio(0);
   } else {
     // ========================================================================= MFMA waves: 64 x 64 each (2 x 2 blocks)

@@ -857,6 +857,12 @@ __global__ __launch_bounds__(256) void to_p8_kernel(const float* __restrict__ x,
     out[plane_units + i] = m;
     out[2 * plane_units + i] = l;
   }
+  if (blockIdx.x == 0 && threadIdx.x < 3) {     // the zero unit that closes every plane (what consumers read for padding columns)
+    p8_bf16x8 z;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) z[k] = (__bf16)0.f;
+    out[(long long)threadIdx.x * plane_units + n] = z;
+  }
 }
 }  // namespace fac
 
@@ -865,6 +871,6 @@ extern "C" int fac_to_p8(const float* x, const float* alpha, void* out, int B, i
   FAC_REQUIRE(x && out && B > 0 && C > 0 && C % 8 == 0 && T > 0, "to_p8: bad arguments (C must be a multiple of 8)");
   const long long n = (long long)B * (C / 8) * T;
   const int blocks = (int)((n + 255) / 256 < 262144 ? (n + 255) / 256 : 262144);
-  hipLaunchKernelGGL(to_p8_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, alpha, reinterpret_cast<p8_bf16x8*>(out), C / 8, T, n, n);
+  hipLaunchKernelGGL(to_p8_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, alpha, reinterpret_cast<p8_bf16x8*>(out), C / 8, T, n, n + 1);
   return check_launch("to_p8");
 }

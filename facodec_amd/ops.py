@@ -456,10 +456,15 @@ def conv_out_len(t_in, k, stride, dilation):
 class P8:
     """An activation tensor (B, C, T) as three bf16 planes hi / mid / lo (hi + mid + lo == value exactly), each laid out
     [b][c / 8][t][8] -- the operand format of the split-bf16 kernels' LDS stages (fac_conv_desc.x_p8): `planes` is a (3, B, C / 8, T, 8)
-    bfloat16 tensor."""
+    bfloat16 tensor; every plane ends with one zero unit (what consumers read for padding columns), so `planes` is stored as
+    (3, B * C / 8 * T + 1, 8) bfloat16."""
 
     def __init__(self, planes, shape):
         self.planes, self.shape = planes, tuple(shape)
+
+    @staticmethod
+    def empty(B, C, T, device):
+        return P8(torch.empty(3, B * (C // 8) * T + 1, 8, device=device, dtype=torch.bfloat16), (B, C, T))
 
     @property
     def plane_bytes(self):
@@ -468,7 +473,7 @@ class P8:
     def to_float(self):
         """The fp32 tensor the planes add up to (tests)."""
         B, C, T = self.shape
-        v = self.planes.float().sum(0)                     # (B, C/8, T, 8): exact, three addends of disjoint significance
+        v = self.planes[:, :-1].float().sum(0).reshape(B, C // 8, T, 8)     # exact: three addends of disjoint significance
         return v.permute(0, 1, 3, 2).reshape(B, C, T).contiguous()
 
 
@@ -476,9 +481,9 @@ def to_p8(x, alpha=None):
     """fp32 (B, C, T) [-> snake(x, alpha)] -> P8 (fac_to_p8)."""
     x = _dev(x, "x")
     B, C, T = x.shape
-    planes = torch.empty(3, B, C // 8, T, 8, device=x.device, dtype=torch.bfloat16)
-    _lib.check(_lib.load().fac_to_p8(_ptr(x), _ptr(alpha), _ptr(planes), B, C, T, _stream()), "fac_to_p8")
-    return P8(planes, (B, C, T))
+    out = P8.empty(B, C, T, x.device)
+    _lib.check(_lib.load().fac_to_p8(_ptr(x), _ptr(alpha), _ptr(out.planes), B, C, T, _stream()), "fac_to_p8")
+    return out
 
 
 def conv1d(x, w_packed, c_out, k, bias=None, stride=1, dilation=1, pad_left=None, pad_mode=PAD_REFLECT,

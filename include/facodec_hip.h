@@ -151,11 +151,14 @@ typedef struct fac_conv_desc {
   int32_t row_phases;
   /* Optional "P8" operands: an activation tensor as three bf16 planes hi / mid / lo with hi + mid + lo == value exactly
    * (round-to-nearest splits), each plane laid out [b][c / 8][t][8 channels] (16 bytes per (8-channel group, time step); C a
-   * multiple of 8; planes `*_plane_bytes` apart).  That is the operand format of the split-bf16 kernels' LDS stages, so a
+   * multiple of 8; planes `*_plane_bytes` apart; every plane is CLOSED BY ONE ZERO UNIT of 16 bytes at offset B * C/8 * T * 16,
+   * which consumers read for columns outside the signal, so a plane takes (B * C/8 * T + 1) * 16 bytes).  That is the operand format of the split-bf16 kernels' LDS stages, so a
    * consumer copies it (16 B per lane, no arithmetic beside the matrix instructions) instead of loading fp32 and splitting it:
    * in-kernel splitting costs every split kernel 15 - 50 % of its matrix-pipe time, because vector ALU instructions of the
    * staging waves and the MFMAs of the same SIMD do not overlap.
-   *   x_p8  : the INPUT in P8 (then `x` may be NULL); taken by the K = 3 / 5 / 7 split kernel (C_in % 16 == 0).
+   *   x_p8  : the INPUT in P8 (then `x` may be NULL); taken by the K = 3 / 5 / 7 split kernel (C_in % 16 == 0) and by the 1- / 2-tap
+   *           split GEMM kernel (plain, strided and all-phases transposed launches; C_in % 8 == 0), where both operands then move by
+   *           LDS-DMA.
    *   y2_p8 : the pre-activated second output snake(y, alpha_y2) written in P8 instead of (or beside) fp32 `y2`. */
   const void* x_p8;
   int64_t x_p8_plane_bytes;
@@ -165,7 +168,7 @@ typedef struct fac_conv_desc {
 
 int fac_conv1d_fwd(const fac_conv_desc* d, fac_stream_t stream);
 /* x (B, C, T) fp32 [-> snake(x, alpha) when alpha != NULL] -> the P8 planes described at fac_conv_desc.x_p8
- * (out: 3 * B * (C / 8) * T * 16 bytes, planes contiguous one after the other).  C % 8 == 0. */
+ * (out: 3 planes of (B * (C / 8) * T + 1) * 16 bytes one after the other, the zero unit included).  C % 8 == 0. */
 int fac_to_p8(const float* x, const float* alpha, void* out, int B, int C, int T, fac_stream_t stream);
 /* Weights (C_out, C_in, K) [* scale per output channel, as fac_pack_conv_w] -> three bf16 planes hi/mid/lo with
  * hi + mid + lo == w exactly, laid out per (64-channel tile, 16-input-channel stage) for LDS-DMA.

@@ -553,8 +553,8 @@ def test_standalone_rvq_train_mode_against_oracle(O, cuda):
     assert out[0].shape == (B, 256, T) and out[1].shape == (B, 3, T) and out[2].shape == (B, 24, T) and out[3].dim() == 0
 
 
-@pytest.mark.parametrize("B,C,T,k,d,pad", [(2, 64, 1000, 7, 1, "reflect"), (1, 192, 777, 7, 9, "reflect"), (2, 128, 300, 5, 1, "zero"),
-                                            (1, 768, 520, 7, 3, "reflect"), (1, 64, 20, 7, 9, "reflect"), (1, 1024, 700, 3, 1, "reflect")])
+@pytest.mark.parametrize("B,C,T,k,d,pad", [(2, 64, 1000, 7, 1, "reflect"), (1, 192, 777, 7, 9, "reflect"), (2, 128, 400, 5, 1, "zero"),
+                                            (1, 768, 700, 7, 3, "reflect"), (40, 64, 20, 7, 9, "reflect"), (1, 1024, 700, 3, 1, "reflect")])
 def test_split_conv_takes_p8_input_bit_identically(ops, cuda, B, C, T, k, d, pad):
     """fac_conv_desc.x_p8: the split k = 3 / 5 / 7 kernel fed with the pre-split planes (fac_to_p8: exact round-to-nearest
     three-way bf16 split, [b][c/8][t][8]) multiplies the same bf16 operands in the same order as when it splits the fp32 tensor
@@ -574,6 +574,38 @@ def test_split_conv_takes_p8_input_bit_identically(ops, cuda, B, C, T, k, d, pad
     assert torch.equal(y_p8, y_ref)
     xs = ops.snake(x, al)
     assert torch.equal(ops.to_p8(x, al).to_float(), xs)
+
+
+@pytest.mark.parametrize("kind,B,ci,co,T,k,s", [("flat", 4, 512, 512, 960, 1, 1), ("flat", 32, 1024, 4096, 160, 1, 1), ("flat", 3, 328, 200, 1001, 1, 1),
+                                                ("strided", 2, 128, 256, 2400, 10, 5), ("strided", 2, 64, 128, 1203, 4, 2),
+                                                ("strided_zero", 1, 128, 512, 2672, 5, 3)])
+def test_split_gemm_takes_p8_input_bit_identically(ops, cuda, kind, B, ci, co, T, k, s):
+    """conv1d_gemm_split.hip with fac_conv_desc.x_p8: flattened-column 1x1 GEMMs (tiles that span two clips, ragged channel and row
+    counts), strided convs over the phase sub-signals (reflect and zero padding, ragged last frame): both operands by LDS-DMA,
+    same bf16 operands as the in-kernel split -> identical outputs."""
+    g = _g(200 + ci + k)
+    x = torch.randn(B, ci, T, generator=g).to(cuda)
+    w = (torch.randn(co, ci, k, generator=g) / (ci * k) ** 0.5).to(cuda)
+    bias = torch.randn(co, generator=g).to(cuda)
+    if kind == "flat":
+        ws = ops.pack_gemm_weight_split(w)
+        kw = dict(bias=bias, pad_left=0, pad_mode=ops.PAD_ZERO, t_out=T)
+    elif kind == "strided":
+        ws = ops.pack_gemm_weight_split(w, in_stride=s)
+        kw = dict(bias=bias, stride=s)
+    else:
+        ws = ops.pack_gemm_weight_split(w, in_stride=s)
+        kw = dict(bias=bias, stride=s, pad_left=2, pad_mode=ops.PAD_ZERO, t_out=(T + 4 - k) // s + 1)
+    prof = ops.ConvLaunchProfile()
+    ops.set_conv_profile(prof)
+    try:
+        y_ref = ops.conv1d(x, None, co, k, w_split=ws, **kw)
+        y_p8 = ops.conv1d(ops.to_p8(x), None, co, k, w_split=ws, **kw)
+        torch.cuda.synchronize()
+    finally:
+        ops.set_conv_profile(None)
+    assert all("gemm_split" in n for n in prof.summary()), prof.summary().keys()
+    assert torch.equal(y_p8, y_ref)
 
 
 def test_spectral_losses_against_oracle(O, cuda):
