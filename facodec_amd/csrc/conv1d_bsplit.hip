@@ -24,6 +24,7 @@
 // (8-channel stages with tap pairs: 80 KB; a single stage of 73 KB with the co-resident workgroup as the
 // second pipeline stage) ran at 100-120 TFLOP/s-equivalent against 125-180 for this layout.
 #include "conv1d_mfma.h"
+#include <type_traits>
 #include "inflight_regs.h"
 
 namespace fac {
@@ -495,8 +496,12 @@ __global__ __launch_bounds__((NMW + NSW) * 64, (NMW + NSW) / 4) void conv1d_bspl
     //    at the end, every stage started with an exposed LDS round trip and a drained matrix pipe.
     // H / 2 is odd (7, 5, 3 steps), so the register-set parity flips from stage to stage: the loop body covers two stages.
     constexpr int S = H / 2;
-    bf16x8 A[2][MB][3], Bf[2][NB][3];
-    auto ld = [&](int buf, int st, bf16x8 (&Ad)[MB][3], bf16x8 (&Bd)[NB][3]) {
+    // A tile whose upper 32 rows lie beyond C_out (the second tile of the 96-channel layers: a quarter of their matrix work was
+    // spent on zero rows) runs the same pipeline with ONE row block per wave.
+    auto pipeline = [&](auto MBc) {
+    constexpr int MBv = decltype(MBc)::value;
+    bf16x8 A[2][MBv][3], Bf[2][NB][3];
+    auto ld = [&](int buf, int st, bf16x8 (&Ad)[MBv][3], bf16x8 (&Bd)[NB][3]) {
       const unsigned char* Wb = Wbuf + buf * W_STAGE + (kq * BS_CO + l31) * 16;          // half slot 2 st + kq
       const unsigned char* Xb = Xbuf + buf * X_STAGE + (n0 + l31) * 16 + x_lane + st * x_step;
       constexpr int PO[3] = {1, 0, 2};   // planes in order of first use: mid, hi, lo
@@ -505,24 +510,24 @@ __global__ __launch_bounds__((NMW + NSW) * 64, (NMW + NSW) / 4) void conv1d_bspl
 #pragma unroll
         for (int n = 0; n < NB; ++n) Bd[n][PO[pi]] = *reinterpret_cast<const bf16x8*>(Xb + (PO[pi] * G * XW + n * 32) * 16);
 #pragma unroll
-        for (int m = 0; m < MB; ++m) Ad[m][PO[pi]] = *reinterpret_cast<const bf16x8*>(Wb + ((PO[pi] * H + 2 * st) * BS_CO + m * 32) * 16);
+        for (int m = 0; m < MBv; ++m) Ad[m][PO[pi]] = *reinterpret_cast<const bf16x8*>(Wb + ((PO[pi] * H + 2 * st) * BS_CO + m * 32) * 16);
       }
     };
-    auto mma = [&](const bf16x8 (&Ac)[MB][3], const bf16x8 (&Bc)[NB][3]) {
+    auto mma = [&](const bf16x8 (&Ac)[MBv][3], const bf16x8 (&Bc)[NB][3]) {
       // smallest terms first: mid*mid, lo*hi, hi*lo, mid*hi, hi*mid, hi*hi; the term loop is OUTSIDE the block loops so that
       // consecutive MFMAs write different accumulators
       constexpr int TA[6] = {1, 2, 0, 1, 0, 0}, TB[6] = {1, 0, 2, 0, 1, 0};
 #pragma unroll
       for (int q = 0; q < 6; ++q)
 #pragma unroll
-        for (int m = 0; m < MB; ++m)
+        for (int m = 0; m < MBv; ++m)
 #pragma unroll
           for (int n = 0; n < NB; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ac[m][TA[q]], Bc[n][TB[q]], acc[m][n], 0, 0, 0);
     };
     auto interleave = [&]() {            // 24 MFMAs and 12 LDS reads in the region: M M R  M M R ...
 #pragma unroll
-      for (int i = 0; i < 3 * (MB + NB); ++i) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+      for (int i = 0; i < 3 * (MBv + NB); ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, (6 * MBv * NB) / (3 * (MBv + NB)) > 0 ? (6 * MBv * NB) / (3 * (MBv + NB)) : 1, 0);
         __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
       }
     };
@@ -557,6 +562,9 @@ __global__ __launch_bounds__((NMW + NSW) * 64, (NMW + NSW) / 4) void conv1d_bspl
         }
       }
     }
+    };
+    if (co0 + 32 >= a.C_out) pipeline(std::integral_constant<int, 1>{});
+    else pipeline(std::integral_constant<int, MB>{});
   } else {
 #ifdef FAC_PROF2
   long long pm[3] = {0, 0, 0};
