@@ -460,6 +460,10 @@ __global__ __launch_bounds__((NMW + NSW) * 64, (NMW + NSW) / 4) void conv1d_bspl
   const unsigned long long tp0 = wall_clock64();
 #endif
   __builtin_amdgcn_s_setprio(FAC_PRIO_MFMA);
+#ifdef FAC_PROF2
+  const long long ck0 = clock64();
+  const unsigned long long wk0 = wall_clock64();
+#endif
   const int l31 = lane & 31;
   const int kq = lane >> 5;
   const int n0 = wave * 64;
@@ -666,6 +670,14 @@ __global__ __launch_bounds__((NMW + NSW) * 64, (NMW + NSW) / 4) void conv1d_bspl
   pf0 = tp0; pf1 = tp1; pf2 = tp2;
 #endif
   __builtin_amdgcn_s_setprio(0);
+#ifdef FAC_PROF2
+  if (a.dbg && wave == 0 && lane == 0) {      // shader clock (s_memtime) against the constant 100 MHz clock over the main loop
+    unsigned long long* d = a.dbg + (long long)blockIdx.x * 16;
+    d[3] = (unsigned long long)(clock64() - ck0);
+    d[4] = wall_clock64() - wk0;
+    d[5] = (unsigned long long)n_chunks;
+  }
+#endif
   // ---- accumulators -> LDS (both stage buffers are free now): tile[co][t] fp32, row pitch BS_TT + 4 floats.
   // C/D layout of the 32x32 block: register r <-> row (r & 3) + 8 (r >> 2) + 4 kq, column l31.
   {

@@ -15,7 +15,7 @@ for (C, T, d) in ((192, 24000, 3), (768, 960, 1)):
     al = torch.ones(C, device=dev)
     bias = torch.zeros(C, device=dev)
     dbg = torch.zeros(1 << 21, dtype=torch.int64, device=dev)
-    for _ in range(3):
+    for _ in range(40):          # sustained load: the clock settles
         ops.conv1d(x, None, C, 7, dilation=d, bias=bias, alpha_out=al, w_split=ws)
     torch.cuda.synchronize()
     lib.fac_debug_set_buffer(ctypes.c_void_p(dbg.data_ptr()))
@@ -26,10 +26,15 @@ for (C, T, d) in ((192, 24000, 3), (768, 960, 1)):
     torch.cuda.synchronize()
     lib.fac_debug_set_buffer(ctypes.c_void_p(0))
     a = dbg.cpu().numpy().reshape(-1, 16).astype(np.float64)
-    a = a[a[:, 2] > 0]
+    a = a[a[:, 4] > 0]
+    ghz = a[:, 3].sum() / a[:, 4].sum() * 0.1
+    stages = a[:, 5].sum()
+    print(f"   shader clock over the main loops: {ghz:.3f} GHz (s_memtime / s_memrealtime); {a[:, 3].sum() / stages:.0f} shader cycles per stage "
+          f"(168 MFMAs x 32 cycles = 5376)")
+    a = a[a[:, 2] > 0] if (a[:, 2] > 0).any() else a
     m = a[:, :3].sum(0)
     s = a[:, 8:16].sum(0)
-    n_m, n_s = m[2], max(s[7], 1)
+    n_m, n_s = max(m[2], 1), max(s[7], 1)
     names = ["wait inputs landed", "take (24 v_cndmask)", "issue 24 loads", "split + 9 ds_write (+lgkm)", "wait weights landed", "11 ds_write W + lgkm", "barrier wait"]
     print(f"C={C} T={T} d={d}: kernel {e0.elapsed_time(e1):.3f} ms, {len(a)} WGs")
     print(f"   MFMA wave 0: compute {m[0] / n_m:8.0f} cyc/stage, barrier wait {m[1] / n_m:8.0f}")
