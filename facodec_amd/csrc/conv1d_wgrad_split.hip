@@ -504,6 +504,7 @@ struct WkArgs {
   int B, C_in_real, CV, C_out, K, stride, dil, K2, dil2s;
   int NBk;                   // blocks = ceil(CV / 32) * K
   int n_tt, tiles_per_split;
+  int MT;                    // 128-row tiles per workgroup (1 or 2)
 };
 
 __device__ __forceinline__ void wk_barrier() {
@@ -512,12 +513,24 @@ __device__ __forceinline__ void wk_barrier() {
   asm volatile("" ::: "memory");
 }
 
-__global__ __launch_bounds__(512, 2) void conv1d_wgrad_kmajor_kernel(WkArgs a) {
+// MT = row tiles of 128 per workgroup.  MT = 1: 4 MFMA waves (64 x 64 each) + 4 DMA waves, three LDS stages of 48 KB.
+// MT = 2 (round 4, C_out > 128): 256 x 128 tile, EIGHT MFMA waves -- two per SIMD, so one wave's fragment reads and barrier skew hide
+// under the other's MFMAs -- + 4 DMA waves, two stages of 72 KB.  What the stage costs the matrix pipe is its LDS WRITE traffic
+// (DESIGN 9.2), and a 128 x 128 tile writes 48 KB per 48 MFMAs of a wave; 256 x 128 writes 72 KB per 96 MFMAs of a SIMD: a quarter
+// less per MFMA, and half the barriers.
+template <int MT>
+__global__ __launch_bounds__((4 * MT + 4) * 64, MT == 1 ? 2 : 1) void conv1d_wgrad_kmajor_kernel(WkArgs a) {
+  constexpr int NMW = 4 * MT;                     // MFMA waves
+  constexpr int A_PLANE = MT * WK_PLANE;          // one plane of the dy operand
+  constexpr int A_OPND = 3 * A_PLANE;
+  constexpr int STAGE = A_OPND + WK_OPND;
+  constexpr int NST = MT == 1 ? 3 : 2;
+  constexpr int PA = WK_PIECES * MT, PB = WK_PIECES;      // 16-byte pieces per staging lane, operand and stage
   extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int co0 = blockIdx.x * 128;
+  const int co0 = blockIdx.x * 128 * MT;
   const int gb0 = blockIdx.y * 4;
   const int z = blockIdx.z;
   const int tile_lo = z * a.tiles_per_split;
@@ -525,19 +538,26 @@ __global__ __launch_bounds__(512, 2) void conv1d_wgrad_kmajor_kernel(WkArgs a) {
   const int n_chunks = tile_hi - tile_lo;
   const int s = a.stride;
 
-  if (wave >= 4) {
+  if (wave >= NMW) {
     // ===================================================================== staging waves: planes -> LDS by LDS-DMA
-    const int lw = wave - 4;
+    const int lw = wave - NMW;
     __builtin_amdgcn_s_setprio(3);
-    unsigned a_off[WK_PIECES], b_off[WK_PIECES];
+    unsigned a_off[PA], b_off[PB];
 #pragma unroll
-    for (int j = 0; j < WK_PIECES; ++j) {
+    for (int j = 0; j < PA; ++j) {
       const int blk = j * 4 + lw;                 // 1 KB block of the operand: 16 rows of one plane
-      const int plane = blk >> 3;
-      const int row = (blk & 7) * 16 + (lane >> 2);
+      const int plane = blk / (8 * MT);
+      const int row = (blk - plane * 8 * MT) * 16 + (lane >> 2);
       const int piece = (lane & 3) ^ ((row >> 2) & 3);      // the global piece that belongs in this lane's slot
       const int co = co0 + row < a.C_out ? co0 + row : a.C_out - 1;        // rows past C_out: computed, never stored
       a_off[j] = (unsigned)(plane * a.a_plane_bytes + ((long long)co * a.UA + 8 * piece) * 2);
+    }
+#pragma unroll
+    for (int j = 0; j < PB; ++j) {
+      const int blk = j * 4 + lw;
+      const int plane = blk >> 3;
+      const int row = (blk & 7) * 16 + (lane >> 2);
+      const int piece = (lane & 3) ^ ((row >> 2) & 3);
       int gb = gb0 + (row >> 5);
       gb = gb < a.NBk ? gb : a.NBk - 1;                                    // blocks past the end: never stored
       const int g = gb / a.K, k = gb - g * a.K;
@@ -547,20 +567,20 @@ __global__ __launch_bounds__(512, 2) void conv1d_wgrad_kmajor_kernel(WkArgs a) {
       const int kd = k * a.dil, shift = kd / s, ph = kd - shift * s;
       b_off[j] = (unsigned)(plane * a.b_plane_bytes + ((long long)(ci * s + ph) * a.UB + shift + k2 * a.dil2s + 8 * piece) * 2);
     }
-    constexpr int LPT = 2 * WK_PIECES;            // DMA instructions per lane and stage
+    constexpr int LPT = PA + PB;                  // DMA instructions per lane and stage
     auto issue = [&](int chunk, int buf) {
       const int tile = tile_lo + (chunk < n_chunks ? chunk : n_chunks - 1);     // past the end: reload the last tile (keeps LPT)
       const int b = tile / a.n_tt;
       const int t0 = (tile - b * a.n_tt) * WS_TT;
       const unsigned char* ab = a.ap + ((long long)b * a.C_out * a.UA + t0) * 2;                 // uniform
       const unsigned char* bb = a.bp + ((long long)b * a.C_in_real * s * a.UB + t0) * 2;        // uniform
-      unsigned char* st = sm + buf * WK_STAGE;
+      unsigned char* st = sm + buf * STAGE;
 #pragma unroll
-      for (int j = 0; j < WK_PIECES; ++j)
+      for (int j = 0; j < PA; ++j)
         __builtin_amdgcn_global_load_lds((glb_void_t*)(ab + a_off[j]), (lds_void_t*)(st + (j * 4 + lw) * 1024), 16, 0, 0);
 #pragma unroll
-      for (int j = 0; j < WK_PIECES; ++j)
-        __builtin_amdgcn_global_load_lds((glb_void_t*)(bb + b_off[j]), (lds_void_t*)(st + WK_OPND + (j * 4 + lw) * 1024), 16, 0, 0);
+      for (int j = 0; j < PB; ++j)
+        __builtin_amdgcn_global_load_lds((glb_void_t*)(bb + b_off[j]), (lds_void_t*)(st + A_OPND + (j * 4 + lw) * 1024), 16, 0, 0);
     };
     // everything but the youngest stage's loads has landed (loads return in order)
     auto landed = [&](bool younger_in_flight) {
@@ -568,17 +588,17 @@ __global__ __launch_bounds__(512, 2) void conv1d_wgrad_kmajor_kernel(WkArgs a) {
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     };
     issue(0, 0);
-    issue(1, 1);
-    landed(true);
+    if (NST == 3) issue(1, 1);
+    landed(NST == 3);
     wk_barrier();                                 // stage 0 visible to the MFMA waves
-    for (int base = 0; base < n_chunks; base += 3) {
+    for (int base = 0; base < n_chunks; base += NST) {
 #pragma unroll
-      for (int i = 0; i < 3; ++i) {               // static LDS stage
+      for (int i = 0; i < NST; ++i) {             // static LDS stage
         const int c = base + i;
         if (c < n_chunks) {
-          // stage (c + 2) % 3 was read during iteration c - 1, which every wave has left
-          if (c + 2 < n_chunks) issue(c + 2, (i + 2) % 3);
-          if (c + 1 < n_chunks) landed(c + 2 < n_chunks);
+          // stage (c + NST - 1) % NST was read during iteration c - 1, which every wave has left
+          if (c + NST - 1 < n_chunks) issue(c + NST - 1, (i + NST - 1) % NST);
+          if (c + 1 < n_chunks) landed(NST == 3 && c + 2 < n_chunks);
           wk_barrier();
         }
       }
@@ -592,7 +612,7 @@ __global__ __launch_bounds__(512, 2) void conv1d_wgrad_kmajor_kernel(WkArgs a) {
   const int mh = wave >> 1, nh = wave & 1;
   const int sw = (l31 >> 2) & 3;
   const int aoff = (mh * 64 + l31) * WK_ROWB;
-  const int boff = WK_OPND + (nh * 64 + l31) * WK_ROWB;
+  const int boff = A_OPND + (nh * 64 + l31) * WK_ROWB;
   int poff[WS_TT / 16];
 #pragma unroll
   for (int ks = 0; ks < WS_TT / 16; ++ks) poff[ks] = ((ks * 2 + kq) ^ sw) * 16;
@@ -605,12 +625,14 @@ __global__ __launch_bounds__(512, 2) void conv1d_wgrad_kmajor_kernel(WkArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
 
-  auto ld_frags = [&](const unsigned char* st, int ks, bf16x8 (&A)[2][3], bf16x8 (&Bf)[2][3]) {
+  auto ld_a = [&](const unsigned char* st, int ks, bf16x8 (&A)[2][3]) {
 #pragma unroll
     for (int p = 0; p < 3; ++p)
 #pragma unroll
       for (int m = 0; m < 2; ++m)
-        A[m][p] = *reinterpret_cast<const bf16x8*>(st + aoff + p * WK_PLANE + m * 32 * WK_ROWB + poff[ks]);
+        A[m][p] = *reinterpret_cast<const bf16x8*>(st + aoff + p * A_PLANE + m * 32 * WK_ROWB + poff[ks]);
+  };
+  auto ld_b = [&](const unsigned char* st, int ks, bf16x8 (&Bf)[2][3]) {
 #pragma unroll
     for (int p = 0; p < 3; ++p)
 #pragma unroll
@@ -619,17 +641,25 @@ __global__ __launch_bounds__(512, 2) void conv1d_wgrad_kmajor_kernel(WkArgs a) {
   };
 
   wk_barrier();   // stage 0 staged
-  bf16x8 A[2][2][3], Bf[2][2][3];
-  for (int base = 0; base < n_chunks; base += 3) {
+  // MT = 1: both operands' fragments are requested a step ahead (two register sets).  MT = 2 (three waves per SIMD: 168 registers):
+  // only the dy fragments are; the x fragments are requested at the start of their step and the sibling MFMA wave covers the wait.
+  constexpr int NBS = MT == 1 ? 2 : 1;
+  bf16x8 A[2][2][3], Bf[NBS][2][3];
+  for (int base = 0; base < n_chunks; base += NST) {
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
+    for (int i = 0; i < NST; ++i) {
       const int chunk = base + i;
       if (chunk < n_chunks) {
-        const unsigned char* st = sm + i * WK_STAGE;
-        ld_frags(st, 0, A[0], Bf[0]);
+        const unsigned char* st = sm + i * STAGE;
+        ld_a(st, 0, A[0]);
+        if (NBS == 2) ld_b(st, 0, Bf[0]);
 #pragma unroll
         for (int ks = 0; ks < WS_TT / 16; ++ks) {
-          if (ks + 1 < WS_TT / 16) ld_frags(st, ks + 1, A[(ks + 1) & 1], Bf[(ks + 1) & 1]);
+          if (NBS == 1) ld_b(st, ks, Bf[0]);
+          if (ks + 1 < WS_TT / 16) {
+            ld_a(st, ks + 1, A[(ks + 1) & 1]);
+            if (NBS == 2) ld_b(st, ks + 1, Bf[(ks + 1) & 1]);
+          }
           __builtin_amdgcn_sched_barrier(0);
           constexpr int TA[6] = {1, 2, 0, 1, 0, 0}, TB[6] = {1, 0, 2, 0, 1, 0};     // smallest terms first (see above)
 #pragma unroll
@@ -638,7 +668,7 @@ __global__ __launch_bounds__(512, 2) void conv1d_wgrad_kmajor_kernel(WkArgs a) {
             for (int m = 0; m < 2; ++m)
 #pragma unroll
               for (int n = 0; n < 2; ++n)
-                acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[ks & 1][m][TA[q]], Bf[ks & 1][n][TB[q]], acc[m][n], 0, 0, 0);
+                acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[ks & 1][m][TA[q]], Bf[NBS == 2 ? (ks & 1) : 0][n][TB[q]], acc[m][n], 0, 0, 0);
           __builtin_amdgcn_sched_barrier(0);
         }
         wk_barrier();
@@ -710,7 +740,9 @@ static int wk_geometry(int B, int C_in_real, int T_in, int C_out, int T_out, int
   a->b_plane_bytes = (long long)B * C_in_real * stride * a->UB * 2;
   if (3 * a->a_plane_bytes >= (1ll << 32) || 3 * a->b_plane_bytes >= (1ll << 32)) return -1;     // 32-bit per-lane offsets
   const long long tiles = (long long)B * a->n_tt;
-  const long long wgs = (long long)((C_out + 127) / 128) * ((a->NBk + 3) / 4);
+  static const bool wide_on = !(getenv("FAC_WGRAD_WIDE") && getenv("FAC_WGRAD_WIDE")[0] == '0');
+  a->MT = (wide_on && C_out > 128) ? 2 : 1;
+  const long long wgs = (long long)((C_out + 128 * a->MT - 1) / (128 * a->MT)) * ((a->NBk + 3) / 4);
   const long long per_split_bytes = (long long)C_out * a->NBk * 32 * 4;
   long long s_max = (2048 + wgs - 1) / wgs;
   if (s_max > tiles) s_max = tiles;
@@ -837,12 +869,15 @@ static int bwd_weight_split_impl(const float* x, const float* dy, float* dw, flo
                          pad_left, pad_mode, k.b_plane_bytes);
       static bool attr_set = false;
       if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv1d_wgrad_kmajor_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv1d_wgrad_kmajor_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv1d_wgrad_kmajor_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   160 * 1024);
         attr_set = true;
       }
-      dim3 grid((C_out + 127) / 128, (k.NBk + 3) / 4, S);
-      hipLaunchKernelGGL(conv1d_wgrad_kmajor_kernel, grid, dim3(512), (size_t)WK_NST * WK_STAGE, st, k);
+      dim3 grid((C_out + 128 * k.MT - 1) / (128 * k.MT), (k.NBk + 3) / 4, S);
+      if (k.MT == 2) hipLaunchKernelGGL(conv1d_wgrad_kmajor_kernel<2>, grid, dim3(768), (size_t)2 * (3 * 2 * WK_PLANE + WK_OPND), st, k);
+      else hipLaunchKernelGGL(conv1d_wgrad_kmajor_kernel<1>, grid, dim3(512), (size_t)WK_NST * WK_STAGE, st, k);
       const long long n = (long long)C_out * k.NBk * 32;
       const int blocks = (int)((n + 255) / 256 < 65535 ? (n + 255) / 256 : 65535);
       hipLaunchKernelGGL(wgrad_kmajor_reduce_kernel, dim3(blocks), dim3(256), 0, st, k.part, dw, S, C_out, k.NBk, k.K, k.CV);
