@@ -740,7 +740,10 @@ static int wk_geometry(int B, int C_in_real, int T_in, int C_out, int T_out, int
   a->b_plane_bytes = (long long)B * C_in_real * stride * a->UB * 2;
   if (3 * a->a_plane_bytes >= (1ll << 32) || 3 * a->b_plane_bytes >= (1ll << 32)) return -1;     // 32-bit per-lane offsets
   const long long tiles = (long long)B * a->n_tt;
-  static const bool wide_on = !(getenv("FAC_WGRAD_WIDE") && getenv("FAC_WGRAD_WIDE")[0] == '0');
+  // measured SLOWER than the 128-row tile on every layer (C = 512 k7: 145 vs 163 TFLOP/s-eq, LSTM W_ih: 121 vs 135,
+  // profiles/r04_wgrad_wide_tile.log): two LDS stages expose the DMA latency that three stages hide, and that outweighs the
+  // quarter fewer LDS writes per MFMA.  Opt-in (FAC_WGRAD_WIDE=1).
+  static const bool wide_on = getenv("FAC_WGRAD_WIDE") && getenv("FAC_WGRAD_WIDE")[0] == '1';
   a->MT = (wide_on && C_out > 128) ? 2 : 1;
   const long long wgs = (long long)((C_out + 128 * a->MT - 1) / (128 * a->MT)) * ((a->NBk + 3) / 4);
   const long long per_split_bytes = (long long)C_out * a->NBk * 32 * 4;
