@@ -52,7 +52,7 @@ def test_resident_slstm_against_oracle(B, H, T, O, ops, cuda):
     assert rel(yg, y) < 1e-5
 
 
-@pytest.mark.parametrize("B,H,T", [(16, 1536, 160), (16, 1024, 160), (24, 512, 33)])
+@pytest.mark.parametrize("B,H,T", [(16, 1536, 160), (16, 1024, 160), (24, 512, 33), (32, 1536, 160), (32, 1024, 40)])
 def test_resident_layer_matches_per_step_kernels(B, H, T, ops, cuda):
     """Forward (h sequence, saved gates / cell states) and BPTT (dgates) of one layer, resident vs per-step launch path."""
     g = _g(B + H)
