@@ -7,6 +7,7 @@ Reference counterparts: dac/model/encodec.py (SConv1d :192-228, SConvTranspose1d
 SLSTM :272-288, NormConv1d :125-139), dac/nn/layers.py (Snake1d :27-33, WNConv1d :9-10).
 """
 import math
+import os
 
 import torch
 from torch import nn
@@ -109,6 +110,10 @@ class _Norm(nn.Module):
         setattr(self, name, weights)
 
 
+# Short clips through the split GEMM kernel as one flattened signal (SConv1d._run_flat, SConvTranspose1d.run): inference only.
+FLAT_SHORT_CLIPS = os.environ.get("FAC_FLAT_SHORT", "1") != "0"
+
+
 class SConv1d(nn.Module):
     """Causal / asymmetric-padded Conv1d (dac/model/encodec.py:192-228).  State-dict keys:
     conv.conv.{weight_g,weight_v,bias} (norm='weight_norm') or conv.conv.{weight,bias}."""
@@ -138,10 +143,41 @@ class SConv1d(nn.Module):
         elif (self.stride > 1 and alpha_in is None and self.dilation == 1
               and ops.gemm_split_strided_ok(w.c_out, w.c_in, self.kernel_size, self.stride, x.shape[0], -(-x.shape[-1] // self.stride))):
             split = w.packed_split_strided(self.stride)     # downsampling conv: 2 taps over `stride` phase sub-signals
+        elif (FLAT_SHORT_CLIPS and self.stride > 1 and alpha_in is None and res is None and self.dilation == 1 and self.causal
+              and self.pad_mode == ops.PAD_REFLECT and self.kernel_size == 2 * self.stride and x.shape[-1] % self.stride == 0
+              and x.shape[-1] > self.stride and not torch.is_grad_enabled()
+              and ops.gemm_split_strided_ok(w.c_out, w.c_in, self.kernel_size, self.stride, 1,
+                                            x.shape[0] * (x.shape[-1] // self.stride + 1) - 1)):
+            return self._run_flat(x, alpha_out, act, alpha_y2, want_y)
         return ops.conv1d(x, w.packed() if split is None else None, w.c_out, self.kernel_size, bias=w.bias,
                           stride=self.stride, dilation=self.dilation, pad_mode=self.pad_mode, alpha_in=alpha_in,
                           alpha_out=alpha_out, res=res, act=act, causal=self.causal, alpha_y2=alpha_y2, want_y=want_y,
                           w_split=split)
+
+    def _run_flat(self, x, alpha_out, act, alpha_y2, want_y):
+        """Short clips (the 160-frame latent rate): per-clip column tiles would be half empty, so the split GEMM kernel refuses them
+        and the launch fell to the fp32 tile at ~72 TFLOP/s.  No new kernel is needed: every clip is reflect-padded on the left
+        by k - s = s samples (the causal padding of dac/model/encodec.py:212-222; T % s == 0, so there is no right padding) and
+        the padded clips are laid one after another as ONE signal of B (T / s + 1) s samples; the same strided conv without
+        padding then computes every real output exactly (output t of clip b is column b (T / s + 1) + t) plus one junk column
+        per clip where the window straddles two clips, which is dropped on the way back to (B, C, T / s)."""
+        w, s_ = self.w, self.stride
+        B, c_in, T = x.shape
+        n = T // s_
+        xp = torch.nn.functional.pad(x, (s_, 0), mode="reflect")                    # data movement only
+        xf = xp.permute(1, 0, 2).reshape(1, c_in, B * (n + 1) * s_)
+        t_out = B * (n + 1) - 1
+        got = ops.conv1d(xf, None, w.c_out, self.kernel_size, bias=w.bias, stride=s_, pad_left=0, pad_mode=ops.PAD_ZERO, t_out=t_out,
+                         alpha_out=alpha_out, act=act, alpha_y2=alpha_y2, want_y=want_y, w_split=w.packed_split_strided(s_))
+
+        def back(y):
+            if y is None:
+                return None
+            full = torch.empty(w.c_out, B * (n + 1), device=y.device, dtype=y.dtype)
+            full[:, :t_out] = y[0]
+            return full.reshape(w.c_out, B, n + 1)[:, :, :n].permute(1, 0, 2).contiguous()
+
+        return (back(got[0]), back(got[1])) if alpha_y2 is not None else back(got)
 
     def forward(self, x):
         return self.run(x)
@@ -166,6 +202,18 @@ class SConvTranspose1d(nn.Module):
         w = self.w
         if ops.convtr_split_ok(w.c_in, w.c_out, self.stride, x.shape[0], x.shape[-1], self.causal, alpha_in):
             wp = w.packed_rows_split()
+        elif (FLAT_SHORT_CLIPS and not torch.is_grad_enabled() and x.shape[-1] < 256
+              and ops.convtr_split_ok(w.c_in, w.c_out, self.stride, 1, x.shape[0] * (x.shape[-1] + 1), self.causal, alpha_in)):
+            # short clips: ONE signal of B (T + 1) columns with a zero column in front of every clip (the x[t - 1] of its first
+            # frame); the s output samples of that column are dropped on the way back (see SConv1d._run_flat)
+            B, c_in, T = x.shape
+            xf = torch.cat([torch.zeros(B, c_in, 1, device=x.device, dtype=x.dtype), x], -1).permute(1, 0, 2).reshape(1, c_in, B * (T + 1))
+            got = ops.conv_transpose1d(xf, w.packed_rows_split(), w.c_out, self.stride, bias=w.bias, alpha_y2=alpha_y2, causal=True)
+
+            def back(y):
+                return y.reshape(w.c_out, B, (T + 1) * self.stride)[:, :, self.stride:].permute(1, 0, 2).contiguous()
+
+            return (back(got[0]), back(got[1])) if alpha_y2 is not None else back(got)
         else:
             wp = w.packed_rows() if ops.convtr_rows_ok(x.shape[-1], self.stride, self.causal) else w.packed()
         return ops.conv_transpose1d(x, wp, w.c_out, self.stride, bias=w.bias, alpha_in=alpha_in,

@@ -608,6 +608,42 @@ def test_split_gemm_takes_p8_input_bit_identically(ops, cuda, kind, B, ci, co, T
     assert torch.equal(y_p8, y_ref)
 
 
+def test_short_clips_run_flattened_on_the_split_gemm(O, cuda, monkeypatch):
+    """The 160-frame layers (encoder's last downsampling conv 512 -> 1024 k 12 s 6, decoder's first ConvTranspose1d 1536 -> 768 s 6)
+    at B = 32: too short for per-clip column tiles, so they run as ONE flattened signal on the split GEMM kernel
+    (SConv1d._run_flat / SConvTranspose1d.run).  Same results as the oracle and as the per-clip launch (FAC_FLAT_SHORT=0 path)."""
+    from facodec_amd import layers, ops
+    B, T = 32, 960
+    conv = layers.SConv1d(64, 128, 12, stride=6, causal=True, norm="weight_norm")
+    tr = layers.SConvTranspose1d(128, 64, 12, stride=6, causal=True, norm="weight_norm")
+    sd_c, sd_t = synth.load_synthetic(conv, seed=31), synth.load_synthetic(tr, seed=32)
+    conv.to(cuda)
+    tr.to(cuda)
+    x = torch.randn(B, 64, T, generator=_g(33))
+    z = torch.randn(B, 128, T // 6, generator=_g(34))
+    a2 = 1 + 0.2 * torch.rand(128, generator=_g(35))
+    prof = ops.ConvLaunchProfile()
+    ops.set_conv_profile(prof)
+    try:
+        with torch.no_grad():
+            y, y2 = conv.run(x.to(cuda), alpha_y2=a2.to(cuda))
+            u = tr.run(z.to(cuda))
+            torch.cuda.synchronize()
+    finally:
+        ops.set_conv_profile(None)
+    assert all("gemm_split" in n for n in prof.summary()), prof.summary().keys()
+    y_ref = O.sconv1d(x, O.conv_weight(sd_c, "conv.conv."), sd_c["conv.conv.bias"], stride=6, causal=True)
+    al = a2.view(1, -1, 1)
+    assert y.shape == y_ref.shape and rel(y, y_ref) < OP_TOL and rel(y2, y_ref + torch.sin(al * y_ref) ** 2 / (al + 1e-9)) < OP_TOL
+    u_ref = O.sconvtr1d(z, O.weight_norm_weight(sd_t["convtr.convtr.weight_v"], sd_t["convtr.convtr.weight_g"]), sd_t["convtr.convtr.bias"], 6)
+    assert u.shape == u_ref.shape and rel(u, u_ref) < OP_TOL
+    monkeypatch.setattr(layers, "FLAT_SHORT_CLIPS", False)
+    with torch.no_grad():
+        y0 = conv.run(x.to(cuda))
+        u0 = tr.run(z.to(cuda))
+    assert rel(y, y0) < OP_TOL and rel(u, u0) < OP_TOL
+
+
 def test_spectral_losses_against_oracle(O, cuda):
     """MelSpectrogramLoss (train.py:155-163 arguments), MultiScaleSTFTLoss, L1Loss, reconstruction_loss on
     2 s clips; bar 1e-4 relative.  Third-party STFT/mel semantics restated on both sides: parity unpinned."""
