@@ -20,6 +20,7 @@ rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_WAVE_
 python $R/tools/pmc_mfma.py $(find $O/pmc_m -name "*counter_collection.csv" | head -1) $O/pmc_mfma_fwd.json bsplit gemm_split conv1d_pw lstm > /dev/null 2>&1
 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --kernel-trace --output-format csv -d $O/pmc_l -o l -- python $R/$CMD > $O/pmc_l.log 2>&1
 python $R/tools/pmc_mfma.py $(find $O/pmc_l -name "*counter_collection.csv" | head -1) $O/pmc_lds_fwd.json bsplit gemm_split conv1d_pw lstm > /dev/null 2>&1
+python $R/tests/tools/cpu_thread_sweep.py > $O/cpu_thread_sweep.log 2>&1
 rm -rf $O/pmc_f $O/pmc_w $O/pmc_m $O/pmc_l $O/kb $O/kt
 ls $O
 echo done
