@@ -112,6 +112,7 @@ class _Norm(nn.Module):
 
 # Short clips through the split GEMM kernel as one flattened signal (SConv1d._run_flat, SConvTranspose1d.run): inference only.
 FLAT_SHORT_CLIPS = os.environ.get("FAC_FLAT_SHORT", "1") != "0"
+PW_TAILS_TO_384 = os.environ.get("FAC_PW_TAILS_384", "1") != "0"
 
 
 class SConv1d(nn.Module):
@@ -138,7 +139,9 @@ class SConv1d(nn.Module):
                 and w.c_out > 2 and x.shape[0] * x.shape[-1] > 640 and (self.kernel_size == 7 or (w.c_in >= 64 and w.c_out > 32))):
             split = w.packed_split()
         elif (self.kernel_size == 1 and self.stride == 1 and alpha_in is None
-              and ops.gemm_split_ok(w.c_out, w.c_in, 1, x.shape[0] * x.shape[-1])):
+              and ops.gemm_split_ok(w.c_out, w.c_in, 1, x.shape[0] * x.shape[-1])
+              and not (PW_TAILS_TO_384 and w.c_in == w.c_out and w.c_in in (256, 384) and x.shape[0] * x.shape[-1] >= 65536)):
+            # (the C = 256 / 384 ResidualUnit tails stay on the streaming k = 1 kernel: -0.7 ms per B = 32 forward, round 4)
             split = w.packed_split()          # 1x1 with many channels: split-bf16 GEMM (conv1d_gemm_split.hip)
         elif (self.stride > 1 and alpha_in is None and self.dilation == 1
               and ops.gemm_split_strided_ok(w.c_out, w.c_in, self.kernel_size, self.stride, x.shape[0], -(-x.shape[-1] // self.stride))):
