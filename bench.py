@@ -23,6 +23,7 @@ import os
 import socket
 import subprocess
 import sys
+import threading
 import time
 
 import torch
@@ -262,7 +263,7 @@ def respawn_under_launcher(n):
     raise SystemExit(subprocess.run(cmd, env=env).returncode)
 
 
-def cpu_baseline(batch=4, passes=5, warmups=2, with_train=True):
+def cpu_baseline(batch=4, passes=5, warmups=2, with_train=True, threads=None):
     """The CPU oracle (port of the reference algorithm, pinned to it by tests/golden) timed on this host's cores over a
     bounded sample of the same workload (B = 4 clips of 2 s, median of 5 passes after 2 warm-ups).
     `value` = (A) the eval forward; `train` = (B) the train-mode iteration (forward + backward of encoder / quantizer /
@@ -283,7 +284,7 @@ def cpu_baseline(batch=4, passes=5, warmups=2, with_train=True):
     # thread sweep on the GPU box's host (tests/tools/cpu_thread_sweep.py, output in profiles/r04_cpu_thread_sweep.log):
     # 16 threads is the oracle's best case on the 256-logical-core host, so that is the baseline
     prev_threads = torch.get_num_threads()
-    threads = min(16, os.cpu_count() or 1)
+    threads = min(threads or 16, os.cpu_count() or 1)
     torch.set_num_threads(threads)
     times = []
     with torch.no_grad():
@@ -413,16 +414,6 @@ def main():
     if rank == 0 and world == 1 and not args.no_streaming:
         streaming = streaming_leg(model, device, args.stream_hops)
 
-    train = None
-    if not args.no_train:
-        del step
-        train = train_leg(model, device, rank, world, args.train_steps, args.train_warmup)
-
-    if rank != 0:
-        if torch.distributed.is_initialized():
-            torch.distributed.destroy_process_group()
-        return
-
     out = {
         "metric": "24kHz audio sec encoded+decoded per wall-sec",
         "value": round(value, 2), "unit": "audio-s/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -468,6 +459,32 @@ def main():
                     "The bf16 pipe sustains 1913 TFLOP/s on random operands on this part (tools/microbench), so the practical ceiling of the "
                     "split kernels is ~319 fp32-equivalent TFLOP/s.",
         }
+    # The forward line above is complete at this point.  The train leg runs collectives from gradient hooks; on more than one GPU
+    # that path has only ever run under gloo and one-rank RCCL, so a watchdog makes sure a stall there cannot take the forward
+    # measurement with it: on expiry rank 0 prints the line with the failure recorded and every rank leaves.
+    train = None
+    if not args.no_train:
+        del step
+        limit = float(os.environ.get("FAC_TRAIN_LEG_TIMEOUT", "420"))
+
+        def expired():
+            if rank == 0:
+                out["train_step"] = {"error": f"train leg did not finish within {limit:.0f} s on {world} GPU(s); forward line unaffected"}
+                print(json.dumps(out), flush=True)
+            os._exit(0)
+
+        dog = threading.Timer(limit, expired)
+        dog.daemon = True
+        dog.start()
+        try:
+            train = train_leg(model, device, rank, world, args.train_steps, args.train_warmup)
+        finally:
+            dog.cancel()
+
+    if rank != 0:
+        if torch.distributed.is_initialized():
+            torch.distributed.destroy_process_group()
+        return
     if train is not None:
         out["train_step"] = train
     if streaming is not None:
