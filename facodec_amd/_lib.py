@@ -74,6 +74,9 @@ SIGNATURES = {
     "fac_pack_lstm_whh16": (_i, [_p, _p, _i, _i, _p]),
     "fac_lstm_layer_fwd_persist": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "fac_lstm_layer_bwd_persist": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
+    "fac_lstm_persist_split_ok": (_i, [_i, _i]),
+    "fac_pack_lstm_whh_split": (_i, [_p, _p, _i, _p]),
+    "fac_lstm_layer_fwd_persist_split": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "fac_snake_bwd_fused": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
     "fac_bias_grad": (_i, [_p, _p, _p, _i, _i, _i, _p]),
     "fac_pack_convtr_w": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),

@@ -280,6 +280,202 @@ __global__ __launch_bounds__(1024) void lstm_fwd_persist_kernel(const float* __r
   leave_launch(sync, base, (unsigned)T, (unsigned)nwg);
 }
 
+// ------------------------------------------------------------------------------------------ forward, bf16 x 3 operands
+// The same resident recurrence with W_hh . h on the bf16 matrix pipe, fp32-exact in the sense of conv1d_bsplit.hip: every
+// weight and every state value is the sum of three round-to-nearest bf16 terms, six of the nine cross products are kept,
+// accumulation in fp32.  At 32 batch columns the fp32 kernel above is bound by its v_mfma_f32_16x16x4_f32 time (32 x 32 x H
+// MACs per workgroup and step at 128 MAC / clk: 5.1 us at H = 1536); six v_mfma_f32_32x32x16_bf16 per 16 k do the same
+// product in 2.2 us.
+//   grid      H/8 workgroups of 512 threads (2 waves per SIMD: up to 256 VGPRs each); workgroup ub owns units ub*8 .. +8
+//   weights   wave w contracts k in [w*H/8, (w+1)*H/8) in NK = H/128 MFMA steps; its A fragments (rows = gate*8 + unit,
+//             3 planes) stay in 12*NK VGPRs for the whole sequence (144 at H = 1536): fac_pack_lstm_whh_split
+//   state     h_t crosses the device ALREADY split, in B-fragment order: hs[t][plane][k/16][lane] 16-byte pieces, lane =
+//             32*((k%16)/8) + column, piece = 8 consecutive k.  The 8 units of a workgroup are exactly one piece per column:
+//             per plane it writes 32 lanes x 16 B = 512 contiguous bytes = four whole 128-byte lines of a FRESH region per
+//             step that nobody else writes (exchange mode 2 above; the only mode of this kernel), by write-through stores.
+//             Consumers read their 3*NK pieces per lane with plain 16-byte loads through a 4-step register window.
+typedef __bf16 ls_bf16x8 __attribute__((ext_vector_type(8)));
+typedef float ls_f32x16 __attribute__((ext_vector_type(16)));
+constexpr int LS_NW = 8;
+
+__device__ __forceinline__ void ls_split3(float x, __bf16& h, __bf16& m, __bf16& l) {
+  h = (__bf16)x;
+  const float r1 = x - (float)h;
+  m = (__bf16)r1;
+  l = (__bf16)(r1 - (float)m);
+}
+
+// 16-byte piece at (uniform base, lane offset): request only; the value is valid behind ls_wait_pieces
+__device__ __forceinline__ ls_bf16x8 ls_load_piece(const ls_bf16x8* base, unsigned lane_off) {
+  ls_bf16x8 v;
+  asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(v) : "v"(lane_off), "s"(base) : "memory");
+  return v;
+}
+__device__ __forceinline__ void ls_wait_pieces(ls_bf16x8 (&d)[3], int behind) {
+  switch (behind) {   // constant after unrolling
+    case 0: asm volatile("s_waitcnt vmcnt(0)" : "+v"(d[0]), "+v"(d[1]), "+v"(d[2])::"memory"); break;
+    case 3: asm volatile("s_waitcnt vmcnt(3)" : "+v"(d[0]), "+v"(d[1]), "+v"(d[2])::"memory"); break;
+    case 6: asm volatile("s_waitcnt vmcnt(6)" : "+v"(d[0]), "+v"(d[1]), "+v"(d[2])::"memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(9)" : "+v"(d[0]), "+v"(d[1]), "+v"(d[2])::"memory"); break;
+  }
+}
+
+// W_hh (4H, H) -> packed[((ub*8 + w)*NK + s)*3 + plane][lane]: A fragment of step s of wave w (lane: row l%32 = gate*8 + unit,
+// k = (w*NK + s)*16 + 8*(l/32) .. +8)
+__global__ __launch_bounds__(256) void pack_whh_split_kernel(const float* __restrict__ w, ls_bf16x8* __restrict__ out, int H) {
+  const int NK = H / (16 * LS_NW);
+  const long long n = (long long)(H / 8) * LS_NW * NK * 64;
+  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < n; idx += (long long)gridDim.x * 256) {
+    const int lane = (int)(idx & 63);
+    long long r = idx >> 6;
+    const int s = (int)(r % NK);
+    r /= NK;
+    const int wv = (int)(r % LS_NW);
+    const int ub = (int)(r / LS_NW);
+    const int l31 = lane & 31, kq = lane >> 5;
+    const int row = (l31 >> 3) * H + ub * 8 + (l31 & 7);
+    const int k0 = (wv * NK + s) * 16 + 8 * kq;
+    ls_bf16x8 ph, pm, pl;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      __bf16 a, b, c;
+      ls_split3(w[(long long)row * H + k0 + i], a, b, c);
+      ph[i] = a; pm[i] = b; pl[i] = c;
+    }
+    const long long o = (r * NK + s) * 3;      // r = ub*8 + wv
+    out[(o + 0) * 64 + lane] = ph;
+    out[(o + 1) * 64 + lane] = pm;
+    out[(o + 2) * 64 + lane] = pl;
+  }
+}
+
+template <int NK>
+__global__ __launch_bounds__(LS_NW * 64) void lstm_fwd_persist_split_kernel(const float* __restrict__ pre,          // (4H, T, BP)
+                                                                           const ls_bf16x8* __restrict__ wsplit,   // pack_whh_split_kernel
+                                                                           ls_bf16x8* hs,                          // T x 3 x H/16 x 64 pieces
+                                                                           float* __restrict__ yT,                 // (H, T, BP)
+                                                                           int slot, int T, int H, int BP) {
+  constexpr int WIN = NK < 4 ? NK : 4;
+  __shared__ float red[LS_NW][32][33];
+  __shared__ __attribute__((aligned(16))) __bf16 piece[3][32][8];
+  __shared__ unsigned s_base;
+  LstmSync* sync = &g_lstm_sync[slot];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, kq = lane >> 5;
+  const unsigned lane16 = (unsigned)lane << 4;
+  const int ub = blockIdx.x, nwg = gridDim.x;
+  const long long rs = (long long)T * BP;
+  const int nS = H >> 4;                         // 16-k steps of the whole contraction
+  const long long hregion = 3ll * nS * 64;       // pieces per time step
+
+  ls_bf16x8 W[NK][3];
+  {
+    const ls_bf16x8* wp = wsplit + ((long long)(ub * LS_NW + wave) * NK * 3) * 64 + lane;
+#pragma unroll
+    for (int s = 0; s < NK; ++s)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) W[s][p] = wp[(long long)(s * 3 + p) * 64];
+  }
+  const unsigned base = launch_epoch(sync, &s_base);
+
+  const bool gate_thread = tid < 256;            // (unit u, column col) of the 8 x 32 outputs of a step
+  const int u = tid >> 5, col = tid & 31;
+  const int unit = ub * 8 + u;
+  float pre_v[4] = {0.f, 0.f, 0.f, 0.f};
+  float c_reg = 0.f;
+  if (gate_thread) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) pre_v[q] = pre[(long long)(q * H + unit) * rs + col];
+  }
+  // the three pieces of this workgroup per column: threads 0 .. 95 = (plane, column)
+  const int sp = tid >> 5, sc = tid & 31;
+  const long long spos = ((long long)sp * nS + (ub >> 1)) * 64 + 32 * (ub & 1) + sc;
+
+  for (int t = 0; t < T; ++t) {
+    float gate[4] = {pre_v[0], pre_v[1], pre_v[2], pre_v[3]};
+    if (t > 0) {
+      wait_flags(sync->flags, 0, nwg, base + (unsigned)t, 2);   // every workgroup has published h_{t-1}
+      {
+        // The pieces of step s are requested WIN steps ahead.  hipcc sinks plain loads down to their first use (one memory round
+        // trip per step), so the loads and their waits are explicit: in-order return, s_waitcnt vmcnt(n) with n = the loads issued
+        // behind the ones needed (tools/check_inflight_regs.py replays the queue on the ISA: tests/test_isa_inflight.py).
+        const ls_bf16x8* hp;                                                                       // uniform: scalar base
+        {
+          const unsigned long long a = reinterpret_cast<unsigned long long>(hs + (long long)(t - 1) * hregion + (long long)(wave * NK) * 64);
+          const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+          hp = reinterpret_cast<const ls_bf16x8*>(((unsigned long long)hi << 32) | lo);
+        }
+        ls_bf16x8 hb[WIN][3];
+        ls_f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < WIN; ++s)
+#pragma unroll
+          for (int p = 0; p < 3; ++p) hb[s][p] = ls_load_piece(hp + ((long long)p * nS + s) * 64, lane16);
+        // smallest terms first, as in conv1d_bsplit.hip: mid*mid, lo*hi, hi*lo, mid*hi, hi*mid, hi*hi
+        constexpr int TA[6] = {1, 2, 0, 1, 0, 0}, TB[6] = {1, 0, 2, 0, 1, 0};
+#pragma unroll
+        for (int s = 0; s < NK; ++s) {
+          constexpr int AHEAD = WIN - 1;
+          ls_wait_pieces(hb[s % WIN], 3 * (NK - 1 - s < AHEAD ? NK - 1 - s : AHEAD));
+#pragma unroll
+          for (int q = 0; q < 6; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W[s][TA[q]], hb[s % WIN][TB[q]], acc, 0, 0, 0);
+          if (s + WIN < NK) {
+#pragma unroll
+            for (int p = 0; p < 3; ++p) hb[s % WIN][p] = ls_load_piece(hp + ((long long)p * nS + s + WIN) * 64, lane16);
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[wave][(r & 3) + 8 * (r >> 2) + 4 * kq][l31] = acc[r];
+      }
+      __syncthreads();
+      if (gate_thread) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float sum = 0.f;
+#pragma unroll
+          for (int w = 0; w < LS_NW; ++w) sum += red[w][q * 8 + u][col];
+          gate[q] += sum;
+        }
+      }
+    }
+    float hv = 0.f;
+    if (gate_thread) {
+      const float ig = sigmoid_f(gate[0]);
+      const float fg = sigmoid_f(gate[1]);
+      const float gg = tanhf(gate[2]);
+      const float og = sigmoid_f(gate[3]);
+      const float c_new = __fadd_rn(__fmul_rn(fg, c_reg), __fmul_rn(ig, gg));
+      c_reg = c_new;
+      hv = __fmul_rn(og, tanhf(c_new));
+      if (t + 1 < T) {
+        __bf16 a, b, c;
+        ls_split3(hv, a, b, c);
+        piece[0][col][u] = a;
+        piece[1][col][u] = b;
+        piece[2][col][u] = c;
+      }
+    }
+    if (t + 1 < T) {
+      __syncthreads();
+      if (tid < 96) {    // first: the write-through of the pieces is the critical path
+        const ls_bf16x8 v = *reinterpret_cast<const ls_bf16x8*>(&piece[sp][sc][0]);
+        asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(hs + (long long)t * hregion + spos), "v"(v) : "memory");
+      }
+    }
+    if (gate_thread) yT[(long long)unit * rs + (long long)t * BP + col] = hv;
+    if (t + 1 < T) {
+      publish_flag(sync->flags + ub, base + (unsigned)t + 1u, 128, 2);
+      if (gate_thread) {      // next step's gate pre-activations arrive while the flags are polled
+#pragma unroll
+        for (int q = 0; q < 4; ++q) pre_v[q] = pre[(long long)(q * H + unit) * rs + (long long)(t + 1) * BP + col];
+      }
+    }
+  }
+  leave_launch(sync, base, (unsigned)T, (unsigned)nwg);
+}
+
 // --------------------------------------------------------------------------------------------------------- backward
 // grid = H/8 workgroups: workgroup (ub, q) = blockIdx.x / 4, blockIdx.x % 4 computes, for the 32 hidden units
 // ub*32 .. +32, the quarter-q part of  W_hh^T dgates_{t+1}  (contraction over the H gate rows q*H .. q*H+H) and then
@@ -438,9 +634,9 @@ static int device_cus() {
 //    own launches are ordered by the graph, and replaying such a graph next to other resident launches is the caller's to order.
 //  Several PROCESSES sharing one device cannot be ordered from here: facodec_amd.ops.lstm_persist_ok refuses the resident path
 //  when ranks share a device.
-static bool grid_fits(const void* kern, int grid) {
+static bool grid_fits(const void* kern, int grid, int threads = 1024) {
   int per_cu = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 1024, 0) != hipSuccess) return false;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, threads, 0) != hipSuccess) return false;
   return (long long)per_cu * device_cus() >= grid;
 }
 
@@ -484,7 +680,48 @@ static bool persist_shape_ok(int H, int B) {
   return wgs <= LSTM_MAX_WG && wgs <= device_cus();
 }
 
+static bool persist_split_shape_ok(int H, int B) {
+  if (B <= 0 || B > 32 || (H != 512 && H != 1024 && H != 1536)) return false;
+  const int wgs = H / 8;
+  return wgs <= LSTM_MAX_WG && wgs <= device_cus();
+}
+
 }  // namespace fac
+
+extern "C" int fac_lstm_persist_split_ok(int H, int B) { return fac::persist_split_shape_ok(H, B) ? 1 : 0; }
+
+extern "C" int fac_pack_lstm_whh_split(const float* w_hh, void* packed, int H, fac_stream_t stream) {
+  using namespace fac;
+  FAC_REQUIRE(w_hh && packed && H > 0 && H % 128 == 0, "pack_lstm_whh_split: H must be a multiple of 128");
+  hipLaunchKernelGGL(pack_whh_split_kernel, dim3(2048), dim3(256), 0, (hipStream_t)stream, w_hh, reinterpret_cast<ls_bf16x8*>(packed), H);
+  return check_launch("pack_lstm_whh_split");
+}
+
+extern "C" int fac_lstm_layer_fwd_persist_split(const float* pre, const void* wsplit, void* hsplit, float* yT, int T, int H, int B, int BP,
+                                                fac_stream_t stream) {
+  using namespace fac;
+  FAC_REQUIRE(pre && wsplit && hsplit && yT, "lstm_layer_fwd_persist_split: null pointer");
+  FAC_REQUIRE(T > 0 && BP >= 32 && BP >= B && BP % 32 == 0, "lstm_layer_fwd_persist_split: bad T / BP");
+  FAC_REQUIRE(persist_split_shape_ok(H, B), "lstm_layer_fwd_persist_split: H=%d B=%d is outside the kernel (fac_lstm_persist_split_ok)", H, B);
+  const int slot = lstm_sync_slot((hipStream_t)stream);
+  FAC_REQUIRE(slot >= 0, "lstm_layer_fwd_persist_split: more than %d streams in use", LSTM_SYNC_SLOTS);
+  void (*kern)(const float*, const ls_bf16x8*, ls_bf16x8*, float*, int, int, int, int) = nullptr;
+  switch (H) {
+    case 512: kern = lstm_fwd_persist_split_kernel<4>; break;
+    case 1024: kern = lstm_fwd_persist_split_kernel<8>; break;
+    case 1536: kern = lstm_fwd_persist_split_kernel<12>; break;
+  }
+  FAC_REQUIRE(kern != nullptr, "lstm_layer_fwd_persist_split: no kernel for H=%d", H);
+  FAC_REQUIRE(grid_fits(reinterpret_cast<const void*>(kern), H / 8, LS_NW * 64),
+              "lstm_layer_fwd_persist_split: %d workgroups are not co-resident on this device", H / 8);
+  order_resident_launch((hipStream_t)stream, true);
+  hipLaunchKernelGGL(kern, dim3(H / 8), dim3(LS_NW * 64), 0, (hipStream_t)stream, pre, reinterpret_cast<const ls_bf16x8*>(wsplit),
+                     reinterpret_cast<ls_bf16x8*>(hsplit), yT, slot, T, H, BP);
+  const int rc = check_launch("lstm_layer_fwd_persist_split");
+  order_resident_launch((hipStream_t)stream, false);
+  return rc;
+}
+
 
 extern "C" int fac_lstm_persist_ok(int H, int B) { return fac::persist_shape_ok(H, B) ? 1 : 0; }
 

@@ -632,6 +632,42 @@ def lstm_persist_ok(H, batch):
             and bool(_lib.load().fac_lstm_persist_stream_ok(_stream())))
 
 
+LSTM_PERSIST_SPLIT = os.environ.get("FAC_LSTM_PERSIST_SPLIT", "1") != "0"
+LSTM_PERSIST_SPLIT_MIN_BATCH = int(os.environ.get("FAC_LSTM_PERSIST_SPLIT_MIN_BATCH", "17"))
+
+
+def lstm_persist_split_ok(H, batch):
+    """True when an inference layer runs on the resident kernel with bf16 x 3 operands (lstm_persist.hip,
+    fac_lstm_layer_fwd_persist_split): 17 .. 32 batch columns, where the fp32 resident kernel is bound by its fp32 MFMA time and
+    the per-step kernel by re-streaming W_hh.  Follows FAC_BF16_SPLIT like the conv kernels of the same arithmetic."""
+    return (LSTM_PERSIST and LSTM_PERSIST_SPLIT and BF16_SPLIT and batch is not None
+            and LSTM_PERSIST_SPLIT_MIN_BATCH <= batch <= 32 and not _ranks_share_a_device()
+            and bool(_lib.load().fac_lstm_persist_split_ok(int(H), int(batch)))
+            and bool(_lib.load().fac_lstm_persist_stream_ok(_stream())))
+
+
+def pack_lstm_whh_split(w_hh):
+    """W_hh (4H, H) as the three-plane bf16 A fragments of the split resident kernel (fac_pack_lstm_whh_split)."""
+    w_hh = _dev(w_hh, "weight_hh")
+    out = torch.empty(w_hh.numel() * 6, device=w_hh.device, dtype=torch.uint8)
+    _lib.check(_lib.load().fac_pack_lstm_whh_split(_ptr(w_hh), _ptr(out), w_hh.shape[1], _stream()), "fac_pack_lstm_whh_split")
+    return out
+
+
+def lstm_layer_persist_split(pre, w_hh, H, batch):
+    """The whole inference layer in ONE launch on the bf16 matrix pipe: pre (4H, T, BP), raw W_hh (4H, H) -> yT (H, T, BP)."""
+    _, T, BP = pre.shape
+    if _FLOPS is not None:
+        _FLOPS.add("lstm", 2.0 * 4 * H * H * T * BP)
+    yT = torch.empty(H, T, BP, device=pre.device, dtype=torch.float32)
+    if BP > 32:
+        yT[..., 32:].zero_()
+    hsplit = torch.empty(T * H * 32 * 6, device=pre.device, dtype=torch.uint8)       # one fresh exchange region per step
+    _lib.check(_lib.load().fac_lstm_layer_fwd_persist_split(_ptr(pre), _ptr(pack_lstm_whh_split(w_hh)), _ptr(hsplit), _ptr(yT),
+                                                            T, H, batch, BP, _stream()), "fac_lstm_layer_fwd_persist_split")
+    return yT
+
+
 def _ranks_share_a_device():
     """The resident LSTM grids of two PROCESSES on one GPU could each hold part of the CUs and spin on workgroups that never get
     one (launches are only serialised inside a process, lstm_persist.hip): with more local ranks than visible devices (the

@@ -263,6 +263,17 @@ int fac_lstm_layer_fwd_persist(const float* pre, const float* whh16, float* hfra
                                int T, int H, int B, int BP, fac_stream_t stream);
 int fac_lstm_layer_bwd_persist(const float* dyT, const float* whh16t, const float* gates, const float* cs, float* dgates,
                                float* scratch, int T, int H, int B, int BP, fac_stream_t stream);
+/* Forward recurrence of a layer in one launch with W_hh . h on the bf16 matrix pipe (fp32-exact three-way bf16 split of both
+ * operands, six products, fp32 accumulation -- the arithmetic of the k = 7 conv kernel): what the fp32 resident kernel cannot do
+ * at 17 .. 32 batch columns, where its step is its fp32 MFMA time.  Inference only (no saved gates).  fac_lstm_persist_split_ok(H, B)
+ * != 0 for H in {512, 1024, 1536}, B <= 32, H/8 <= CUs.  wsplit: fac_pack_lstm_whh_split(W_hh (4H, H), out (4H*H*6 bytes), H);
+ * hsplit: T * H * 32 * 6 bytes of scratch (h_t crosses the device as three bf16 planes in MFMA B-fragment order, one fresh region
+ * per step); all 32 columns of yT (H, T, BP) are computed.  Same stream / co-residency rules as the fp32 resident kernels.
+ * Replaces the per-step launches of dac/model/encodec.py:272-288 at the benchmark batch. */
+int fac_lstm_persist_split_ok(int H, int B);
+int fac_pack_lstm_whh_split(const float* w_hh, void* packed, int H, fac_stream_t stream);
+int fac_lstm_layer_fwd_persist_split(const float* pre, const void* wsplit, void* hsplit, float* yT, int T, int H, int B, int BP,
+                                     fac_stream_t stream);
 /* dx = dy * (1 - y^2) */
 int fac_tanh_bwd(const float* y, const float* dy, float* dx, int64_t n, fac_stream_t stream);
 /* Backward of the spectral losses w.r.t. the estimate: da (+)= scale * d|a - b|/da (mode 0) or

@@ -26,3 +26,20 @@ def test_named_landing_registers_are_left_alone(src, n_kernels):
     # the 32 / 48-channel shape of the k = 7 kernel spill 443)
     spills = C.spill_counts(asm)
     assert spills and max(spills.values()) <= 32, spills
+
+
+@pytest.mark.skipif(not (os.path.exists("/opt/rocm/bin/hipcc") or shutil.which("hipcc")), reason="needs hipcc")
+def test_split_resident_lstm_keeps_its_state_pieces_in_flight_safely():
+    """lstm_fwd_persist_split_kernel requests the h pieces of four MFMA steps ahead with inline-asm loads into compiler-allocated
+    registers.  The code between request and `s_waitcnt` is straight-line, so the dataflow replay of the vmcnt queue is exact there:
+    no instruction may touch a destination register before the wait that covers it; and the 12-step kernel (144 weight registers)
+    must not spill."""
+    import check_inflight_regs as C
+    asm = C.compile_to_asm(os.path.join(REPO, "facodec_amd", "csrc", "lstm_persist.hip"))
+    report, bad = C.check(asm)
+    split = {k: v for k, v in report.items() if "lstm_fwd_persist_split_kernel" in k}
+    assert len(split) == 3, sorted(report)
+    assert sorted(v["asm_loads"] >= n for v, n in zip(sorted(split.values(), key=lambda v: v["asm_loads"]), (12, 24, 36))) == [True] * 3   # 3 planes x NK steps
+    assert not [b for b in bad if "lstm_fwd_persist_split_kernel" in b[0]], bad[:5]
+    spills = C.spill_counts(asm)
+    assert all(n == 0 for k, n in spills.items() if "lstm_fwd_persist_split_kernel" in k), spills

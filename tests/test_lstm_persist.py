@@ -27,10 +27,18 @@ def cuda():
 @pytest.fixture(scope="module")
 def ops():
     from facodec_amd import ops
-    old = ops.LSTM_PERSIST_MAX_BATCH
+    old, old_split = ops.LSTM_PERSIST_MAX_BATCH, ops.LSTM_PERSIST_SPLIT
     ops.LSTM_PERSIST_MAX_BATCH = 32        # the policy stops at 16 columns; the kernels are held to parity up to 32
+    ops.LSTM_PERSIST_SPLIT = False         # ... and 17 .. 32 columns go to the bf16 x 3 kernel, which has its own tests below
     yield ops
-    ops.LSTM_PERSIST_MAX_BATCH = old
+    ops.LSTM_PERSIST_MAX_BATCH, ops.LSTM_PERSIST_SPLIT = old, old_split
+
+
+@pytest.fixture
+def split_ops(ops):
+    ops.LSTM_PERSIST_SPLIT = True
+    yield ops
+    ops.LSTM_PERSIST_SPLIT = False
 
 
 @pytest.fixture(scope="module")
@@ -132,3 +140,69 @@ def test_slstm_training_step_resident_vs_per_step(ops, cuda):
     assert rel(ya, yb) < 2e-6 and rel(dxa, dxb) < 1e-5
     for n in ga:
         assert rel(ga[n], gb[n]) < 1e-5, n
+
+
+# ------------------------------------------------------------------ resident forward with bf16 x 3 operands (17 .. 32 columns)
+@pytest.mark.parametrize("B,H,T", [(32, 1536, 160), (32, 1024, 160), (20, 512, 33), (17, 1024, 5), (32, 1536, 1), (32, 512, 2)])
+def test_split_resident_layer_matches_per_step_kernels(B, H, T, split_ops, cuda):
+    """fac_lstm_layer_fwd_persist_split (W_hh . h as six bf16 products of exactly split operands, fp32 accumulation) against the
+    per-step fp32-MFMA kernel on the same layer: fp32-grade agreement over the whole sequence, twice the same bits."""
+    ops = split_ops
+    assert ops.lstm_persist_split_ok(H, B), "the split resident kernel must be the one that runs here"
+    g = _g(B + H + T)
+    pre = torch.zeros(4 * H, T, 32)
+    pre[:, :, :B] = torch.randn(4 * H, T, B, generator=g)
+    w_hh = (torch.rand(4 * H, H, generator=g) * 2 - 1) / H ** 0.5
+    pre, w_hh = pre.to(cuda), w_hh.to(cuda)
+    ya = ops.lstm_layer_persist_split(pre, w_hh, H, B)
+    yb = ops.lstm_layer(pre, ops.pack_lstm_whh(w_hh), H)
+    assert torch.isfinite(ya).all()
+    assert rel(ya[:, :, :B], yb[:, :, :B]) < 1e-5
+    assert torch.equal(ops.lstm_layer_persist_split(pre, w_hh, H, B), ya)
+    # against float64 on the host, beside the fp32 kernel's own error (the bar of the split conv kernels)
+    if T <= 33:
+        w64, p64 = w_hh.double().cpu(), pre.double().cpu()
+        h, c, out = torch.zeros(H, 32, dtype=torch.float64), torch.zeros(H, 32, dtype=torch.float64), []
+        for t in range(T):
+            gts = p64[:, t] + w64 @ h
+            i, f, gg, o = gts[:H].sigmoid(), gts[H:2 * H].sigmoid(), gts[2 * H:3 * H].tanh(), gts[3 * H:].sigmoid()
+            c = f * c + i * gg
+            h = o * c.tanh()
+            out.append(h)
+        ref = torch.stack(out, 1)
+        e_split, e_fp32 = rel(ya[:, :, :B], ref[:, :, :B]), rel(yb[:, :, :B], ref[:, :, :B])
+        assert e_split < 1.5 * e_fp32 + 1e-7, (e_split, e_fp32)
+
+
+@pytest.mark.parametrize("B,H,T", [(32, 1024, 7), (17, 512, 9), (24, 1536, 12)])
+def test_split_resident_slstm_against_oracle(B, H, T, O, split_ops, cuda):
+    from facodec_amd.layers import SLSTM
+    assert split_ops.lstm_persist_split_ok(H, B)
+    m = SLSTM(H, 2)
+    sd = synth.load_synthetic(m, seed=5)
+    x = torch.randn(B, H, T, generator=_g(H + T))
+    y = O.slstm(x, sd, "lstm.", 2)
+    with torch.no_grad():
+        yg = m.to(cuda)(x.to(cuda))
+    assert rel(yg, y) < 1e-5
+
+
+def test_split_resident_layer_replays_in_a_graph(split_ops, cuda):
+    ops = split_ops
+    B, H, T = 32, 512, 20
+    g = _g(4)
+    pre = torch.randn(4 * H, T, 32, generator=g).to(cuda)
+    w_hh = ((torch.rand(4 * H, H, generator=g) * 2 - 1) / H ** 0.5).to(cuda)
+    ref = ops.lstm_layer_persist_split(pre, w_hh, H, B).clone()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        ops.lstm_layer_persist_split(pre, w_hh, H, B)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=s):
+            out = ops.lstm_layer_persist_split(pre, w_hh, H, B)
+            out2 = ops.lstm_layer_persist(pre[:, :, :32].contiguous(), w_hh, H, 16)     # an fp32 resident launch behind it
+    for _ in range(3):
+        graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref) and torch.isfinite(out2).all()
