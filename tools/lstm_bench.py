@@ -1,4 +1,5 @@
-"""Times one SLSTM layer's recurrence and BPTT: resident kernels (lstm_persist.hip) vs one launch per step (lstm.hip)."""
+"""Times one SLSTM layer's recurrence and BPTT: resident kernels (lstm_persist.hip; fp32, and bf16 x 3 for 17 .. 32 columns) vs one
+launch per step (lstm.hip).  FAC_LSTM_PERSIST_MAX_BATCH=32 times the fp32 resident kernel at 32 columns too."""
 import json
 import sys
 
@@ -41,6 +42,11 @@ def main():
             row["bwd_resident_ms"] = timed(lambda: ops.lstm_layer_bwd(d_out, w, gates, cs, H, batch=B))
             row["fwd_resident_us_per_step"] = 1e3 * row["fwd_resident_ms"] / T
             row["bwd_resident_us_per_step"] = 1e3 * row["bwd_resident_ms"] / T
+        if ops.lstm_persist_split_ok(H, B):
+            row["fwd_infer_per_step_ms"] = timed(lambda: ops.lstm_layer(pre, whh, H))
+            row["fwd_split_resident_ms"] = timed(lambda: ops.lstm_layer_persist_split(pre, w, H, B))
+            row["fwd_split_resident_us_per_step"] = 1e3 * row["fwd_split_resident_ms"] / T
+            row["split_vs_per_step_rel"] = float((ops.lstm_layer_persist_split(pre, w, H, B)[:, :, :B] - ops.lstm_layer(pre, whh, H)[:, :, :B]).abs().max())
         out.append(row)
         print(json.dumps(row), flush=True)
 
