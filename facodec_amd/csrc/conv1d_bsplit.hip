@@ -38,6 +38,16 @@ constexpr int BS_NSW = 4;   // staging waves
 #endif
 constexpr int BS_NSW_WIDE = FAC_BS_NSW_WIDE;
 constexpr int BS_XU = 3;    // (ci group, 64-column block) staging units per staging wave
+#ifndef FAC_BS_PERSIST
+#define FAC_BS_PERSIST 1
+#endif
+static int conv_device_cus() {
+  static int cus[16] = {0};
+  int dev = 0, v = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return 0;
+  if (cus[dev] == 0 && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess) cus[dev] = v;
+  return cus[dev];
+}
 // Two shapes of the same kernel (the weight layout depends on G, so the choice is a pure function of C_in):
 //   wide    (C_in >= BS_WIDE_MIN): G = 2 groups of 8 channels per stage, 4 MFMA waves, tile 64 x 256
 //   narrow  (C_in <  BS_WIDE_MIN): G = 1, tap PAIRS per MFMA (7 taps + one zero tap), 8 MFMA waves, tile 64 x 512:
@@ -108,30 +118,64 @@ __global__ __launch_bounds__((NMW + NSW) * 64, (NMW + NSW) / 4) void conv1d_bspl
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // [0, NMW): MFMA waves, then the staging waves
   const int XW = a.XW;
   const int X_STAGE = 48 * G * XW;                              // 3 planes x G groups x XW x 16 B
-  unsigned char* Wbuf = sm;              // [2][W_STAGE]
-  unsigned char* Xbuf = sm + 2 * W_STAGE;   // [2][X_STAGE]
-
-  // XCD-aware work decode (see conv1d_mfma.h): each XCD walks a contiguous range of (co tile, b, t tile)
-  int t0, co0, b;
-  {
-    const int n = gridDim.x;
-    const int q8 = n >> 3, r8 = n & 7;
-    const int xcd = blockIdx.x & 7, within = blockIdx.x >> 3;
-    const int id = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + within;
-    const int nt = a.n_t_tiles;
-    const int tt = id % nt;
-    const int rest = id / nt;
-    b = rest % a.B;
-    co0 = (rest / a.B) * BS_CO;
-    t0 = tt * BS_TT;
-  }
+  const int STG = W_STAGE + X_STAGE;        // one LDS stage: the weights of a chunk, then its inputs
+  unsigned char* Wbuf = sm;                 // stage s at Wbuf + s * STG
+  unsigned char* Xbuf = sm + W_STAGE;       // stage s at Xbuf + s * STG
   const int n_chunks = (a.C_in + 8 * G - 1) / (8 * G);
   const int dil = a.dil;
+
+  // XCD-aware work decode (see conv1d_mfma.h): each XCD walks a contiguous range of (co tile, b, t tile).  v = virtual block id.
+  const int n_tiles = a.n_tiles;
+  // Per-tile code (tile decode, staging parameters, epilogue) reads the launch arguments through a pointer to the kernarg segment
+  // that is laundered once per use site and tile: otherwise hipcc hoists every scalar load of the struct out of the tile loop and
+  // keeps ~70 SGPRs live across the chunk loops (144 spilled, their v_readlane reloads landing in the staging waves' steps).
+  typedef const __attribute__((address_space(4))) ConvArgs* KArgP;
+  const KArgP kargs = (KArgP)__builtin_amdgcn_kernarg_segment_ptr();
+  auto fresh_args = [&]() {
+    KArgP q = kargs;
+    asm volatile("" : "+s"(q));
+    return q;
+  };
+  auto decode = [&](KArgP ka, int v, int& t0_, int& co0_, int& b_) {
+    const int q8 = n_tiles >> 3, r8 = n_tiles & 7;
+    const int xcd = v & 7, within = v >> 3;
+    const int id = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + within;
+    const int nt = ka->n_t_tiles;
+    const int tt = id % nt;
+    const int rest = id / nt;
+    const int nb = ka->B;
+    b_ = rest % nb;
+    co0_ = (rest / nb) * BS_CO;
+    t0_ = tt * BS_TT;
+  };
+  // Round 4: the workgroup walks SEVERAL tiles (v = blockIdx.x, + gridDim.x, ...; one workgroup per CU).  With a.persist (host:
+  // wide shape, fp32 inputs, an even number of chunks) the staging waves treat the tiles as ONE chunk stream: while the MFMA waves
+  // multiply the last chunk of a tile (stage 1), chunk 0 of the next tile is staged into stage 0 and chunk 1 is requested, so a
+  // tile costs its stages plus the epilogue -- not a workgroup launch, a cold prologue (one stage of staging behind a memory round
+  // trip) and a drain.  The epilogue's fp32 tile then lives in stage 1 (free behind the last chunk) instead of at the LDS base.
+  const bool overlap = a.persist != 0;
+  unsigned char* epi_base = sm + (overlap ? STG : 0);
+  // The roles run the tile walk as separate instantiations of one generic lambda: the register allocator then sees the staging
+  // waves' cross-tile state and the MFMA waves' accumulators / fragment sets as unrelated live ranges (one loop around both roles
+  // made the MFMA loop spill).
+  auto walk = [&](auto role) {
+  constexpr int ROLE = decltype(role)::value;          // 0: MFMA waves, 1: staging waves (fp32 inputs), 2: staging waves (P8 inputs)
+  constexpr bool STAGING = ROLE != 0;
+  bool first = true;                                  // this tile starts cold (always, without a.persist)
+  // staging waves, overlap mode: load offsets / real-sample masks / bases of the CURRENT tile (c*) and of the next one (n*)
+  unsigned cboff[BS_XU] = {}, nboff[BS_XU] = {};
+  unsigned long long cmask[BS_XU] = {}, nmask[BS_XU] = {};
+  const float *cxg = nullptr, *nxg = nullptr;
+  const unsigned char *cws = nullptr, *nws = nullptr;
+  for (int vb = blockIdx.x; vb < n_tiles; vb += gridDim.x) {
+  int t0, co0, b;
+  decode(fresh_args(), vb, t0, co0, b);
+  const bool has_nt = overlap && vb + (int)gridDim.x < n_tiles;
 
 #ifdef FAC_PROF
   unsigned long long pf0 = 0, pf1 = 0, pf2 = 0;
 #endif
-  if (wave >= NMW) {
+  if constexpr (STAGING) {
     // ===================== staging waves
     const int lw = wave - NMW;
     __builtin_amdgcn_s_setprio(FAC_PRIO_STAGE);
@@ -165,7 +209,7 @@ __global__ __launch_bounds__((NMW + NSW) * 64, (NMW + NSW) / 4) void conv1d_bspl
 #if !defined(FAC_ABL_NOSTAGE) && !defined(FAC_ABL_NOSTAGE_W)
       constexpr int N16 = W_STAGE / 16;
       const unsigned char* src = wsrc + (long long)chunk * W_STAGE;
-      unsigned char* dst = Wbuf + buf * W_STAGE;
+      unsigned char* dst = Wbuf + buf * STG;
       for (int i = lw; i * 64 < N16; i += NSW) {
         const int q = i * 64 + lane;
         if (q < N16)
@@ -175,7 +219,7 @@ __global__ __launch_bounds__((NMW + NSW) * 64, (NMW + NSW) / 4) void conv1d_bspl
     };
     auto write_x = [&](int buf, const float (&xr)[BS_XU][8]) {       // xr: landed samples, padding lanes already zero
 #if !defined(FAC_ABL_NOSTAGE) && !defined(FAC_ABL_NOSTAGE_X)
-      unsigned char* xd = Xbuf + buf * X_STAGE;
+      unsigned char* xd = Xbuf + buf * STG;
 #pragma unroll
       for (int j = 0; j < BS_XU; ++j) {
         if (u_c[j] < 0) continue;
@@ -196,7 +240,7 @@ __global__ __launch_bounds__((NMW + NSW) * 64, (NMW + NSW) / 4) void conv1d_bspl
     // each: the channel row is a uniform (scalar) base, the column a per-lane 32-bit byte offset resolved once per tile; lanes on
     // padding read a clamped column and are zeroed when the value is taken out of its landing register, and C_in % (8 G) == 0
     // (dispatcher) makes every channel of a stage real.
-    if (G == 2 && a.x_p8 != nullptr) {
+    if constexpr (ROLE == 2) {
       // ---- P8 input (fac_conv_desc.x_p8): the producer wrote the three bf16 planes, 8 channels x 16 B per time step -- exactly
       // a column of this kernel's input stage.  A unit (channel group, column) is three 16-byte loads and three ds_write_b128: NO
       // vector-ALU work at all (the fp32 path below spends ~170 VALU instructions per staging wave and stage on the split, and
@@ -228,7 +272,7 @@ __global__ __launch_bounds__((NMW + NSW) * 64, (NMW + NSW) / 4) void conv1d_bspl
 #pragma unroll
             for (int pl = 0; pl < 3; ++pl) xv[j][pl] = *reinterpret_cast<const wv4*>(grp + pl * a.x_p8_ps + u_poff[j]);
           }
-          unsigned char* xd = Xbuf + buf * X_STAGE;
+          unsigned char* xd = Xbuf + buf * STG;
 #pragma unroll
           for (int j = 0; j < BS_XU; ++j) {
             if (u_c[j] < 0) continue;
@@ -239,7 +283,7 @@ __global__ __launch_bounds__((NMW + NSW) * 64, (NMW + NSW) / 4) void conv1d_bspl
               *reinterpret_cast<wv4*>(xd + ((pl * G + u_g[j]) * XW + u_c[j]) * 16) = v;
             }
           }
-          unsigned char* dst = Wbuf + buf * W_STAGE;
+          unsigned char* dst = Wbuf + buf * STG;
 #pragma unroll
           for (int j = 0; j < ND; ++j) {
             const int bi = min(lw + NSW * j, NBLK - 1);
@@ -264,145 +308,143 @@ __global__ __launch_bounds__((NMW + NSW) * 64, (NMW + NSW) / 4) void conv1d_bspl
 #define BS_LD(n, R)                                                                                                          \
   asm volatile("global_load_dword v" #R ", %0, %1" : : "v"(u_boff[(n) / 8]), "s"(grp[(n) / 8] + (long long)((n) % 8) * xcs) : "memory", "v" #R);
 #define BS_RD(n, R) asm volatile("v_cndmask_b32_e64 %0, 0, v" #R ", %1" : "=v"(xr[(n) / 8][(n) % 8]) : "s"(u_mask[(n) / 8]) : "memory");
-      unsigned u_boff[BS_XU];
-      unsigned long long u_mask[BS_XU];                               // lanes of unit j that hold a real sample
+      // per-tile parameters of the loads: byte offset of the lane's column (padding lanes read a clamped column), mask of the lanes
+      // that hold a real sample, the clip's rows, the co tile's weight slabs
+      auto tile_params = [&](int t0_, int b_, int co0_, unsigned (&boff)[BS_XU], unsigned long long (&mask)[BS_XU], const float*& xgp,
+                             const unsigned char*& wsp) {
+        const KArgP ka = fresh_args();
+        const int pad_left = ka->pad_left, pad_mode = ka->pad_mode, T_in = ka->T_in, T_ext = ka->T_ext;
 #pragma unroll
-      for (int j = 0; j < BS_XU; ++j) {
-        u_boff[j] = (unsigned)(u_idx[j] >= 0 ? u_idx[j] : 0) * 4u;
-        u_mask[j] = __builtin_amdgcn_ballot_w64(u_idx[j] >= 0);
-      }
-      auto rows_of = [&](int chunk, const float* (&grp)[BS_XU]) {
-#pragma unroll
-        for (int j = 0; j < BS_XU; ++j) grp[j] = xg + (long long)((chunk * G + u_g[j]) * 8) * xcs;
+        for (int j = 0; j < BS_XU; ++j) {
+          const int tin = t0_ - pad_left + u_c[j];
+          int idx;
+          if (pad_mode == FAC_PAD_REFLECT) idx = reflect_index(tin, T_in, T_ext);
+          else idx = (tin >= 0 && tin < T_in) ? tin : -1;
+          if (u_c[j] < 0) idx = -1;
+          boff[j] = (unsigned)(idx >= 0 ? idx : 0) * 4u;
+          mask[j] = __builtin_amdgcn_ballot_w64(idx >= 0);
+        }
+        xgp = ka->x + (long long)b_ * ka->x_bs;
+        wsp = reinterpret_cast<const unsigned char*>(ka->w) + (long long)(co0_ / BS_CO) * n_chunks * W_STAGE;
       };
-      auto load_a = [&](int chunk) {
+      if (first) tile_params(t0, b, co0, cboff, cmask, cxg, cws);
+      if (has_nt) {
+        int nt0, nco0, nb;
+        decode(fresh_args(), vb + (int)gridDim.x, nt0, nco0, nb);
+        tile_params(nt0, nb, nco0, nboff, nmask, nxg, nws);
+      }
+      auto load_a = [&](const float* xgp, const unsigned (&u_boff)[BS_XU], int chunk) {
 #if !defined(FAC_ABL_NOSTAGE) && !defined(FAC_ABL_NOSTAGE_X)
         const float* grp[BS_XU];
-        rows_of(chunk, grp);
+#pragma unroll
+        for (int j = 0; j < BS_XU; ++j) grp[j] = xgp + (long long)((chunk * G + u_g[j]) * 8) * xcs;
         FAC_XREGS24_A(BS_LD)
 #endif
       };
-      auto load_b = [&](int chunk) {
+      auto load_b = [&](const float* xgp, const unsigned (&u_boff)[BS_XU], int chunk) {
 #if !defined(FAC_ABL_NOSTAGE) && !defined(FAC_ABL_NOSTAGE_X)
         const float* grp[BS_XU];
-        rows_of(chunk, grp);
+#pragma unroll
+        for (int j = 0; j < BS_XU; ++j) grp[j] = xgp + (long long)((chunk * G + u_g[j]) * 8) * xcs;
         FAC_XREGS24_B(BS_LD)
 #endif
       };
-      auto stage_w_fixed = [&](int chunk, int buf) {       // FAC_BS_W_VGPR=0: exactly ND LDS-DMA instructions per wave
-        const unsigned char* src = wsrc + (long long)chunk * W_STAGE;
-        unsigned char* dst = Wbuf + buf * W_STAGE;
-#pragma unroll
-        for (int j = 0; j < ND; ++j) {
-          const int i = min(lw + NSW * j, NBLK - 1);
-          __builtin_amdgcn_global_load_lds((glb_void_t*)(src + (long long)i * 1024 + lane * 16), (lds_void_t*)(dst + i * 1024), 16, 0, 0);
-        }
-      };
-      (void)stage_w_fixed;
-      auto take_a = [&](float (&xr)[BS_XU][8]) { FAC_XREGS24_A(BS_RD) };
-      auto take_b = [&](float (&xr)[BS_XU][8]) { FAC_XREGS24_B(BS_RD) };
-      // ONE software-pipelined loop from c = -2: step(c) = { weight DMA of chunk c + 1 into stage (c + 1) & 1; wait for the inputs
-      // of c + 1 (requested by step(c - 1), older than that DMA: vmcnt(ND)); request the inputs of c + 2; take c + 1 out of its
-      // landing registers, split, write; wait for the DMA (vmcnt(NX): the inputs of c + 2 stay in flight); barrier }, each part
-      // skipped where its chunk does not exist.  At most ND + NX loads are in flight.
+      auto take_a = [&](float (&xr)[BS_XU][8], const unsigned long long (&u_mask)[BS_XU]) { FAC_XREGS24_A(BS_RD) };
+      auto take_b = [&](float (&xr)[BS_XU][8], const unsigned long long (&u_mask)[BS_XU]) { FAC_XREGS24_B(BS_RD) };
+      // ONE software-pipelined loop: step(c) = { request the weights of chunk c + 1 (registers); wait for the inputs of c + 1
+      // (requested by step(c - 1), older than those weight loads: vmcnt(ND)) and take them out of their landing registers; request
+      // the inputs of c + 2; split + write c + 1 into stage (c + 1) & 1; wait for the weights (vmcnt(NX): the inputs of c + 2 stay
+      // in flight) and write them; barrier }, each part skipped where its chunk does not exist.  At most ND + NX loads are in
+      // flight.  A cold tile starts at c = -2; in overlap mode chunks n_chunks and n_chunks + 1 are chunks 0 and 1 of the NEXT
+      // tile (n_chunks is even: same stage and register-set parity), and a tile that was started that way begins at c = 0.
+      // The weight slab goes through registers (global_load_dwordx4 -> ds_write_b128, requested before the input work of the
+      // stage, written behind it -- plain compiler-allocated registers, no value crosses a barrier) instead of LDS-DMA: measured
+      // +2 .. 4 % (profiles/r04_bsplit_ablation.log: what the weight stage costs is its LDS write traffic either way).
+      typedef float wv4 __attribute__((ext_vector_type(4)));
+      const int wblk0 = min(lw * ND, NBLK - ND);
+      const unsigned lane16 = (unsigned)lane * 16u;
 #ifdef FAC_PROF2
       long long pq[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define BSQ(k) q[k] = clock64();
+#else
+#define BSQ(k)
 #endif
-      for (int base = -2; base < n_chunks; base += 2) {
+      for (int base = first ? -2 : 0; base < n_chunks; base += 2) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {                                // c + 1 has parity 1 - i: its stage and its register set
           const int c = base + i;
           if (c >= n_chunks) break;
-          const bool has_next = c + 1 >= 0 && c + 1 < n_chunks, has_next2 = c + 2 < n_chunks;
+          const bool nx1 = c + 1 >= n_chunks, nx2 = c + 2 >= n_chunks;          // the chunk belongs to the next tile
+          const bool has_next = c + 1 >= 0 && (!nx1 || has_nt), has_next2 = !nx2 || has_nt;
           float xr[BS_XU][8];
-#ifndef FAC_BS_W_VGPR
-#define FAC_BS_W_VGPR 1
-#endif
-#if FAC_BS_W_VGPR
-          // The weight slab goes through registers (global_load_dwordx4 -> ds_write_b128, requested before the input work of the
-          // stage, written behind it -- no value crosses a barrier, plain compiler-allocated registers) instead of LDS-DMA:
-          // measured +2 .. 4 % (C = 192 .. 768).  Ablations of round 4 (profiles/r04_bsplit_ablation.log): what the weight
-          // stage costs the MFMA waves is its LDS WRITE traffic, whichever way it arrives (a DMA that reads one cache-resident
-          // KiB over and over costs the same as the real one), not the L2 fetch.  FAC_BS_W_VGPR=0: LDS-DMA.
-          typedef float wv4 __attribute__((ext_vector_type(4)));
           wv4 wv[ND];
 #ifdef FAC_PROF2
-          const long long q0 = clock64();
-          long long q1 = q0, q2 = q0, q3 = q0, q4 = q0, q5 = q0, q6 = q0;
+          long long q[7];
+          for (int k = 0; k < 7; ++k) q[k] = clock64();
 #endif
           if (has_next) {
-            const unsigned char* src = wsrc + (long long)(c + 1) * W_STAGE;
+            // this wave's ND consecutive 1 KiB blocks of the slab (the last wave's range is shifted back onto its neighbour's
+            // instead of running over the end: the same bytes go to the same place twice) -- one lane offset for all of them, block
+            // j as a scalar base on the load side and as an immediate offset on the LDS side: no per-block vector arithmetic
+            const unsigned char* src = (nx1 ? nws : cws) + (long long)(nx1 ? c + 1 - n_chunks : c + 1) * W_STAGE + wblk0 * 1024;
 #pragma unroll
-            for (int j = 0; j < ND; ++j) {
-              const int bi = min(lw + NSW * j, NBLK - 1);
-              asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(wv[j]) : "v"((unsigned)(bi * 1024 + lane * 16)), "s"(src) : "memory");
-            }
+            for (int j = 0; j < ND; ++j)
+              asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(wv[j]) : "v"(lane16), "s"(src + j * 1024) : "memory");
             asm volatile("s_waitcnt vmcnt(%0)" : : "n"(ND) : "memory");
-#ifdef FAC_PROF2
-            q1 = clock64();
-#endif
-            if (i == 0) take_b(xr); else take_a(xr);
-#ifdef FAC_PROF2
-            q2 = clock64();
-#endif
+            BSQ(1)
+            unsigned long long u_mask[BS_XU];
+#pragma unroll
+            for (int j = 0; j < BS_XU; ++j) u_mask[j] = nx1 ? nmask[j] : cmask[j];
+            if (i == 0) take_b(xr, u_mask); else take_a(xr, u_mask);
+            BSQ(2)
           }
           if (has_next2) {
-            if (i == 0) load_a(c + 2); else load_b(c + 2);
+            unsigned u_boff[BS_XU];
+#pragma unroll
+            for (int j = 0; j < BS_XU; ++j) u_boff[j] = nx2 ? nboff[j] : cboff[j];
+            const float* xgp = nx2 ? nxg : cxg;
+            const int chunk = nx2 ? c + 2 - n_chunks : c + 2;
+            if (i == 0) load_a(xgp, u_boff, chunk); else load_b(xgp, u_boff, chunk);
           }
-#ifdef FAC_PROF2
-          q3 = clock64();
-#endif
+          BSQ(3)
           if (has_next) {
             write_x(1 - i, xr);
 #ifdef FAC_PROF2
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            q4 = clock64();
 #endif
+            BSQ(4)
             if (has_next2) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(NX) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#ifdef FAC_PROF2
-            q5 = clock64();
-#endif
-            unsigned char* dst = Wbuf + (1 - i) * W_STAGE;
+            BSQ(5)
+            unsigned char* dst = Wbuf + (1 - i) * STG + wblk0 * 1024 + lane16;
 #pragma unroll
             for (int j = 0; j < ND; ++j) {
               asm volatile("" : "+v"(wv[j]) : : "memory");
-              const int bi = min(lw + NSW * j, NBLK - 1);
-              *reinterpret_cast<wv4*>(dst + bi * 1024 + lane * 16) = wv[j];
+              *reinterpret_cast<wv4*>(dst + j * 1024) = wv[j];
             }
           }
           if (c >= -1) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#ifdef FAC_PROF2
-            q6 = clock64();
-#endif
-            __builtin_amdgcn_s_barrier();
+            BSQ(6)
+            __builtin_amdgcn_s_barrier();      // c = -1: chunk 0 staged; later: pairs with the MFMA waves' barrier behind chunk c
             asm volatile("" ::: "memory");
 #ifdef FAC_PROF2
-            if (c >= 0 && has_next2) {      // steady-state iterations only
-              pq[0] += q1 - q0; pq[1] += q2 - q1; pq[2] += q3 - q2; pq[3] += q4 - q3; pq[4] += q5 - q4; pq[5] += q6 - q5;
-              pq[6] += clock64() - q6; pq[7] += 1;
+            if (c >= 0 && c + 2 < n_chunks) {      // steady-state iterations only
+              pq[0] += q[1] - q[0]; pq[1] += q[2] - q[1]; pq[2] += q[3] - q[2]; pq[3] += q[4] - q[3]; pq[4] += q[5] - q[4];
+              pq[5] += q[6] - q[5]; pq[6] += clock64() - q[6]; pq[7] += 1;
             }
 #endif
           }
-#else
-          if (has_next) {
-            stage_w_fixed(c + 1, 1 - i);                             // that stage was read during chunk c - 1
-            asm volatile("s_waitcnt vmcnt(%0)" : : "n"(ND) : "memory");
-            if (i == 0) take_b(xr); else take_a(xr);
-          }
-          if (has_next2) {
-            if (i == 0) load_a(c + 2); else load_b(c + 2);
-          }
-          if (has_next) write_x(1 - i, xr);
-          if (c >= -1) {
-            if (has_next2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" : : "n"(NX) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();      // c = -1: chunk 0 staged; later: pairs with the MFMA waves' barrier behind chunk c
-            asm volatile("" ::: "memory");
-          }
-#endif
         }
+      }
+      if (has_nt) {       // the next tile's parameters become the current ones
+#pragma unroll
+        for (int j = 0; j < BS_XU; ++j) {
+          cboff[j] = nboff[j];
+          cmask[j] = nmask[j];
+        }
+        cxg = nxg;
+        cws = nws;
       }
 #ifdef FAC_PROF2
       if (a.dbg && lw == 0 && lane == 0) {
@@ -410,6 +452,7 @@ __global__ __launch_bounds__((NMW + NSW) * 64, (NMW + NSW) / 4) void conv1d_bspl
         for (int k = 0; k < 8; ++k) d[k] = (unsigned long long)pq[k];
       }
 #endif
+#undef BSQ
 #undef BS_LD
 #undef BS_RD
     } else {
@@ -481,7 +524,7 @@ __global__ __launch_bounds__((NMW + NSW) * 64, (NMW + NSW) / 4) void conv1d_bspl
   const int x_lane = (G == 2 ? kq * XW : kq * dil) * 16;
   const int x_step = (G == 2 ? dil : 2 * dil) * 16;
 
-  __syncthreads();   // chunk 0 staged
+  if (first) __syncthreads();   // chunk 0 staged (a tile started by the previous tile's last step needs no barrier: overlap mode)
 #ifdef FAC_PROF
   const unsigned long long tp1 = wall_clock64();
 #endif
@@ -506,8 +549,8 @@ __global__ __launch_bounds__((NMW + NSW) * 64, (NMW + NSW) / 4) void conv1d_bspl
     constexpr int MBv = decltype(MBc)::value;
     bf16x8 A[2][MBv][3], Bf[2][NB][3];
     auto ld = [&](int buf, int st, bf16x8 (&Ad)[MBv][3], bf16x8 (&Bd)[NB][3]) {
-      const unsigned char* Wb = Wbuf + buf * W_STAGE + (kq * BS_CO + l31) * 16;          // half slot 2 st + kq
-      const unsigned char* Xb = Xbuf + buf * X_STAGE + (n0 + l31) * 16 + x_lane + st * x_step;
+      const unsigned char* Wb = Wbuf + buf * STG + (kq * BS_CO + l31) * 16;          // half slot 2 st + kq
+      const unsigned char* Xb = Xbuf + buf * STG + (n0 + l31) * 16 + x_lane + st * x_step;
       constexpr int PO[3] = {1, 0, 2};   // planes in order of first use: mid, hi, lo
 #pragma unroll
       for (int pi = 0; pi < 3; ++pi) {
@@ -578,8 +621,8 @@ __global__ __launch_bounds__((NMW + NSW) * 64, (NMW + NSW) / 4) void conv1d_bspl
     const long long m0 = clock64();
 #endif
     const int buf = chunk & 1;
-    const unsigned char* Wb = Wbuf + buf * W_STAGE + (kq * BS_CO + l31) * 16;          // half slot 2s + kq
-    const unsigned char* Xb = Xbuf + buf * X_STAGE + (n0 + l31) * 16 + x_lane;
+    const unsigned char* Wb = Wbuf + buf * STG + (kq * BS_CO + l31) * 16;          // half slot 2s + kq
+    const unsigned char* Xb = Xbuf + buf * STG + (n0 + l31) * 16 + x_lane;
     // A fragments are requested one step ahead (register double buffer); B fragments at the start of their
     // step, in the order the six terms consume them (the compiler waits per fragment, and the second workgroup
     // on the CU covers what latency remains) -- keeps the kernel under the 170 VGPRs of 3 waves per SIMD.
@@ -678,10 +721,11 @@ __global__ __launch_bounds__((NMW + NSW) * 64, (NMW + NSW) / 4) void conv1d_bspl
     d[5] = (unsigned long long)n_chunks;
   }
 #endif
-  // ---- accumulators -> LDS (both stage buffers are free now): tile[co][t] fp32, row pitch BS_TT + 4 floats.
+  // ---- accumulators -> LDS (both stage buffers are free now; overlap mode: stage 1 is, stage 0 already holds the next tile's
+  // chunk 0): tile[co][t] fp32, row pitch BS_TT + 4 floats.
   // C/D layout of the 32x32 block: register r <-> row (r & 3) + 8 (r >> 2) + 4 kq, column l31.
   {
-    float* tile = reinterpret_cast<float*>(sm);
+    float* tile = reinterpret_cast<float*>(epi_base);
     constexpr int EP = BS_TT + 4;
 #pragma unroll
     for (int m = 0; m < MB; ++m)
@@ -700,27 +744,28 @@ __global__ __launch_bounds__((NMW + NSW) * 64, (NMW + NSW) / 4) void conv1d_bspl
   // scalar 4-byte accesses in C/D order, one workgroup per CU so nothing else to overlap with -- the epilogue cost the
   // C <= 192 layers a third of their time.)
   {
-    const float* tile = reinterpret_cast<const float*>(sm);
+    const KArgP e = fresh_args();
+    const float* tile = reinterpret_cast<const float*>(epi_base);
     constexpr int EP = BS_TT + 4;
     constexpr int NTH = (NMW + NSW) * 64;
     constexpr int QPR = BS_TT / 4;                       // quads per row
-    float* yg = a.y ? a.y + (long long)b * a.y_bs : nullptr;
-    float* y2g = a.y2 ? a.y2 + (long long)b * a.y_bs : nullptr;
-    const float* rg = a.res ? a.res + (long long)b * a.y_bs : nullptr;
-    const bool vec_ok = (a.y_cs & 3) == 0 && (a.y_bs & 3) == 0 && (!yg || (reinterpret_cast<unsigned long long>(a.y) & 15) == 0) &&
-                        (!y2g || (reinterpret_cast<unsigned long long>(a.y2) & 15) == 0) &&
-                        (!rg || (reinterpret_cast<unsigned long long>(a.res) & 15) == 0);
+    float* yg = e->y ? e->y + (long long)b * e->y_bs : nullptr;
+    float* y2g = e->y2 ? e->y2 + (long long)b * e->y_bs : nullptr;
+    const float* rg = e->res ? e->res + (long long)b * e->y_bs : nullptr;
+    const bool vec_ok = (e->y_cs & 3) == 0 && (e->y_bs & 3) == 0 && (!yg || (reinterpret_cast<unsigned long long>(e->y) & 15) == 0) &&
+                        (!y2g || (reinterpret_cast<unsigned long long>(e->y2) & 15) == 0) &&
+                        (!rg || (reinterpret_cast<unsigned long long>(e->res) & 15) == 0);
     for (int q = tid; q < BS_CO * QPR; q += NTH) {
       const int row = q / QPR, tq = q - row * QPR;
       const int co = co0 + row, t = t0 + 4 * tq;
-      if (co >= a.C_out || t >= a.T_out) continue;
+      if (co >= e->C_out || t >= e->T_out) continue;
       const float4 av = *reinterpret_cast<const float4*>(tile + row * EP + 4 * tq);
       float v[4] = {av.x, av.y, av.z, av.w};
-      const float bs = a.bias ? a.bias[co] : 0.f;
-      const float al = a.alpha_out ? a.alpha_out[co] : 0.f;
-      const float inv = a.alpha_out ? snake_inv(al) : 0.f;
-      const long long o = (long long)co * a.y_cs + t;
-      const bool full = vec_ok && t + 3 < a.T_out;
+      const float bs = e->bias ? e->bias[co] : 0.f;
+      const float al = e->alpha_out ? e->alpha_out[co] : 0.f;
+      const float inv = e->alpha_out ? snake_inv(al) : 0.f;
+      const long long o = (long long)co * e->y_cs + t;
+      const bool full = vec_ok && t + 3 < e->T_out;
       float rv[4] = {0.f, 0.f, 0.f, 0.f};
       if (rg) {
         if (full) {
@@ -728,19 +773,19 @@ __global__ __launch_bounds__((NMW + NSW) * 64, (NMW + NSW) / 4) void conv1d_bspl
           rv[0] = r4.x; rv[1] = r4.y; rv[2] = r4.z; rv[3] = r4.w;
         } else {
 #pragma unroll
-          for (int i = 0; i < 4; ++i) rv[i] = t + i < a.T_out ? rg[o + i] : 0.f;
+          for (int i = 0; i < 4; ++i) rv[i] = t + i < e->T_out ? rg[o + i] : 0.f;
         }
       }
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         float x = v[i] + bs;
-        if (a.alpha_out) x = snake_apply(x, al, inv);
-        if (a.act != FAC_ACT_NONE) x = apply_act_slow(x, a.act);
+        if (e->alpha_out) x = snake_apply(x, al, inv);
+        if (e->act != FAC_ACT_NONE) x = apply_act_slow(x, e->act);
         v[i] = x + rv[i];
       }
       float w[4];
       if (y2g) {
-        const float a2 = a.alpha2[co], i2 = snake_inv(a2);
+        const float a2 = e->alpha2[co], i2 = snake_inv(a2);
 #pragma unroll
         for (int i = 0; i < 4; ++i) w[i] = snake_apply(v[i], a2, i2);
       }
@@ -750,7 +795,7 @@ __global__ __launch_bounds__((NMW + NSW) * 64, (NMW + NSW) / 4) void conv1d_bspl
       } else {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          if (t + i >= a.T_out) continue;
+          if (t + i >= e->T_out) continue;
           if (yg) yg[o + i] = v[i];
           if (y2g) y2g[o + i] = w[i];
         }
@@ -763,6 +808,22 @@ __global__ __launch_bounds__((NMW + NSW) * 64, (NMW + NSW) / 4) void conv1d_bspl
     d[0] = pf0; d[1] = pf1; d[2] = pf2; d[3] = wall_clock64(); d[4] = 0; d[5] = 0;
   }
 #endif
+  first = !overlap;
+  if (vb + (int)gridDim.x < n_tiles) __syncthreads();     // the epilogue has read its tile: the stage buffers may be written again
+  }   // tiles of this workgroup
+  };
+  if (wave >= NMW) {
+    // P8 inputs get their own instantiation: it keeps nothing in flight across statements, and the ISA check of the named landing
+    // registers (tools/check_inflight_regs.py: named_lifetime_violations) then sees no path from a load site into its code
+    if constexpr (G == 2) {
+      if (a.x_p8 != nullptr) walk(std::integral_constant<int, 2>{});
+      else walk(std::integral_constant<int, 1>{});
+    } else {
+      walk(std::integral_constant<int, 1>{});
+    }
+  } else {
+    walk(std::integral_constant<int, 0>{});
+  }
 }
 
 bool conv_bsplit_ok(const ConvArgs& a) {
@@ -783,9 +844,22 @@ template <int KT, int G, int NMW, int NSW>
 static int bsplit_launch(ConvArgs& a, hipStream_t s) {
   constexpr int H = bs_slots(KT, G), TT = 64 * NMW;
   a.XW = TT + (H / G - 1) * a.dil;       // G = 1: the padded zero tap still reads (finite) staged columns
-  size_t lds = 2 * ((size_t)3 * H * BS_CO * 16 + (size_t)48 * G * a.XW);
+  const size_t stg = (size_t)3 * H * BS_CO * 16 + (size_t)48 * G * a.XW;
   const size_t epi = (size_t)BS_CO * (TT + 4) * sizeof(float);      // the accumulator tile of the all-waves epilogue
-  if (lds < epi) lds = epi;
+  a.n_t_tiles = (a.T_out + TT - 1) / TT;
+  const long long n_wg = (long long)a.n_t_tiles * ((a.C_out + BS_CO - 1) / BS_CO) * a.B;
+  if (n_wg > 0x7fffffffll) {
+    set_error("conv1d: too many workgroups (%lld)", n_wg);
+    return FAC_ERR_ARG;
+  }
+  // One workgroup per CU walking several tiles, the next tile's first chunk staged under the last chunk of the current one
+  // (kernel header): wide shape with fp32 inputs, an even number of chunks (stage / register-set parity continues across tiles),
+  // more tiles than CUs, and the epilogue tile must fit behind stage 0.  FAC_BS_PERSIST=0 restores one tile per workgroup.
+  const int n_chunks = (a.C_in + 8 * G - 1) / (8 * G);
+  int cus = conv_device_cus() & ~7;
+  a.persist = (FAC_BS_PERSIST && G == 2 && NMW == 4 && a.x_p8 == nullptr && n_chunks % 2 == 0 && cus >= 8 && n_wg > cus &&
+               stg + (stg > epi ? stg : epi) <= 160 * 1024) ? 1 : 0;
+  size_t lds = a.persist ? stg + (stg > epi ? stg : epi) : (2 * stg > epi ? 2 * stg : epi);
   if (lds > 160 * 1024) {
     set_error("conv1d(bf16 split): tile needs %zu B of LDS (dil=%d)", lds, a.dil);
     return FAC_ERR_ARG;
@@ -796,16 +870,11 @@ static int bsplit_launch(ConvArgs& a, hipStream_t s) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  a.n_t_tiles = (a.T_out + TT - 1) / TT;
-  const long long n_wg = (long long)a.n_t_tiles * ((a.C_out + BS_CO - 1) / BS_CO) * a.B;
-  if (n_wg > 0x7fffffffll) {
-    set_error("conv1d: too many workgroups (%lld)", n_wg);
-    return FAC_ERR_ARG;
-  }
+  a.n_tiles = (int)n_wg;
 #if defined(FAC_PROF) || defined(FAC_PROF2)
   a.dbg = g_conv_dbg;
 #endif
-  hipLaunchKernelGGL(kern, dim3((unsigned)n_wg), dim3((NMW + NSW) * 64), lds, s, a);
+  hipLaunchKernelGGL(kern, dim3((unsigned)(a.persist ? cus : n_wg)), dim3((NMW + NSW) * 64), lds, s, a);
   return check_launch("conv1d_bsplit");
 }
 

@@ -61,6 +61,7 @@ struct ConvArgs {
   int XB;   // 64-wide column blocks per staged row = ceil(XW/64)
   int XQ, XR;  // 4 / XB, 4 % XB: (row, block) advance of one wave per staging iteration
   int n_t_tiles;
+  int n_tiles, persist;   // conv1d_bsplit.hip: tiles of the launch; 1 = workgroups walk several tiles as one chunk stream
 #if defined(FAC_PROF) || defined(FAC_PROF2)
   unsigned long long* dbg;   // per-workgroup cycle counters (tuning builds only)
 #endif

@@ -21,7 +21,17 @@ def test_named_landing_registers_are_left_alone(src, n_kernels):
     assert len(res) == n_kernels, sorted(res)          # every wide k = 7 / 5 / 3 kernel, every (K1, stride) of the 32-row kernel
     for name, (lo, bad) in res.items():
         assert lo in (176, 208), (name, lo)
+    # Exact form: between the inline-asm load that writes a landing register and the inline-asm v_cndmask that takes the value out,
+    # nothing else may touch it -- on any path of the control-flow graph.  (Since the k = 7 kernel walks several tiles per workgroup
+    # with the next tile's inputs in flight across the epilogue, the MFMA waves' and the P8 staging waves' instantiations of the tile
+    # walk do use v208.. for their own values; they are not reachable from a load site.)
+    live = C.named_lifetime_violations(asm)
+    assert set(live) == set(res)
+    for name, bad in live.items():
         assert not bad, (name, bad[:5])
+    if src == "conv1d_bsplit2.hip":                    # one role per kernel there: the whole reserved range stays untouched
+        for name, (lo, bad) in res.items():
+            assert not bad, (name, bad[:5])
     # no kernel of the file may spill more than a handful of registers to scratch (round 4: an innocent-looking unrolled DMA loop made
     # the 32 / 48-channel shape of the k = 7 kernel spill 443)
     spills = C.spill_counts(asm)

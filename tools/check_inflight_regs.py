@@ -202,6 +202,102 @@ def reserved_violations(asm_path):
     return out
 
 
+def named_lifetime_violations(asm_path):
+    """{kernel: [(instruction, registers)]}: the exact form of `reserved_violations`.  A named landing register is LIVE from the
+    inline-asm load that writes it to the inline-asm `v_cndmask_b32_e64 dst, 0, vR, mask` that takes the value out; a forward
+    may-analysis over the control-flow graph (union at joins) carries the live set, and any other instruction that touches a
+    live register -- compiler-generated or another asm load -- is a violation.  Code that only waves without loads in flight
+    execute (the MFMA waves' instantiation of the tile walk in conv1d_bsplit.hip, the launch prologue) may use the same
+    physical registers freely: it is not reachable from a load site."""
+    out = {}
+    kernels, cur, in_asm = {}, None, False
+    for line in open(asm_path):
+        m = re.match(r"^(_Z\w+):", line)
+        if m:
+            cur, in_asm = m.group(1), False
+            kernels[cur] = []
+            continue
+        t = line.strip()
+        if cur is None:
+            continue
+        if t.startswith(";;#ASMSTART"):
+            in_asm = True
+        elif t.startswith(";;#ASMEND"):
+            in_asm = False
+        elif t.startswith(".Lfunc_end"):
+            cur = None
+        elif re.match(r"^\.LBB\w+:", t):
+            kernels[cur].append((t.split(":")[0] + ":", False))
+        elif line.startswith("\t") and t and not t.startswith((";", ".")):
+            kernels[cur].append((t, in_asm))
+    for name, body in kernels.items():
+        named = {r for ins, a in body if a and re.match(r"global_load_dword(x\d)? v\d+, v\d+, s\[", ins) for (_, r) in regs_of(ins.split(",")[0])}
+        named = {r for r in named if r >= 128}
+        if not named:
+            continue
+        blocks, labels, cb = [], {}, []
+        for ins, a in body:
+            if ins.endswith(":"):
+                if cb:
+                    blocks.append(cb)
+                    cb = []
+                labels[ins[:-1]] = len(blocks)
+                continue
+            cb.append((ins, a))
+            if ins.split()[0].startswith(("s_branch", "s_cbranch", "s_endpgm", "s_setpc")):
+                blocks.append(cb)
+                cb = []
+        if cb:
+            blocks.append(cb)
+        succ = []
+        for i, b in enumerate(blocks):
+            last = b[-1][0].split() if b else ["nop"]
+            nxt = []
+            if last[0].startswith(("s_branch", "s_cbranch")) and last[1] in labels:
+                nxt.append(labels[last[1]])
+            if not last[0].startswith(("s_branch", "s_endpgm", "s_setpc")) and i + 1 < len(blocks):
+                nxt.append(i + 1)
+            succ.append([j for j in nxt if j < len(blocks)])
+
+        def step(live, ins, a, report):
+            op = ins.split()[0]
+            regs = {r for k, r in regs_of(ins) if k == "v" and r in named}
+            if a and op.startswith("global_load_dword"):      # (a re-issued load on a path whose take was guarded out is not reported:
+                dest = {r for k, r in regs_of(ins.split(",")[0]) if k == "v" and r in named}      # the guards are correlated)
+                return live | dest
+            if a and op.startswith("v_cndmask_b32"):
+                src = {r for k, r in regs_of(ins.split(",", 1)[1]) if k == "v" and r in named}
+                return live - src
+            if report is not None and (regs & live):
+                report.append((ins, sorted(regs & live)))
+            return live
+
+        instate = [None] * len(blocks)
+        instate[0] = frozenset()
+        work = [0]
+        while work:
+            i = work.pop()
+            live = set(instate[i])
+            for ins, a in blocks[i]:
+                live = step(live, ins, a, None)
+            for j in succ[i]:
+                if instate[j] is None:
+                    instate[j] = frozenset(live)
+                    work.append(j)
+                elif not live <= instate[j]:
+                    instate[j] = frozenset(instate[j] | live)
+                    work.append(j)
+        bad = []
+        for i, b in enumerate(blocks):
+            if instate[i] is None:
+                continue
+            live = set(instate[i])
+            for ins, a in b:
+                live = step(live, ins, a, bad)
+        out[name] = bad
+    return out
+
+
 def spill_counts(asm_path):
     """{kernel: vgpr_spill_count} from the kernel metadata of the assembly."""
     out, name = {}, None
