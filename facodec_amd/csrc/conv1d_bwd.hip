@@ -42,18 +42,8 @@ __global__ void pad_fold_bwd_kernel(const float* __restrict__ dxpad, float* __re
                                     int pad_left, int mode, long long n) {
   const int pad_right = Tp - pad_left - T;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-    // one 32-bit division per element instead of two 64-bit ones (the flat index of every training tensor fits 32 bits; the
-    // 64-bit form made this 8-bytes-per-element pass ALU-bound)
-    long long row;
-    int j;
-    if ((i >> 32) == 0) {
-      const unsigned q = (unsigned)i / (unsigned)T;
-      row = q;
-      j = (int)((unsigned)i - q * (unsigned)T);
-    } else {
-      row = i / T;
-      j = (int)(i - row * T);
-    }
+    const int j = (int)(i % T);
+    const long long row = i / T;
     const float* p = dxpad + row * Tp;
     float g = p[pad_left + j];
     if (mode == FAC_PAD_REFLECT) {
@@ -373,7 +363,7 @@ extern "C" int fac_pad_fold_bwd(const float* dxpad, float* dx, int B, int C, int
   FAC_REQUIRE(pad_mode != FAC_PAD_REFLECT || (T > pad_left && T > Tp - pad_left - T),
               "pad_fold_bwd: reflect padding needs a signal longer than the pad");
   const long long n = (long long)B * C * T;
-  const int blocks = (int)((n + 255) / 256 < (1 << 20) ? (n + 255) / 256 : (1 << 20));
+  const int blocks = (int)((n + 255) / 256 < 65535 ? (n + 255) / 256 : 65535);
   hipLaunchKernelGGL(pad_fold_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dxpad, dx, T, Tp, pad_left,
                      pad_mode, n);
   return check_launch("pad_fold_bwd");

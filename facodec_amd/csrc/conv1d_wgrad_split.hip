@@ -74,45 +74,19 @@ __device__ __forceinline__ void split3w(float x, __bf16& h, __bf16& m, __bf16& l
 __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ src, unsigned char* __restrict__ dst, long long rows,
                                                            int T, int T_ext, int T_pad, int s, int U, int pad_left, int pad_mode,
                                                            long long plane_bytes) {
-  // A block covers a 256-lane patch of the (destination row, 8-step piece) plane: W = min(256, next power of two >= U / 8) pieces
-  // of 256 / W consecutive rows, so that the only divisions are one uniform 32-bit one per block and (strided convs) one by the
-  // stride per lane -- the flat 64-bit index of the first version cost ~3 x the split's own arithmetic in integer division.
   const int u8 = U >> 3;
-  const int lw = u8 >= 256 ? 8 : (u8 <= 1 ? 0 : 32 - __clz(u8 - 1));
-  const int W = 1 << lw, RPB = 256 >> lw;
-  const unsigned nchunk = (unsigned)((u8 + W - 1) >> lw);
-  const long long nrows = rows * s;
-  const unsigned long long nblk = (unsigned long long)((nrows + RPB - 1) / RPB) * nchunk;
-  for (unsigned long long blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
-    const unsigned long long rg = blk / nchunk;          // uniform
-    const unsigned chunk = (unsigned)(blk - rg * nchunk);
-    const int uq = (int)(chunk << lw) + (int)(threadIdx.x & (W - 1));
-    const long long drow = (long long)rg * RPB + (threadIdx.x >> lw);
-    if (uq >= u8 || drow >= nrows) continue;
-    long long row = drow;
-    int ph = 0;
-    if (s > 1) {
-      if (nrows < 0x7fffffffll) {
-        const unsigned d = (unsigned)drow, q = d / (unsigned)s;
-        row = q;
-        ph = (int)(d - q * (unsigned)s);
-      } else {
-        row = drow / s;
-        ph = (int)(drow - row * s);
-      }
-    }
+  const long long n = rows * s * u8;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const int uq = (int)(i % u8);
+    const long long drow = i / u8;
+    const long long row = drow / s;
+    const int ph = (int)(drow - row * s);
     const float* xr = src + row * T;
     const int p0 = (uq * 8) * s + ph - pad_left;
     float v[8];
     if (s == 1 && p0 >= 0 && p0 + 7 < T) {
-      if ((((unsigned long long)(xr + p0)) & 15) == 0) {          // 16-byte aligned run: two 16-byte loads
-        const f32x4 q0 = *reinterpret_cast<const f32x4*>(xr + p0), q1 = *reinterpret_cast<const f32x4*>(xr + p0 + 4);
-        v[0] = q0[0]; v[1] = q0[1]; v[2] = q0[2]; v[3] = q0[3];
-        v[4] = q1[0]; v[5] = q1[1]; v[6] = q1[2]; v[7] = q1[3];
-      } else {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = xr[p0 + j];
-      }
+      for (int j = 0; j < 8; ++j) v[j] = xr[p0 + j];
     } else {
 #pragma unroll
       for (int j = 0; j < 8; ++j) {

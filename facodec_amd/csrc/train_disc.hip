@@ -87,18 +87,9 @@ __global__ void period_fold_bwd_kernel(const float* __restrict__ dout, float* __
 // dy (rows, T) -> up (rows, (T-1)*s + 1) with zeros between samples (data gradient of a strided conv as a stride-1 conv)
 __global__ void zero_insert_kernel(const float* __restrict__ dy, float* __restrict__ up, int T, int s, int Tu, long long n) {
   GRID_STRIDE(i, n) {
-    long long r;
-    int u;
-    if ((i >> 32) == 0) {          // 32-bit divisions where the flat index allows (always, in the training step)
-      const unsigned q = (unsigned)i / (unsigned)Tu;
-      r = q;
-      u = (int)((unsigned)i - q * (unsigned)Tu);
-    } else {
-      r = i / Tu;
-      u = (int)(i - r * Tu);
-    }
-    const unsigned us = (unsigned)u / (unsigned)s;
-    up[i] = (us * (unsigned)s == (unsigned)u) ? dy[r * T + us] : 0.f;
+    const int u = (int)(i % Tu);
+    const long long r = i / Tu;
+    up[i] = (u % s == 0) ? dy[r * T + u / s] : 0.f;
   }
 }
 
