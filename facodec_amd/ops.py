@@ -255,6 +255,20 @@ def side_streams(device, n):
     return _SIDE_STREAMS[key]
 
 
+def join_side_streams(device):
+    """The current stream waits for everything queued so far on the concurrent-chain side streams of `device`.  Used in front of a
+    gradient collective launched from inside backward: autograd orders a node behind the nodes that feed it, not behind the
+    parameter-gradient kernels other chains queued on their own streams, and the collective reads the whole bucket."""
+    if device.type != "cuda":
+        return
+    cur = torch.cuda.current_stream(device)
+    for (dev, _), streams in _SIDE_STREAMS.items():
+        if dev.type == "cuda" and (dev.index is None or device.index is None or dev.index == device.index):
+            for st in streams:
+                if st != cur:
+                    cur.wait_stream(st)
+
+
 def run_chains(chains, device, n_streams):
     """Independent chains of launches (callables) side by side on up to n_streams side streams that fork from and join the
     caller's stream; returns their results in order.  Kernels with fewer workgroups than CUs (or a partly filled last round)

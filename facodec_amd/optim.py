@@ -243,6 +243,8 @@ class FlatAdamW:
             self._launch_log.append(("flags", where))
             self._works.append(dist.all_reduce(self._flags, op=dist.ReduceOp.MAX, async_op=True))
             return
+        if self.g.is_cuda and self._next_bucket < len(self.buckets) and self.buckets[self._next_bucket][0] >= from_param:
+            ops.join_side_streams(self.g.device)    # parameter gradients written by chains on side streams (discriminators, heads)
         nccl = dist.get_backend() == "nccl"         # RCCL: the mean is part of the collective; gloo (CPU scaffold) has no AVG
         op = dist.ReduceOp.AVG if nccl else dist.ReduceOp.SUM
         while self._next_bucket < len(self.buckets) and self.buckets[self._next_bucket][0] >= from_param:
