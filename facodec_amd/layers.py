@@ -152,6 +152,8 @@ class SConv1d(nn.Module):
               and ops.gemm_split_strided_ok(w.c_out, w.c_in, self.kernel_size, self.stride, 1,
                                             x.shape[0] * (x.shape[-1] // self.stride + 1) - 1)):
             return self._run_flat(x, alpha_out, act, alpha_y2, want_y)
+        if split is not None and self.stride > 1:      # split GEMM over the phase sub-signals: P8 input where it pays (ops.p8_prepass)
+            x = ops.p8_prepass(x, 2.0 * w.c_out * self.kernel_size / (4.0 * self.stride))
         return ops.conv1d(x, w.packed() if split is None else None, w.c_out, self.kernel_size, bias=w.bias,
                           stride=self.stride, dilation=self.dilation, pad_mode=self.pad_mode, alpha_in=alpha_in,
                           alpha_out=alpha_out, res=res, act=act, causal=self.causal, alpha_y2=alpha_y2, want_y=want_y,
@@ -170,6 +172,7 @@ class SConv1d(nn.Module):
         xp = torch.nn.functional.pad(x, (s_, 0), mode="reflect")                    # data movement only
         xf = xp.permute(1, 0, 2).reshape(1, c_in, B * (n + 1) * s_)
         t_out = B * (n + 1) - 1
+        xf = ops.p8_prepass(xf, 2.0 * w.c_out * self.kernel_size / (4.0 * s_))
         got = ops.conv1d(xf, None, w.c_out, self.kernel_size, bias=w.bias, stride=s_, pad_left=0, pad_mode=ops.PAD_ZERO, t_out=t_out,
                          alpha_out=alpha_out, act=act, alpha_y2=alpha_y2, want_y=want_y, w_split=w.packed_split_strided(s_))
 
@@ -205,12 +208,14 @@ class SConvTranspose1d(nn.Module):
         w = self.w
         if ops.convtr_split_ok(w.c_in, w.c_out, self.stride, x.shape[0], x.shape[-1], self.causal, alpha_in):
             wp = w.packed_rows_split()
+            x = ops.p8_prepass(x, 2.0 * w.c_out * 2 * self.stride / 4.0)      # all output phases as GEMM rows: 2 s C_out MACs per input sample
         elif (FLAT_SHORT_CLIPS and not torch.is_grad_enabled() and x.shape[-1] < 256
               and ops.convtr_split_ok(w.c_in, w.c_out, self.stride, 1, x.shape[0] * (x.shape[-1] + 1), self.causal, alpha_in)):
             # short clips: ONE signal of B (T + 1) columns with a zero column in front of every clip (the x[t - 1] of its first
             # frame); the s output samples of that column are dropped on the way back (see SConv1d._run_flat)
             B, c_in, T = x.shape
             xf = torch.cat([torch.zeros(B, c_in, 1, device=x.device, dtype=x.dtype), x], -1).permute(1, 0, 2).reshape(1, c_in, B * (T + 1))
+            xf = ops.p8_prepass(xf, 2.0 * w.c_out * 2 * self.stride / 4.0)
             got = ops.conv_transpose1d(xf, w.packed_rows_split(), w.c_out, self.stride, bias=w.bias, alpha_y2=alpha_y2, causal=True)
 
             def back(y):
@@ -279,8 +284,11 @@ class SLSTM(nn.Module):
             persist = ops.lstm_persist_ok(H, B)
             T_, BP = inp.shape[1], inp.shape[2]
             # one GEMM over every (t, b): the channel-major buffer is a (1, H, T*BP) "signal"
+            sig = inp.view(1, H, T_ * BP)
+            if use_split:
+                sig = ops.p8_prepass(sig, 2.0 * 4 * H / 4.0)
             with ops.flop_scale(B / BP):
-                pre = ops.conv1d(inp.view(1, H, T_ * BP), w_ih, 4 * H, 1, bias=bias, pad_left=0, t_out=T_ * BP,
+                pre = ops.conv1d(sig, w_ih, 4 * H, 1, bias=bias, pad_left=0, t_out=T_ * BP,
                                  pad_mode=ops.PAD_ZERO, w_split=w_ih_split)
                 if ops.lstm_persist_split_ok(H, B):      # 17 .. 32 columns: resident, W_hh . h on the bf16 matrix pipe
                     inp = ops.lstm_layer_persist_split(pre.view(4 * H, T_, BP), w_hh, H, B)

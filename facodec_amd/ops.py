@@ -500,6 +500,22 @@ def to_p8(x, alpha=None):
     return out
 
 
+# Inference launches of the split GEMM kernel whose every input byte feeds at least this many FLOPs take their input as P8
+# planes made by ONE extra pass over it (fac_to_p8: 4 bytes read, 6 written per element at ~6 TB/s): the kernel then stages both
+# operands by LDS-DMA instead of splitting fp32 values in its staging waves (+11 .. 20 % on such a launch), which
+# pays for the pass when the input is small next to the GEMM -- the LSTM input projections, the transposed convs with many output
+# rows per input sample, the last strided conv of the encoder.  0 disables.
+P8_PREPASS_MIN_FLOP_PER_BYTE = float(os.environ.get("FAC_P8_PREPASS", "700"))
+
+
+def p8_prepass(x, flop_per_in_byte):
+    """x (B, C, T) fp32 -> P8 when the policy above says the pass pays for itself (inference only: no autograd node), else x."""
+    if (P8_PREPASS_MIN_FLOP_PER_BYTE <= 0 or flop_per_in_byte < P8_PREPASS_MIN_FLOP_PER_BYTE or not BF16_SPLIT or isinstance(x, P8)
+            or torch.is_grad_enabled() or not x.is_cuda or x.shape[1] % 8 != 0 or x.shape[0] * (x.shape[1] // 8) * x.shape[2] * 16 >= (1 << 32)):
+        return x
+    return to_p8(x)
+
+
 def conv1d(x, w_packed, c_out, k, bias=None, stride=1, dilation=1, pad_left=None, pad_mode=PAD_REFLECT,
            t_out=None, alpha_in=None, alpha_out=None, res=None, act=ACT_NONE, out=None, causal=True,
            alpha_y2=None, want_y=True, w_k1=None, bias_k1=None, w_split=None, k1=0, dilation2=0):
@@ -560,10 +576,18 @@ def conv_transpose1d(x, w_packed, c_out, stride, bias=None, alpha_in=None, out=N
     as `stride` polyphase 2-tap convs: y[., t*s+p] = W[p] x[t] + W[p+s] x[t-1].
     has_history (streaming): x's first column is x[t0-1] of an earlier chunk (instead of the zero of
     the start of the signal); x may then be a time-contiguous view of a wider buffer."""
-    if not (has_history and x.is_cuda and x.dtype == torch.float32 and x.stride(2) == 1):
-        x = _dev(x, "x")
-    B, c_in, t_in = x.shape
-    x_bs, x_cs = x.stride(0), x.stride(1)
+    x_p8 = x if isinstance(x, P8) else None
+    if x_p8 is not None:       # all-phases split-GEMM launch only (fac_conv1d_fwd rejects P8 operands anywhere else)
+        assert not has_history
+        B, c_in, t_in = x_p8.shape
+        x_bs, x_cs = c_in * t_in, t_in
+    else:
+        if not (has_history and x.is_cuda and x.dtype == torch.float32 and x.stride(2) == 1):
+            x = _dev(x, "x")
+        B, c_in, t_in = x.shape
+        x_bs, x_cs = x.stride(0), x.stride(1)
+    dev_ = x_p8.planes.device if x_p8 is not None else x.device
+    t_in_full = t_in
     if has_history:
         assert causal
         t_in -= 1
@@ -571,9 +595,13 @@ def conv_transpose1d(x, w_packed, c_out, stride, bias=None, alpha_in=None, out=N
     split_rows = isinstance(w_packed, tuple)       # (split GEMM buffer, rows) from pack_convtr_weight_rows_split
     cp = w_packed[1] if split_rows else w_packed.shape[-1]
     if out is None:
-        out = torch.empty(B, c_out, t_total, device=x.device, dtype=torch.float32)
+        out = torch.empty(B, c_out, t_total, device=dev_, dtype=torch.float32)
     d = ConvDesc()
-    d.x, d.bias = x.data_ptr(), (bias.data_ptr() if bias is not None else None)
+    d.bias = bias.data_ptr() if bias is not None else None
+    if x_p8 is not None:
+        d.x, d.x_p8, d.x_p8_plane_bytes = None, x_p8.planes.data_ptr(), x_p8.plane_bytes
+    else:
+        d.x = x.data_ptr()
     if split_rows:
         d.w, d.w_split = None, w_packed[0].data_ptr()
     else:
@@ -585,7 +613,7 @@ def conv_transpose1d(x, w_packed, c_out, stride, bias=None, alpha_in=None, out=N
     d.alpha_y2 = alpha_y2.data_ptr() if alpha_y2 is not None else None
     d.x_bs, d.x_cs = x_bs, x_cs
     d.y_bs, d.y_cs = c_out * t_total, t_total
-    d.B, d.C_in, d.T_in, d.C_out, d.C_out_pad, d.T_out = B, c_in, x.shape[-1], c_out, cp, t_in
+    d.B, d.C_in, d.T_in, d.C_out, d.C_out_pad, d.T_out = B, c_in, t_in_full, c_out, cp, t_in
     d.K, d.stride, d.dilation, d.pad_left, d.pad_mode = 2, 1, 1, (0 if has_history else 1), PAD_ZERO
     d.n_phase, d.y_tstride, d.act, d.w_batched, d.w_bs = stride, stride, ACT_NONE, 0, 0
     # non-causal: trim ceil(s/2) on the left, floor(s/2) on the right (dac/model/encodec.py:265-269)

@@ -644,6 +644,45 @@ def test_short_clips_run_flattened_on_the_split_gemm(O, cuda, monkeypatch):
     assert rel(y, y0) < OP_TOL and rel(u, u0) < OP_TOL
 
 
+def test_p8_prepass_policy_is_bit_identical(cuda, monkeypatch):
+    """Inference launches of the split GEMM kernel with a small input next to the GEMM (LSTM input projections, transposed convs,
+    the flattened last strided conv) take their input through ONE fac_to_p8 pass (ops.p8_prepass): same bf16 operands in the same
+    order as the in-kernel split, so the outputs are the same bits with the policy on and off -- and the policy must actually fire."""
+    from facodec_amd import layers, ops
+    calls = []
+    real = ops.to_p8
+
+    def counting(x, alpha=None):
+        calls.append(tuple(x.shape))
+        return real(x, alpha)
+
+    monkeypatch.setattr(ops, "to_p8", counting)
+    tr = layers.SConvTranspose1d(384, 192, 10, stride=5, causal=True, norm="weight_norm")          # 960 FLOP per input byte
+    tr_flat = layers.SConvTranspose1d(512, 256, 12, stride=6, causal=True, norm="weight_norm")     # short clips: flattened launch
+    conv_flat = layers.SConv1d(256, 512, 12, stride=6, causal=True, norm="weight_norm")           # 512 FLOP / byte: below the bar
+    conv_flat2 = layers.SConv1d(512, 1024, 12, stride=6, causal=True, norm="weight_norm")         # 1024: above
+    lstm = layers.SLSTM(1024, 2)
+    mods = (tr, tr_flat, conv_flat, conv_flat2, lstm)
+    for i, m in enumerate(mods):
+        synth.load_synthetic(m, seed=70 + i)
+        m.to(cuda)
+    ins = (torch.randn(4, 384, 700, generator=_g(81)), torch.randn(32, 512, 160, generator=_g(82)), torch.randn(32, 256, 960, generator=_g(83)),
+           torch.randn(32, 512, 960, generator=_g(84)), torch.randn(20, 1024, 40, generator=_g(85)))
+
+    def run_all():
+        with torch.no_grad():
+            return [(m.run if hasattr(m, "run") else m)(x.to(cuda)) for m, x in zip(mods, ins)]
+
+    on = run_all()
+    fired = list(calls)
+    monkeypatch.setattr(ops, "P8_PREPASS_MIN_FLOP_PER_BYTE", 0.0)
+    off = run_all()
+    assert len(calls) == len(fired), "the pass must not run with the policy off"
+    assert [c[1] for c in fired] == [384, 512, 512, 1024, 1024], fired      # tr, tr_flat, conv_flat2, two LSTM layers; not conv_flat
+    for a, b in zip(on, off):
+        assert torch.equal(a, b)
+
+
 def test_spectral_losses_against_oracle(O, cuda):
     """MelSpectrogramLoss (train.py:155-163 arguments), MultiScaleSTFTLoss, L1Loss, reconstruction_loss on
     2 s clips; bar 1e-4 relative.  Third-party STFT/mel semantics restated on both sides: parity unpinned."""
