@@ -26,18 +26,30 @@ def main():
     dev = torch.device(f"cuda:{local_rank % torch.cuda.device_count()}")
     torch.cuda.set_device(dev)
     model = build_model(default_model_params())
-    for k in ("encoder", "quantizer", "decoder", "discriminator"):
+    heads = "--predictors" in sys.argv
+    for k in ("encoder", "quantizer", "decoder", "discriminator") + (("fa_predictors",) if heads else ()):
         synth.load_synthetic(model[k], seed=0, prefix=k + ".")
         model[k].to(dev)
-    step = TrainStep(model, lr=1e-4)
+    step = TrainStep(model, lr=1e-4, with_predictors=heads)
     B, T = 2, 12000
-    masks = dict(p=torch.ones(1, B), c=torch.ones(2, B), r=torch.ones(3, B), res=torch.ones(B), dropout=False)
+    # rank-ASYMMETRIC quantizer dropout: odd ranks drop the residual quantizers of their clips, so the ranks reach different
+    # parameter sets while issuing the same collectives (the hook-time exchange must not depend on which gradients arrived)
+    r_on = torch.ones(3, B) if rank % 2 == 0 else torch.tensor([[1.0] * B, [0.0] * B, [0.0] * B])
+    masks = dict(p=torch.ones(1, B), c=torch.ones(2, B), r=r_on, res=torch.ones(B), dropout=rank % 2 == 1)
     masks = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in masks.items()}
+    targets = None
+    if heads:
+        from bench import synthetic_predictor_targets
+        targets = synthetic_predictor_targets(B, T // 300, dev, seed=7 + rank)
     out = None
     for it in range(3):
         wave = synth.synth_clips(B, T, seed=it, rank=rank).to(dev)
-        out = step(wave, masks=masks)
+        out = step(wave, masks=masks, targets=targets) if heads else step(wave, masks=masks)
     torch.cuda.synchronize()
+    report = {k: ["%s:%s" % (b, w) for b, w in e["buckets"]] for k, e in step.exchange_report().items()}
+    reports = [None] * world
+    dist.all_gather_object(reports, report)
+    assert all(r == reports[0] for r in reports), reports        # the same collectives in the same order on every rank
     # identical parameters on every rank
     sums = torch.stack([step.opt[k].p.double().sum() for k in sorted(step.opt)]).to(dev)
     gathered = [torch.zeros_like(sums) for _ in range(world)]
@@ -49,7 +61,8 @@ def main():
     if rank == 0:
         print(json.dumps({"world": world, "backend": dist.get_backend(), "params_identical_across_ranks": same, "losses_finite": finite,
                           "loss": float(out["loss"]), "grad_norm": {k: float(v) for k, v in out["grad_norm"].items()},
-                          "grad_arena_norms": {k: float(v.norm()) for k, v in g_avg.items()}}))
+                          "grad_arena_norms": {k: float(v.norm()) for k, v in g_avg.items()}, "with_predictors": heads,
+                          "bucket_launches": report}))
     assert same and finite
     dist.destroy_process_group()
 
