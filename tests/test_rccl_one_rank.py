@@ -49,3 +49,25 @@ def test_one_rank_rccl_exchange_is_the_identity():
     assert last["encoder"][-1][1] == "end" and last["encoder"][0][1] == "hook"                  # only the remainder waits for the end
     os.makedirs(os.path.join(REPO, "gpurun_out"), exist_ok=True)
     json.dump(dict(plain=plain, forced=forced), open(os.path.join(REPO, "gpurun_out", "rccl_one_rank.json"), "w"), indent=1)
+
+
+@pytest.mark.gpu
+def test_two_ranks_share_the_gpu_over_gloo_with_asymmetric_masks():
+    """The closest thing to a second GPU on a one-GPU box: two processes run the whole train step (real kernels, side streams,
+    gradient hooks) on the same device and exchange over gloo; odd ranks drop their residual quantizers, so the ranks reach
+    different parameter sets.  tools/ddp_smoke.py asserts identical parameters on both ranks and the same bucket launch sequence."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    env = dict(os.environ, FAC_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "FAC_FORCE_ALLREDUCE"):
+        env.pop(k, None)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(REPO, "tools", "ddp_smoke.py"), "--predictors"],
+                       env=env, capture_output=True, text=True, timeout=900, cwd=REPO)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-2500:])
+    rep = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert rep["world"] == 2 and rep["params_identical_across_ranks"] and rep["losses_finite"] and rep["with_predictors"]
+    assert all(w.endswith(":hook") for w in rep["bucket_launches"]["decoder"] + rep["bucket_launches"]["fa_predictors"])
