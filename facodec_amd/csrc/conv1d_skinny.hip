@@ -12,9 +12,7 @@
 //   * the B operand (x[ci][t*stride + k*dil - pad]) is a few KB, served by L1/L2;
 //   * S > 1: partial tiles go to the caller's workspace and a second small kernel adds them in slice order
 //     (deterministic, unlike atomics on the outputs) and runs the epilogue.  (A single-kernel version with a
-//     ticket counter + __threadfence per workgroup was measured 5x slower: every fence is an L2 write-back.  Round 4: the
-//     single-kernel form without fences -- write-through stores, acknowledged, then a relaxed ticket; the last workgroup of a tile
-//     reads the slices back with sc1 loads -- is the default, FAC_SKINNY_ONE_LAUNCH=0 restores the two launches.)
+//     ticket counter + __threadfence per workgroup was measured 5x slower: every fence is an L2 write-back.)
 //   * the epilogue is the tiled kernel's: bias, Snake, activation, residual, pre-activated second output.
 #include "conv1d_mfma.h"
 
@@ -23,10 +21,6 @@ namespace fac {
 constexpr int SK_CO = 128;           // output channels per tile
 constexpr int SK_MAX_COLS = 640;
 constexpr int SK_MAX_S = 32;
-constexpr int SK_TICKET_BYTES = 65536;   // the last 64 KB of the caller's (zero-filled) workspace: one launch ticket per tile
-#ifndef FAC_SKINNY_ONE_LAUNCH
-#define FAC_SKINNY_ONE_LAUNCH 1
-#endif
 
 struct SkinnyGeom {
   int S;            // slices of the reduction
@@ -52,24 +46,8 @@ __device__ __forceinline__ void skinny_emit(const ConvArgs& a, int e, float v, i
   if (a.y2) { const float al2 = a.alpha2[co]; a.y2[o] = snake_apply(v, al2, snake_inv(al2)); }
 }
 
-// Partial tiles cross the device the way the resident LSTM's state does (lstm_persist.hip): write-through (agent-scope, sc1)
-// 16-byte stores, `s_waitcnt vmcnt(0)` = acknowledged, then a relaxed ticket; the reader uses sc1 loads.  No memory-model fence.
-typedef float sk_f4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void sk_store_agent(float4* p, float4 v) {
-  const sk_f4 x = {v.x, v.y, v.z, v.w};
-  asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(x) : "memory");
-}
-__device__ __forceinline__ sk_f4 sk_load_agent(const float4* p) {
-  sk_f4 v;
-  asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
-  return v;
-}
-
-// tickets != nullptr (S > 1): ONE launch -- the workgroup that draws the last ticket of a tile adds the S partial tiles in slice
-// order (the arithmetic of conv1d_skinny_reduce_kernel, bit for bit) and runs the epilogue; the ticket returns to zero.
-__global__ __launch_bounds__(256) void conv1d_skinny_kernel(ConvArgs a, SkinnyGeom g, float* __restrict__ part, unsigned* tickets) {
+__global__ __launch_bounds__(256) void conv1d_skinny_kernel(ConvArgs a, SkinnyGeom g, float* __restrict__ part) {
   extern __shared__ __attribute__((aligned(16))) float red[];   // [4 waves][4 m][16 r][64 lanes]
-  __shared__ int s_last;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, kk = lane >> 5;
   const int co0 = blockIdx.x * SK_CO;
@@ -148,44 +126,12 @@ __global__ __launch_bounds__(256) void conv1d_skinny_kernel(ConvArgs a, SkinnyGe
     sum.z = ((p0.z + p1.z) + p2.z) + p3.z;
     sum.w = ((p0.w + p1.w) + p2.w) + p3.w;
     if (g.S > 1) {
-      if (tickets != nullptr) sk_store_agent(mine + e4, sum);
-      else mine[e4] = sum;
+      mine[e4] = sum;
     } else {
       skinny_emit(a, 4 * e4 + 0, sum.x, co0, cb, phase, ncol);
       skinny_emit(a, 4 * e4 + 1, sum.y, co0, cb, phase, ncol);
       skinny_emit(a, 4 * e4 + 2, sum.z, co0, cb, phase, ncol);
       skinny_emit(a, 4 * e4 + 3, sum.w, co0, cb, phase, ncol);
-    }
-  }
-  if (g.S > 1 && tickets != nullptr) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's partial-tile stores are acknowledged
-    __syncthreads();
-    if (tid == 0) {
-      const unsigned t = __hip_atomic_fetch_add(tickets + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      s_last = t == (unsigned)g.S - 1u;
-      if (s_last) __hip_atomic_store(tickets + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    __syncthreads();
-    if (!s_last) return;
-    const float4* base = reinterpret_cast<const float4*>(part) + (long long)tile * g.S * 1024;
-#pragma unroll 1
-    for (int q = 0; q < 4; ++q) {
-      const int e4 = q * 256 + tid;
-      sk_f4 pv[SK_MAX_S];
-#pragma unroll
-      for (int sl = 0; sl < SK_MAX_S; ++sl)      // unconditional (slices past S re-read the last one): no branch between a request and its wait
-        pv[sl] = sk_load_agent(base + (long long)(sl < g.S ? sl : g.S - 1) * 1024 + e4);
-#pragma unroll
-      for (int sl = 0; sl < SK_MAX_S; ++sl) asm volatile("s_waitcnt vmcnt(0)" : "+v"(pv[sl])::"memory");
-      sk_f4 sum = pv[0];
-#pragma unroll
-      for (int sl = 1; sl < SK_MAX_S; ++sl) {
-        if (sl < g.S) { sum[0] += pv[sl][0]; sum[1] += pv[sl][1]; sum[2] += pv[sl][2]; sum[3] += pv[sl][3]; }
-      }
-      skinny_emit(a, 4 * e4 + 0, sum[0], co0, cb, phase, ncol);
-      skinny_emit(a, 4 * e4 + 1, sum[1], co0, cb, phase, ncol);
-      skinny_emit(a, 4 * e4 + 2, sum[2], co0, cb, phase, ncol);
-      skinny_emit(a, 4 * e4 + 3, sum[3], co0, cb, phase, ncol);
     }
   }
 }
@@ -242,12 +188,13 @@ bool conv_skinny_ok(const ConvArgs& a, const void* ws, long long ws_bytes) {
   if (rows < 24) return false;                          // too little to split: the tiled kernel is fine
   int tiles;
   const SkinnyGeom g = skinny_geom(a, &tiles);
-  return ws_bytes >= (long long)tiles * g.S * 16384 + SK_TICKET_BYTES;
+  return ws_bytes >= (long long)tiles * g.S * 16384;
 }
 
 int conv_dispatch_skinny(ConvArgs& a, void* ws, long long ws_bytes, hipStream_t s) {
   int tiles;
   const SkinnyGeom g = skinny_geom(a, &tiles);
+  (void)ws_bytes;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv1d_skinny_kernel),
@@ -255,11 +202,8 @@ int conv_dispatch_skinny(ConvArgs& a, void* ws, long long ws_bytes, hipStream_t 
     attr_set = true;
   }
   float* part = reinterpret_cast<float*>(ws);
-  static const bool one_launch = FAC_SKINNY_ONE_LAUNCH && !(getenv("FAC_SKINNY_ONE_LAUNCH") && getenv("FAC_SKINNY_ONE_LAUNCH")[0] == '0');
-  unsigned* tickets = (one_launch && g.S > 1 && tiles * 4 <= SK_TICKET_BYTES)
-                          ? reinterpret_cast<unsigned*>(reinterpret_cast<unsigned char*>(ws) + ws_bytes - SK_TICKET_BYTES) : nullptr;
-  hipLaunchKernelGGL(conv1d_skinny_kernel, dim3(g.co_tiles, g.S, g.n_cb * a.n_phase), dim3(256), 65536, s, a, g, part, tickets);
-  if (g.S > 1 && tickets == nullptr)
+  hipLaunchKernelGGL(conv1d_skinny_kernel, dim3(g.co_tiles, g.S, g.n_cb * a.n_phase), dim3(256), 65536, s, a, g, part);
+  if (g.S > 1)
     hipLaunchKernelGGL(conv1d_skinny_reduce_kernel, dim3(tiles * 4), dim3(256), 0, s, a, g, part);
   return check_launch("conv1d_skinny");
 }

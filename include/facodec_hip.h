@@ -128,10 +128,8 @@ typedef struct fac_conv_desc {
   int64_t w_bs;
   /* Optional scratch for launches with few output columns (B*T_out <= 128: streaming hops, per-clip
    * Linears): lets the library split the C_in*K reduction across workgroups (conv1d_skinny.hip).  At least
-   * FAC_CONV_WS_BYTES, owned by ONE stream at a time (partial sums live there during a launch), and ZERO-FILLED by the
-   * caller once: the library keeps per-tile launch tickets in its last 64 KB (the workgroup that draws a tile's last
-   * ticket adds the slices in a fixed order and runs the epilogue -- one launch instead of two) and returns every ticket
-   * to zero before the launch ends.  NULL: the tiled kernel is used for every shape. */
+   * FAC_CONV_WS_BYTES, owned by ONE stream at a time (partial sums live there between the two kernels of a
+   * launch).  NULL: the tiled kernel is used for every shape. */
   void* ws;
   int64_t ws_bytes;
   /* Optional: the same weights in the split-bf16 layout of fac_pack_conv_w_split (K = 5 / 7) or fac_pack_gemm_w_split
