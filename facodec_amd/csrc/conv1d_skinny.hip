@@ -12,7 +12,10 @@
 //   * the B operand (x[ci][t*stride + k*dil - pad]) is a few KB, served by L1/L2;
 //   * S > 1: partial tiles go to the caller's workspace and a second small kernel adds them in slice order
 //     (deterministic, unlike atomics on the outputs) and runs the epilogue.  (A single-kernel version with a
-//     ticket counter + __threadfence per workgroup was measured 5x slower: every fence is an L2 write-back.)
+//     ticket counter + __threadfence per workgroup was measured 5x slower: every fence is an L2 write-back.  Round 4 tried it
+//     again without fences -- write-through (sc1) partial tiles, `s_waitcnt vmcnt(0)`, a relaxed per-tile ticket, the last
+//     workgroup of a tile reading the S slices back with sc1 loads: bit-identical, but the streaming hop went from p50 1.24 to
+//     1.69 ms: one workgroup pulling S x 16 KB past the L2 costs more than the dependent launch it saves.  Two launches it is.)
 //   * the epilogue is the tiled kernel's: bias, Snake, activation, residual, pre-activated second output.
 #include "conv1d_mfma.h"
 
