@@ -504,8 +504,9 @@ def to_p8(x, alpha=None):
 # planes made by ONE extra pass over it (fac_to_p8: 4 bytes read, 6 written per element at ~6 TB/s): the kernel then stages both
 # operands by LDS-DMA instead of splitting fp32 values in its staging waves (+11 .. 20 % on such a launch), which
 # pays for the pass when the input is small next to the GEMM -- the LSTM input projections, the transposed convs with many output
-# rows per input sample, the last strided conv of the encoder.  0 disables.
-P8_PREPASS_MIN_FLOP_PER_BYTE = float(os.environ.get("FAC_P8_PREPASS", "700"))
+# rows per input sample, the last two strided convs of the encoder (threshold sweep 150 / 300 / 450 / 700 on one box: 56.3 / 56.0 /
+# 55.5 / 56.0 ms per forward).  0 disables.
+P8_PREPASS_MIN_FLOP_PER_BYTE = float(os.environ.get("FAC_P8_PREPASS", "450"))
 
 
 def p8_prepass(x, flop_per_in_byte):

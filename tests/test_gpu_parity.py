@@ -659,7 +659,7 @@ def test_p8_prepass_policy_is_bit_identical(cuda, monkeypatch):
     monkeypatch.setattr(ops, "to_p8", counting)
     tr = layers.SConvTranspose1d(384, 192, 10, stride=5, causal=True, norm="weight_norm")          # 960 FLOP per input byte
     tr_flat = layers.SConvTranspose1d(512, 256, 12, stride=6, causal=True, norm="weight_norm")     # short clips: flattened launch
-    conv_flat = layers.SConv1d(256, 512, 12, stride=6, causal=True, norm="weight_norm")           # 512 FLOP / byte: below the bar
+    conv_flat = layers.SConv1d(256, 256, 12, stride=6, causal=True, norm="weight_norm")           # 256 FLOP / byte: below the bar
     conv_flat2 = layers.SConv1d(512, 1024, 12, stride=6, causal=True, norm="weight_norm")         # 1024: above
     lstm = layers.SLSTM(1024, 2)
     mods = (tr, tr_flat, conv_flat, conv_flat2, lstm)
