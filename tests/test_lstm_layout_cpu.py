@@ -100,3 +100,89 @@ def test_a_workgroup_publishes_whole_cache_lines(H):
     for ub in range(H // 8):
         idx = sorted(frag_index(ub * 8 + u, c, H) for u in range(8) for c in range(16))
         assert idx == list(range(idx[0], idx[0] + 128)) and idx[0] % 32 == 0, ub      # 128 floats = four 128-byte lines
+
+
+# ----------------------------------------------------------------- bf16 x 3 resident forward (lstm_fwd_persist_split_kernel)
+def _split3(x):
+    """fp32 -> three round-to-nearest-even bf16 terms (as float32 arrays), the ls_split3 of the kernel."""
+    import torch
+    t = torch.as_tensor(np.asarray(x, dtype=np.float32))
+    hi = t.to(torch.bfloat16).float()
+    r1 = t - hi
+    mid = r1.to(torch.bfloat16).float()
+    lo = (r1 - mid).to(torch.bfloat16).float()
+    return hi.numpy(), mid.numpy(), lo.numpy()
+
+
+def pack_whh_split(w, H):
+    """pack_whh_split_kernel: packed[((ub*8 + wave)*NK + s)*3 + plane][lane][i]; lane: row l%32 = gate*8 + unit, k = (wave*NK + s)*16 + 8*(l/32) + i."""
+    NK = H // 128
+    planes = _split3(w)
+    out = np.zeros(((H // 8) * 8 * NK * 3, 64, 8), dtype=np.float32)
+    lanes = np.arange(64)
+    l31, kq = lanes & 31, lanes >> 5
+    for ub in range(H // 8):
+        rows = (l31 >> 3) * H + ub * 8 + (l31 & 7)
+        for wv in range(8):
+            for s in range(NK):
+                k0 = (wv * NK + s) * 16 + 8 * kq
+                for p in range(3):
+                    out[((ub * 8 + wv) * NK + s) * 3 + p] = planes[p][rows[:, None], k0[:, None] + np.arange(8)[None, :]]
+    return out
+
+
+def exchange_pieces(h, H):
+    """What the workgroups publish for one step: hs[plane][k/16][lane][i], lane = 32*((k%16)/8) + column, i = k%8; returns the array
+    and, per workgroup, the byte ranges it writes in each plane."""
+    planes = _split3(h)                                   # (H, 32) each
+    hs = np.zeros((3, H // 16, 64, 8), dtype=np.float32)
+    spans = []
+    for ub in range(H // 8):
+        S, half = ub >> 1, ub & 1
+        for p in range(3):
+            for col in range(32):
+                hs[p, S, 32 * half + col] = planes[p][ub * 8:ub * 8 + 8, col]
+        start = ((S * 64) + 32 * half) * 16               # byte offset inside a plane
+        spans.append((start, start + 32 * 16))
+    return hs, spans
+
+
+def split_workgroup_product(packed, hs, ub, H):
+    """Eight waves x NK steps x six bf16 products (TA / TB of the kernel) through an emulated v_mfma_f32_32x32x16_bf16
+    (A: lane l = row l%32, k 8*(l/32)+i; B: lane l = col l%32, same k)."""
+    NK = H // 128
+    TA, TB = (1, 2, 0, 1, 0, 0), (1, 0, 2, 0, 1, 0)
+    lanes = np.arange(64)
+    out = np.zeros((32, 32))
+    for wv in range(8):
+        for s in range(NK):
+            for ta, tb in zip(TA, TB):
+                a = packed[((ub * 8 + wv) * NK + s) * 3 + ta]          # (64, 8)
+                b = hs[tb, wv * NK + s]                               # (64, 8)
+                A, B = np.zeros((32, 16)), np.zeros((16, 32))
+                for i in range(8):
+                    A[lanes & 31, 8 * (lanes >> 5) + i] = a[:, i]
+                    B[8 * (lanes >> 5) + i, lanes & 31] = b[:, i]
+                out += A.astype(np.float64) @ B.astype(np.float64)
+    return out
+
+
+@pytest.mark.parametrize("H", [512, 1024])
+def test_split_resident_layouts_reproduce_w_hh_times_h(H):
+    rng = np.random.default_rng(1)
+    w = (rng.standard_normal((4 * H, H)) / np.sqrt(H)).astype(np.float32)
+    h = np.tanh(rng.standard_normal((H, 32))).astype(np.float32)
+    packed = pack_whh_split(w, H)
+    hs, spans = exchange_pieces(h, H)
+    ref = w.astype(np.float64) @ h.astype(np.float64)
+    for ub in (0, 1, H // 16 + 1, H // 8 - 1):
+        got = split_workgroup_product(packed, hs, ub, H)
+        rows = np.array([(r >> 3) * H + ub * 8 + (r & 7) for r in range(32)])
+        # six of the nine cross products of exactly split operands: fp32-grade agreement with the exact product
+        assert np.abs(got - ref[rows]).max() < 2e-6 * np.abs(ref).max()
+    # every workgroup writes, per plane, 512 contiguous bytes = four whole 128-byte lines, and no two workgroups share a line
+    assert all(a % 128 == 0 and b - a == 512 for a, b in spans)
+    assert len({a for a, _ in spans}) == len(spans) and sorted(a for a, _ in spans) == list(range(0, H * 64, 512))
+    # the three terms of a split are an exact decomposition
+    hi, mid, lo = _split3(h)
+    assert np.array_equal((hi.astype(np.float64) + mid + lo).astype(np.float32), h)
