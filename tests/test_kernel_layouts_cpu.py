@@ -1,4 +1,4 @@
-"""Host-side check of the operand layouts documented at the top of facodec_amd/csrc/lstm_persist.hip (no GPU): the index
+"""Host-side checks of kernel index arithmetic (no GPU).  First part: the operand layouts documented at the top of facodec_amd/csrc/lstm_persist.hip: the index
 formulas of `pack_whh16_kernel`, `frag_index` and `k_of_unit` are restated here and run through an emulation of
 v_mfma_f32_16x16x4_f32 (A: lane l = row l%16, k l/16; B: lane l = k l/16, col l%16) -- the 16 waves' partial products must add up
 to W_hh h (forward) and to the gate-quarter partial products of W_hh^T dgates (BPTT), and the 8 units x 16 columns a workgroup
@@ -186,3 +186,32 @@ def test_split_resident_layouts_reproduce_w_hh_times_h(H):
     # the three terms of a split are an exact decomposition
     hi, mid, lo = _split3(h)
     assert np.array_equal((hi.astype(np.float64) + mid + lo).astype(np.float32), h)
+
+
+# ----------------------------------------------------------------- tile walk of conv1d_bsplit_kernel (host-side restatement)
+def _decode(v, n_tiles, n_t_tiles, B):
+    """The XCD-aware decode of conv1d_bsplit.hip: virtual block id v -> (co tile, clip, time tile)."""
+    q8, r8 = n_tiles >> 3, n_tiles & 7
+    xcd, within = v & 7, v >> 3
+    tid = (xcd * (q8 + 1) if xcd < r8 else r8 * (q8 + 1) + (xcd - r8) * q8) + within
+    tt, rest = tid % n_t_tiles, tid // n_t_tiles
+    return rest // B, rest % B, tt
+
+
+@pytest.mark.parametrize("n_t_tiles,B,co_tiles,grid", [(188, 32, 2, 256), (4, 32, 12, 256), (7, 3, 5, 64), (1, 1, 9, 8), (94, 32, 3, 248)])
+def test_tile_walk_visits_every_tile_once_and_stays_on_its_xcd(n_t_tiles, B, co_tiles, grid):
+    """Workgroup b of a persistent launch handles v = b, b + grid, ... (grid a multiple of 8): together they must cover every
+    (co tile, clip, time tile) exactly once, every workgroup must stay on one XCD's contiguous range (its blockIdx & 7), and the
+    tiles of an XCD must form one contiguous id range -- what keeps a weight slab in that XCD's L2."""
+    n_tiles = n_t_tiles * B * co_tiles
+    seen = {}
+    for b in range(min(grid, n_tiles)):
+        for v in range(b, n_tiles, grid):
+            assert (v & 7) == (b & 7)
+            t = _decode(v, n_tiles, n_t_tiles, B)
+            assert t not in seen
+            seen[t] = b & 7
+    assert len(seen) == n_tiles and all(0 <= c < co_tiles and 0 <= bb < B and 0 <= tt < n_t_tiles for c, bb, tt in seen)
+    flat = sorted(((c * B + bb) * n_t_tiles + tt, x) for (c, bb, tt), x in seen.items())
+    xs = [x for _, x in flat]
+    assert xs == sorted(xs)                      # ids grouped by XCD in increasing order: contiguous ranges
