@@ -46,7 +46,7 @@ class _Conv(Function):
         sc = ops.wn_scale(vd, gd) if gd is not None else None          # g / ||v||: once per forward, re-used by the backward
         if stride > 1 and dilation == 1 and ops.gemm_split_strided_ok(v.shape[0], v.shape[1], k, stride, x.shape[0], -(-x.shape[-1] // stride)):
             wp, ws = None, ops.pack_gemm_weight_split(vd, gd, in_stride=stride, scale=sc)     # downsampling conv on the split GEMM kernel
-        elif _split_ok(v.shape[0], v.shape[1], k, stride, x):       # k = 7 / k = 1 convs: fp32-exact split on the bf16 pipe
+        elif _split_ok(v.shape[0], v.shape[1], k, stride, x):       # k = 7 / k = 1 convs: fp32-grade split on the bf16 pipe
             wp, ws = None, ops.pack_conv_weight_split(vd, gd, scale=sc)
         else:
             wp, ws = ops.pack_conv_weight(vd, gd, scale=sc), None

@@ -15,7 +15,7 @@ _p = ops._ptr
 
 
 def _split_ok(k, stride, c_in, c_out, ncol):
-    """k = 5 / 7 stride-1 convs with enough channels and columns: fp32-exact split on the bf16 pipe."""
+    """k = 5 / 7 stride-1 convs with enough channels and columns: fp32-grade split on the bf16 pipe."""
     return ops.BF16_SPLIT and k in (5, 7) and stride == 1 and c_in % 16 == 0 and c_out % 16 == 0 and c_out > 2 and ncol > 640
 
 

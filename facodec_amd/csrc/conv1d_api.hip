@@ -105,7 +105,7 @@ extern "C" int fac_conv1d_fwd(const fac_conv_desc* d, fac_stream_t stream) {
     return conv_dispatch_bsplit2(a, s);
   }
   FAC_REQUIRE(!conv_two_level(a) || d->w, "conv1d: two-level taps outside the split kernel's shapes need fp32 weights");
-  // 1- / 2-tap convs with split weights in the GEMM layout (fac_pack_gemm_w_split): the bf16 matrix pipe, fp32-exact
+  // 1- / 2-tap convs with split weights in the GEMM layout (fac_pack_gemm_w_split): the bf16 matrix pipe, fp32-grade
   if (d->w_split && (d->K <= 2 || (d->stride > 1 && d->K <= 2 * d->stride)) && conv_gsplit_ok(a) &&
       !conv_skinny_ok(a, d->ws, d->ws_bytes)) {
     a.w = reinterpret_cast<const float*>(d->w_split);
@@ -161,7 +161,7 @@ extern "C" int fac_conv1d_variant(const fac_conv_desc* d, char* name, int name_l
     a.rp = d->row_phases > 1 ? d->row_phases : 1; a.alpha_in = d->alpha_in; a.w1 = d->w_k1; a.w_batched = d->w_batched;
     a.pad_mode = d->pad_mode; a.C_out = d->C_out; a.B = d->B; a.T_out = d->T_out; a.T_in = d->T_in; a.x_cs = d->x_cs;
     if ((a.KV == 9 || a.KV == 3) && conv_bsplit2_ok(a)) {
-      if (name && name_len > 0) snprintf(name, name_len, "conv1d_bsplit2_kernel<%d,%d> 32x512 (bf16x3 split, fp32-exact)", a.KV, a.stride);
+      if (name && name_len > 0) snprintf(name, name_len, "conv1d_bsplit2_kernel<%d,%d> 32x512 (bf16x3 split, fp32-grade)", a.KV, a.stride);
       return 16;
     }
   }
@@ -173,7 +173,7 @@ extern "C" int fac_conv1d_variant(const fac_conv_desc* d, char* name, int name_l
     a.rp = d->row_phases > 1 ? d->row_phases : 1; a.x_cs = d->x_cs;
     if (conv_gsplit_ok(a) && !conv_skinny_ok(a, d->ws, d->ws_bytes)) {
       if (name && name_len > 0)
-        snprintf(name, name_len, "conv1d_gemm_split_kernel<%d> 128x128 (bf16x3 split GEMM, fp32-exact)", d->stride > 1 ? 2 : d->K);
+        snprintf(name, name_len, "conv1d_gemm_split_kernel<%d> 128x128 (bf16x3 split GEMM, fp32-grade)", d->stride > 1 ? 2 : d->K);
       return 15;
     }
   }
@@ -227,7 +227,7 @@ extern "C" int fac_conv1d_variant(const fac_conv_desc* d, char* name, int name_l
     a.alpha_in = d->alpha_in; a.w1 = d->w_k1; a.w_batched = d->w_batched; a.C_in = d->C_in; a.dil = d->dilation;
     a.B = d->B; a.T_out = d->T_out;
     if (conv_bsplit_ok(a)) {
-      if (name && name_len > 0) snprintf(name, name_len, "conv1d_bsplit_kernel<%d> 64x256 (bf16x3 split, fp32-exact)", d->K);
+      if (name && name_len > 0) snprintf(name, name_len, "conv1d_bsplit_kernel<%d> 64x256 (bf16x3 split, fp32-grade)", d->K);
       return 11;
     }
   }

@@ -1,4 +1,4 @@
-// Few-output-channel convs with many taps on the bf16 matrix pipe, fp32-exact (the 3-way operand split of conv1d_bsplit.hip):
+// Few-output-channel convs with many taps on the bf16 matrix pipe, fp32-grade (the 3-way operand split of conv1d_bsplit.hip):
 // the (3, 9) / (3, 3) Conv2d stacks of the multi-resolution discriminator (dac/model/discriminator.py:101-170) in their
 // row-concatenated 1-D form (two-level taps, stride 1 or 2 along frequency, 32 output channels).
 //

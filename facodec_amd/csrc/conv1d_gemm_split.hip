@@ -1,4 +1,4 @@
-// 1- and 2-tap stride-1 convs as a split-bf16 GEMM (fp32-exact: the 3-way operand split of conv1d_bsplit.hip, six
+// 1- and 2-tap stride-1 convs as a split-bf16 GEMM (fp32-grade: the 3-way operand split of conv1d_bsplit.hip, six
 // v_mfma_f32_32x32x16_bf16 per K = 16 step, fp32 accumulate, smallest terms first).
 //
 // Which layers: the k = 1 convs with many channels (ResidualUnit tails at C = 512 / 768, the LSTM input projections

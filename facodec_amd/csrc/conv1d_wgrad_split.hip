@@ -1,4 +1,4 @@
-// Weight gradient of the conv stack on the bf16 matrix pipe, fp32-exact (the same 3-way operand split as
+// Weight gradient of the conv stack on the bf16 matrix pipe, fp32-grade (the same 3-way operand split as
 // conv1d_bsplit.hip: six v_mfma_f32_32x32x16_bf16 per K = 16 step, fp32 accumulate, smallest terms first).
 //
 //   dW[co][ci][k] = sum_{b,t} dy[b][co][t] * xpad[b][ci][t*stride + k*dil]        (torch autograd of F.conv1d behind

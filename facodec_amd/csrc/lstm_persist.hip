@@ -281,7 +281,7 @@ __global__ __launch_bounds__(1024) void lstm_fwd_persist_kernel(const float* __r
 }
 
 // ------------------------------------------------------------------------------------------ forward, bf16 x 3 operands
-// The same resident recurrence with W_hh . h on the bf16 matrix pipe, fp32-exact in the sense of conv1d_bsplit.hip: every
+// The same resident recurrence with W_hh . h on the bf16 matrix pipe, fp32-grade in the sense of conv1d_bsplit.hip: every
 // weight and every state value is the sum of three round-to-nearest bf16 terms, six of the nine cross products are kept,
 // accumulation in fp32.  At 32 batch columns the fp32 kernel above is bound by its v_mfma_f32_16x16x4_f32 time (32 x 32 x H
 // MACs per workgroup and step at 128 MAC / clk: 5.1 us at H = 1536); six v_mfma_f32_32x32x16_bf16 per 16 k do the same

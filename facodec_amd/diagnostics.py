@@ -5,9 +5,57 @@ errors: per (stream, clip, frame) it looks at the FIRST residual stage that diff
 projected latent, how much farther the expected code is than the chosen one (dac/nn/quantize.py:78-94 distance: squared
 distance between the L2-normalised latent and the L2-normalised code).  A gap below `tie_tol` is a near-tie flip, stages
 after it are its cascade; anything else is a genuine mismatch."""
+import hashlib
+
+import numpy as np
 import torch
 
 from .quantize import ResidualVectorQuantize
+
+REFERENCE_RUNS = ("f32_mt", "f32_1t", "f64")
+
+
+def check_codes_decidable(codes, fixture):
+    """Exact code check of configs[1] with the only exception the REFERENCE ITSELF makes.
+
+    fixture: tests/golden/codec_b32_decidable.npz (tests/golden/make_golden_bench.py b32_decidable): the real reference on the
+    timed batch in fp32 / all threads, fp32 / one thread and fp64; `decidable[b, i, t]` = the three runs chose the same code.
+    codes: (B, 6, T) -- prosody | content x 2 | residual x 3, the order FAquantizer.forward_v2 runs them
+    (modules/quantize.py:398-417), or the list of the three streams it returns.
+
+    Rule (no tolerance anywhere):
+      * a decidable position must equal the reference's code;
+      * a frame (b, t) that holds an undecidable position must, as a whole 6-code column, equal the column of ONE of the
+        reference's own runs -- so an undecidable position takes one of the reference's answers, and the later residual stages
+        of that frame (their input depends on that choice, dac/nn/quantize.py:173-193) follow THAT run, nothing else.
+    -> dict(ok, decidable_mismatches, undecidable_frames_not_a_reference_column, differs_from_fp32_reference, equals_run, ...)."""
+    if isinstance(codes, (list, tuple)):
+        codes = torch.cat([torch.as_tensor(c) for c in codes], 1)
+    got = torch.as_tensor(codes).cpu().numpy().astype(np.int64)
+    runs = {k: fixture["codes_" + k].astype(np.int64) for k in REFERENCE_RUNS}
+    dec = fixture["decidable"].astype(bool)
+    assert got.shape == dec.shape, (got.shape, dec.shape)
+    ref = runs["f32_mt"]
+    diff = got != ref
+    undec_frames = (~dec).any(1)                                           # (B, T)
+    column_of_a_run = np.zeros_like(undec_frames)
+    for r in runs.values():
+        column_of_a_run |= (got == r).all(1)
+    bad_cols = undec_frames & ~column_of_a_run
+    bad_dec = diff & dec
+    sha = lambda a: hashlib.sha256(a.astype(np.int16).tobytes()).hexdigest()   # noqa: E731
+    got_sha = sha(got)
+    return dict(
+        ok=bool(bad_dec.sum() == 0 and bad_cols.sum() == 0),
+        positions=int(dec.size), decidable=int(dec.sum()),
+        decidable_mismatches=int(bad_dec.sum()),
+        decidable_mismatch_positions=np.argwhere(bad_dec)[:16].tolist(),
+        undecidable_positions=np.argwhere(~dec).tolist(),
+        undecidable_frames=int(undec_frames.sum()),
+        undecidable_frames_not_a_reference_column=int(bad_cols.sum()),
+        differs_from_fp32_reference=int(diff.sum()),
+        equals_run=[k for k, r in runs.items() if np.array_equal(got, r)],
+        sha256=got_sha, sha256_equal=got_sha == sha(ref), sha256_equal_fp64_reference=got_sha == sha(runs["f64"]))
 
 
 class LatentCapture:

@@ -36,7 +36,7 @@ class _SpectralScale:
         basis_t = torch.from_numpy(basis).to(device).unsqueeze(-1)
         self.basis = ops.pack_conv_weight(basis_t)
         self.basis_bwd = ops.pack_conv_weight_bwd(basis_t)       # transposed GEMM of the backward pass
-        # the same two matrices as split-bf16 planes for the GEMM kernel (conv1d_gemm_split.hip; fp32-exact): the windowed-DFT
+        # the same two matrices as split-bf16 planes for the GEMM kernel (conv1d_gemm_split.hip; fp32-grade): the windowed-DFT
         # GEMMs of the long windows are 1x1 convs with 256 .. 2048 "channels" and ran at 23 TFLOP/s on the fp32 tile
         self.basis_t = basis_t
         self._basis_split = self._basis_split_t = None

@@ -215,7 +215,7 @@ class flop_scale:
         global _FLOP_SCALE
         _FLOP_SCALE = self.prev
 
-# k = 7 convs on the bf16 matrix pipe with fp32-exact operand splitting (conv1d_bsplit.hip).  Results have
+# k = 7 convs on the bf16 matrix pipe with fp32-grade operand splitting (conv1d_bsplit.hip).  Results have
 # fp32-MFMA-grade error; FAC_BF16_SPLIT=0 keeps every conv on the fp32 MFMA kernel.
 BF16_SPLIT = os.environ.get("FAC_BF16_SPLIT", "1") != "0"
 
@@ -1056,7 +1056,7 @@ def _wgrad_workspace(device, nbytes):
 
 
 def _bwd_weight_launch(x, dy, dw, B, c_in, t_in, c_out, t_out, k, stride, dilation, pad_left, pad_mode, k1=0, dilation2=0, db=None):
-    """dW on the bf16 matrix pipe with fp32-exact splitting (conv1d_wgrad_split.hip) when the shape qualifies and
+    """dW on the bf16 matrix pipe with fp32-grade splitting (conv1d_wgrad_split.hip) when the shape qualifies and
     FAC_BF16_SPLIT is on, else on the fp32 MFMA kernel.  db: optional (C_out) buffer for the bias gradient; returns True when the
     launch filled it."""
     lib = _lib.load()

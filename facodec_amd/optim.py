@@ -89,6 +89,7 @@ class FlatAdamW:
         self._works = []                                      # pending asynchronous collectives of this step, in launch order
         self._next_bucket = 0                                 # buckets [0, _next_bucket) have been launched this step
         self._at_launch = [False] * P                         # `_touched` of a bucket's parameters when it was launched
+        self._late_accum = []                                 # parameters accumulated into while their bucket was in flight
         self._need_scale = False
         self._flags_final = False                             # flags uploaded (and exchanged) for the pending step
         self._flags_pat, self._flags_cache = None, None
@@ -98,9 +99,24 @@ class FlatAdamW:
         self.time_exchange, self._wait_events = False, None
 
     def _mark(self, i):
+        """Post-accumulate hook: fires on EVERY accumulation into parameter i (a tied parameter, a module used twice in one graph, a
+        second backward before `step`).  An accumulation into a bucket whose exchange has already been launched is an in-place add
+        into memory the asynchronous collective may be reading: recorded here, raised by `step` / `wait_all_reduce` (an exception
+        inside the autograd engine's thread would leave the collectives of the other ranks unmatched at an arbitrary point)."""
         def hook(_p):
+            if self._next_bucket and i >= self.buckets[self._next_bucket - 1][0] and (self._works or self._flags_final):
+                self._late_accum.append(i)
             self._touched[i] = True
         return hook
+
+    def _raise_late(self):
+        late = sorted(set(self._late_accum) | set(self._late_gradients() if self._exchanging() else []))
+        if late:
+            self._late_accum = []
+            raise RuntimeError(f"FlatAdamW: parameters {late[:8]} received a gradient after the exchange of their bucket was launched "
+                               "(a second backward / a shared parameter / a launch point that is too early for this graph; "
+                               "FAC_EARLY_EXCHANGE=0 launches after backward, and gradient accumulation over several backward "
+                               "passes needs the exchange launched after the last one)")
 
     # ------------------------------------------------------------------------------------------ torch-optimizer shims
     @property
@@ -143,12 +159,20 @@ class FlatAdamW:
         self._rebind()
         self._gx.zero_()
         self._touched = [False] * len(self.params)
-        self._flags_final = False
-        self._next_bucket = 0
-        self._launch_log = []
+        self._reset_exchange_state()
         if unbind:
             for p in self.params:
                 p.grad = None
+
+    def _reset_exchange_state(self):
+        """Nothing of this key is in flight or marked launched: the next `launch_all_reduce` starts from bucket 0 again.  (`step`
+        used to clear only `_flags_final`; after `step(zero_grad=False)` a further backward + exchange then skipped every bucket
+        -- `_next_bucket == len(buckets)` -- and re-exchanged the flags only: un-averaged gradients, ranks drifting apart.)"""
+        self._flags_final = False
+        self._next_bucket = 0
+        self._launch_log = []
+        self._at_launch = [False] * len(self.params)
+        self._late_accum = []
 
     def _rebind(self, lo=0, hi=None):
         """`p.grad` must be the arena view (someone may have set it to None or to a foreign tensor), `p.data` must still
@@ -304,17 +328,32 @@ class FlatAdamW:
             dist.broadcast(self.p, src=src)
 
     # ------------------------------------------------------------------------------------------ step
+    def exchange_for_step(self):
+        """Everything of `step` that precedes the two kernels: late-gradient check, fold foreign gradient tensors into the arena,
+        launch whatever has not been launched, wait, final flags.  (Separate so that the CPU / gloo tests can drive the exchange
+        protocol of a whole step without the HIP library.)"""
+        self._raise_late()
+        self._rebind()                                         # raises as well if a stolen gradient belongs to a launched bucket
+        self.all_reduce_mean()                                 # whatever has not been launched yet, then wait for everything
+        self._raise_late()                                     # an accumulation that raced the collectives just waited for
+        if not self._flags_final:                              # single rank (or no process group): local flags
+            self._upload_flags()
+
+    def end_step(self, zero_grad=True, advance_lr=True):
+        self._expected = tuple(self._touched)
+        self.exchange_log.append(list(self._launch_log))
+        if len(self.exchange_log) > 64:
+            del self.exchange_log[:-64]
+        self._reset_exchange_state()                           # also without zero_grad(): the next backward + exchange starts over
+        if advance_lr:
+            self.scheduler_step()
+        if zero_grad:
+            self.zero_grad()
+
     def step(self, zero_grad=True, advance_lr=True):
         lib = _lib.load()
         st = ops._stream()
-        late = self._late_gradients() if self._exchanging() else []
-        if late:
-            raise RuntimeError(f"FlatAdamW: parameters {late[:8]} received a gradient after the exchange of their bucket was launched "
-                               "(the launch point is too early for this graph; FAC_EARLY_EXCHANGE=0 launches after backward)")
-        self._rebind()                                         # raises as well if a stolen gradient belongs to a launched bucket
-        self.all_reduce_mean()                                 # whatever has not been launched yet, then wait for everything
-        if not self._flags_final:                              # single rank (or no process group): local flags
-            self._upload_flags()
+        self.exchange_for_step()
         clip = None
         if self.max_norm is not None:
             _lib.check(lib.fac_grad_norm_clip(ops._ptr(self.g), self.n, self.max_norm, ops._ptr(self._scratch), ops._ptr(self.norm), st),
@@ -324,15 +363,7 @@ class FlatAdamW:
                                              ops._ptr(self._offsets), len(self.params), ops._ptr(self._flags), ops._ptr(self._steps_dev),
                                              ops._ptr(self._bc), self.lr, self.betas[0], self.betas[1], self.eps, self.wd,
                                              ops._ptr(clip), st), "fac_adamw_step_masked")
-        self._expected = tuple(self._touched)
-        self.exchange_log.append(list(self._launch_log))
-        if len(self.exchange_log) > 64:
-            del self.exchange_log[:-64]
-        self._flags_final = False
-        if advance_lr:
-            self.scheduler_step()
-        if zero_grad:
-            self.zero_grad()
+        self.end_step(zero_grad, advance_lr)
 
     def scheduler_step(self):
         """ExponentialLR.step(), once per iteration (train.py:372-374)."""

@@ -134,7 +134,7 @@ typedef struct fac_conv_desc {
   int64_t ws_bytes;
   /* Optional: the same weights in the split-bf16 layout of fac_pack_conv_w_split (K = 5 / 7) or fac_pack_gemm_w_split
    * (K = 1 / 2).  When given and the shape qualifies (stride 1, no Snake prologue, C_in % 16 == 0 resp. % 32 == 0, enough
-   * columns), the conv runs on the bf16 matrix pipe with fp32-exact operand splitting (conv1d_bsplit.hip /
+   * columns), the conv runs on the bf16 matrix pipe with fp32-grade operand splitting (conv1d_bsplit.hip /
    * conv1d_gemm_split.hip); `w` is still required for every other shape. */
   const void* w_split;
   /* Optional two-level taps (0 = plain): tap k = k2 * K1 + k1 reads the input at offset k2 * dilation2 + k1 * dilation
@@ -263,7 +263,7 @@ int fac_lstm_layer_fwd_persist(const float* pre, const float* whh16, float* hfra
                                int T, int H, int B, int BP, fac_stream_t stream);
 int fac_lstm_layer_bwd_persist(const float* dyT, const float* whh16t, const float* gates, const float* cs, float* dgates,
                                float* scratch, int T, int H, int B, int BP, fac_stream_t stream);
-/* Forward recurrence of a layer in one launch with W_hh . h on the bf16 matrix pipe (fp32-exact three-way bf16 split of both
+/* Forward recurrence of a layer in one launch with W_hh . h on the bf16 matrix pipe (fp32-grade three-way bf16 split of both
  * operands, six products, fp32 accumulation -- the arithmetic of the k = 7 conv kernel): what the fp32 resident kernel cannot do
  * at 17 .. 32 batch columns, where its step is its fp32 MFMA time.  Inference only (no saved gates).  fac_lstm_persist_split_ok(H, B)
  * != 0 for H in {512, 1024, 1536}, B <= 32, H/8 <= CUs.  wsplit: fac_pack_lstm_whh_split(W_hh (4H, H), out (4H*H*6 bytes), H);
@@ -405,7 +405,7 @@ int64_t fac_conv1d_bwd_weight_ws_bytes(int B, int C_in, int C_out, int T_out, in
 int fac_conv1d_bwd_weight(const float* x, const float* dy, float* dw, void* ws, int64_t ws_bytes, int B, int C_in,
                           int T_in, int C_out, int T_out, int K, int stride, int dilation, int pad_left, int pad_mode,
                           int K1, int dilation2, fac_stream_t stream);
-/* The same gradient on the bf16 matrix pipe with fp32-exact operand splitting (conv1d_wgrad_split.hip; same arguments
+/* The same gradient on the bf16 matrix pipe with fp32-grade operand splitting (conv1d_wgrad_split.hip; same arguments
  * and result layout as fac_conv1d_bwd_weight, error vs fp64 no larger than the fp32 MFMA's).  The workspace query
  * returns -1 for a (K, stride, dilation) the kernel does not cover: use fac_conv1d_bwd_weight then.  K1 / dilation2:
  * two-level taps as in fac_conv_desc (0 = plain); dW stays (C_out, C_in, K) with k = k2 * K1 + k1.  The workspace also

@@ -15,7 +15,11 @@ tensors per activation): `DiskOffload` is a torch.autograd.graph.saved_tensors_h
 >= 16 MB in a file under /tmp (deduplicated by content hash) and reads it back when backward asks for it -- the reference's
 code and arithmetic are untouched, only where its saved activations wait changes.
 
-Run:  python tests/golden/make_golden_bench.py [b32] [train16]      (about 2 + 30 minutes on 8 cores, < 60 GB RAM, ~100 GB of /tmp)
+  codec_b32_decidable.npz   which of those 30 720 indices the reference itself decides: the same batch through the reference in
+                  fp32 / all threads, fp32 / 1 thread and fp64; per position the three answers, the fp64 top-2 gap, `decidable` =
+                  all three agree (b32_decidable() below; + codec_b32_decidable_report.json)
+
+Run:  python tests/golden/make_golden_bench.py [b32] [b32_decidable] [train16]   (about 2 + 25 + 30 minutes on 8 cores, < 60 GB RAM, ~100 GB of /tmp)
 """
 import hashlib
 import json
@@ -104,6 +108,108 @@ def b32():
           f"codes sha256 {hashlib.sha256(allc.tobytes()).hexdigest()[:16]}")
 
 
+# ------------------------------------------------------------------------------------------------------------------------------
+# Which of the 30 720 code indices of configs[1] does the reference itself decide?  
+# The reference is not bit-reproducible against itself (8 threads vs 1 thread differ by 8.8e-7), so ONE fp32 run is
+# not "the" answer at a frame whose two best codes are nearly tied.  b32_decidable() runs the real reference on the timed batch
+# three ways -- fp32 on all threads (the run codec_b32.npz holds), fp32 on ONE thread (another summation order inside oneDNN /
+# MKL) and fp64 (same fp32-valued weights and inputs, every operation in double) -- and stores, per (clip, codebook, frame):
+# the three answers, the fp64 run's gap between its best and second-best code (dac/nn/quantize.py:86-91 distance) and the
+# margin each fp32 run saw between those same two codes.  `decidable` = the three runs agree.  Nothing here is tuned to this
+# build: the script never imports facodec_amd beyond the synthetic weights / clips.
+def _run_reference_with_vq_capture(dtype, threads, tag):
+    build_model, recursive_munch = MG.ref_imports()
+    from dac.nn.quantize import VectorQuantize
+    torch.set_num_threads(threads)
+    old = torch.get_default_dtype()
+    torch.set_default_dtype(dtype)
+    try:
+        with torch.no_grad():
+            model = build_model(recursive_munch(MG.model_params()))
+            for k in ("encoder", "quantizer", "decoder"):
+                synth.load_synthetic(model[k], seed=0, prefix=k + ".")           # fp32-valued weights, exact in fp64
+                model[k].to(dtype).eval()
+            wave = synth.synth_clips(32, 48000, seed=0).to(dtype)
+            cap = []                                                               # call order = prosody, content x 2, residual x 3
+            hooks = [m.register_forward_hook(lambda mod, args, out: cap.append((mod, out[4].detach().clone(), out[3].detach().clone())))
+                     for m in model.quantizer.modules() if isinstance(m, VectorQuantize)]
+            t0 = time.time()
+            z = model.encoder(wave)
+            outs, quantized, commit, cbl, timbre, codes = model.quantizer(z, wave, n_c=2, return_codes=True)
+            dt = time.time() - t0
+            for h in hooks:
+                h.remove()
+        assert len(cap) == 6, len(cap)
+        allc = torch.cat(codes, 1).numpy().astype(np.int16)
+        assert all(torch.equal(cap[i][2], torch.from_numpy(allc[:, i].astype(np.int64))) for i in range(6))
+        print(f"[b32_decidable] {tag}: {dt:.1f} s, sha256 {hashlib.sha256(allc.tobytes()).hexdigest()[:16]}", flush=True)
+        return dict(codes=allc, z_e=[c[1].double() for c in cap], codebooks=[c[0].codebook.weight.detach().double() for c in cap],
+                    z=z.double(), seconds=dt)
+    finally:
+        torch.set_default_dtype(old)
+
+
+def _pair_margin(z_e, codebook, first, second):
+    """d(second) - d(first) of dac/nn/quantize.py:86-91's distance, evaluated in fp64 on the given projected latents (B, 8, T)."""
+    e = torch.nn.functional.normalize(z_e.permute(0, 2, 1).reshape(-1, z_e.shape[1]), dim=1)
+    c = torch.nn.functional.normalize(codebook, dim=1)
+    d = e.pow(2).sum(1, keepdim=True) - 2 * e @ c.t() + c.pow(2).sum(1, keepdim=True).t()
+    idx = torch.arange(d.shape[0])
+    return (d[idx, second.reshape(-1)] - d[idx, first.reshape(-1)]).reshape(first.shape), d
+
+
+def b32_decidable():
+    ncpu = os.cpu_count()
+    runs = {"f32_mt": _run_reference_with_vq_capture(torch.float32, ncpu, f"fp32, {ncpu} threads"),
+            "f32_1t": _run_reference_with_vq_capture(torch.float32, 1, "fp32, 1 thread"),
+            "f64": _run_reference_with_vq_capture(torch.float64, ncpu, f"fp64, {ncpu} threads")}
+    held = np.load(os.path.join(HERE, "codec_b32.npz"))
+    assert np.array_equal(runs["f32_mt"]["codes"], held["codes"]), "the fp32 all-threads run no longer reproduces codec_b32.npz"
+    B, n, T = runs["f64"]["codes"].shape
+    gap64 = np.zeros((B, n, T), np.float64)
+    second64 = np.zeros((B, n, T), np.int16)
+    margins = {k: np.zeros((B, n, T), np.float64) for k in ("f32_mt", "f32_1t")}
+    for i in range(n):
+        r = runs["f64"]
+        _, d = _pair_margin(r["z_e"][i], r["codebooks"][i], torch.zeros(B, T, dtype=torch.int64), torch.zeros(B, T, dtype=torch.int64))
+        top2 = torch.topk(-d, 2, dim=1)
+        best = top2.indices[:, 0].reshape(B, T)
+        assert torch.equal(best, torch.from_numpy(r["codes"][:, i].astype(np.int64))), i
+        sec = top2.indices[:, 1].reshape(B, T)
+        gap64[:, i] = (top2.values[:, 0] - top2.values[:, 1]).reshape(B, T).numpy()
+        second64[:, i] = sec.numpy()
+        for k in margins:          # what the fp32 run saw between the SAME two codes (meaningful where its upstream stages agree with fp64's)
+            m, _ = _pair_margin(runs[k]["z_e"][i], runs[k]["codebooks"][i], best, sec)
+            margins[k][:, i] = m.numpy()
+    agree = (runs["f32_mt"]["codes"] == runs["f32_1t"]["codes"]) & (runs["f32_mt"]["codes"] == runs["f64"]["codes"])
+    # a stage's input is final only if every stage feeding it agrees too: prosody -> nothing; content i -> content < i;
+    # residual i -> prosody, content, residual < i (modules/quantize.py:398-417: residual input = x - z_p - z_c)
+    feeds = {0: [], 1: [], 2: [1], 3: [0, 1, 2], 4: [0, 1, 2, 3], 5: [0, 1, 2, 3, 4]}
+    upstream_agree = np.stack([np.all(agree[:, feeds[i]], axis=1) if feeds[i] else np.ones((B, T), bool) for i in range(n)], 1)
+    clean = agree & upstream_agree
+    noise = {k: np.abs(margins[k] - gap64)[upstream_agree] for k in margins}
+    zrel = {k: float((runs[k]["z"] - runs["f64"]["z"]).abs().max() / runs["f64"]["z"].abs().max()) for k in margins}
+    report = {
+        "positions": int(agree.size), "decidable": int(agree.sum()), "undecidable": int((~agree).sum()),
+        "undecidable_with_agreeing_upstream": int((~agree & upstream_agree).sum()),
+        "undecidable_positions_clip_codebook_frame": np.argwhere(~agree).tolist(),
+        "fp64_gap_at_undecidable": [float(gap64[tuple(p)]) for p in np.argwhere(~agree)],
+        "smallest_fp64_gap_among_decidable": float(gap64[clean].min()),
+        "decidable_with_fp64_gap_below_1e-6": int((gap64[clean] < 1e-6).sum()),
+        "reference_margin_noise_fp32_vs_fp64": {k: {"max": float(v.max()), "p99.9": float(np.quantile(v, 0.999)), "median": float(np.median(v))} for k, v in noise.items()},
+        "reference_latent_rel_err_fp32_vs_fp64": zrel,
+        "seconds": {k: float(r["seconds"]) for k, r in runs.items()}, "threads": ncpu,
+    }
+    np.savez_compressed(
+        os.path.join(HERE, "codec_b32_decidable.npz"), codes_f32_mt=runs["f32_mt"]["codes"], codes_f32_1t=runs["f32_1t"]["codes"],
+        codes_f64=runs["f64"]["codes"], second_f64=second64, gap_f64=gap64.astype(np.float32), decidable=agree,
+        margin_f32_mt=margins["f32_mt"].astype(np.float32), margin_f32_1t=margins["f32_1t"].astype(np.float32),
+        z_e_f64_probe=np.stack([r.numpy() for r in runs["f64"]["z_e"]], 1)[PROBE_CLIPS].astype(np.float32),
+        report=np.array(json.dumps(report)))
+    json.dump(report, open(os.path.join(HERE, "codec_b32_decidable_report.json"), "w"), indent=1)
+    print(json.dumps(report, indent=1))
+
+
 def train16():
     model, _ = MGT.build_reference_in_train_mode()
     cfg = dict(B=B16, SEG_FRAMES=160, T_FULL=T_FULL16, WAVE_LENS=WAVE_LENS16, CROP_START=CROP16, DROPOUT_DRAWS=DRAWS16,
@@ -136,5 +242,7 @@ if __name__ == "__main__":
     what = sys.argv[1:] or ["b32", "train16"]
     if "b32" in what:
         b32()
+    if "b32_decidable" in what:
+        b32_decidable()
     if "train16" in what:
         train16()

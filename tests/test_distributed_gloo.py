@@ -259,6 +259,68 @@ def test_two_rank_bucketed_progressive_exchange():
     assert late0 and late1
 
 
+def _accumulation_worker(rank, world, port, q):
+    sys.path.insert(0, REPO)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from facodec_amd import benchutil
+    from facodec_amd.optim import FlatAdamW
+    benchutil.init_distributed("gloo")
+    torch.manual_seed(0)
+    net = _Chain()
+    opt = FlatAdamW(net.parameters(), bucket_bytes=280)
+    x = torch.randn(5, 8, generator=torch.Generator().manual_seed(20 + rank))
+    # (a) two backward passes before one step, the first one's buckets already in flight: the second accumulates IN PLACE into
+    # the bound views (no foreign tensor for _rebind to notice) -- the post-accumulate hook sees it, step raises
+    opt.zero_grad(unbind=True)
+    net(x).pow(2).sum().backward()
+    opt.launch_all_reduce(from_param=2 * 2, from_hook=True)         # buckets of blocks 2 and 3 have left
+    net(x).pow(2).sum().backward()
+    late = sorted(set(opt._late_accum))
+    try:
+        opt.exchange_for_step()
+        raised = False
+    except RuntimeError:
+        raised = True
+    opt.launch_all_reduce()                                         # (both ranks raised at the same point: finish the key's collectives)
+    opt.wait_all_reduce()
+    opt.zero_grad(unbind=True)
+    # (b) accumulation done right: both backward passes first, the exchange after the last one
+    net(x).pow(2).sum().backward()
+    net(x).pow(2).sum().backward()
+    opt.exchange_for_step()
+    acc = opt.g.clone()
+    opt.end_step(zero_grad=True, advance_lr=False)
+    # (c) step(zero_grad=False) -- what TrainStep uses -- followed by another backward + step WITHOUT zero_grad: every bucket is
+    # exchanged again (it used to re-exchange the flags only and apply un-averaged gradients)
+    opt.zero_grad(unbind=True)
+    net(x).pow(2).sum().backward()
+    opt.exchange_for_step()
+    first = opt.g.clone()
+    opt.end_step(zero_grad=False, advance_lr=False)
+    net(x).pow(2).sum().backward()                                  # adds this rank's gradient onto the averaged one
+    opt.exchange_for_step()
+    second, log = opt.g.clone(), list(opt._launch_log)
+    opt.end_step(zero_grad=False, advance_lr=False)
+    q.put(_portable((rank, late, raised, acc, first, second, log, [list(e) for e in opt.exchange_log])))
+    torch.distributed.destroy_process_group()
+
+
+def test_two_rank_accumulation_and_repeated_step_without_zero_grad():
+    """(a) a second backward while the first one's buckets are in flight is caught by the post-accumulate hook (the
+    in-place add into the bound view is invisible to `_rebind`) and raised by the step; (b) accumulating over two backward passes
+    with the exchange after the last one gives the mean of the summed gradients on both ranks; (c) after `step(zero_grad=False)` a
+    further backward + step exchanges every bucket again: both ranks hold the same arena."""
+    (_, late0, r0, acc0, f0, s0, log0, elog0), (_, late1, r1, acc1, f1, s1, log1, elog1) = _run_ranks(_accumulation_worker)
+    assert r0 and r1 and late0 == late1 == [4, 5, 6, 7]            # weights and biases of blocks 2, 3 (launched), not 0, 1
+    assert torch.equal(acc0, acc1) and torch.equal(f0, f1)
+    assert torch.allclose(acc0, 2 * f0, atol=1e-6)                  # two identical passes accumulated, then averaged
+    assert torch.equal(s0, s1)                                      # the second step's exchange really averaged
+    assert torch.allclose(s0, 2 * f0, atol=1e-6)                    # averaged first gradient + mean of the second pass
+    assert log0 == log1 == [(0, "end"), (1, "end"), (2, "end"), (3, "end")]
+    assert elog0[-1] == log0 and elog0[-2] == log0
+
+
 def _flag_worker(rank, world, port, q):
     sys.path.insert(0, REPO)
     os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",

@@ -981,7 +981,7 @@ def test_skinny_conv_variant_and_second_output(O, ops, cuda):
     assert rel(tail, full[:, :, 6 * s:]) < OP_TOL
 
 
-# ------------------------------------------------------------------------------ fp32-exact bf16 split convs
+# ------------------------------------------------------------------------------ fp32-grade bf16 split convs
 @pytest.mark.parametrize("B,C,T,d,mode", [(2, 128, 1000, 1, "reflect"), (1, 192, 777, 3, "reflect"), (2, 768, 960, 9, "reflect"),
                                            (1, 96, 2000, 9, "zero"), (3, 256, 300, 1, "reflect")])
 def test_split_bf16_conv_matches_fp32_grade(B, C, T, d, mode, O, ops, cuda):

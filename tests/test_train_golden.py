@@ -94,11 +94,16 @@ def test_train_step_against_reference_golden(cuda, golden_dir):
 
 def test_batch32_codes_against_reference_golden(cuda, golden_dir):
     """configs[1] at its real size against REFERENCE-MADE numbers (tests/golden/codec_b32.npz: the real reference run on the 32 clips
-    x 2 s that bench.py times): all 32 x 6 x 160 code indices (a flip between two codes whose distances differ by <= 1e-5, and the
-    residual stages it drags along, is triaged and reported by bench.py; here none is allowed beyond that triage and the
-    count is asserted small), latent / quantizer-output / waveform / timbre probes of four clips at 1e-4."""
-    from facodec_amd.diagnostics import LatentCapture, classify_faquantizer_codes
+    x 2 s that bench.py times): all 32 x 6 x 160 code indices EXACTLY, with the one exception the reference itself makes
+    (tests/golden/codec_b32_decidable.npz: the reference in fp32 / all threads, fp32 / 1 thread and fp64 on this batch; at one
+    frame of clip 15 its fp32 and fp64 runs pick different codes -- fp64 top-2 gap 3.9e-7 -- and the third residual stage of
+    that frame follows): every position where the three runs agree must equal them (zero allowance), a frame with a position
+    where they disagree must equal ONE run's whole column (facodec_amd.diagnostics.check_codes_decidable).  Then latent /
+    quantizer-output / waveform / timbre probes of four clips at 1e-4."""
+    from facodec_amd.diagnostics import LatentCapture, check_codes_decidable, classify_faquantizer_codes
     d = np.load(os.path.join(golden_dir, "codec_b32.npz"))
+    fx = np.load(os.path.join(golden_dir, "codec_b32_decidable.npz"))
+    assert np.array_equal(fx["codes_f32_mt"], d["codes"])
     model = _model(cuda, ("encoder", "quantizer", "decoder"))
     for k in ("encoder", "quantizer", "decoder"):
         model[k].eval()
@@ -107,9 +112,11 @@ def test_batch32_codes_against_reference_golden(cuda, golden_dir):
         z = model.encoder(wave)
         outs, _, commit, cbl, timbre, codes = model.quantizer(z, wave, n_c=2, return_codes=True)
         y = model.decoder(outs)
-    report = classify_faquantizer_codes(cap, codes, [d["codes"][:, lo:hi] for lo, hi in ((0, 1), (1, 3), (3, 6))])
-    assert sum(c.shape[1] for c in codes) == 6 and sum(r["genuine"] for r in report.values()) == 0, report
-    assert sum(r["mismatches"] for r in report.values()) <= 6, report           # measured: 0 of 30 720
+    assert sum(c.shape[1] for c in codes) == 6
+    verdict = check_codes_decidable(codes, fx)
+    triage = classify_faquantizer_codes(cap, codes, [d["codes"][:, lo:hi] for lo, hi in ((0, 1), (1, 3), (3, 6))])   # diagnostics only
+    assert verdict["ok"] and verdict["decidable_mismatches"] == 0, (verdict, triage)
+    assert verdict["differs_from_fp32_reference"] <= int((~fx["decidable"]).sum()), verdict
     pc = d["probe_clips"].tolist()
     rel = lambda a, b, scale: float(np.abs(a.detach().cpu().numpy() - b).max()) / float(scale)   # noqa: E731
     assert rel(z[pc][:, ::8, :], d["z_probe"], d["z_absmax"]) < 1e-4

@@ -1,4 +1,4 @@
-"""Weight-gradient GEMM on the bf16 matrix pipe with fp32-exact operand splitting (facodec_amd/csrc/conv1d_wgrad_split.hip)
+"""Weight-gradient GEMM on the bf16 matrix pipe with fp32-grade operand splitting (facodec_amd/csrc/conv1d_wgrad_split.hip)
 against an fp64 restatement of torch's conv1d weight gradient, next to the fp32-MFMA kernel it replaces."""
 import pytest
 import torch
