@@ -164,6 +164,21 @@ def train_leg(model, device, rank, world, steps, warmup):
     fn()
     torch.cuda.synchronize()
     ops.set_flop_counter(None)
+    # ... and one with HIP events around every conv / weight-gradient launch (recorded on the stream each one is launched on):
+    # which kernel the step spends most time in, and that kernel's own rate against the pipe it runs on
+    # (the concurrent chains are run one after the other for this one step, so that a launch's event time is its own time)
+    from facodec_amd import autograd_pred, discriminator
+    prof = ops.ConvLaunchProfile()
+    ops.set_conv_profile(prof)
+    n_d, n_p = discriminator.N_STREAMS, autograd_pred.PRED_STREAMS
+    discriminator.N_STREAMS, autograd_pred.PRED_STREAMS = 1, 1
+    try:
+        fn()
+        torch.cuda.synchronize()
+    finally:
+        discriminator.N_STREAMS, autograd_pred.PRED_STREAMS = n_d, n_p
+        ops.set_conv_profile(None)
+    ksum = prof.summary()
     exchange = step.exchange_report()
     for o in step.opt.values():
         o.time_exchange = False
@@ -208,11 +223,34 @@ def train_leg(model, device, rank, world, steps, warmup):
                           "basis": "counted at the C-ABI call sites of one real step (facodec_amd/ops.py FlopCounter): conv fwd / "
                                    "data-grad / weight-grad launches + LSTM recurrences, batch padding excluded; 'dft' = windowed-DFT "
                                    "and mel GEMMs of the STFT front-ends, NOT part of the total"},
-        "roofline": {"bound": "mfma", "achieved": round(per_gpu_tflops, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": round(per_gpu_tflops / FP32_MFMA_PEAK_TFLOPS, 4),
-                     "basis": "whole step, per GPU: audio-s/s x COUNTED TFLOP per audio-second against the fp32 MFMA peak; "
-                              "per-kernel numbers in profiles/"},
+        "roofline": train_roofline(ksum, per_gpu_tflops),
     }
+
+
+def train_roofline(ksum, per_gpu_tflops):
+    """Dominant kernel of the train step (largest summed launch time in the event-timed extra step, which runs the concurrent
+    chains one after the other so that a launch's event time is its own) priced against the pipe it runs on, next to the
+    whole-step figures.  A weight-gradient record is the whole launch: operand planes + GEMM + split-K reduction."""
+    name, best = max(ksum.items(), key=lambda kv: kv[1]["ms"])
+    is_split = any(t in name for t in ("bsplit", "gemm_split", "wgrad_split", "kmajor"))
+    peak = SPLIT_PEAK_TFLOPS if is_split else FP32_MFMA_PEAK_TFLOPS
+    achieved = best["flops"] / (best["ms"] * 1e-3) / 1e12
+    tot_ms = sum(v["ms"] for v in ksum.values())
+    return {"bound": "mfma", "kernel": name, "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
+            "frac": round(achieved / peak, 4),
+            "launches_per_step": best["launches"], "avg_launch_us": round(1e3 * best["ms"] / best["launches"], 2),
+            "avg_launch_gflop": round(best["flops"] / best["launches"] / 1e9, 3),
+            "kernel_share_of_gemm_launch_time": round(best["ms"] / tot_ms, 4),
+            "all_variants": {k: {"launches_per_step": v["launches"], "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2),
+                                 "ms_per_step": round(v["ms"], 3)}
+                             for k, v in sorted(ksum.items(), key=lambda kv: -kv[1]["ms"])[:12]},
+            "whole_step_tflops": round(per_gpu_tflops, 2),
+            "whole_step_frac_of_fp32_mfma_peak": round(per_gpu_tflops / FP32_MFMA_PEAK_TFLOPS, 4),
+            "whole_step_frac_of_split_peak": round(per_gpu_tflops / SPLIT_PEAK_TFLOPS, 4),
+            "basis": "kernel / achieved / frac: HIP events around every conv and weight-gradient launch of one extra step (chains serialised), the variant with "
+                     "the largest total time, algorithmic FLOPs / its time, against the pipe it runs on (bf16 dense / 6 for the "
+                     "three-way-split kernels).  whole_step_*: audio-s/s x COUNTED TFLOP per audio-second, per GPU; most of those FLOPs "
+                     "run on the bf16 pipe, so the fp32-peak fraction flatters and the split-peak fraction is the honest one"}
 
 
 def _disc_streams():
@@ -225,34 +263,14 @@ def _pred_streams():
     return autograd_pred.PRED_STREAMS
 
 
-def streaming_leg(model, device, hops=2000):
-    """configs[4], short: 480-sample hops through the streaming session (HIP-graph replay), per-hop latency measured on the
-    host around push() + device sync.  tools/stream_bench.py is the 30-minute version."""
-    from facodec_amd.streaming import HOP, StreamingCodec
-    loop = synth.synth_clips(1, SAMPLE_RATE * 20, seed=0).to(device)
-    with torch.no_grad():
-        enrol = loop[:, :, :48000]
-        timbre = model.quantizer(model.encoder(enrol), enrol, n_c=2)[4]
-        sess = StreamingCodec(model, timbre, n_c=2, use_graphs=True)
-        sess.prime(loop[:, :, :4800])
-        torch.cuda.synchronize()
-        lat, pos = [], 4800
-        t_all = time.perf_counter()
-        for _ in range(hops):
-            if pos + HOP > loop.shape[-1]:
-                pos = 0
-            hop = loop[:, :, pos:pos + HOP]
-            pos += HOP
-            t0 = time.perf_counter()
-            sess.push(hop)
-            torch.cuda.synchronize()
-            lat.append(time.perf_counter() - t0)
-        wall = time.perf_counter() - t_all
-    steady = sorted(lat[10:])
-    q = lambda p: round(1e3 * steady[min(len(steady) - 1, int(p * len(steady)))], 4)  # noqa: E731
-    return {"workload": f"configs[4] (short): {hops} hops of {HOP} samples, one stream, carried conv / LSTM state, HIP-graph replay, "
-                        "encoder and quantizer+decoder halves of a hop as two concurrent chains",
-            "hops": hops, "p50_ms": q(0.5), "p99_ms": q(0.99), "rtf": round(wall / (hops * HOP / SAMPLE_RATE), 5)}
+def streaming_leg(model, device, hops=90000, check_minutes=5.0):
+    """configs[4] at its stated size: 30 min of 24 kHz audio = 90 000 hops of 480 samples through one streaming session
+    (HIP-graph replay, two chains per hop), p50 / p99 / max per-hop latency and RTF; the first `check_minutes` of the stream are
+    compared code by code and sample by sample with the offline causal model (facodec_amd.benchutil.streaming_soak)."""
+    r = benchutil.streaming_soak(model, device, hops, check_minutes=check_minutes)
+    r["workload"] = (f"configs[4]: {r['hops']} hops of {r['hop_samples']} samples ({r['audio_minutes']} min of audio), one stream, carried "
+                     "conv / LSTM state, HIP-graph replay, encoder and quantizer+decoder halves of a hop as two concurrent chains")
+    return r
 
 
 def respawn_under_launcher(n):
@@ -366,7 +384,8 @@ def main():
     ap.add_argument("--train-steps", type=int, default=4)
     ap.add_argument("--train-warmup", type=int, default=2)
     ap.add_argument("--no-streaming", action="store_true", help="skip the configs[4] streaming-latency leg")
-    ap.add_argument("--stream-hops", type=int, default=2000)
+    ap.add_argument("--stream-hops", type=int, default=90000, help="configs[4]: 90 000 hops of 480 samples = 30 min of audio (~110 s)")
+    ap.add_argument("--stream-check-minutes", type=float, default=5.0, help="prefix of the stream compared with the offline model")
     args = ap.parse_args()
 
     if not torch.cuda.is_available():
@@ -376,6 +395,14 @@ def main():
     rank, local_rank, world = benchutil.init_distributed()
     if world != args.gpus:
         raise SystemExit(f"[bench] --gpus {args.gpus} but WORLD_SIZE={world}")
+    if world > 1:
+        backend = torch.distributed.get_backend()
+        if backend != "nccl" and os.environ.get("FAC_DIST_BACKEND") != backend:
+            raise SystemExit(f"[bench] {world} ranks over '{backend}': multi-GPU numbers are RCCL numbers (backend 'nccl'); "
+                             "FAC_DIST_BACKEND=gloo is the explicit opt-in for the two-ranks-on-one-GPU smoke run")
+        local_world = int(os.environ.get("LOCAL_WORLD_SIZE", world))
+        if torch.cuda.device_count() < local_world and os.environ.get("FAC_DIST_BACKEND") != "gloo":
+            raise SystemExit(f"[bench] {local_world} local ranks but {torch.cuda.device_count()} GPU(s) visible: one process per GPU")
     device = torch.device(f"cuda:{local_rank % torch.cuda.device_count()}")
     torch.cuda.set_device(device)
 
@@ -425,7 +452,7 @@ def main():
 
     streaming = None
     if rank == 0 and world == 1 and not args.no_streaming:
-        streaming = streaming_leg(model, device, args.stream_hops)
+        streaming = streaming_leg(model, device, args.stream_hops, args.stream_check_minutes)
 
     out = {
         "metric": "24kHz audio sec encoded+decoded per wall-sec",
@@ -486,7 +513,7 @@ def main():
             if rank == 0:
                 out["train_step"] = {"error": f"train leg did not finish within {limit:.0f} s on {world} GPU(s); forward line unaffected"}
                 print(json.dumps(out), flush=True)
-            os._exit(0)
+            os._exit(3)                     # the line is printed, but a stalled exchange must not look like a clean run
 
         dog = threading.Timer(limit, expired)
         dog.daemon = True

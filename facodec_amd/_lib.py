@@ -75,6 +75,7 @@ SIGNATURES = {
     "fac_lstm_layer_fwd_persist": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "fac_lstm_layer_bwd_persist": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "fac_lstm_persist_split_ok": (_i, [_i, _i]),
+    "fac_lstm_persist_timeouts": (_i, []),
     "fac_pack_lstm_whh_split": (_i, [_p, _p, _i, _p]),
     "fac_lstm_layer_fwd_persist_split": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "fac_snake_bwd_fused": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
@@ -126,6 +127,7 @@ SIGNATURES = {
     "fac_crop_rows": (_i, [_p, _p, _p, _i, _i, _i64, _i, _i, _p]),
     "fac_stream_push": (_i, [_p, _p, _i64, _i64, _i, _i, _i, _p]),
     "fac_vq_fwd": (_i, [C.POINTER(VqDesc), _p]),
+    "fac_vq_loss_tiles": (_i, [_i]),
     "fac_vq_search": (_i, [_p, _p, _p, _i64, _i, _p]),
     "fac_gate_tanh_sigmoid": (_i, [_p, _p, _i64, _p, _i, _i, _i, _p]),
     "fac_embed_sum": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p]),

@@ -357,7 +357,7 @@ class _RVQ(Function):
         zd = z.detach()
         z_q = torch.zeros_like(zd)
         residuals, z_es = [], []
-        nt = (T + 63) // 64
+        nt = ops.vq_loss_tiles(T)
         lp = torch.empty(n, B, nt, device=z.device)
         src = zd
         for i in range(n):

@@ -29,7 +29,9 @@
 //   four whole 128-byte lines of the state buffer; the weights are packed with the same permutation (unit_of_k).
 #include <stdlib.h>
 
+#include <map>
 #include <mutex>
+#include <utility>
 #include <unordered_map>
 
 #include "common.h"
@@ -50,7 +52,15 @@ struct alignas(256) LstmSync {
 };
 __device__ LstmSync g_lstm_sync[LSTM_SYNC_SLOTS];
 
-constexpr long long LSTM_SPIN_LIMIT = 400000000ll;   // wall_clock64 ticks (100 MHz): 4 s without progress -> trap
+constexpr long long LSTM_SPIN_LIMIT = 400000000ll;   // wall_clock64 ticks (100 MHz): 4 s without progress -> give up (no trap)
+
+// A wait that sees no progress for LSTM_SPIN_LIMIT gives up WITHOUT trapping (round 5; a trap kills the whole context, and under
+// eight ranks one slow rank would become seven hung RCCL collectives): it raises g_lstm_abort, which every other waiter of the
+// device notices on its next slow-path check, counts the event in a host-mapped word the HOST reads without synchronising
+// (fac_lstm_persist_timeouts; fac_lstm_persist_ok / _split_ok answer 0 from then on, so callers fall back to the per-step
+// kernels of lstm.hip), and the launch runs to its end with meaningless results.
+__device__ unsigned g_lstm_abort;
+__device__ unsigned* g_lstm_host_timeouts;
 
 // wave 0: wait until flags[first .. first+count) have all reached `target`; then the workgroup passes a barrier (mode 0
 // only: and every wave takes an agent-scope acquire that drops stale L1 / L2 lines of the exchanged buffers).
@@ -78,7 +88,17 @@ __device__ __forceinline__ void wait_flags(const unsigned* flags, int first, int
       }
       if (__ballot(behind) == 0ull) break;
       __builtin_amdgcn_s_sleep(1);
-      if ((it & 1023u) == 0 && wall_clock64() - t0 > LSTM_SPIN_LIMIT) __builtin_trap();
+      if ((it & 1023u) == 0) {
+        if (__hip_atomic_load(&g_lstm_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
+        if (wall_clock64() - t0 > LSTM_SPIN_LIMIT) {
+          if (lane == 0) {
+            __hip_atomic_store(&g_lstm_abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            unsigned* h = g_lstm_host_timeouts;
+            if (h) __hip_atomic_fetch_add(h, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          }
+          break;
+        }
+      }
     }
   }
   __syncthreads();
@@ -647,19 +667,63 @@ struct PersistOrder {
 };
 static PersistOrder g_order;
 
-// before == true: make `stream` wait for the previous resident launch of this process on this device; false: record behind this one
-static void order_resident_launch(hipStream_t stream, bool before) {
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= LSTM_MAX_DEV) return;
-  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-  if (hipStreamIsCapturing(stream, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return;
-  std::lock_guard<std::mutex> lock(g_order.mu);
-  if (before) {
+// Holds the process-wide mutex ACROSS "wait for the previous resident launch", the launch itself and "record behind it"
+// (as three critical sections two host threads -- ctypes releases the GIL, autograd runs backward on its own thread --
+// could both wait on the same old event and then launch unordered: the two-half-resident-grids deadlock).
+struct ResidentLaunch {
+  std::unique_lock<std::mutex> lock;
+  hipStream_t stream;
+  int dev = -1;
+  explicit ResidentLaunch(hipStream_t st) : lock(g_order.mu), stream(st) {
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= LSTM_MAX_DEV) return;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return;
+    dev = d;
     if (g_order.have[dev]) (void)hipStreamWaitEvent(stream, g_order.ev[dev], 0);
-  } else {
+  }
+  ~ResidentLaunch() {
+    if (dev < 0) return;
     if (!g_order.ev[dev] && hipEventCreateWithFlags(&g_order.ev[dev], hipEventDisableTiming) != hipSuccess) return;
     g_order.have[dev] = hipEventRecord(g_order.ev[dev], stream) == hipSuccess;
   }
+};
+
+// Host-mapped counter of waits that gave up (g_lstm_host_timeouts on every device of this process points at it).
+struct TimeoutWord {
+  std::mutex mu;
+  unsigned* host = nullptr;
+  bool armed[LSTM_MAX_DEV] = {};
+};
+static TimeoutWord g_timeouts;
+
+static unsigned persist_timeouts() {
+  std::lock_guard<std::mutex> lock(g_timeouts.mu);
+  return g_timeouts.host ? *reinterpret_cast<volatile unsigned*>(g_timeouts.host) : 0u;
+}
+
+__global__ void lstm_arm_timeout_word_kernel(unsigned* p) { g_lstm_host_timeouts = p; }
+
+// Called in front of every resident launch (under ResidentLaunch's lock): the first launch on a device tells the device where to
+// count its timeouts -- by a one-thread kernel on the same stream (no synchronising call, nothing allocated inside a stream
+// capture: a launch issued during capture before the word exists simply runs un-armed, the abort word still ends its waits).
+static void arm_timeout_word(hipStream_t stream) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= LSTM_MAX_DEV) return;
+  std::lock_guard<std::mutex> lock(g_timeouts.mu);
+  if (g_timeouts.armed[dev]) return;
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(stream, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return;
+  if (!g_timeouts.host) {
+    void* p = nullptr;
+    if (hipHostMalloc(&p, 64, hipHostMallocMapped | hipHostMallocPortable) != hipSuccess) return;
+    g_timeouts.host = static_cast<unsigned*>(p);
+    *g_timeouts.host = 0u;
+  }
+  void* dptr = nullptr;
+  if (hipHostGetDevicePointer(&dptr, g_timeouts.host, 0) != hipSuccess) return;
+  hipLaunchKernelGGL(lstm_arm_timeout_word_kernel, dim3(1), dim3(1), 0, stream, static_cast<unsigned*>(dptr));
+  g_timeouts.armed[dev] = hipGetLastError() == hipSuccess;
 }
 
 // FAC_LSTM_EXCHANGE = fence (mode 0) | sc1 (mode 1) | fresh (mode 2, default)
@@ -686,9 +750,78 @@ static bool persist_split_shape_ok(int H, int B) {
   return wgs <= LSTM_MAX_WG && wgs <= device_cus();
 }
 
+using FwdKern = void (*)(const float*, const float*, float*, float*, float*, float*, int, int, int, int, int);
+using BwdKern = void (*)(const float*, const float*, const float*, const float*, float*, float*, float*, int, int, int, int, int);
+using SplitKern = void (*)(const float*, const ls_bf16x8*, ls_bf16x8*, float*, int, int, int, int);
+
+static FwdKern fwd_kernel_for(int H, int B) {
+  switch ((H / 64) * 10 + (B + 15) / 16) {
+    case 81: return lstm_fwd_persist_kernel<8, 1>;
+    case 82: return lstm_fwd_persist_kernel<8, 2>;
+    case 161: return lstm_fwd_persist_kernel<16, 1>;
+    case 162: return lstm_fwd_persist_kernel<16, 2>;
+    case 241: return lstm_fwd_persist_kernel<24, 1>;
+    case 242: return lstm_fwd_persist_kernel<24, 2>;
+  }
+  return nullptr;
+}
+
+static BwdKern bwd_kernel_for(int H, int B) {
+  switch ((H / 64) * 10 + (B + 15) / 16) {
+    case 81: return lstm_bwd_persist_kernel<8, 1>;
+    case 82: return lstm_bwd_persist_kernel<8, 2>;
+    case 161: return lstm_bwd_persist_kernel<16, 1>;
+    case 162: return lstm_bwd_persist_kernel<16, 2>;
+    case 241: return lstm_bwd_persist_kernel<24, 1>;
+    case 242: return lstm_bwd_persist_kernel<24, 2>;
+  }
+  return nullptr;
+}
+
+static SplitKern split_kernel_for(int H) {
+  switch (H) {
+    case 512: return lstm_fwd_persist_split_kernel<4>;
+    case 1024: return lstm_fwd_persist_split_kernel<8>;
+    case 1536: return lstm_fwd_persist_split_kernel<12>;
+  }
+  return nullptr;
+}
+
+// the occupancy answer per (device, kernel) is asked once
+static bool grid_fits_cached(const void* kern, int grid, int threads) {
+  static std::mutex mu;
+  static std::map<std::pair<int, const void*>, bool> cache;
+  if (kern == nullptr) return false;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return false;
+  std::lock_guard<std::mutex> lock(mu);
+  auto key = std::make_pair(dev, kern);
+  auto it = cache.find(key);
+  if (it != cache.end()) return it->second;
+  const bool ok = grid_fits(kern, grid, threads);
+  cache[key] = ok;
+  return ok;
+}
+
+// What fac_lstm_persist_ok / _split_ok answer: the shape is inside the kernels, the whole grid of the forward AND the backward
+// kernel is co-resident by the runtime's own occupancy figure (a shape or device that fails it used to be a hard
+// FAC_REQUIRE error in the launch instead of a fall-back), and no resident wait of this process has ever timed out.
+static bool persist_usable(int H, int B) {
+  return persist_shape_ok(H, B) && persist_timeouts() == 0u &&
+         grid_fits_cached(reinterpret_cast<const void*>(fwd_kernel_for(H, B)), H / 8, 1024) &&
+         grid_fits_cached(reinterpret_cast<const void*>(bwd_kernel_for(H, B)), H / 8, 1024);
+}
+
+static bool persist_split_usable(int H, int B) {
+  return persist_split_shape_ok(H, B) && persist_timeouts() == 0u &&
+         grid_fits_cached(reinterpret_cast<const void*>(split_kernel_for(H)), H / 8, LS_NW * 64);
+}
+
 }  // namespace fac
 
-extern "C" int fac_lstm_persist_split_ok(int H, int B) { return fac::persist_split_shape_ok(H, B) ? 1 : 0; }
+extern "C" int fac_lstm_persist_split_ok(int H, int B) { return fac::persist_split_usable(H, B) ? 1 : 0; }
+
+extern "C" int fac_lstm_persist_timeouts(void) { return (int)fac::persist_timeouts(); }
 
 extern "C" int fac_pack_lstm_whh_split(const float* w_hh, void* packed, int H, fac_stream_t stream) {
   using namespace fac;
@@ -705,25 +838,23 @@ extern "C" int fac_lstm_layer_fwd_persist_split(const float* pre, const void* ws
   FAC_REQUIRE(persist_split_shape_ok(H, B), "lstm_layer_fwd_persist_split: H=%d B=%d is outside the kernel (fac_lstm_persist_split_ok)", H, B);
   const int slot = lstm_sync_slot((hipStream_t)stream);
   FAC_REQUIRE(slot >= 0, "lstm_layer_fwd_persist_split: more than %d streams in use", LSTM_SYNC_SLOTS);
-  void (*kern)(const float*, const ls_bf16x8*, ls_bf16x8*, float*, int, int, int, int) = nullptr;
-  switch (H) {
-    case 512: kern = lstm_fwd_persist_split_kernel<4>; break;
-    case 1024: kern = lstm_fwd_persist_split_kernel<8>; break;
-    case 1536: kern = lstm_fwd_persist_split_kernel<12>; break;
-  }
+  SplitKern kern = split_kernel_for(H);
   FAC_REQUIRE(kern != nullptr, "lstm_layer_fwd_persist_split: no kernel for H=%d", H);
-  FAC_REQUIRE(grid_fits(reinterpret_cast<const void*>(kern), H / 8, LS_NW * 64),
-              "lstm_layer_fwd_persist_split: %d workgroups are not co-resident on this device", H / 8);
-  order_resident_launch((hipStream_t)stream, true);
-  hipLaunchKernelGGL(kern, dim3(H / 8), dim3(LS_NW * 64), 0, (hipStream_t)stream, pre, reinterpret_cast<const ls_bf16x8*>(wsplit),
-                     reinterpret_cast<ls_bf16x8*>(hsplit), yT, slot, T, H, BP);
-  const int rc = check_launch("lstm_layer_fwd_persist_split");
-  order_resident_launch((hipStream_t)stream, false);
+  FAC_REQUIRE(persist_split_usable(H, B), "lstm_layer_fwd_persist_split: %d workgroups are not co-resident on this device, or an earlier "
+              "resident launch timed out (%u): ask fac_lstm_persist_split_ok first and fall back to fac_lstm_layer_fwd", H / 8, persist_timeouts());
+  int rc;
+  {
+    ResidentLaunch order((hipStream_t)stream);
+    arm_timeout_word((hipStream_t)stream);
+    hipLaunchKernelGGL(kern, dim3(H / 8), dim3(LS_NW * 64), 0, (hipStream_t)stream, pre, reinterpret_cast<const ls_bf16x8*>(wsplit),
+                       reinterpret_cast<ls_bf16x8*>(hsplit), yT, slot, T, H, BP);
+    rc = check_launch("lstm_layer_fwd_persist_split");
+  }
   return rc;
 }
 
 
-extern "C" int fac_lstm_persist_ok(int H, int B) { return fac::persist_shape_ok(H, B) ? 1 : 0; }
+extern "C" int fac_lstm_persist_ok(int H, int B) { return fac::persist_usable(H, B) ? 1 : 0; }
 
 extern "C" int fac_lstm_persist_stream_ok(fac_stream_t stream) { return fac::lstm_sync_slot((hipStream_t)stream) >= 0 ? 1 : 0; }
 
@@ -743,23 +874,18 @@ extern "C" int fac_lstm_layer_fwd_persist(const float* pre, const float* whh16, 
   FAC_REQUIRE(persist_shape_ok(H, B), "lstm_layer_fwd_persist: H=%d B=%d is outside the resident kernel (fac_lstm_persist_ok)", H, B);
   const int slot = lstm_sync_slot((hipStream_t)stream);
   FAC_REQUIRE(slot >= 0, "lstm_layer_fwd_persist: more than %d streams in use", LSTM_SYNC_SLOTS);
-  const int ncb = (B + 15) / 16;
-  void (*kern)(const float*, const float*, float*, float*, float*, float*, int, int, int, int, int) = nullptr;
-  switch ((H / 64) * 10 + ncb) {
-    case 81: kern = lstm_fwd_persist_kernel<8, 1>; break;
-    case 82: kern = lstm_fwd_persist_kernel<8, 2>; break;
-    case 161: kern = lstm_fwd_persist_kernel<16, 1>; break;
-    case 162: kern = lstm_fwd_persist_kernel<16, 2>; break;
-    case 241: kern = lstm_fwd_persist_kernel<24, 1>; break;
-    case 242: kern = lstm_fwd_persist_kernel<24, 2>; break;
-  }
+  FwdKern kern = fwd_kernel_for(H, B);
   FAC_REQUIRE(kern != nullptr, "lstm_layer_fwd_persist: no kernel for H=%d", H);
-  FAC_REQUIRE(grid_fits(reinterpret_cast<const void*>(kern), H / 8), "lstm_layer_fwd_persist: %d workgroups are not co-resident on this device", H / 8);
-  order_resident_launch((hipStream_t)stream, true);
-  hipLaunchKernelGGL(kern, dim3(H / 8), dim3(1024), 0, (hipStream_t)stream, pre, whh16, hfrag, yT, gates_save, c_save, slot, T, H, BP,
-                     exchange_mode());
-  const int rc = check_launch("lstm_layer_fwd_persist");
-  order_resident_launch((hipStream_t)stream, false);
+  FAC_REQUIRE(persist_usable(H, B), "lstm_layer_fwd_persist: %d workgroups are not co-resident on this device, or an earlier resident "
+              "launch timed out (%u): ask fac_lstm_persist_ok first and fall back to fac_lstm_layer_fwd", H / 8, persist_timeouts());
+  int rc;
+  {
+    ResidentLaunch order((hipStream_t)stream);
+    arm_timeout_word((hipStream_t)stream);
+    hipLaunchKernelGGL(kern, dim3(H / 8), dim3(1024), 0, (hipStream_t)stream, pre, whh16, hfrag, yT, gates_save, c_save, slot, T, H, BP,
+                       exchange_mode());
+    rc = check_launch("lstm_layer_fwd_persist");
+  }
   return rc;
 }
 
@@ -775,21 +901,17 @@ extern "C" int fac_lstm_layer_bwd_persist(const float* dyT, const float* whh16t,
   const long long hbuf = (long long)H * ncb * 16;
   float* partial = scratch;              // scratch = [partial 4*H*NC | dgates fragments T * 4*H*NC]
   float* dgfrag = scratch + 4 * hbuf;
-  void (*kern)(const float*, const float*, const float*, const float*, float*, float*, float*, int, int, int, int, int) = nullptr;
-  switch ((H / 64) * 10 + ncb) {
-    case 81: kern = lstm_bwd_persist_kernel<8, 1>; break;
-    case 82: kern = lstm_bwd_persist_kernel<8, 2>; break;
-    case 161: kern = lstm_bwd_persist_kernel<16, 1>; break;
-    case 162: kern = lstm_bwd_persist_kernel<16, 2>; break;
-    case 241: kern = lstm_bwd_persist_kernel<24, 1>; break;
-    case 242: kern = lstm_bwd_persist_kernel<24, 2>; break;
-  }
+  BwdKern kern = bwd_kernel_for(H, B);
   FAC_REQUIRE(kern != nullptr, "lstm_layer_bwd_persist: no kernel for H=%d", H);
-  FAC_REQUIRE(grid_fits(reinterpret_cast<const void*>(kern), H / 8), "lstm_layer_bwd_persist: %d workgroups are not co-resident on this device", H / 8);
-  order_resident_launch((hipStream_t)stream, true);
-  hipLaunchKernelGGL(kern, dim3(H / 8), dim3(1024), 0, (hipStream_t)stream, dyT, whh16t, gates, cs, dgates, partial, dgfrag, slot, T, H, BP,
-                     exchange_mode());
-  const int rc = check_launch("lstm_layer_bwd_persist");
-  order_resident_launch((hipStream_t)stream, false);
+  FAC_REQUIRE(persist_usable(H, B), "lstm_layer_bwd_persist: %d workgroups are not co-resident on this device, or an earlier resident "
+              "launch timed out (%u)", H / 8, persist_timeouts());
+  int rc;
+  {
+    ResidentLaunch order((hipStream_t)stream);
+    arm_timeout_word((hipStream_t)stream);
+    hipLaunchKernelGGL(kern, dim3(H / 8), dim3(1024), 0, (hipStream_t)stream, dyT, whh16t, gates, cs, dgates, partial, dgfrag, slot, T, H, BP,
+                       exchange_mode());
+    rc = check_launch("lstm_layer_bwd_persist");
+  }
   return rc;
 }

@@ -93,61 +93,93 @@ __device__ __forceinline__ void scan_codes(const float* e, float ee, const float
   }
 }
 
-__global__ __launch_bounds__(256) void vq_fwd_kernel(VqArgs a) {
+// 16 time steps per workgroup (round 5; 64 before: 96 workgroups at B = 32 x 160 frames, 5/8 of the chip idle and every wave a
+// chain of 256 dependent-looking loads).  256 threads = 16 time steps x 16 groups:
+//   in-proj   wave = channel quarter (the SAME four sequential FMA chains per (t, d) as before -- z_e is bit-identical), lane =
+//             (d pair, t): one x load (64 B per 16 lanes) + one 8-byte weight read from LDS + 2 FMAs per channel, 32 channels of
+//             loads in flight per wave;
+//   search    group g scans codes [64 g, 64 g + 64) with strict '>', then a fixed ascending combine: first maximum wins;
+//   out-proj  group g owns channels g, g + 16, ...: the same per-element expressions as before.
+// The 1-D grid is decoded so that an XCD gets a contiguous range of (clip, tile) pairs: the tiles of a clip share the 128-byte
+// lines of its rows, and consecutive workgroup ids land on different XCDs (each with its own L2).
+constexpr int VT = 16;      // time steps per workgroup of vq_fwd_kernel
+constexpr int VG = 16;      // thread groups per time step
+
+__global__ __launch_bounds__(256) void vq_fwd_kernel(VqArgs a, int n_tiles, int per_xcd) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   float* cbn = sm;                              // [Kc][8]
   float* cc = cbn + a.Kc * VQ_CD;               // [Kc]
-  float* part = cc + a.Kc;                      // [4][8][64]
-  float* zes = part + 4 * VQ_CD * VQ_TT;        // [8][64]  z_e, later z_st
-  float* bestv = zes + VQ_CD * VQ_TT;           // [4][64]
-  int* bestk = reinterpret_cast<int*>(bestv + 4 * VQ_TT);  // [4][64]
-  float* lred = reinterpret_cast<float*>(bestk + 4 * VQ_TT);  // [64]
+  float* part = cc + a.Kc;                      // [4][8][16]
+  float* zes = part + 4 * VQ_CD * VT;           // [8][16]  z_e
+  float* bestv = zes + VQ_CD * VT;              // [16 groups][16]
+  int* bestk = reinterpret_cast<int*>(bestv + VG * VT);  // [16][16]
+  float* wsm = reinterpret_cast<float*>(bestk + VG * VT);   // [D][8] in-proj weights
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int b = blockIdx.y;
-  const int tile = blockIdx.x;
-  const int t = tile * VQ_TT + lane;
+  const int tid = threadIdx.x, tl = tid & (VT - 1), g = tid >> 4, wave = tid >> 6;
+  // XCD-aware decode: workgroup id i runs on XCD i % 8
+  const int logical = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  if ((blockIdx.x >> 3) >= per_xcd || logical >= a.B * n_tiles) return;
+  const int b = logical / n_tiles;
+  const int tile = logical - b * n_tiles;
+  const int t = tile * VT + tl;
   const bool tv = t < a.T;
   const long long bofs = (long long)b * a.D * a.T;
 
   load_codebook(a.codebook, cbn, cc, a.Kc, tid, 256);
+  for (int c = tid; c < a.D; c += 256) {
+    const float4 lo = *reinterpret_cast<const float4*>(a.w_in + (long long)c * 32);
+    const float4 hi = *reinterpret_cast<const float4*>(a.w_in + (long long)c * 32 + 4);
+    *reinterpret_cast<float4*>(wsm + c * VQ_CD) = lo;
+    *reinterpret_cast<float4*>(wsm + c * VQ_CD + 4) = hi;
+  }
+  __syncthreads();
 
-  // ---- in_proj: each wave reduces a quarter of the D input channels
+  // ---- in_proj: wave = quarter of the D input channels, thread = (t, two of the eight output dims)
   {
-    float s[VQ_CD];
-#pragma unroll
-    for (int d = 0; d < VQ_CD; ++d) s[d] = 0.f;
+    const int dq = g & 3;
     const int cper = (a.D + 3) / 4;
     const int c_begin = wave * cper;
     const int c_end = min(a.D, c_begin + cper);
-    const float* zp = a.z_in + bofs + t;
-#pragma unroll 8
-    for (int c = c_begin; c < c_end; ++c) {
-      const float xv = tv ? zp[(long long)c * a.T] : 0.f;
-      const float* wr = a.w_in + (long long)c * 32;
+    const float* zp = a.z_in + bofs + (tv ? t : 0);
+    float s0 = 0.f, s1 = 0.f;
+    constexpr int UN = 32;
+    int c = c_begin;
+    for (; c + UN <= c_end; c += UN) {
+      float xv[UN];
 #pragma unroll
-      for (int d = 0; d < VQ_CD; ++d) s[d] = fmaf(wr[d], xv, s[d]);
+      for (int u = 0; u < UN; ++u) xv[u] = zp[(long long)(c + u) * a.T];
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        const float2 w = *reinterpret_cast<const float2*>(wsm + (c + u) * VQ_CD + 2 * dq);
+        const float x = tv ? xv[u] : 0.f;
+        s0 = fmaf(w.x, x, s0);
+        s1 = fmaf(w.y, x, s1);
+      }
     }
-#pragma unroll
-    for (int d = 0; d < VQ_CD; ++d) part[(wave * VQ_CD + d) * VQ_TT + lane] = s[d];
+    for (; c < c_end; ++c) {
+      const float2 w = *reinterpret_cast<const float2*>(wsm + c * VQ_CD + 2 * dq);
+      const float x = tv ? zp[(long long)c * a.T] : 0.f;
+      s0 = fmaf(w.x, x, s0);
+      s1 = fmaf(w.y, x, s1);
+    }
+    part[(wave * VQ_CD + 2 * dq) * VT + tl] = s0;
+    part[(wave * VQ_CD + 2 * dq + 1) * VT + tl] = s1;
   }
   __syncthreads();
-  if (wave == 0) {
-#pragma unroll
-    for (int d = 0; d < VQ_CD; ++d) {
-      float v = (part[(0 * VQ_CD + d) * VQ_TT + lane] + part[(1 * VQ_CD + d) * VQ_TT + lane]) +
-                (part[(2 * VQ_CD + d) * VQ_TT + lane] + part[(3 * VQ_CD + d) * VQ_TT + lane]);
-      v = __fadd_rn(v, a.b_in[d]);
-      zes[d * VQ_TT + lane] = v;
-      if (a.z_e && tv) a.z_e[((long long)b * VQ_CD + d) * a.T + t] = v;
-    }
+  if (tid < VQ_CD * VT) {
+    const int d = tid >> 4;
+    float v = (part[(0 * VQ_CD + d) * VT + tl] + part[(1 * VQ_CD + d) * VT + tl]) +
+              (part[(2 * VQ_CD + d) * VT + tl] + part[(3 * VQ_CD + d) * VT + tl]);
+    v = __fadd_rn(v, a.b_in[d]);
+    zes[d * VT + tl] = v;
+    if (a.z_e && tv) a.z_e[((long long)b * VQ_CD + d) * a.T + t] = v;
   }
   __syncthreads();
 
-  // ---- normalise + search (every wave normalises the same query; cheap)
+  // ---- normalise + search (every group normalises its time step's query; cheap)
   float ze[VQ_CD], e[VQ_CD];
 #pragma unroll
-  for (int d = 0; d < VQ_CD; ++d) ze[d] = zes[d * VQ_TT + lane];
+  for (int d = 0; d < VQ_CD; ++d) ze[d] = zes[d * VT + tl];
   {
     const float nrm = fmaxf(sqrtf(row_norm_sq(ze)), 1e-12f);
 #pragma unroll
@@ -155,25 +187,25 @@ __global__ __launch_bounds__(256) void vq_fwd_kernel(VqArgs a) {
   }
   const float ee = row_norm_sq(e);
   {
-    const int kper = (a.Kc + 3) / 4;
-    const int k_begin = wave * kper;
+    const int kper = (a.Kc + VG - 1) / VG;
+    const int k_begin = min(a.Kc, g * kper);
     const int k_end = min(a.Kc, k_begin + kper);
     float bv;
     int bk;
     scan_codes(e, ee, cbn, cc, k_begin, k_end, bv, bk);
-    bestv[wave * VQ_TT + lane] = bv;
-    bestk[wave * VQ_TT + lane] = bk;
+    bestv[g * VT + tl] = bv;              // an empty range leaves -inf: never chosen by the strict '>' below
+    bestk[g * VT + tl] = bk;
   }
   __syncthreads();
-  int idx = bestk[lane];
+  int idx = bestk[tl];
   {
-    float bv = bestv[lane];
+    float bv = bestv[tl];
 #pragma unroll
-    for (int w = 1; w < 4; ++w) {
-      const float v = bestv[w * VQ_TT + lane];
+    for (int w = 1; w < VG; ++w) {
+      const float v = bestv[w * VT + tl];
       if (v > bv) {
         bv = v;
-        idx = bestk[w * VQ_TT + lane];
+        idx = bestk[w * VT + tl];
       }
     }
   }
@@ -191,25 +223,25 @@ __global__ __launch_bounds__(256) void vq_fwd_kernel(VqArgs a) {
       zst[d] = __fadd_rn(ze[d], __fsub_rn(zq, ze[d]));
     }
   }
-  if (wave == 0) {
+  if (g == 0) {                           // lanes 0..15 of wave 0
     if (tv) a.codes[(long long)b * a.codes_bs + t] = idx;
     float l = tv ? lsum : 0.f;
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) l += __shfl_down(l, o, 64);
-    if (lane == 0 && a.loss_part) a.loss_part[(long long)b * gridDim.x + tile] = l;
+    for (int o = 8; o > 0; o >>= 1) l += __shfl_down(l, o, 16);
+    if (tl == 0 && a.loss_part) a.loss_part[(long long)b * n_tiles + tile] = l;
   }
 
-  // ---- out_proj + residual bookkeeping: wave w handles channels w, w+4, ...  The loads of 8 channels
+  // ---- out_proj + residual bookkeeping: group g handles channels g, g+16, ...  The loads of 8 channels
   // are issued together before their math (the accumulator / residual may alias the input, so the
-  // compiler would otherwise serialise one memory round trip per channel: 256 of them per wave).
+  // compiler would otherwise serialise one memory round trip per channel).
   if (tv) {
     const float mk = a.mask ? a.mask[b] : 1.0f;
     constexpr int UB = 8;
-    for (int c0 = wave; c0 < a.D; c0 += 4 * UB) {
+    for (int c0 = g; c0 < a.D; c0 += VG * UB) {
       float zin[UB], zacc[UB], bo[UB], sc[UB], wv[UB][VQ_CD];
 #pragma unroll
       for (int u = 0; u < UB; ++u) {
-        const int c = c0 + 4 * u;
+        const int c = c0 + VG * u;
         const bool cv = c < a.D;
         const int cc = cv ? c : a.D - 1;
         const long long off = bofs + (long long)cc * a.T + t;
@@ -217,12 +249,14 @@ __global__ __launch_bounds__(256) void vq_fwd_kernel(VqArgs a) {
         zacc[u] = a.zq_acc ? a.zq_acc[off] : 0.f;
         bo[u] = a.b_out[cc];
         sc[u] = a.w_out_scale ? a.w_out_scale[cc] : 1.0f;
-#pragma unroll
-        for (int d = 0; d < VQ_CD; ++d) wv[u][d] = a.w_out[(long long)cc * VQ_CD + d];
+        const float4 lo = *reinterpret_cast<const float4*>(a.w_out + (long long)cc * VQ_CD);
+        const float4 hi = *reinterpret_cast<const float4*>(a.w_out + (long long)cc * VQ_CD + 4);
+        wv[u][0] = lo.x; wv[u][1] = lo.y; wv[u][2] = lo.z; wv[u][3] = lo.w;
+        wv[u][4] = hi.x; wv[u][5] = hi.y; wv[u][6] = hi.z; wv[u][7] = hi.w;
       }
 #pragma unroll
       for (int u = 0; u < UB; ++u) {
-        const int c = c0 + 4 * u;
+        const int c = c0 + VG * u;
         if (c >= a.D) continue;
         float o = __fmul_rn(__fmul_rn(wv[u][0], sc[u]), zst[0]);
 #pragma unroll
@@ -396,6 +430,8 @@ __global__ __launch_bounds__(256) void vq_search_kernel(const float* __restrict_
 
 }  // namespace fac
 
+extern "C" int fac_vq_loss_tiles(int T) { return (T + fac::VT - 1) / fac::VT; }
+
 extern "C" int fac_vq_fwd(const fac_vq_desc* d, fac_stream_t stream) {
   using namespace fac;
   FAC_REQUIRE(d && d->z_in && d->w_in && d->b_in && d->codebook && d->w_out && d->b_out && d->codes,
@@ -408,8 +444,8 @@ extern "C" int fac_vq_fwd(const fac_vq_desc* d, fac_stream_t stream) {
   a.b_out = d->b_out; a.mask = d->mask; a.codes = (long long*)d->codes; a.z_e = d->z_e;
   a.loss_part = d->loss_part; a.codes_bs = d->codes_bs;
   a.B = d->B; a.D = d->D; a.T = d->T; a.Kc = d->Kc;
-  const size_t lds = ((size_t)d->Kc * (VQ_CD + 1) + 4 * VQ_CD * VQ_TT + VQ_CD * VQ_TT + 8 * VQ_TT + VQ_TT) * 4;
-  FAC_REQUIRE(lds <= 160 * 1024, "vq_fwd: codebook of %d entries does not fit LDS", d->Kc);
+  const size_t lds = ((size_t)d->Kc * (VQ_CD + 1) + 4 * VQ_CD * VT + VQ_CD * VT + 2 * VG * VT + (size_t)d->D * VQ_CD) * 4;
+  FAC_REQUIRE(lds <= 160 * 1024, "vq_fwd: codebook of %d entries + %d in-proj rows do not fit LDS", d->Kc, d->D);
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(vq_fwd_kernel),
@@ -429,8 +465,11 @@ extern "C" int fac_vq_fwd(const fac_vq_desc* d, fac_stream_t stream) {
       return check_launch("vq_fwd(small T)");
     }
   }
-  dim3 grid((d->T + VQ_TT - 1) / VQ_TT, d->B);
-  hipLaunchKernelGGL(vq_fwd_kernel, grid, dim3(256), lds, (hipStream_t)stream, a);
+  const int n_tiles = (d->T + VT - 1) / VT;
+  const long long total = (long long)d->B * n_tiles;
+  FAC_REQUIRE(total <= (1ll << 28), "vq_fwd: too many tiles");
+  const int per_xcd = (int)((total + 7) / 8);
+  hipLaunchKernelGGL(vq_fwd_kernel, dim3(8 * per_xcd), dim3(256), lds, (hipStream_t)stream, a, n_tiles, per_xcd);
   return check_launch("vq_fwd");
 }
 

@@ -62,7 +62,7 @@ class FactorizedVectorQuantize(nn.Module):
         s_out = ops.wn_scale(v_out, self.out_proj.weight_g.detach())
         codes = torch.empty(B, T, device=z.device, dtype=torch.int64)
         out = torch.empty_like(z)
-        lp = torch.empty(B, (T + 63) // 64, device=z.device, dtype=torch.float32)
+        lp = torch.empty(B, ops.vq_loss_tiles(T), device=z.device, dtype=torch.float32)
         ops.vq_step(z, w_in, self.in_proj.bias.detach(), self._codebook.weight.detach(), v_out, s_out,
                     self.out_proj.bias.detach(), codes, zq_out=out, loss_part=lp)
         if self.training:
@@ -92,7 +92,7 @@ class _FVQ(Function):
         zd = z.detach().contiguous()
         out = torch.empty_like(zd)
         z_e = torch.empty(B, 8, T, device=z.device, dtype=torch.float32)
-        lp = torch.empty(B, (T + 63) // 64, device=z.device, dtype=torch.float32)
+        lp = torch.empty(B, ops.vq_loss_tiles(T), device=z.device, dtype=torch.float32)
         ops.vq_step(zd, ops.pack_conv_weight(v_in.detach(), g_in.detach()), b_in.detach(), cb.detach(), v_out.detach(),
                     ops.wn_scale(v_out.detach(), g_out.detach()), b_out.detach(), codes, zq_out=out, z_e=z_e, loss_part=lp)
         mse = lp.sum(1) / float(8 * T)

@@ -806,6 +806,11 @@ def vq_step(z_in, w_in_packed, b_in, codebook, w_out, w_out_scale, b_out, codes_
     _lib.check(_lib.load().fac_vq_fwd(C.byref(d), _stream()), "fac_vq_fwd")
 
 
+def vq_loss_tiles(T):
+    """Row length of `vq_step`'s loss_part buffer (one partial sum per time tile of the kernel)."""
+    return int(_lib.load().fac_vq_loss_tiles(int(T)))
+
+
 def vq_search(latents, codebook):
     """latents (N, 8) -> int64 (N,) nearest normalised code (dac/nn/quantize.py:78-94)."""
     latents = _dev(latents, "latents")
@@ -1056,12 +1061,28 @@ def _wgrad_workspace(device, nbytes):
 
 
 def _bwd_weight_launch(x, dy, dw, B, c_in, t_in, c_out, t_out, k, stride, dilation, pad_left, pad_mode, k1=0, dilation2=0, db=None):
+    """Weight gradient of one conv (see _bwd_weight_launch_inner); counted by the FLOP counter and, under a ConvLaunchProfile,
+    timed as ONE record per conv: operand planes + GEMM + split-K reduction together."""
+    flops = 2.0 * B * c_out * c_in * k * t_out
+    if _FLOPS is not None:
+        _FLOPS.add("wgrad", flops)
+    if _PROFILE is None:
+        return _bwd_weight_launch_inner(x, dy, dw, B, c_in, t_in, c_out, t_out, k, stride, dilation, pad_left, pad_mode, k1, dilation2, db)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    r = _bwd_weight_launch_inner(x, dy, dw, B, c_in, t_in, c_out, t_out, k, stride, dilation, pad_left, pad_mode, k1, dilation2, db)
+    e1.record()
+    split = BF16_SPLIT and _lib.load().fac_conv1d_bwd_weight_split_ws_bytes(B, c_in, t_in, c_out, t_out, k, stride, dilation, k1, dilation2) > 0
+    _PROFILE.records.append(("weight gradient: split_planes + conv1d_wgrad_split/kmajor + reduce (bf16x3 split)" if split
+                             else "weight gradient: conv1d_wgrad_kernel (fp32 MFMA) + reduce", flops, e0, e1))
+    return r
+
+
+def _bwd_weight_launch_inner(x, dy, dw, B, c_in, t_in, c_out, t_out, k, stride, dilation, pad_left, pad_mode, k1=0, dilation2=0, db=None):
     """dW on the bf16 matrix pipe with fp32-grade splitting (conv1d_wgrad_split.hip) when the shape qualifies and
     FAC_BF16_SPLIT is on, else on the fp32 MFMA kernel.  db: optional (C_out) buffer for the bias gradient; returns True when the
     launch filled it."""
     lib = _lib.load()
-    if _FLOPS is not None:
-        _FLOPS.add("wgrad", 2.0 * B * c_out * c_in * k * t_out)
     nbytes = lib.fac_conv1d_bwd_weight_split_ws_bytes(B, c_in, t_in, c_out, t_out, k, stride, dilation, k1, dilation2) if BF16_SPLIT else -1
     if nbytes > WGRAD_WS_CAP:       # beyond the workspace budget: the fp32 kernel (no operand planes) takes the layer
         nbytes = -1

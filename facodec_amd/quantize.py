@@ -52,7 +52,7 @@ class VectorQuantize(nn.Module):
         codes = torch.empty(B, T, device=z.device, dtype=torch.int64)
         z_e = torch.empty(B, 8, T, device=z.device, dtype=torch.float32)
         out = torch.empty_like(z)
-        nt = (T + 63) // 64
+        nt = ops.vq_loss_tiles(T)
         lp = torch.empty(B, nt, device=z.device, dtype=torch.float32)
         w_in, w_out, w_out_scale = self._weights()
         ops.vq_step(z, w_in, self.in_proj.bias.detach(), self.codebook.weight.detach(), w_out, w_out_scale,
@@ -89,7 +89,7 @@ class ResidualVectorQuantize(nn.Module):
         z_q = torch.zeros_like(z)
         codes = torch.empty(B, n, T, device=dev, dtype=torch.int64)
         latents = torch.empty(B, 8 * n, T, device=dev, dtype=torch.float32)
-        nt = (T + 63) // 64
+        nt = ops.vq_loss_tiles(T)
         lp = torch.empty(n, B, nt, device=dev, dtype=torch.float32)
         residual = torch.empty_like(z) if n > 1 else None
         src = z

@@ -248,7 +248,7 @@ int fac_lstm_layer_bwd(const float* dyT, const float* whh_t_packed, const float*
 
 /* The same recurrence and its BPTT as ONE launch per layer (lstm_persist.hip): the H/8 workgroups stay resident for all T steps
  * with their slice of W_hh in registers and exchange h_t (dgates_t) through device-wide flags.  Covers zero-initial-state layers
- * with fac_lstm_persist_ok(H, B) != 0 (H in {512, 1024, 1536}, B <= 32, H/8 <= CUs); B = number of real batch columns, only the
+ * with fac_lstm_persist_ok(H, B) != 0 (H in {512, 1024, 1536}, B <= 32, H/8 <= CUs, the grids of the forward and backward kernels co-resident by the runtime's occupancy figure, no earlier timeout); B = number of real batch columns, only the
  * column blocks ceil(B/16)*16 are computed and written (the caller zero-fills the padded columns of yT / saves / dgates).
  * whh16: fac_pack_lstm_whh16(W_hh, out (4H*H floats), H, transposed = 0 forward / 1 BPTT).  With NC = 16 * ceil(B/16): hfrag is
  * T * H * NC floats of scratch, fac_lstm_layer_bwd_persist's scratch (4 + 4 * T) * H * NC floats (one fresh exchange region per
@@ -271,6 +271,11 @@ int fac_lstm_layer_bwd_persist(const float* dyT, const float* whh16t, const floa
  * per step); all 32 columns of yT (H, T, BP) are computed.  Same stream / co-residency rules as the fp32 resident kernels.
  * Replaces the per-step launches of dac/model/encodec.py:272-288 at the benchmark batch. */
 int fac_lstm_persist_split_ok(int H, int B);
+/* Resident-kernel waits of this process that gave up after 4 s without progress (a workgroup of the grid never ran: the device
+ * was shared, or a launch was not co-resident).  Such a launch finishes with meaningless results instead of trapping the
+ * context; from then on fac_lstm_persist_ok / fac_lstm_persist_split_ok answer 0 (callers use the per-step kernels).  Reads a
+ * host-mapped counter: no synchronisation. */
+int fac_lstm_persist_timeouts(void);
 int fac_pack_lstm_whh_split(const float* w_hh, void* packed, int H, fac_stream_t stream);
 int fac_lstm_layer_fwd_persist_split(const float* pre, const void* wsplit, void* hsplit, float* yT, int T, int H, int B, int BP,
                                      fac_stream_t stream);
@@ -461,12 +466,14 @@ typedef struct fac_vq_desc {
   const float* mask;      /* (B) multiplies out in zq_acc (quantizer dropout), NULL == 1 */
   int64_t* codes;         /* (B, T) at codes[b*codes_bs + t] */
   float* z_e;             /* (B, 8, T) projected latents, or NULL */
-  float* loss_part;       /* (B, n_tiles) partial sums of (z_e-z_q)^2, n_tiles = ceil(T/64) */
+  float* loss_part;       /* (B, n_tiles) partial sums of (z_e-z_q)^2, n_tiles = fac_vq_loss_tiles(T) */
   int64_t codes_bs;
   int32_t B, D, T, Kc;
 } fac_vq_desc;
 
 int fac_vq_fwd(const fac_vq_desc* d, fac_stream_t stream);
+/* Number of time tiles fac_vq_fwd cuts T frames into (= the row length of loss_part; 16 frames per workgroup). */
+int fac_vq_loss_tiles(int T);
 
 /* Nearest-code search only, on already-projected latents (N, 8) row-major -> idx (N) int64.
  * The isolated kernel of dac/nn/quantize.py:78-94 / quantize/fvq.py:101-116. */

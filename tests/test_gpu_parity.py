@@ -300,6 +300,32 @@ def test_rvq_forward_against_oracle(B, D, T, n, O, cuda):
     assert abs(float(cm_g) - float(cm)) / float(cm) < 1e-5 and abs(float(cb_g) - float(cb)) / float(cb) < 1e-5
 
 
+@pytest.mark.parametrize("B,D,T", [(3, 1024, 8), (2, 256, 5), (33, 512, 1)])
+def test_vq_tile_kernel_is_bit_identical_to_the_per_frame_kernel(B, D, T, ops, cuda):
+    """fac_vq_fwd has two kernels: 16 frames per workgroup (offline; round 5: 64 before) and one workgroup per frame (streaming
+    hops, T <= 8 without loss partials).  Both keep the in-proj's four sequential channel-quarter FMA chains, the strict '>'
+    first-index scan and the per-element out-proj expressions, so every output is the same bits -- which is what lets the
+    streaming session reproduce the offline codes exactly (test_streaming_matches_offline)."""
+    from facodec_amd.quantize import VectorQuantize
+    q = VectorQuantize(D, 1024, 8).eval()
+    synth.load_synthetic(q, seed=5)
+    q = q.to(cuda)
+    z = torch.randn(B, D, T, generator=_g(B + D + T)).to(cuda)
+    acc0 = torch.randn(B, D, T, generator=_g(7)).to(cuda)
+    w_in, w_out, sc = q._weights()
+    outs = []
+    for with_loss in (True, False):         # loss partials requested -> the tile kernel; not requested and T <= 8 -> per-frame kernel
+        codes = torch.empty(B, T, device=cuda, dtype=torch.int64)
+        z_e = torch.empty(B, 8, T, device=cuda)
+        res, acc, zq = torch.empty_like(z), acc0.clone(), torch.empty_like(z)
+        lp = torch.empty(B, ops.vq_loss_tiles(T), device=cuda) if with_loss else None
+        ops.vq_step(z, w_in, q.in_proj.bias.detach(), q.codebook.weight.detach(), w_out, sc, q.out_proj.bias.detach(), codes,
+                    residual=res, zq_acc=acc, zq_out=zq, z_e=z_e, loss_part=lp)
+        outs.append((codes, z_e, res, acc, zq))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+
+
 def test_logmel_frontend_against_oracle(O, cuda):
     """Parity-unpinned row (torchaudio semantics restated on both sides)."""
     from facodec_amd.quantize import LogMelFrontend
