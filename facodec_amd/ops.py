@@ -40,6 +40,33 @@ def _dev(t, what="tensor"):
 
 
 # --------------------------------------------------------------------------------- weights (K6)
+# Timing experiment only (tools/train_ab.py): FAC_EXP_STALE_PACKS=1 memoises the weight-norm scales and packed weight layouts
+# ACROSS steps -- the weights go stale, results are wrong -- to measure what the ~1 500 small scale / pack launches of a train step
+# cost in wall time (the upper bound of what batching them into multi-tensor launches could buy).
+_EXP_STALE_PACKS = os.environ.get("FAC_EXP_STALE_PACKS") == "1"
+_EXP_MEMO = {}
+
+
+def _exp_memo(fn):
+    if not _EXP_STALE_PACKS:
+        return fn
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(*args, **kw):
+        key = [fn.__name__]
+        for a in list(args) + [kw.get(k) for k in sorted(kw) if k not in ("out", "scale")]:
+            key.append((a.data_ptr(), tuple(a.shape)) if torch.is_tensor(a) else a)
+        key = tuple(key)
+        r = _EXP_MEMO.get(key)
+        if r is None:
+            kw.pop("out", None)
+            r = _EXP_MEMO[key] = fn(*args, **kw)
+        return r
+    return wrapped
+
+
+@_exp_memo
 def wn_scale(v, g):
     """scale[i] = g[i]/||v[i]|| (dac/model/encodec.py:42-51)."""
     v = _dev(v, "weight_v")
@@ -50,6 +77,7 @@ def wn_scale(v, g):
     return scale
 
 
+@_exp_memo
 def pack_conv_weight(v, g=None, out=None, scale=None):
     """(C_out, C_in, K) [+ weight-norm gain g (C_out,1,1)] -> packed (cin_pad(C_in), K, pad32(C_out));
     the rows of the padding channels are written as zeros by the kernel (no separate fill)."""
@@ -67,6 +95,7 @@ def pack_conv_weight(v, g=None, out=None, scale=None):
     return out
 
 
+@_exp_memo
 def pack_convtr_weight(v, g, stride, out=None):
     """ConvTranspose1d (C_in, C_out, 2*stride) -> polyphase packed (stride, cin_pad(C_in), 2, pad32(C_out))."""
     v = _dev(v, "weight")
@@ -98,6 +127,7 @@ def convtr_rows_ok(t_in, stride, causal=True):
     return CONVTR_ROWS and causal and 2 <= stride <= 16 and t_in >= CONVTR_ROWS_MIN_T
 
 
+@_exp_memo
 def pack_convtr_weight_rows(v, g, stride, out=None):
     """ConvTranspose1d (C_in, C_out, 2*stride) -> (cin_pad(C_in), 2, rows) with rows = (channel, phase) pairs in 128-row
     tiles (fac_pack_convtr_w_rows); conv_transpose1d recognises the layout by its 3 dimensions."""
@@ -362,6 +392,7 @@ def gemm_split_strided_ok(c_out, c_in, k, stride, batch, t_out):
             and c_out >= 64 and t_out >= 256 and batch * t_out >= 1024)
 
 
+@_exp_memo
 def pack_gemm_weight_split(v, g=None, out=None, in_stride=1, scale=None):
     """(C_out, C_in, K) [weight-normed with g over dim 0] -> fac_pack_gemm_w_split layout (uint8 buffer); K <= 2, or a strided
     conv's taps (in_stride < K <= 2 * in_stride)."""
@@ -408,6 +439,7 @@ def split2_ok(c_out, k, k1, stride, n_cols):
             and n_cols >= 4096)
 
 
+@_exp_memo
 def pack_conv_weight_split2(v, g=None, k1=0, out=None, scale=None):
     """(C_out <= 32, C_in, K) [weight-normed with g] -> fac_pack_conv_w_split2 layout (uint8 buffer); k1: taps per level."""
     v = _dev(v, "weight")
@@ -423,6 +455,7 @@ def pack_conv_weight_split2(v, g=None, k1=0, out=None, scale=None):
     return out
 
 
+@_exp_memo
 def pack_convtr_weight_rows_split(v, g, stride, out=None):
     """ConvTranspose1d (C_in, C_out, 2*stride) -> split GEMM weights of the all-phases launch: the (channel, phase) rows of
     pack_convtr_weight_rows, each row's (C_in, 2) taps as bf16 planes.  Returns (split buffer, rows)."""
@@ -438,6 +471,7 @@ def pack_convtr_weight_rows_split(v, g, stride, out=None):
     return out, R
 
 
+@_exp_memo
 def pack_conv_weight_split(v, g=None, out=None, scale=None):
     """(C_out, C_in, K) [weight-normed with g] -> split-bf16 layout of fac_pack_conv_w_split (K = 5 / 7; uint8 buffer) or of
     fac_pack_gemm_w_split (K = 1 / 2)."""
@@ -961,6 +995,7 @@ def aa_snakebeta(x, alpha_log, beta_log, filter12):
 
 
 # --------------------------------------------------------------------------------- backward of the conv stack
+@_exp_memo
 def flipped_weight(v, g=None, scale=None):
     """(C_out, C_in, K) [weight-normed] -> (C_in, C_out, K) weights of the data-gradient conv (channels swapped, taps flipped),
     one launch (fac_flip_transpose_w)."""
@@ -973,6 +1008,7 @@ def flipped_weight(v, g=None, scale=None):
     return out
 
 
+@_exp_memo
 def pack_conv_weight_bwd(v, g=None, scale=None):
     """(C_out, C_in, K) [weight-normed] -> packed weights of the bwd-data conv (taps flipped, channels swapped)."""
     v = _dev(v, "weight")

@@ -14,6 +14,13 @@ from facodec_amd import synth
 pytestmark = pytest.mark.gpu
 
 LOSS_TOL = 1e-5          # north_star asks for 1e-4 relative; measured <= 2.2e-7
+# Element probes of ~60 gradient tensors.  These bars are WIDE on purpose and are not what guards the gradients: the losses are
+# kinked (L1 terms, LeakyReLU, arg-max codes), and on the CPU a 1e-7 relative perturbation of the INPUT alone moves single probe
+# elements by up to 4.7e-4 (generator keys) / 2.6e-3 (discriminator) -- tests/test_oracle_golden.py's conditioning test,
+# profiles/r03_gradient_conditioning_cpu.json.  A 1e-3 error in one discriminator weight gradient would pass these bars.  The
+# guard is the per-tensor NORM check next to it (`w[1] < 2e-4` below: relative error of every probed tensor's gradient norm,
+# measured <= 7.6e-6), plus the five whole-key gradient norms at 2e-4 and the per-op backward tests against torch autograd in
+# tests/test_gpu_parity.py (every trained tensor at <= 2e-4).
 PROBE_BAR = dict(discriminator=3e-3, encoder=5e-4, quantizer=5e-4, decoder=5e-4, fa_predictors=5e-5)
 
 
