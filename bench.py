@@ -466,6 +466,9 @@ def main():
             except SystemExit as e:
                 fp32_ref["codes_match"] = False
                 fp32_ref["codes_error"] = str(e)[:2000]
+                fp32_ref["codes_note"] = ("comparison leg only (every conv on the fp32 matrix pipe; NOT the product path, whose gates passed above). "
+                                          "decidable_mismatch_fp64_gaps = the reference's own fp64 top-2 gap at the flipped positions; the "
+                                          "reference's fp32-vs-fp64 margin noise on this batch reaches 4.1e-6 (tests/golden/codec_b32_decidable_report.json)")
         finally:
             ops.BF16_SPLIT = True
 

@@ -128,6 +128,11 @@ SIGNATURES = {
     "fac_stream_push": (_i, [_p, _p, _i64, _i64, _i, _i, _i, _p]),
     "fac_vq_fwd": (_i, [C.POINTER(VqDesc), _p]),
     "fac_vq_loss_tiles": (_i, [_i]),
+    "fac_rccl_available": (_i, []),
+    "fac_rccl_unique_id": (_i, [_p]),
+    "fac_rccl_comm_init": (_i, [C.POINTER(_p), _p, _i, _i]),
+    "fac_rccl_comm_destroy": (_i, [_p]),
+    "fac_allreduce_arena": (_i, [_p, _p, _i64, _i, _p]),
     "fac_vq_search": (_i, [_p, _p, _p, _i64, _i, _p]),
     "fac_gate_tanh_sigmoid": (_i, [_p, _p, _i64, _p, _i, _i, _i, _p]),
     "fac_embed_sum": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p]),

@@ -50,6 +50,9 @@ def check_codes_decidable(codes, fixture):
         positions=int(dec.size), decidable=int(dec.sum()),
         decidable_mismatches=int(bad_dec.sum()),
         decidable_mismatch_positions=np.argwhere(bad_dec)[:16].tolist(),
+        # how close the reference's own call was at those positions: its fp64 top-2 gap there (the first differing stage of a frame is
+        # the flip, later stages of the same frame follow it)
+        decidable_mismatch_fp64_gaps=[float(fixture["gap_f64"][tuple(p)]) for p in np.argwhere(bad_dec)[:16]] if "gap_f64" in fixture else None,
         undecidable_positions=np.argwhere(~dec).tolist(),
         undecidable_frames=int(undec_frames.sum()),
         undecidable_frames_not_a_reference_column=int(bad_cols.sum()),

@@ -37,6 +37,64 @@ def _dist_on():
     return dist.is_available() and dist.is_initialized()
 
 
+class _NativeWork:
+    """Handle of a collective issued on the exchange stream: wait() makes the CURRENT stream wait for it (what a torch work
+    handle's wait() does for the process group's stream)."""
+
+    def __init__(self, event):
+        self.event = event
+
+    def wait(self):
+        torch.cuda.current_stream().wait_event(self.event)
+
+
+class NativeRccl:
+    """FAC_NATIVE_RCCL=1: the arenas are exchanged by `fac_allreduce_arena` (include/facodec_hip.h) -- ncclAllReduce(ncclAvg) called
+    through the C ABI on an exchange stream this class owns -- instead of torch.distributed's all_reduce.  One communicator per
+    process, shared by all model keys (every rank issues the keys' buckets in the same order).  The 128-byte unique id is made
+    by rank 0 and shipped through the torch.distributed process group (any backend), the only thing that group is used for here."""
+
+    _instance = None
+
+    @classmethod
+    def get(cls):
+        if cls._instance is None and os.environ.get("FAC_NATIVE_RCCL") == "1" and _dist_on() and torch.cuda.is_available():
+            cls._instance = cls()
+        return cls._instance
+
+    def __init__(self):
+        import ctypes as C
+        lib = _lib.load()
+        if not lib.fac_rccl_available():
+            raise _lib.FacodecHipError("FAC_NATIVE_RCCL=1 but librccl.so.1 could not be loaded")
+        world, rank = dist.get_world_size(), dist.get_rank()
+        buf = C.create_string_buffer(128)
+        if rank == 0:
+            _lib.check(lib.fac_rccl_unique_id(buf), "fac_rccl_unique_id")
+        box = [buf.raw if rank == 0 else None]
+        if world > 1:
+            dist.broadcast_object_list(box, src=0)
+        self._id = C.create_string_buffer(box[0], 128)
+        self.comm = C.c_void_p()
+        _lib.check(lib.fac_rccl_comm_init(C.byref(self.comm), self._id, world, rank), "fac_rccl_comm_init")
+        self.stream = torch.cuda.Stream()
+        self.calls = 0
+
+    def all_reduce_mean(self, t):
+        """Asynchronous in-place mean over the ranks of a contiguous fp32 tensor: ordered after everything queued on the current
+        stream, runs on the exchange stream; -> handle with wait()."""
+        assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()
+        ready = torch.cuda.Event()
+        ready.record()
+        self.stream.wait_event(ready)
+        _lib.check(_lib.load().fac_allreduce_arena(self.comm, t.data_ptr(), t.numel(), 1, self.stream.cuda_stream), "fac_allreduce_arena")
+        done = torch.cuda.Event()
+        done.record(self.stream)
+        t.record_stream(self.stream)
+        self.calls += 1
+        return _NativeWork(done)
+
+
 class FlatAdamW:
     def __init__(self, params, lr=1e-4, betas=(0.9, 0.98), eps=1e-9, weight_decay=0.1, gamma=0.999996, max_norm=1000.0,
                  data_parallel=True, bucket_bytes=None):
@@ -269,21 +327,23 @@ class FlatAdamW:
             return
         if self.g.is_cuda and self._next_bucket < len(self.buckets) and self.buckets[self._next_bucket][0] >= from_param:
             ops.join_side_streams(self.g.device)    # parameter gradients written by chains on side streams (discriminators, heads)
-        nccl = dist.get_backend() == "nccl"         # RCCL: the mean is part of the collective; gloo (CPU scaffold) has no AVG
+        native = NativeRccl.get() if self.g.is_cuda else None      # FAC_NATIVE_RCCL=1: fac_allreduce_arena instead of torch's all_reduce
+        nccl = native is not None or dist.get_backend() == "nccl"   # RCCL: the mean is part of the collective; gloo (CPU scaffold) has no AVG
         op = dist.ReduceOp.AVG if nccl else dist.ReduceOp.SUM
+        reduce = (lambda t: native.all_reduce_mean(t)) if native is not None else (lambda t: dist.all_reduce(t, op=op, async_op=True))
         while self._next_bucket < len(self.buckets) and self.buckets[self._next_bucket][0] >= from_param:
             lo, hi = self.buckets[self._next_bucket]
             self._rebind(lo, hi)                    # gradients autograd kept outside the arena (zero_grad(unbind=True))
             self._at_launch[lo:hi] = self._touched[lo:hi]
             e_lo, e_hi = self.slices[lo][0], self.slices[hi - 1][0] + self.slices[hi - 1][1]
-            self._works.append(dist.all_reduce(self.g[e_lo:e_hi], op=op, async_op=True))
+            self._works.append(reduce(self.g[e_lo:e_hi]))
             self._launch_log.append((self._next_bucket, where))
             self._next_bucket += 1
             self._need_scale = self._need_scale or not nccl
         if self._next_bucket == len(self.buckets):
             self._upload_flags()
             self._flags_final = True
-            self._works.append(dist.all_reduce(self._flags, op=op, async_op=True))
+            self._works.append(reduce(self._flags))
 
     def _late_gradients(self):
         """Parameters of already launched buckets that were marked after the launch (in-place accumulation into the bound views

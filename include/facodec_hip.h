@@ -561,6 +561,24 @@ static inline int fac_pad32(int n) { return (n + 31) & ~31; }
  * channels-per-stage choices), so a partially filled last stage multiplies zeros */
 static inline int fac_cin_pad(int c) { return ((c + 47) / 48) * 48; }
 
+/* ------------------------------------------------------------------------------------------
+ * Data-parallel gradient exchange as an explicit RCCL collective over a flat fp32 arena (what
+ * DistributedDataParallel does behind train.py:110-111 / :289 / :361 -- bucketed all-reduce of the gradients, mean over the ranks).
+ * facodec_amd/optim.py exchanges its arenas through torch.distributed by default (backend "nccl" is RCCL on ROCm) and through this
+ * entry point with FAC_NATIVE_RCCL=1; a caller without torch binds it directly.  RCCL is resolved at run time (the librccl.so.1
+ * already in the process, else dlopen): the library has no link-time dependency on it.
+ *   fac_rccl_unique_id     one rank creates the 128-byte id and ships it to the others by any means (the Python side: the
+ *                          torch.distributed store);
+ *   fac_rccl_comm_init     collective over the ranks; binds the calling thread's current device;
+ *   fac_allreduce_arena    in place over `count` floats on `stream` (asynchronous; average != 0: mean over the ranks, ncclAvg);
+ *                          calls on one communicator must be issued in the same order on every rank.
+ * ---------------------------------------------------------------------------------------- */
+int fac_rccl_available(void);
+int fac_rccl_unique_id(void* id128);
+int fac_rccl_comm_init(void** comm, const void* id128, int nranks, int rank);
+int fac_rccl_comm_destroy(void* comm);
+int fac_allreduce_arena(void* comm, float* arena, int64_t count, int average, fac_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

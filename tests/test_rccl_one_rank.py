@@ -13,10 +13,12 @@ import torch
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(force):
+def _run(force, native=False):
     env = dict(os.environ)
-    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "FAC_FORCE_ALLREDUCE"):
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "FAC_FORCE_ALLREDUCE", "FAC_NATIVE_RCCL"):
         env.pop(k, None)
+    if native:
+        env["FAC_NATIVE_RCCL"] = "1"
     if force:
         with socket.socket() as s:
             s.bind(("127.0.0.1", 0))
@@ -49,6 +51,20 @@ def test_one_rank_rccl_exchange_is_the_identity():
     assert last["encoder"][-1][1] == "end" and last["encoder"][0][1] == "hook"                  # only the remainder waits for the end
     os.makedirs(os.path.join(REPO, "gpurun_out"), exist_ok=True)
     json.dump(dict(plain=plain, forced=forced), open(os.path.join(REPO, "gpurun_out", "rccl_one_rank.json"), "w"), indent=1)
+
+
+@pytest.mark.gpu
+def test_one_rank_native_rccl_arena_exchange_is_the_identity():
+    """The same with FAC_NATIVE_RCCL=1: every bucket goes through `fac_allreduce_arena` (include/facodec_hip.h: ncclAllReduce(ncclAvg)
+    behind the C ABI, on the exchange stream facodec_amd.optim.NativeRccl owns, communicator made by fac_rccl_comm_init from an id
+    of fac_rccl_unique_id) instead of torch.distributed's all_reduce -- same launch points, bit-identical losses and parameters."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    plain, native = _run(False), _run(True, native=True)
+    assert plain["native_rccl_calls"] is None and native["native_rccl_calls"] > 3 * 10       # >= 10 buckets + 4 flag words, 3 steps
+    assert native["losses"] == plain["losses"] and native["param_sums"] == plain["param_sums"]
+    for rep in native["exchange_launched_from"]:
+        assert rep["decoder"] == "hook" and rep["quantizer"] == "hook" and rep["encoder"] == "hook" and rep["discriminator"] == "end", rep
 
 
 @pytest.mark.gpu

@@ -41,7 +41,10 @@ def main():
     torch.cuda.synchronize()
     sums = {k: float(step.opt[k].p.double().sum()) for k in sorted(step.opt)}
     import torch.distributed as dist
+    from facodec_amd.optim import NativeRccl
+    native = NativeRccl._instance
     print(json.dumps({"process_group": dist.is_initialized() and dist.get_backend(), "world": world, "losses": losses,
+                      "native_rccl_calls": None if native is None else native.calls,
                       "param_sums": sums, "exchange_launched_from": reports, "bucket_launches": buckets,
                       "wait_ms": {k: v["wait_ms"] for k, v in step.exchange_report().items()}}))
     if dist.is_initialized():
