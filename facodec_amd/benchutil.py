@@ -76,8 +76,8 @@ def streaming_soak(model, device, hops, check_minutes=0.0, streams=1, use_graphs
     The remaining hops continue on the same session (finite outputs and contiguous frame numbering are checked to the end).
 
     The cyclic garbage collector is kept out of the timed brackets: it is switched off for the loop and run explicitly every 5 000
-    hops BETWEEN two hops (round 4's unexplained 31.6 ms maximum in 90 000 hops was a generation-2 collection landing inside a
-    bracket; the five slowest hops are reported with their indices so that anything else would be visible)."""
+    hops BETWEEN two hops (the suspect for round 4's one unexplained 31.6 ms hop in 90 000: a generation-2 collection landing
+    inside a bracket; the five slowest hops are reported with their indices so that anything else stays visible)."""
     import gc
     from .streaming import HOP, StreamingCodec
     hops -= hops % 5

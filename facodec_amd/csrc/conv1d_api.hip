@@ -99,6 +99,7 @@ extern "C" int fac_conv1d_fwd(const fac_conv_desc* d, fac_stream_t stream) {
   }
   if (d->w_k1) return conv_dispatch_fused_ru(a, s);
   a.gflat = 0;
+  a.grt = 0;
   // few-output-channel 9- / 3-tap convs (two-level taps included) with split weights of fac_pack_conv_w_split2
   if (d->w_split && (a.KV == 9 || a.KV == 3) && d->C_out <= 32 && conv_bsplit2_ok(a)) {
     a.w = reinterpret_cast<const float*>(d->w_split);

@@ -113,11 +113,25 @@ __global__ __launch_bounds__(512, 2) void conv1d_gemm_split_kernel(ConvArgs a) {
     const int xcd = blockIdx.x & 7, within = blockIdx.x >> 3;
     const int id = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + within;
     const int nt = a.n_t_tiles, nb = flat ? 1 : a.B;
-    const int tt = id % nt;
-    const int rest = id / nt;
-    b = rest % nb;
-    row0 = (rest / nb) * GS_ROWS;
-    n0 = tt * GS_COLS;
+    if (a.grt > 0) {
+      // Row tile fastest (round 5): the workgroups that are co-resident on an XCD cover ALL row tiles of a few consecutive
+      // column tiles, so every input tile is fetched into that XCD's L2 once and then read by every row tile from there.  With
+      // the row tile slowest (below) an XCD sits on one row tile -- its weight slab stays in L2 -- and streams the WHOLE input
+      // past it: the input leaves HBM / the Infinity Cache once per row tile (counters: 2.0 GB per transposed-conv launch
+      // against 0.6 GB algorithmic, profiles/r04_pmc_traffic.json).  Which side to keep resident is the host's choice.
+      const int rt = id % a.grt;
+      const int rest = id / a.grt;
+      const int tt = rest % nt;
+      b = rest / nt;
+      row0 = rt * GS_ROWS;
+      n0 = tt * GS_COLS;
+    } else {
+      const int tt = id % nt;
+      const int rest = id / nt;
+      b = rest % nb;
+      row0 = (rest / nb) * GS_ROWS;
+      n0 = tt * GS_COLS;
+    }
   }
   const int S = (K == 2 && a.stride > 1) ? a.stride : 1;      // input stride: S phase sub-signals as virtual channel chunks
   const int n_chunks = ((a.C_in + GS_CI - 1) / GS_CI) * S;   // a ragged last chunk multiplies the packed weights' zero padding
@@ -577,7 +591,25 @@ static int gsplit_launch(ConvArgs& a, hipStream_t s) {
   const long long n_total = a.gflat ? (long long)a.B * a.T_out : (long long)a.T_out;
   a.n_t_tiles = (int)((n_total + GS_COLS - 1) / GS_COLS);
   const int rows = a.rp > 1 ? a.C_out_pad : a.C_out;
-  const long long n_wg = (long long)a.n_t_tiles * ((rows + GS_ROWS - 1) / GS_ROWS) * (a.gflat ? 1 : a.B);
+  const int n_rt = (rows + GS_ROWS - 1) / GS_ROWS;
+  const long long n_wg = (long long)a.n_t_tiles * n_rt * (a.gflat ? 1 : a.B);
+  // order of the tiles inside an XCD's share (see the kernel): FAC_GS_ROW_FAST = 0 / 1 forces, default = by bytes: keep the
+  // weights resident when re-reading the input per row tile is the cheaper side, else the input
+  {
+    static const int env = [] { const char* e = getenv("FAC_GS_ROW_FAST"); return e == nullptr ? -1 : (e[0] != '0' ? 1 : 0); }();
+    // bytes that leave the L2s under either order (model): x = the input, W = all split weights, n_ct column tiles.
+    //   row tile slowest: the input once per row tile, the weights once                          -> x * n_rt + W
+    //   row tile fastest: the input once; the weights stay in an XCD's 4 MB L2 if they fit (8 copies), else they are streamed
+    //                     once per group of g column tiles that are co-resident with all n_rt row tiles -> x + W * n_ct / g
+    const double x_bytes = 4.0 * a.B * a.C_in * (double)a.T_in;
+    const double w_bytes = 6.0 * rows * (double)a.C_in * K * (a.stride > 1 && K == 2 ? a.stride : 1);
+    const double n_ct = (double)a.n_t_tiles * (a.gflat ? 1 : a.B);
+    const double g = 48.0 / n_rt > 1.0 ? 48.0 / n_rt : 1.0;
+    const double slow = x_bytes * n_rt + w_bytes;
+    const double fast = x_bytes + (w_bytes <= 3.5 * 1048576.0 ? 8.0 * w_bytes : w_bytes * n_ct / g);
+    const bool by_bytes = n_rt > 1 && fast < 0.8 * slow;
+    a.grt = (env >= 0 ? env == 1 : by_bytes) ? n_rt : 0;
+  }
   if (n_wg > 0x7fffffffll) {
     set_error("conv1d(gemm split): too many workgroups (%lld)", n_wg);
     return FAC_ERR_ARG;

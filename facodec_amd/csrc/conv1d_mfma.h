@@ -67,6 +67,7 @@ struct ConvArgs {
 #endif
   int x_off;   // columns staged to the left of the receptive field so that the slab starts 16-B aligned
   int gflat;   // conv1d_gemm_split.hip: columns are the flattened (clip, time) index (K = 1)
+  int grt;     // conv1d_gemm_split.hip: > 0 = number of row tiles, and the row tile is the FASTEST index of the logical order
   const unsigned char* x_p8;   // input as P8 planes (fac_conv_desc.x_p8) or NULL
   long long x_p8_ps;           // bytes between planes
   unsigned char* y2_p8;        // second output as P8 planes or NULL

@@ -505,6 +505,7 @@ struct WkArgs {
   int NBk;                   // blocks = ceil(CV / 32) * K
   int n_tt, tiles_per_split;
   int MT;                    // 128-row tiles per workgroup (1 or 2)
+  int gx, gy, gz, per_xcd;   // logical grid (row tiles, column-block quads, (b, t) slices) and workgroups per XCD (0: plain 3-D grid)
 };
 
 __device__ __forceinline__ void wk_barrier() {
@@ -518,8 +519,9 @@ __device__ __forceinline__ void wk_barrier() {
 // under the other's MFMAs -- + 4 DMA waves, two stages of 72 KB.  What the stage costs the matrix pipe is its LDS WRITE traffic
 // (DESIGN 9.2), and a 128 x 128 tile writes 48 KB per 48 MFMAs of a wave; 256 x 128 writes 72 KB per 96 MFMAs of a SIMD: a quarter
 // less per MFMA, and half the barriers.
-template <int MT>
+template <int MT, bool KSP = false>
 __global__ __launch_bounds__((4 * MT + 4) * 64, MT == 1 ? 2 : 1) void conv1d_wgrad_kmajor_kernel(WkArgs a) {
+  static_assert(!KSP || MT == 1, "the k-split wave layout is a 128 x 128 tile");
   constexpr int NMW = 4 * MT;                     // MFMA waves
   constexpr int A_PLANE = MT * WK_PLANE;          // one plane of the dy operand
   constexpr int A_OPND = 3 * A_PLANE;
@@ -530,9 +532,22 @@ __global__ __launch_bounds__((4 * MT + 4) * 64, MT == 1 ? 2 : 1) void conv1d_wgr
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int co0 = blockIdx.x * 128 * MT;
-  const int gb0 = blockIdx.y * 4;
-  const int z = blockIdx.z;
+  // XCD-aware order (round 5): the launch is 1-D; workgroup id i runs on XCD i % 8 (each XCD has its own L2), and XCD k takes
+  // the contiguous range [k * per_xcd, (k + 1) * per_xcd) of the logical order (row tile fastest, then column blocks, slice
+  // slowest).  Workgroups of one (b, t) slice read the SAME rows of both operand planes at the same time -- all row tiles share
+  // the x planes, all column blocks the dy planes -- so a slice's workgroups now meet in one L2 instead of eight.
+  int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+  if (a.per_xcd > 0) {
+    const int logical = (blockIdx.x & 7) * a.per_xcd + (blockIdx.x >> 3);
+    if ((int)(blockIdx.x >> 3) >= a.per_xcd || logical >= a.gx * a.gy * a.gz) return;
+    bx = logical % a.gx;
+    const int r = logical / a.gx;
+    by = r % a.gy;
+    bz = r / a.gy;
+  }
+  const int co0 = bx * 128 * MT;
+  const int gb0 = by * 4;
+  const int z = bz;
   const int tile_lo = z * a.tiles_per_split;
   const int tile_hi = min(a.B * a.n_tt, tile_lo + a.tiles_per_split);
   const int n_chunks = tile_hi - tile_lo;
@@ -588,8 +603,8 @@ __global__ __launch_bounds__((4 * MT + 4) * 64, MT == 1 ? 2 : 1) void conv1d_wgr
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     };
     issue(0, 0);
-    if (NST == 3) issue(1, 1);
-    landed(NST == 3);
+    if (NST == 3 && n_chunks > 1) issue(1, 1);
+    landed(NST == 3 && n_chunks > 1);
     wk_barrier();                                 // stage 0 visible to the MFMA waves
     for (int base = 0; base < n_chunks; base += NST) {
 #pragma unroll
@@ -604,6 +619,108 @@ __global__ __launch_bounds__((4 * MT + 4) * 64, MT == 1 ? 2 : 1) void conv1d_wgr
       }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    return;
+  }
+
+  if constexpr (KSP) {
+    // ===================================================== MFMA waves, k-split layout (round 5): 64 rows x ALL 128 columns each,
+    // wave (mh, kh) contracts only time steps [16 kh, 16 kh + 16) of every 32-step stage.  A stage then costs a wave
+    // 6 + 12 = 18 fragment reads for its 48 MFMAs where the 64 x 64 layout needs 24 (12 per k step): a quarter less LDS read
+    // traffic on a loop that is LDS-bandwidth-bound.  The two k halves of a 64-row block meet once, at the end,
+    // through LDS (fixed order: kh = 0 + kh = 1).
+    // Products in the order (lo,hi) (hi,lo) (mid,mid) (mid,hi) (hi,mid) (hi,hi) -- the three 2^-16 terms first, as before, but
+    // with the two lo fragments FIRST: they are dead after two products, and their registers (plus one spare set) take the next
+    // stage's (A lo, B lo, A hi, B hi) fragments while the last four products run.  The stage barrier sits right behind the point
+    // where every fragment of the stage is in registers, i.e. in FRONT of those four products: the next stage's first two products
+    // never wait for LDS.
+    const int l31 = lane & 31, kq = lane >> 5;
+    const int mh = wave >> 1, kh = wave & 1;
+    const int sw = (l31 >> 2) & 3;
+    const int po = ((kh * 2 + kq) ^ sw) * 16;
+    const int aoff = (mh * 64 + l31) * WK_ROWB + po;
+    const int boff = A_OPND + l31 * WK_ROWB + po;
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int n = 0; n < 4; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+    // fragment sets: Ahi / Bhi alternate between two register sets (the current stage's stay live to its last product);
+    // lo and mid fragments are re-used in place
+    bf16x8 Ahi[2][2], Bhi[2][4], Amid[2], Bmid[4], Alo[2], Blo[4];
+    auto rd_a = [&](const unsigned char* st, int plane, bf16x8 (&d)[2]) {
+#pragma unroll
+      for (int m = 0; m < 2; ++m) d[m] = *reinterpret_cast<const bf16x8*>(st + aoff + plane * A_PLANE + m * 32 * WK_ROWB);
+    };
+    auto rd_b = [&](const unsigned char* st, int plane, bf16x8 (&d)[4]) {
+#pragma unroll
+      for (int n = 0; n < 4; ++n) d[n] = *reinterpret_cast<const bf16x8*>(st + boff + plane * WK_PLANE + n * 32 * WK_ROWB);
+    };
+    auto mm = [&](const bf16x8 (&x)[2], const bf16x8 (&y)[4]) {
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x[m], y[n], acc[m][n], 0, 0, 0);
+    };
+    wk_barrier();   // stage 0 staged
+    rd_a(sm, 2, Alo); rd_b(sm, 0, Bhi[0]); rd_a(sm, 0, Ahi[0]); rd_b(sm, 2, Blo);
+    // chunk c lives in LDS stage c % 3 and in fragment set c & 1: the pattern repeats every 6 chunks
+    for (int base = 0; base < n_chunks; base += 6) {
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        const int chunk = base + i;
+        if (chunk < n_chunks) {
+          const unsigned char* st = sm + (i % 3) * STAGE;
+          const unsigned char* stn = sm + ((i + 1) % 3) * STAGE;
+          const int cur = i & 1, nxt = cur ^ 1;
+          rd_a(st, 1, Amid); rd_b(st, 1, Bmid);
+          __builtin_amdgcn_sched_barrier(0);
+          mm(Alo, Bhi[cur]);                       // (lo, hi)
+          mm(Ahi[cur], Blo);                       // (hi, lo)
+          __builtin_amdgcn_sched_barrier(0);
+          __builtin_amdgcn_s_waitcnt(0xC07F);      // lgkmcnt(0), as a builtin so that the compiler's own wait-count bookkeeping
+                                                   // sees it: every fragment of this stage is in registers
+          wk_barrier();                            // this stage may be overwritten; the next one has landed
+          // (behind the last chunk this reads a stage nobody filled: valid LDS, values never used -- no branch, no join)
+          rd_a(stn, 2, Alo); rd_b(stn, 0, Bhi[nxt]); rd_a(stn, 0, Ahi[nxt]); rd_b(stn, 2, Blo);
+          __builtin_amdgcn_sched_barrier(0);
+          mm(Amid, Bmid);                          // (mid, mid)
+          mm(Amid, Bhi[cur]);                      // (mid, hi)
+          mm(Ahi[cur], Bmid);                      // (hi, mid)
+          mm(Ahi[cur], Bhi[cur]);                  // (hi, hi)
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    }
+    // the two k halves of each 64-row block: kh = 1 parks its sums in LDS (all three stages are free: the DMA waves issue nothing
+    // past the last chunk and every MFMA wave is past its last fragment read), kh = 0 adds them and stores the partial dW
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    float* ex = reinterpret_cast<float*>(sm) + mh * (8 * 16 * 64);       // [m][n][r][lane] per 64-row block: 32 KB
+    if (kh == 1) {
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) ex[((m * 4 + n) * 16 + r) * 64 + lane] = acc[m][n][r];
+    }
+    __syncthreads();
+    if (kh == 1) return;
+    float* pz = a.part + (long long)z * a.C_out * a.NBk * 32;
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int n = 0; n < 4; ++n) {
+        const int gb = gb0 + n;
+        if (gb >= a.NBk) continue;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int co = co0 + mh * 64 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * kq;
+          const float v = acc[m][n][r] + ex[((m * 4 + n) * 16 + r) * 64 + lane];
+          if (co < a.C_out) pz[((long long)co * a.NBk + gb) * 32 + l31] = v;
+        }
+      }
     return;
   }
 
@@ -876,10 +993,30 @@ static int bwd_weight_split_impl(const float* x, const float* dy, float* dw, flo
                                   160 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv1d_wgrad_kmajor_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv1d_wgrad_kmajor_kernel<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  160 * 1024);
         attr_set = true;
       }
       dim3 grid((C_out + 128 * k.MT - 1) / (128 * k.MT), (k.NBk + 3) / 4, S);
+      // Measured policy (profiles/r05_wgrad_xcd_ksplit.log, same box, B = 16 training shapes):
+      //  * XCD-aware order when the launch has at least 5 (b, t) slices: +4 .. +20 % on the ResidualUnit / strided / transposed
+      //    layers (each XCD then works on whole slices); with 2 - 4 slices (LSTM input projections, the 1024 -> 1536 conv at
+      //    T = 160) an XCD gets a fraction of a slice and the plain order measured 3 - 9 % faster;
+      //  * k-split wave layout for the k = 7 stride-1 layers whose slice is at most one round of workgroups: +2 .. +5 % there,
+      //    -2 .. -8 % on 1-tap / strided / wide layers (their loops are short: the end-of-loop exchange shows).
+      static const int xcd_env = [] { const char* e = getenv("FAC_WGRAD_XCD"); return e == nullptr ? -1 : (e[0] != '0' ? 1 : 0); }();
+      static const int ksp_env = [] { const char* e = getenv("FAC_WGRAD_KSPLIT"); return e == nullptr ? -1 : (e[0] != '0' ? 1 : 0); }();
+      const bool xcd_order = xcd_env >= 0 ? xcd_env == 1 : S >= 5;
+      const bool ksplit = k.MT == 1 && (ksp_env >= 0 ? ksp_env == 1
+                                                     : (k.K == 7 && k.K2 == 1 && stride == 1 && (long long)grid.x * grid.y <= 256 && S >= 4));
+      k.gx = (int)grid.x; k.gy = (int)grid.y; k.gz = (int)grid.z; k.per_xcd = 0;
+      if (xcd_order) {
+        const long long total = (long long)grid.x * grid.y * grid.z;
+        k.per_xcd = (int)((total + 7) / 8);
+        grid = dim3((unsigned)(8 * k.per_xcd), 1, 1);
+      }
       if (k.MT == 2) hipLaunchKernelGGL(conv1d_wgrad_kmajor_kernel<2>, grid, dim3(768), (size_t)2 * (3 * 2 * WK_PLANE + WK_OPND), st, k);
+      else if (ksplit) hipLaunchKernelGGL((conv1d_wgrad_kmajor_kernel<1, true>), grid, dim3(512), (size_t)WK_NST * WK_STAGE, st, k);
       else hipLaunchKernelGGL(conv1d_wgrad_kmajor_kernel<1>, grid, dim3(512), (size_t)WK_NST * WK_STAGE, st, k);
       const long long n = (long long)C_out * k.NBk * 32;
       const int blocks = (int)((n + 255) / 256 < 65535 ? (n + 255) / 256 : 65535);
