@@ -75,9 +75,11 @@ def streaming_soak(model, device, hops, check_minutes=0.0, streams=1, use_graphs
     the hop / frame phase bookkeeping, the ring buffers or the carried LSTM state over tens of thousands of hops shows up there.
     The remaining hops continue on the same session (finite outputs and contiguous frame numbering are checked to the end).
 
-    The cyclic garbage collector is kept out of the timed brackets: it is switched off for the loop and run explicitly every 5 000
-    hops BETWEEN two hops (the suspect for round 4's one unexplained 31.6 ms hop in 90 000: a generation-2 collection landing
-    inside a bracket; the five slowest hops are reported with their indices so that anything else stays visible)."""
+    Outliers: round 4's 30-minute run had ONE hop of 31.6 ms among 90 000.  The cyclic garbage collector is therefore kept out of
+    the timed brackets (switched off for the loop, run explicitly every 5 000 hops BETWEEN two hops) -- and round 5's first run
+    STILL had three hops of 16 - 22 ms, about 10 s apart, so the collector was not it.  Every hop now also carries a HIP-event pair
+    around push() on the session's stream: the five slowest hops are reported as [index, host ms, device ms], which says whether
+    the device executed late or the host thread was held up around a normally executing graph."""
     import gc
     from .streaming import HOP, StreamingCodec
     hops -= hops % 5
@@ -123,7 +125,8 @@ def streaming_soak(model, device, hops, check_minutes=0.0, streams=1, use_graphs
         first = sess.prime(loop[:, :, :4800])
         keep(first)
         torch.cuda.synchronize()
-        lat, pos, out = [], 4800, first
+        lat, dev_ms, pos, out = [], [], 4800, first
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         gc_was_on = gc.isenabled()
         gc.collect()
         gc.disable()
@@ -135,9 +138,12 @@ def streaming_soak(model, device, hops, check_minutes=0.0, streams=1, use_graphs
                 hop = loop[:, :, pos:pos + HOP]
                 pos += HOP
                 t0 = time.perf_counter()
+                ev0.record()
                 out = sess.push(hop)
+                ev1.record()
                 torch.cuda.synchronize()
                 lat.append(time.perf_counter() - t0)
+                dev_ms.append(ev0.elapsed_time(ev1))         # outside the bracket: first to last device timestamp of the hop
                 keep(out)                                    # device-side copies, outside the timed bracket
                 if h % 1000 == 999 and out["wave"] is not None:
                     state["finite"] = state["finite"] and bool(torch.isfinite(out["wave"]).all())
@@ -163,7 +169,8 @@ def streaming_soak(model, device, hops, check_minutes=0.0, streams=1, use_graphs
     slowest = sorted(range(10, len(lat)), key=lambda i: -lat[i])[:5]
     return {"hop_samples": HOP, "streams": streams, "hops": hops, "audio_minutes": round(audio_s / 60, 2), "graphs": use_graphs,
             "p50_ms": q(0.5), "p90_ms": q(0.9), "p99_ms": q(0.99), "p99.9_ms": q(0.999), "max_ms": round(1e3 * steady[-1], 3),
-            "slowest_hops_index_ms": [[i, round(1e3 * lat[i], 3)] for i in slowest],
+            "slowest_hops_index_host_ms_device_ms": [[i, round(1e3 * lat[i], 3), round(dev_ms[i], 3)] for i in slowest],
+            "device_ms_p50": round(sorted(dev_ms[10:])[len(dev_ms[10:]) // 2], 4),
             "rtf": round(wall / audio_s, 5), "wall_s": round(wall, 2),
             "frames_emitted_last_hop": None if out["codes"] is None else int(out["codes"][0].shape[-1]),
             "drift_check": drift}
