@@ -286,7 +286,7 @@ def test_vq_search_idempotent_on_codebook_rows(ops, cuda):
     assert torch.equal(idx, torch.arange(1024))
 
 
-@pytest.mark.parametrize("B,D,T,n", [(3, 256, 150, 3), (1, 64, 7, 1), (2, 1024, 160, 2)])
+@pytest.mark.parametrize("B,D,T,n", [(3, 256, 150, 3), (1, 64, 7, 1), (2, 1024, 160, 2), (5, 72, 17, 2), (1, 1024, 33, 1), (9, 128, 16, 3)])
 def test_rvq_forward_against_oracle(B, D, T, n, O, cuda):
     from facodec_amd.quantize import ResidualVectorQuantize
     m = ResidualVectorQuantize(D, n, 1024, 8).eval()
