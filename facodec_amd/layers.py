@@ -290,7 +290,7 @@ class SLSTM(nn.Module):
             with ops.flop_scale(B / BP):
                 pre = ops.conv1d(sig, w_ih, 4 * H, 1, bias=bias, pad_left=0, t_out=T_ * BP,
                                  pad_mode=ops.PAD_ZERO, w_split=w_ih_split)
-                if ops.lstm_persist_split_ok(H, B):      # 17 .. 32 columns: resident, W_hh . h on the bf16 matrix pipe
+                if ops.lstm_persist_split_ok(H, B, T_):      # 17 .. 32 columns: resident, W_hh . h on the bf16 matrix pipe
                     inp = ops.lstm_layer_persist_split(pre.view(4 * H, T_, BP), w_hh, H, B)
                 elif persist:     # whole layer in one launch, W_hh resident in registers (lstm_persist.hip)
                     inp = ops.lstm_layer_persist(pre.view(4 * H, T_, BP), w_hh, H, B)

@@ -713,10 +713,18 @@ LSTM_PERSIST_SPLIT = os.environ.get("FAC_LSTM_PERSIST_SPLIT", "1") != "0"
 LSTM_PERSIST_SPLIT_MIN_BATCH = int(os.environ.get("FAC_LSTM_PERSIST_SPLIT_MIN_BATCH", "17"))
 
 
-def lstm_persist_split_ok(H, batch):
+LSTM_PERSIST_SPLIT_MAX_SCRATCH = int(float(os.environ.get("FAC_LSTM_PERSIST_SPLIT_MAX_SCRATCH_GB", "1")) * 2 ** 30)
+
+
+def lstm_persist_split_ok(H, batch, T=None):
     """True when an inference layer runs on the resident kernel with bf16 x 3 operands (lstm_persist.hip,
     fac_lstm_layer_fwd_persist_split): 17 .. 32 batch columns, where the fp32 resident kernel is bound by its fp32 MFMA time and
-    the per-step kernel by re-streaming W_hh.  Follows FAC_BF16_SPLIT like the conv kernels of the same arithmetic."""
+    the per-step kernel by re-streaming W_hh.  Follows FAC_BF16_SPLIT like the conv kernels of the same arithmetic.
+    T (frames): the kernel needs one fresh exchange region per step, T * H * 32 * 6 bytes of scratch per layer call -- 47 MB at the
+    benchmark's 160 frames, but 1.5 - 3 GB for 30-second clips; above FAC_LSTM_PERSIST_SPLIT_MAX_SCRATCH_GB (1) the per-step kernels,
+    which need none, take the layer."""
+    if T is not None and int(T) * int(H) * 32 * 6 > LSTM_PERSIST_SPLIT_MAX_SCRATCH:
+        return False
     return (LSTM_PERSIST and LSTM_PERSIST_SPLIT and BF16_SPLIT and batch is not None
             and LSTM_PERSIST_SPLIT_MIN_BATCH <= batch <= 32 and not _ranks_share_a_device()
             and bool(_lib.load().fac_lstm_persist_split_ok(int(H), int(batch)))

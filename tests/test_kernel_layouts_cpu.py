@@ -215,3 +215,13 @@ def test_tile_walk_visits_every_tile_once_and_stays_on_its_xcd(n_t_tiles, B, co_
     flat = sorted(((c * B + bb) * n_t_tiles + tt, x) for (c, bb, tt), x in seen.items())
     xs = [x for _, x in flat]
     assert xs == sorted(xs)                      # ids grouped by XCD in increasing order: contiguous ranges
+
+
+def test_resident_split_lstm_is_refused_when_its_exchange_scratch_would_be_large():
+    """the bf16 x 3 resident LSTM needs one fresh exchange region per step (T * H * 32 * 6 bytes per layer call):
+    45 MB at the benchmark's 160 frames, 2.5 GB at 9 000 frames.  Above the budget the policy answers False before it touches the
+    library, and the caller (layers.SLSTM.forward) takes the per-step kernels, which need no scratch."""
+    from facodec_amd import ops
+    assert 160 * 1536 * 32 * 6 < ops.LSTM_PERSIST_SPLIT_MAX_SCRATCH < 9000 * 1536 * 32 * 6
+    assert ops.lstm_persist_split_ok(1536, 32, T=9000) is False
+    assert ops.lstm_persist_split_ok(1024, 32, T=6000) is False          # 1.1 GB
