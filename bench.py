@@ -287,12 +287,19 @@ def respawn_under_launcher(n):
     raise SystemExit(subprocess.run(cmd, env=env).returncode)
 
 
-def cpu_baseline(batch=4, passes=5, warmups=2, with_train=True, threads=None):
+def cpu_baseline(batch=4, passes=5, warmups=2, with_train=True, threads=None, sweep_only=False):
     """The CPU oracle (port of the reference algorithm, pinned to it by tests/golden) timed on this host's cores over a
     bounded sample of the same workload (B = 4 clips of 2 s, median of 5 passes after 2 warm-ups).
     `value` = (A) the eval forward; `train` = (B) the train-mode iteration (forward + backward of encoder / quantizer /
     predictors / decoder, 7-scale mel loss, both discriminator passes and its AdamW step: oracle/train_iteration.py), with
-    fewer passes when one pass is long (said in `sample`)."""
+    fewer passes when one pass is long (said in `sample`).
+    threads: the intra-op thread count, set BEFORE any CPU work of this call.  sweep_only: one timed pass (after one warm pass) at
+    8, 16, 32, 64 threads in ascending order -> {"threads_swept": {...}}.  bench.py's main() runs the sweep and the measurement in
+    two FRESH processes (cpu_baseline_isolated): a process that has once run with more threads measures up to 45 % lower at the
+    smaller count afterwards (round 5: 3.15 -> 1.74 audio-s/s at 8 threads after the 64-thread probe; heap blocks first touched
+    across the sockets), so the count that is measured must be the largest one its process has ever used."""
+    if threads is not None:
+        torch.set_num_threads(max(1, min(int(threads), os.cpu_count() or 1)))
     import statistics
     from oracle import facodec_oracle as O
     model = build_model(default_model_params())
@@ -307,13 +314,13 @@ def cpu_baseline(batch=4, passes=5, warmups=2, with_train=True, threads=None):
     wave = synth.synth_clips(batch, n_samples, seed=0)
     # Which thread count?  SURVEY 8d says "all host cores"; on the 256-logical-core hosts of the GPU boxes that is the port's WORST
     # case (profiles/r04_cpu_thread_sweep.log: 128 threads 0.72 audio-s/s against 3.2 at 16), so the baseline is the port's BEST
-    # count from a short sweep made right here (one pass per candidate after one warm-up pass), stated in the line.
+    # count from a short ascending sweep (sweep_only, its own process), stated in the line.
     prev_threads = torch.get_num_threads()
     ncpu = os.cpu_count() or 1
-    swept = {}
     with torch.no_grad():
         O.codec_forward(sds, wave[:1], n_c=2)  # page-in, oneDNN primitive cache
-        if threads is None:
+        if sweep_only:
+            swept = {}
             for n in (8, 16, 32, 64):
                 if n > ncpu:
                     break
@@ -321,9 +328,9 @@ def cpu_baseline(batch=4, passes=5, warmups=2, with_train=True, threads=None):
                 O.codec_forward(sds, wave, n_c=2)
                 t0 = time.perf_counter()
                 O.codec_forward(sds, wave, n_c=2)
-                swept[n] = round(batch * CLIP_SECONDS / (time.perf_counter() - t0), 3)
-            threads = max(swept, key=swept.get) if swept else ncpu
-        threads = min(threads, ncpu)
+                swept[str(n)] = round(batch * CLIP_SECONDS / (time.perf_counter() - t0), 3)
+            return {"threads_swept": swept}
+        threads = min(threads or 16, ncpu)
         torch.set_num_threads(threads)
         times = []
         for i in range(warmups + passes):
@@ -335,12 +342,6 @@ def cpu_baseline(batch=4, passes=5, warmups=2, with_train=True, threads=None):
                sample=f"median of {passes} passes after {warmups} warm-ups, {batch} clips x 2 s each (oracle/facodec_oracle.py "
                       f"codec_forward, torch-CPU fp32, {threads} threads, {os.cpu_count()} logical cores on host), "
                       f"{sum(times):.1f} s of CPU work")
-    if swept:
-        out["threads_swept"] = {str(k): v for k, v in swept.items()}
-        out["best_of"] = f"{threads} threads = the best of a one-pass sweep over {sorted(swept)} threads on this host (audio-s/s above)"
-        if ncpu > max(swept):
-            out["best_of"] += (f"; more threads than that only lose on the {ncpu}-logical-core hosts of the GPU boxes (128 threads: 0.72 against "
-                               "3.2 audio-s/s at 16, profiles/r04_cpu_thread_sweep.log), so 'all cores' would understate the CPU")
     if with_train:
         from oracle.train_iteration import oracle_iteration
         frames = n_samples // 300
@@ -373,6 +374,33 @@ def cpu_baseline(batch=4, passes=5, warmups=2, with_train=True, threads=None):
     return out
 
 
+def cpu_baseline_isolated():
+    """cpu_baseline in fresh processes (see its docstring): one ascending thread sweep, then the measurement at the best count in a
+    process that has never used more threads.  The workers see no GPU."""
+    env = dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+
+    def worker(*extra):
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-worker", *extra], env=env, capture_output=True, text=True)
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        if r.returncode != 0 or not lines:
+            raise RuntimeError(f"cpu baseline worker failed ({r.returncode}): {r.stderr[-1500:]}")
+        return json.loads(lines[-1])
+
+    swept = worker("sweep")["threads_swept"]
+    ncpu = os.cpu_count() or 1
+    best = int(max(swept, key=swept.get)) if swept else min(16, ncpu)
+    out = worker("measure", "--cpu-threads", str(best))
+    out["threads_swept"] = swept
+    out["best_of"] = (f"{best} threads = the best of a one-pass ascending sweep over {sorted(int(k) for k in swept)} threads on this host "
+                      "(audio-s/s above); sweep and measurement each in a fresh process")
+    if swept and ncpu > max(int(k) for k in swept):
+        out["best_of"] += (f"; more threads than that only lose on the {ncpu}-logical-core hosts of the GPU boxes (128 threads: 0.7 against "
+                           "3.3 audio-s/s at 8 - 16, profiles/r05_cpu_thread_sweep.log), so 'all cores' would understate the CPU")
+    return out
+
+
 def latest_pmc_traffic():
     """The HBM-traffic counters are collected by separate rocprofv3 --pmc passes (tools/pmc_traffic.py; MI355X_MICROARCH.md HBM
     section), not inside this run: returns (per-kernel dict, source description) of the newest committed profiles/rNN_pmc_traffic.json."""
@@ -398,6 +426,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=32, help="clips per GPU per step (configs[1]: 32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-worker", choices=("sweep", "measure"), default=None, help=argparse.SUPPRESS)
+    ap.add_argument("--cpu-threads", type=int, default=16, help=argparse.SUPPRESS)
     ap.add_argument("--no-roofline", action="store_true", help="skip per-launch HIP-event timing of the conv kernel")
     ap.add_argument("--no-train", action="store_true", help="skip the configs[2] train-step leg")
     ap.add_argument("--train-steps", type=int, default=4)
@@ -407,6 +437,10 @@ def main():
     ap.add_argument("--stream-check-minutes", type=float, default=5.0, help="prefix of the stream compared with the offline model")
     args = ap.parse_args()
 
+    if args.cpu_worker:          # child of cpu_baseline_isolated(): the CPU oracle only, no GPU
+        r = cpu_baseline(sweep_only=True, with_train=False) if args.cpu_worker == "sweep" else cpu_baseline(threads=args.cpu_threads)
+        print(json.dumps(r), flush=True)
+        return
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -556,7 +590,7 @@ def main():
     if fp32_ref is not None:
         out["fp32_mfma_only"] = fp32_ref
     if world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline()
+        out["cpu_baseline"] = cpu_baseline_isolated()
     print(json.dumps(out), flush=True)
     if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
