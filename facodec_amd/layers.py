@@ -113,6 +113,7 @@ class _Norm(nn.Module):
 # Short clips through the split GEMM kernel as one flattened signal (SConv1d._run_flat, SConvTranspose1d.run): inference only.
 FLAT_SHORT_CLIPS = os.environ.get("FAC_FLAT_SHORT", "1") != "0"
 PW_TAILS_TO_384 = os.environ.get("FAC_PW_TAILS_384", "1") != "0"
+FLAT_STRIDE1 = os.environ.get("FAC_FLAT_STRIDE1", "1") != "0"      # wide stride-1 k = 7 convs on short clips (SConv1d._run_flat_stride1)
 
 
 class SConv1d(nn.Module):
@@ -152,6 +153,10 @@ class SConv1d(nn.Module):
               and ops.gemm_split_strided_ok(w.c_out, w.c_in, self.kernel_size, self.stride, 1,
                                             x.shape[0] * (x.shape[-1] // self.stride + 1) - 1)):
             return self._run_flat(x, alpha_out, act, alpha_y2, want_y)
+        if (FLAT_SHORT_CLIPS and FLAT_STRIDE1 and split is not None and self.stride == 1 and self.kernel_size == 7 and res is None
+                and self.causal and self.pad_mode == ops.PAD_REFLECT and not torch.is_grad_enabled() and isinstance(x, torch.Tensor)
+                and x.shape[0] >= 4 and (self.kernel_size - 1) * self.dilation < x.shape[-1] <= 224 and w.c_in * w.c_out >= 1 << 20):
+            return self._run_flat_stride1(x, alpha_out, act, alpha_y2, want_y, split)
         if split is not None and self.stride > 1:      # split GEMM over the phase sub-signals: P8 input where it pays (ops.p8_prepass)
             x = ops.p8_prepass(x, 2.0 * w.c_out * self.kernel_size / (4.0 * self.stride))
         return ops.conv1d(x, w.packed() if split is None else None, w.c_out, self.kernel_size, bias=w.bias,
@@ -182,6 +187,33 @@ class SConv1d(nn.Module):
             full = torch.empty(w.c_out, B * (n + 1), device=y.device, dtype=y.dtype)
             full[:, :t_out] = y[0]
             return full.reshape(w.c_out, B, n + 1)[:, :, :n].permute(1, 0, 2).contiguous()
+
+        return (back(got[0]), back(got[1])) if alpha_y2 is not None else back(got)
+
+    def _run_flat_stride1(self, x, alpha_out, act, alpha_y2, want_y, split):
+        """The stride-1 counterpart of `_run_flat` (round 5) for the decoder's input conv 1024 -> 1536 k 7 at the 160-frame latent
+        rate, which fills 160 of the 256 columns of the split kernel's time tile.  Every clip is reflect-padded on the left by
+        P = (k - 1) d (the causal padding of dac/model/encodec.py:212-222, materialised: data movement only) and the padded clips are
+        laid one after another as ONE signal of B (T + P) samples; the same conv WITHOUT padding computes output t of clip b at column
+        b (T + P) + t -- the same products in the same order as the per-clip launch, so the same bits -- plus P junk columns per
+        clip where the window straddles two clips, dropped on the way back.  Measured at B = 32: 0.756 -> 0.517 ms (149 -> 226
+        TFLOP/s-eq).  The k = 3 / k = 5 layers at the same rate gain nothing (0.269 -> 0.261, 0.059 -> 0.055 ms: few taps per staged
+        column, they are bound by staging, not by tile columns) and stay on the per-clip launch."""
+        w = self.w
+        B, c_in, T = x.shape
+        P = (self.kernel_size - 1) * self.dilation
+        xp = torch.nn.functional.pad(x, (P, 0), mode="reflect")
+        xf = xp.permute(1, 0, 2).reshape(1, c_in, B * (T + P))
+        t_out = B * (T + P) - P
+        got = ops.conv1d(xf, None, w.c_out, self.kernel_size, bias=w.bias, stride=1, dilation=self.dilation, pad_left=0,
+                         pad_mode=ops.PAD_ZERO, t_out=t_out, alpha_out=alpha_out, act=act, alpha_y2=alpha_y2, want_y=want_y, w_split=split)
+
+        def back(y):
+            if y is None:
+                return None
+            full = torch.empty(w.c_out, B * (T + P), device=y.device, dtype=y.dtype)
+            full[:, :t_out] = y[0]
+            return full.reshape(w.c_out, B, T + P)[:, :, :T].permute(1, 0, 2).contiguous()
 
         return (back(got[0]), back(got[1])) if alpha_y2 is not None else back(got)
 

@@ -670,6 +670,39 @@ def test_short_clips_run_flattened_on_the_split_gemm(O, cuda, monkeypatch):
     assert rel(y, y0) < OP_TOL and rel(u, u0) < OP_TOL
 
 
+@pytest.mark.parametrize("c_in,c_out,d,T,a2", [(1024, 1536, 1, 160, False), (1024, 1024, 3, 100, True)])
+def test_short_clips_run_flattened_stride1_bit_identically(c_in, c_out, d, T, a2, O, cuda, monkeypatch):
+    """The decoder's input conv (1024 -> 1536, k = 7) at the latent rate -- 160 frames fill 160 of the split kernel's 256 tile columns --
+    runs as ONE flattened signal of reflect-padded clips (SConv1d._run_flat_stride1): the same products in the same order as the
+    per-clip launch, so the outputs are the same bits; both within the op tolerance of the oracle."""
+    from facodec_amd import layers
+    B = 8
+    conv = layers.SConv1d(c_in, c_out, 7, dilation=d, causal=True, norm="weight_norm")
+    sd = synth.load_synthetic(conv, seed=41)
+    conv.to(cuda)
+    x = torch.randn(B, c_in, T, generator=_g(42)).to(cuda)
+    alpha2 = (1 + 0.2 * torch.rand(c_out, generator=_g(43))).to(cuda) if a2 else None
+    calls = []
+    orig = layers.SConv1d._run_flat_stride1
+    monkeypatch.setattr(layers.SConv1d, "_run_flat_stride1", lambda self, *a: (calls.append(1), orig(self, *a))[1])
+    with torch.no_grad():
+        got = conv.run(x, alpha_y2=alpha2)
+    assert len(calls) == 1
+    monkeypatch.setattr(layers, "FLAT_STRIDE1", False)
+    with torch.no_grad():
+        ref = conv.run(x, alpha_y2=alpha2)
+    assert len(calls) == 1
+    if a2:
+        assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1])
+        y = got[0]
+    else:
+        assert torch.equal(got, ref)
+        y = got
+    assert y.shape == (B, c_out, T)
+    y_ref = O.sconv1d(x.cpu(), O.conv_weight(sd, "conv.conv."), sd["conv.conv.bias"], dilation=d, causal=True)
+    assert rel(y, y_ref) < OP_TOL
+
+
 def test_p8_prepass_policy_is_bit_identical(cuda, monkeypatch):
     """Inference launches of the split GEMM kernel with a small input next to the GEMM (LSTM input projections, transposed convs,
     the flattened last strided conv) take their input through ONE fac_to_p8 pass (ops.p8_prepass): same bf16 operands in the same
