@@ -14,6 +14,7 @@ Launch plan of forward_v2 (B clips):
   output:  LayerNorm over channels * gamma + beta (one kernel).
 """
 import math
+import os
 
 import numpy as np
 import torch
@@ -328,6 +329,9 @@ def sequence_mask(length, max_length=None):
     return x.unsqueeze(0) < length.unsqueeze(1)
 
 
+QUANT_STREAMS = int(os.environ.get("FAC_QUANT_STREAMS", "3"))     # concurrent chains of FAquantizer's eval forward (1 = serial)
+
+
 class FAquantizer(nn.Module):
     """modules/quantize.py:156-454 with timbre_norm=True / separate_prosody_encoder=True
     (configs/config.yml:27-46); `forward` is the reference's forward_v2 (:235-237)."""
@@ -418,26 +422,31 @@ class FAquantizer(nn.Module):
         if self.training:
             return self._forward_train(x, wave_segments, full_waves, wave_lens, return_codes, masks)
         mel = self.to_mel(wave_segments)                      # (B, 80, F) computed once
-        if full_waves is None:
-            timbre = self.timbre_encoder(mel, None)
-        else:
-            mel_full = self.to_mel(full_waves)
-            m = sequence_mask(wave_lens.to(mel_full.device) // self.hop_length, mel_full.shape[-1]).to(torch.float32).contiguous()
-            timbre = self.timbre_encoder(mel_full, m)
-
-        f0 = ops.conv1d(mel[:, :20], self.melspec_linear.w.packed(), 256, 1, bias=self.melspec_linear.w.bias,
-                        pad_left=0, pad_mode=ops.PAD_ZERO, t_out=mel.shape[-1])
-        f0 = self.melspec_encoder(f0)
-        f0 = self.melspec_linear2.run(f0)
-
-        n = min(f0.shape[2], x.shape[2])
-        if f0.shape[2] != n:
-            f0 = f0[:, :, :n].contiguous()
+        n = min(mel.shape[-1], x.shape[2])
         if x.shape[2] != n:
             x = x[:, :, :n].contiguous()
 
-        z_p, codes_p, _, cm_p, cb_p = self.prosody_quantizer(f0, 1)
-        z_c, codes_c, _, cm_c, cb_c = self.content_quantizer(x, n_c)
+        # Three independent chains (round 5): the timbre encoder, the prosody branch (1x1 -> WaveNet -> 1x1 -> prosody RVQ) and the
+        # content RVQ depend only on the log-mel features / the latent; at the 160-frame latent rate their ~60 launches have
+        # 128 - 256 workgroups each, less than one round of the chip.  Side by side on side streams (ops.run_chains, as the eight
+        # discriminators and the predictor heads in training): same kernels, same results, FAC_QUANT_STREAMS=1 runs them in turn.
+        def timbre_chain():
+            if full_waves is None:
+                return self.timbre_encoder(mel, None)
+            mel_full = self.to_mel(full_waves)
+            m = sequence_mask(wave_lens.to(mel_full.device) // self.hop_length, mel_full.shape[-1]).to(torch.float32).contiguous()
+            return self.timbre_encoder(mel_full, m)
+
+        def prosody_chain():
+            f0 = ops.conv1d(mel[:, :20], self.melspec_linear.w.packed(), 256, 1, bias=self.melspec_linear.w.bias,
+                            pad_left=0, pad_mode=ops.PAD_ZERO, t_out=mel.shape[-1])
+            f0 = self.melspec_linear2.run(self.melspec_encoder(f0))
+            if f0.shape[2] != n:
+                f0 = f0[:, :, :n].contiguous()
+            return self.prosody_quantizer(f0, 1)
+
+        timbre, (z_p, codes_p, _, cm_p, cb_p), (z_c, codes_c, _, cm_c, cb_c) = ops.run_chains(
+            [timbre_chain, prosody_chain, lambda: self.content_quantizer(x, n_c)], x.device, QUANT_STREAMS)
         residual_feature = ops.sub2(x, z_p, z_c)
         z_r, codes_r, _, cm_r, cb_r = self.residual_quantizer(residual_feature, 3)
         outs = ops.add(ops.add(z_p, z_c), z_r)

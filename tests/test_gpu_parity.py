@@ -703,6 +703,32 @@ def test_short_clips_run_flattened_stride1_bit_identically(c_in, c_out, d, T, a2
     assert rel(y, y_ref) < OP_TOL
 
 
+def test_quantizer_chains_on_side_streams_are_bit_identical(cuda, monkeypatch):
+    """FAquantizer's eval forward runs its three independent chains -- timbre encoder, prosody branch + prosody RVQ, content RVQ
+    (modules/quantize.py:378-405) -- side by side on side streams (ops.run_chains): same kernels on other streams, so every
+    output and every code equals the serial order's, with and without the full-utterance timbre input, three trials each."""
+    from facodec_amd import quantize as Q
+    from facodec_amd.commons import build_model, default_model_params
+    model = build_model(default_model_params())
+    for k in ("encoder", "quantizer"):
+        synth.load_synthetic(model[k], seed=0, prefix=k + ".")
+        model[k].to(cuda).eval()
+    wave = synth.synth_clips(4, 48000, seed=11).to(cuda)
+    full = synth.synth_clips(4, 60000, seed=12).squeeze(1).to(cuda)
+    lens = torch.tensor([60000, 45000, 51000, 30000], dtype=torch.int64, device=cuda)
+    assert Q.QUANT_STREAMS > 1
+    with torch.no_grad():
+        z = model.encoder(wave)
+        monkeypatch.setattr(Q, "QUANT_STREAMS", 1)
+        ref = [model.quantizer(z, wave, n_c=2, return_codes=True), model.quantizer(z, wave, n_c=2, full_waves=full, wave_lens=lens, return_codes=True)]
+        monkeypatch.setattr(Q, "QUANT_STREAMS", 3)
+        for _ in range(3):
+            got = [model.quantizer(z, wave, n_c=2, return_codes=True), model.quantizer(z, wave, n_c=2, full_waves=full, wave_lens=lens, return_codes=True)]
+            for g, r in zip(got, ref):
+                assert torch.equal(g[0], r[0]) and torch.equal(g[4], r[4]) and torch.equal(g[2], r[2]) and torch.equal(g[3], r[3])
+                assert all(torch.equal(a, b) for a, b in zip(g[1], r[1])) and all(torch.equal(a, b) for a, b in zip(g[5], r[5]))
+
+
 def test_p8_prepass_policy_is_bit_identical(cuda, monkeypatch):
     """Inference launches of the split GEMM kernel with a small input next to the GEMM (LSTM input projections, transposed convs,
     the flattened last strided conv) take their input through ONE fac_to_p8 pass (ops.p8_prepass): same bf16 operands in the same
