@@ -212,7 +212,15 @@ class _Add(Function):
 
     @staticmethod
     def backward(ctx, dy):
-        return dy, dy
+        # NOT `return dy, dy`.  The two inputs' producers may run their backward on DIFFERENT streams (concurrent chains,
+        # ops.run_chains), and the autograd engine accumulates into a buffered gradient IN PLACE once that tensor is uniquely owned.
+        # One tensor object handed to two consumers then gets written on one stream (the later accumulation for consumer A) while
+        # kernels of the other stream (consumer B's own accumulation, already released on the host) still read it.  Round 5 hit
+        # exactly that: with the content RVQ on a side stream the residual path's gradient -- hence the encoder's -- came out 2.6 %
+        # wrong at B = 16, deterministically, and right under AMD_SERIALIZE_KERNEL=3 (tools/tune/chain_probe.py is the minimal
+        # cross-stream fan-in, which is fine; the shared object was the missing ingredient).  A copy per add of latent-rate tensors
+        # is noise.
+        return dy, dy.clone()
 
 
 class _LSTM(Function):

@@ -381,17 +381,7 @@ class FAquantizer(nn.Module):
         dev = x.device
         use_drop = bool((masks or {}).get("dropout", True))      # WaveNet p = 0.2, StyleEncoder p = 0.1
         mel = self.to_mel(wave_segments)                           # constant input features (no gradient)
-        if full_waves is None:
-            timbre = AQ.style_encoder(self.timbre_encoder, mel, None, use_dropout=use_drop)
-        else:
-            mel_full = self.to_mel(full_waves)
-            m = sequence_mask(wave_lens.to(dev) // self.hop_length, mel_full.shape[-1]).to(torch.float32).contiguous()
-            timbre = AQ.style_encoder(self.timbre_encoder, mel_full, m, use_dropout=use_drop)
-        f0 = A.conv(self.melspec_linear, mel[:, :20].contiguous())
-        f0 = A.conv(self.melspec_linear2, AQ.wavenet(self.melspec_encoder, f0, use_dropout=use_drop))
-        n = min(f0.shape[2], x.shape[2])
-        if f0.shape[2] != n:
-            f0 = f0[:, :, :n].contiguous()
+        n = min(mel.shape[-1], x.shape[2])
         if x.shape[2] != n:
             x = x[:, :, :n].contiguous()
         masks = masks or {}
@@ -402,8 +392,25 @@ class FAquantizer(nn.Module):
                 mk = A.draw_quantizer_masks(rvq.n_codebooks, B, rvq.quantizer_dropout)
             return mk.to(dev)
 
-        z_p, codes_p, cm_p, cb_p = A.rvq(self.prosody_quantizer, f0, qmask("p", self.prosody_quantizer))
-        z_c, codes_c, cm_c, cb_c = A.rvq(self.content_quantizer, x, qmask("c", self.content_quantizer))
+        # The same three independent chains as the eval forward, side by side (ops.run_chains; autograd replays each chain's backward
+        # on the chain's stream).  The chains are ISSUED one after the other by the host, so the random draws keep their order:
+        # StyleEncoder dropout, WaveNet dropout, prosody quantizer-dropout draw, content draw (then the residual draw below).
+        def timbre_chain():
+            if full_waves is None:
+                return AQ.style_encoder(self.timbre_encoder, mel, None, use_dropout=use_drop)
+            mel_full = self.to_mel(full_waves)
+            m = sequence_mask(wave_lens.to(dev) // self.hop_length, mel_full.shape[-1]).to(torch.float32).contiguous()
+            return AQ.style_encoder(self.timbre_encoder, mel_full, m, use_dropout=use_drop)
+
+        def prosody_chain():
+            f0 = A.conv(self.melspec_linear, mel[:, :20].contiguous())
+            f0 = A.conv(self.melspec_linear2, AQ.wavenet(self.melspec_encoder, f0, use_dropout=use_drop))
+            if f0.shape[2] != n:
+                f0 = f0[:, :, :n].contiguous()
+            return A.rvq(self.prosody_quantizer, f0, qmask("p", self.prosody_quantizer))
+
+        timbre, (z_p, codes_p, cm_p, cb_p), (z_c, codes_c, cm_c, cb_c) = ops.run_chains(
+            [timbre_chain, prosody_chain, lambda: A.rvq(self.content_quantizer, x, qmask("c", self.content_quantizer))], dev, QUANT_STREAMS)
         z_r, codes_r, cm_r, cb_r = A.rvq(self.residual_quantizer, A.sub_detached(x, z_p, z_c), qmask("r", self.residual_quantizer))
         res = masks.get("res")
         if res is None:
