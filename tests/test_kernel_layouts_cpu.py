@@ -225,3 +225,26 @@ def test_resident_split_lstm_is_refused_when_its_exchange_scratch_would_be_large
     assert 160 * 1536 * 32 * 6 < ops.LSTM_PERSIST_SPLIT_MAX_SCRATCH < 9000 * 1536 * 32 * 6
     assert ops.lstm_persist_split_ok(1536, 32, T=9000) is False
     assert ops.lstm_persist_split_ok(1024, 32, T=6000) is False          # 1.1 GB
+
+
+def test_add_backward_never_hands_one_tensor_to_two_consumers():
+    """Round 5's cross-stream autograd hazard: the engine accumulates IN PLACE into a buffered gradient once it is
+    uniquely owned, so a backward that returns one tensor object for two inputs lets a consumer on one stream write what a consumer
+    on another stream is still reading.  `A.add`'s backward must return two distinct tensors with equal values."""
+    import torch
+    from facodec_amd import autograd as A
+    dy = torch.arange(12, dtype=torch.float32).reshape(3, 4)
+    ga, gb = A._Add.backward(None, dy)
+    assert torch.equal(ga, dy) and torch.equal(gb, dy)
+    assert ga.data_ptr() != gb.data_ptr()
+    # and no other Function of the training path passes an incoming gradient through to two inputs
+    import inspect
+    import re
+    from facodec_amd import autograd_disc, autograd_pred, autograd_quant
+    for mod in (A, autograd_disc, autograd_pred, autograd_quant):
+        src = inspect.getsource(mod)
+        for m in re.finditer(r"def backward\(ctx, (\w+)[^)]*\):(.*?)(?=\n    @staticmethod|\nclass |\ndef |\Z)", src, re.S):
+            name, body = m.group(1), m.group(2)
+            for ret in re.findall(r"return ([^\n]+)", body):
+                parts = [p.strip() for p in ret.split(",")]
+                assert parts.count(name) <= 1, (mod.__name__, ret)
