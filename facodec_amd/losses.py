@@ -13,6 +13,7 @@ Launch plan per scale: estimate and reference are stacked into one batch of 2B s
 Backward (d loss / d estimate) arrives with the training path.
 """
 import math
+import os
 
 import torch
 from torch import nn
@@ -24,6 +25,9 @@ def _audio(x):
     """Accepts a (B, 1, T) / (B, T) tensor or an object exposing `.audio_data` (audiotools.AudioSignal)."""
     x = getattr(x, "audio_data", x)
     return x.reshape(x.shape[0], x.shape[-1])
+
+
+MEL_STREAMS = int(os.environ.get("FAC_MEL_STREAMS", "3"))      # concurrent scales of MelSpectrogramLoss (1 = serial)
 
 
 class _SpectralScale:
@@ -156,19 +160,29 @@ class MelSpectrogramLoss(_LossBase):
             self._scales[key] = _SpectralScale(device, w, w, w // 4, dsp.mel_fbank_slaney(sr, w, nm, fmin, fmax))
         return self._scales[key]
 
+    def _scale_list(self):
+        return list(zip(self.n_mels, self.mel_fmin, self.mel_fmax, self.window_lengths))
+
     def _grad_x(self, x, y):
+        """d value / d x.  The scales are independent pipelines of small launches (framing -> DFT GEMM -> magnitude -> mel GEMM ->
+        pair term and back): they run side by side (ops.run_chains inside this one autograd node: kernel concurrency only, the
+        engine never sees the streams) and their gradients are added in scale order, as the serial loop did: same bits."""
         xs, ys = _audio(x).contiguous(), _audio(y).contiguous()
         sr = self.sample_rate
-        dx = None
-        for nm, fmin, fmax, w in zip(self.n_mels, self.mel_fmin, self.mel_fmax, self.window_lengths):
+
+        def one(nm, fmin, fmax, w):
             sc = self._scale(xs.device, sr, nm, fmin, fmax, w)
             sc._target = sc.mel(sc.spectrum(ys, 1))
             n = sc._target.numel()
             terms = [(1, self.clamp_eps, self.log_weight * self.pow / n)]
             if self.mag_weight != 0.0:
                 terms.append((0, 0.0, self.mag_weight / n))
-            d = sc.backward_to_wave(xs, terms, use_mel=True)
-            dx = d if dx is None else ops.add(dx, d)
+            return sc.backward_to_wave(xs, terms, use_mel=True)
+
+        parts = ops.run_chains([lambda a=a: one(*a) for a in self._scale_list()], xs.device, MEL_STREAMS)
+        dx = parts[0]
+        for d in parts[1:]:
+            dx = ops.add(dx, d)
         return dx
 
     def _value(self, x, y):
@@ -176,16 +190,28 @@ class MelSpectrogramLoss(_LossBase):
         B = xs.shape[0]
         sr = getattr(x, "sample_rate", self.sample_rate)
         both = torch.cat([xs, ys], 0).contiguous()
-        out, scratch = self._bufs(both.device)
-        for nm, fmin, fmax, w in zip(self.n_mels, self.mel_fmin, self.mel_fmax, self.window_lengths):
-            sc = self._scale(both.device, sr, nm, fmin, fmax, w)
+        scales = self._scale_list()
+        dev = both.device
+        if self._scratch is None or self._scratch.device != dev or self._scratch.shape[0] != len(scales):
+            self._scratch = torch.empty(len(scales), 1024, device=dev, dtype=torch.float32)
+        outs = torch.zeros(len(scales), device=dev, dtype=torch.float32)         # one accumulator per scale (chains run concurrently)
+
+        def one(i, nm, fmin, fmax, w):
+            sc = self._scale(dev, sr, nm, fmin, fmax, w)
             mel = sc.mel(sc.spectrum(both, 1))                       # (2B, n_mels, frames)
             n = mel[:B].numel()
+            out, scratch = outs[i:i + 1], self._scratch[i]
             # log10(clamp(m, eps)^pow) = pow * log10(max(m, eps))
             ops.reduce_pair(mel[:B], mel[B:], out, scratch, 1, self.clamp_eps, self.log_weight * self.pow / n, True)
             if self.mag_weight != 0.0:
                 ops.reduce_pair(mel[:B], mel[B:], out, scratch, 0, 0.0, self.mag_weight / n, True)
-        return out[0]
+            return None
+
+        ops.run_chains([lambda i=i, a=a: one(i, *a) for i, a in enumerate(scales)], dev, MEL_STREAMS)
+        total = outs[0]
+        for i in range(1, len(scales)):          # the order the single accumulator of the serial loop summed in
+            total = total + outs[i]
+        return total
 
 
 class MultiScaleSTFTLoss(_LossBase):
