@@ -76,10 +76,15 @@ SIGNATURES = {
     "fac_lstm_layer_bwd_persist": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "fac_lstm_persist_split_ok": (_i, [_i, _i]),
     "fac_lstm_persist_timeouts": (_i, []),
+    "fac_lstm_persist_arm": (_i, [_p]),
+    "fac_lstm_abort_flag": (_i, [_p, _p]),
+    "fac_mask_flags_if": (_i, [_p, _i, _p, _p]),
     "fac_pack_lstm_whh_split": (_i, [_p, _p, _i, _p]),
     "fac_lstm_layer_fwd_persist_split": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "fac_snake_bwd_fused": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
     "fac_bias_grad": (_i, [_p, _p, _p, _i, _i, _i, _p]),
+    "fac_snake_bwd_fused_rs": (_i, [_p, _p, _p, _i64, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
+    "fac_pad_fold_edges": (_i, [_p, _i, _i, _i, _i, _i, _p]),
     "fac_pack_convtr_w": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
     "fac_conv1d_fwd": (_i, [C.POINTER(ConvDesc), _p]),
     "fac_conv1d_variant": (_i, [C.POINTER(ConvDesc), C.c_char_p, _i]),

@@ -130,7 +130,7 @@ class _SnakeDual(Function):
         y, alpha = ctx.saved_tensors
         if dya is None:
             return dy, None
-        dx, da, _ = ops.snake_bwd_fused(y.detach(), alpha.detach().reshape(-1), dya.contiguous(),
+        dx, da, _ = ops.snake_bwd_fused(y.detach(), alpha.detach().reshape(-1), dya,          # dya: possibly a window of padded rows
                                         add=dy.contiguous() if dy is not None else None)
         return dx, da.reshape(alpha.shape)
 
@@ -180,7 +180,7 @@ class _ResUnit(Function):
         v7d, g7d, v1d, g1d = v7.detach(), g7.detach(), v1.detach(), g1.detach()
         # gradient of y: raw consumer (next unit's skip) + the following Snake; also the k1 bias gradient
         if dya is not None:
-            dyt, da_next, db1 = ops.snake_bwd_fused(y.detach(), a_next.detach().reshape(-1), dya.contiguous(),
+            dyt, da_next, db1 = ops.snake_bwd_fused(y.detach(), a_next.detach().reshape(-1), dya,     # (possibly a window of padded rows)
                                                     add=dy.contiguous() if dy is not None else None, want_bias=True)
             da_next = da_next.reshape(a_next.shape)
         else:
@@ -189,7 +189,9 @@ class _ResUnit(Function):
         dha = ops.conv1d_bwd_data(dyt, v1d, g1d, T, pad_mode=pad_mode, causal=causal, scale=s1)
         dv1, dg1 = ops.weight_norm_bwd(v1d, g1d, ops.conv1d_bwd_weight(ha.detach(), dyt, 1, pad_mode=pad_mode, causal=causal))
         dh, da2, db7 = ops.snake_bwd_fused(h.detach(), a2.detach().reshape(-1), dha, want_bias=True)
-        dxa = ops.conv1d_bwd_data(dh, v7d, g7d, T, dilation=dilation, pad_mode=pad_mode, causal=causal, scale=s7)
+        # the gradient of xa goes to the Snake backward of the producing node (the previous unit, or snake_dual), which reads rows
+        # with a stride: no un-padding copy
+        dxa = ops.conv1d_bwd_data(dh, v7d, g7d, T, dilation=dilation, pad_mode=pad_mode, causal=causal, scale=s7, allow_view=True)
         dv7, dg7 = ops.weight_norm_bwd(v7d, g7d, ops.conv1d_bwd_weight(xa.detach(), dh, 7, dilation=dilation, pad_mode=pad_mode,
                                                                        causal=causal))
         return dyt, dxa, dv7, dg7, db7, da2.reshape(a2.shape), dv1, dg1, db1, da_next, None

@@ -160,9 +160,13 @@ def streaming_soak(model, device, hops, check_minutes=0.0, streams=1, use_graphs
                      "checked_hops": int(check_frames * 300 // HOP),
                      "code_mismatches_vs_offline": int((ref_codes != keep_codes).sum()), "codes_compared": int(ref_codes.numel()),
                      "wave_rel_err_vs_offline": float((keep_wave - ref_y).abs().max() / ref_y.abs().max()),
-                     "frames_emitted_total": state["frames_seen"], "frame_numbering_contiguous": True,
+                     "frames_emitted_total": state["frames_seen"],
+                     "frame_numbering_contiguous": True,      # keep() asserts frame0 == frames seen so far on every emission
+
                      "outputs_finite_to_the_end": state["finite"],
                      "reference": "offline causal model (encoder -> quantizer -> decoder) over the same first minutes + 1 s in one pass"}
+    # the drift contract of the docstring, enforced by the callers (bench.py / tools/stream_bench.py exit non-zero on ok = False)
+    ok = bool(state["finite"]) and (drift is None or (drift["code_mismatches_vs_offline"] == 0 and drift["wave_rel_err_vs_offline"] < 1e-4))
     steady = sorted(lat[10:])
     q = lambda p: round(1e3 * steady[min(len(steady) - 1, int(p * len(steady)))], 4)  # noqa: E731
     audio_s = hops * HOP / float(sample_rate)
@@ -173,4 +177,4 @@ def streaming_soak(model, device, hops, check_minutes=0.0, streams=1, use_graphs
             "device_ms_p50": round(sorted(dev_ms[10:])[len(dev_ms[10:]) // 2], 4),
             "rtf": round(wall / audio_s, 5), "wall_s": round(wall, 2),
             "frames_emitted_last_hop": None if out["codes"] is None else int(out["codes"][0].shape[-1]),
-            "drift_check": drift}
+            "drift_check": drift, "ok": ok}

@@ -34,7 +34,8 @@ def _stale(target, deps):
 
 def build_lib(force=False, verbose=True):
     hipcc = _hipcc()
-    headers = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "conv1d_mfma.h"), os.path.join(HERE, "..", "include", "facodec_hip.h")]
+    # every header under csrc/ (common.h, conv1d_mfma.h, inflight_regs.h, ...) + the C ABI: an edit to any of them rebuilds everything
+    headers = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")) + [os.path.join(HERE, "..", "include", "facodec_hip.h")]
     objs, jobs = [], []
     os.makedirs(os.path.join(CSRC, OBJDIR), exist_ok=True)
     for src in SOURCES:

@@ -185,12 +185,20 @@ __global__ __launch_bounds__(512, 2) void conv1d_bsplit2_kernel(ConvArgs a) {
       for (int j = 0; j < XU; ++j) {
         if (u_c[j] < 0) continue;
         bf16x8 h, m, l;
+#if defined(FAC_ABL2_NOSTAGE_X)
+        continue;                      // ablation builds only (tools/tune/abl_bsplit2.py): results are wrong, timing is the point
+#elif defined(FAC_ABL2_NOSPLIT)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) h[i] = (__bf16)xr[j][i];
+        m = h; l = h;
+#else
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
           __bf16 p0, p1, p2;
           b2_split3(xr[j][i], p0, p1, p2);
           h[i] = p0; m[i] = p1; l[i] = p2;
         }
+#endif
         *reinterpret_cast<bf16x8*>(xd + u_pos[j]) = h;
         *reinterpret_cast<bf16x8*>(xd + XWT * 16 + u_pos[j]) = m;
         *reinterpret_cast<bf16x8*>(xd + 2 * XWT * 16 + u_pos[j]) = l;

@@ -55,6 +55,28 @@ __global__ void pad_fold_bwd_kernel(const float* __restrict__ dxpad, float* __re
   }
 }
 
+// The same fold IN PLACE, touching only the edges: afterwards dxpad[row][pad_left + j] is dx[row][j], i.e. the gradient is the
+// window [pad_left, pad_left + T) of every padded row and a consumer that takes a row stride reads it where it lies (round 6:
+// fac_pad_fold_bwd re-read and re-wrote the whole (B, C, T) tensor -- 8 bytes per element -- to add at most 54 mirrored samples per
+// row).  One thread per (row, mirrored position); reflect padding only (zero padding has nothing to add).
+__global__ void pad_fold_edges_kernel(float* __restrict__ dxpad, int T, int Tp, int pad_left, long long rows) {
+  const int pad_right = Tp - pad_left - T;
+  const int per_row = pad_left + pad_right;
+  const long long n = rows * per_row;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const long long row = i / per_row;
+    const int e = (int)(i - row * per_row);
+    float* p = dxpad + row * Tp;
+    if (e < pad_left) {
+      const int j = e + 1;                                   // xpad[pad_left - j] mirrors x[j], j = 1 .. pad_left
+      p[pad_left + j] += p[pad_left - j];
+    } else {
+      const int m = e - pad_left + 1;                        // xpad[pad_left + T - 1 + m] mirrors x[T - 1 - m], m = 1 .. pad_right
+      p[pad_left + T - 1 - m] += p[pad_left + T - 1 + m];
+    }
+  }
+}
+
 struct WgArgs {
   const float* x;      // (B, C_in, T_in)
   const float* dy;     // (B, C_out, T_out)
@@ -231,7 +253,7 @@ __global__ __launch_bounds__(256) void snake_bwd_kernel(const float* __restrict_
 __global__ __launch_bounds__(256) void snake_bwd_fused_kernel(const float* __restrict__ x, const float* __restrict__ alpha,
                                                               const float* __restrict__ dy, const float* __restrict__ add,
                                                               float* __restrict__ dx, float* __restrict__ part,
-                                                              float* __restrict__ part2, int B, int C, int T) {
+                                                              float* __restrict__ part2, int B, int C, int T, long long dy_rs) {
   __shared__ float red[2][256];
   const int c = blockIdx.x, sl = blockIdx.y, tid = threadIdx.x;
   const float al = alpha[c], ae = al + 1e-9f;
@@ -246,10 +268,11 @@ __global__ __launch_bounds__(256) void snake_bwd_fused_kernel(const float* __res
       const int t0 = (int)(lo > base ? lo - base : 0);
       const int t1 = (int)(hi < base + T ? hi - base : T);
       const long long ro = ((long long)b * C + c) * T;
+      const float* dyr = dy + ((long long)b * C + c) * dy_rs;      // dy rows may sit in a wider buffer (fac_snake_bwd_fused_rs)
       const int first = (int)((256 - ((base + t0 - lo) % 256) + tid) % 256);
       for (int t = t0 + first; t < t1; t += 256) {
         const long long o = ro + t;
-        const float xv = x[o], g = dy[o];
+        const float xv = x[o], g = dyr[t];
         const float ax = al * xv;
         const float sn = sinf(ax), cs = cosf(ax);
         const float s2 = 2.f * sn * cs;
@@ -296,7 +319,17 @@ __global__ __launch_bounds__(256) void bias_grad_kernel(const float* __restrict_
         const int a0 = (t0 + 3) & ~3, a1 = t1 & ~3;              // aligned interior [a0, a1), scalar edges
         if (a0 < a1) {
           for (int t = t0 + tid; t < a0; t += 256) s0 += row[t];
-          for (int t = a0 + 4 * tid; t < a1; t += 1024) {
+          // four 16-byte loads in flight per lane (round 6: with one, the kernel ran at 1.4 TB/s -- latency-, not bandwidth-bound)
+          int t = a0 + 4 * tid;
+          for (; t + 3072 < a1; t += 4096) {
+            const float4 v0 = *reinterpret_cast<const float4*>(row + t);
+            const float4 v1 = *reinterpret_cast<const float4*>(row + t + 1024);
+            const float4 v2 = *reinterpret_cast<const float4*>(row + t + 2048);
+            const float4 v3 = *reinterpret_cast<const float4*>(row + t + 3072);
+            s0 += (v0.x + v1.x) + (v2.x + v3.x); s1 += (v0.y + v1.y) + (v2.y + v3.y);
+            s2 += (v0.z + v1.z) + (v2.z + v3.z); s3 += (v0.w + v1.w) + (v2.w + v3.w);
+          }
+          for (; t < a1; t += 1024) {
             const float4 v = *reinterpret_cast<const float4*>(row + t);
             s0 += v.x; s1 += v.y; s2 += v.z; s3 += v.w;
           }
@@ -369,6 +402,20 @@ extern "C" int fac_pad_fold_bwd(const float* dxpad, float* dx, int B, int C, int
   return check_launch("pad_fold_bwd");
 }
 
+extern "C" int fac_pad_fold_edges(float* dxpad, int B, int C, int T, int Tp, int pad_left, fac_stream_t stream) {
+  using namespace fac;
+  FAC_REQUIRE(dxpad && B > 0 && C > 0 && T > 0 && pad_left >= 0 && Tp >= pad_left + T, "pad_fold_edges: bad arguments");
+  const int pad_right = Tp - pad_left - T;
+  // a sample must not be both a mirror target of the left edge and of the right edge, and the mirrored ranges must lie inside
+  // the signal: T > pad_left + pad_right keeps the two edge regions disjoint (each thread then owns its target)
+  FAC_REQUIRE(T > pad_left + pad_right, "pad_fold_edges: signal shorter than its padding (use fac_pad_fold_bwd)");
+  if (pad_left + pad_right == 0) return FAC_OK;
+  const long long n = (long long)B * C * (pad_left + pad_right);
+  const int blocks = (int)((n + 255) / 256 < 65535 ? (n + 255) / 256 : 65535);
+  hipLaunchKernelGGL(pad_fold_edges_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dxpad, T, Tp, pad_left, (long long)B * C);
+  return check_launch("pad_fold_edges");
+}
+
 extern "C" int64_t fac_conv1d_bwd_weight_ws_bytes(int B, int C_in, int C_out, int T_out, int K) {
   int cit, S, n_tt, per;
   if (fac::wgrad_geometry(B, C_in, C_out, T_out, K, &cit, &S, &n_tt, &per)) return -1;
@@ -436,17 +483,22 @@ extern "C" int fac_snake_bwd(const float* x, const float* alpha, const float* dy
   return check_launch("snake_bwd");
 }
 
-extern "C" int fac_snake_bwd_fused(const float* x, const float* alpha, const float* dy, const float* add, float* dx, float* dalpha,
-                                   float* dbias, float* scratch, int B, int C, int T, fac_stream_t stream) {
+extern "C" int fac_snake_bwd_fused_rs(const float* x, const float* alpha, const float* dy, long long dy_row_stride, const float* add, float* dx,
+                                      float* dalpha, float* dbias, float* scratch, int B, int C, int T, fac_stream_t stream) {
   using namespace fac;
-  FAC_REQUIRE(x && alpha && dy && dx && dalpha && scratch && B > 0 && C > 0 && T > 0, "snake_bwd_fused: bad arguments");
+  FAC_REQUIRE(x && alpha && dy && dx && dalpha && scratch && B > 0 && C > 0 && T > 0 && dy_row_stride >= T, "snake_bwd_fused: bad arguments");
   float* part2 = dbias ? scratch + (long long)RED_NS * C : nullptr;
   hipLaunchKernelGGL(snake_bwd_fused_kernel, dim3(C, RED_NS), dim3(256), 0, (hipStream_t)stream, x, alpha, dy, add, dx, scratch, part2,
-                     B, C, T);
+                     B, C, T, dy_row_stride);
   hipLaunchKernelGGL(channel_reduce_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, scratch, dalpha, C);
   if (dbias)
     hipLaunchKernelGGL(channel_reduce_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, part2, dbias, C);
   return check_launch("snake_bwd_fused");
+}
+
+extern "C" int fac_snake_bwd_fused(const float* x, const float* alpha, const float* dy, const float* add, float* dx, float* dalpha,
+                                   float* dbias, float* scratch, int B, int C, int T, fac_stream_t stream) {
+  return fac_snake_bwd_fused_rs(x, alpha, dy, T, add, dx, dalpha, dbias, scratch, B, C, T, stream);
 }
 
 extern "C" int fac_bias_grad(const float* dy, float* db, float* scratch, int B, int C, int T, fac_stream_t stream) {

@@ -726,6 +726,22 @@ static void arm_timeout_word(hipStream_t stream) {
   g_timeouts.armed[dev] = hipGetLastError() == hipSuccess;
 }
 
+static bool timeout_word_armed() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= LSTM_MAX_DEV) return false;
+  std::lock_guard<std::mutex> lock(g_timeouts.mu);
+  return g_timeouts.armed[dev];
+}
+
+// dst[0] = 1 if a resident wait of this device has given up since the process started, else 0 (device-side read of the abort
+// word, ordered on `stream` behind the launches whose outcome it reports; no host synchronisation).
+__global__ void lstm_abort_flag_kernel(float* dst) { dst[0] = __hip_atomic_load(&g_lstm_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u ? 1.f : 0.f; }
+// flags[0 .. n) = 0 when *poison > 0 (after the flag exchange: ANY rank's abort) -- the masked AdamW step then steps nothing.
+__global__ void mask_flags_if_kernel(float* flags, int n, const float* poison) {
+  if (*poison > 0.f)
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) flags[i] = 0.f;
+}
+
 // FAC_LSTM_EXCHANGE = fence (mode 0) | sc1 (mode 1) | fresh (mode 2, default)
 static int exchange_mode() {
   static int mode = -1;
@@ -803,17 +819,19 @@ static bool grid_fits_cached(const void* kern, int grid, int threads) {
   return ok;
 }
 
+// (a launch whose waits can bail out must be able to SAY so -- an un-armed counter word, e.g. because the first resident
+// launch of the process was issued inside a stream capture or hipHostMalloc failed, means "not usable": fac_lstm_persist_arm.)
 // What fac_lstm_persist_ok / _split_ok answer: the shape is inside the kernels, the whole grid of the forward AND the backward
 // kernel is co-resident by the runtime's own occupancy figure (a shape or device that fails it used to be a hard
 // FAC_REQUIRE error in the launch instead of a fall-back), and no resident wait of this process has ever timed out.
 static bool persist_usable(int H, int B) {
-  return persist_shape_ok(H, B) && persist_timeouts() == 0u &&
+  return persist_shape_ok(H, B) && persist_timeouts() == 0u && timeout_word_armed() &&
          grid_fits_cached(reinterpret_cast<const void*>(fwd_kernel_for(H, B)), H / 8, 1024) &&
          grid_fits_cached(reinterpret_cast<const void*>(bwd_kernel_for(H, B)), H / 8, 1024);
 }
 
 static bool persist_split_usable(int H, int B) {
-  return persist_split_shape_ok(H, B) && persist_timeouts() == 0u &&
+  return persist_split_shape_ok(H, B) && persist_timeouts() == 0u && timeout_word_armed() &&
          grid_fits_cached(reinterpret_cast<const void*>(split_kernel_for(H)), H / 8, LS_NW * 64);
 }
 
@@ -822,6 +840,25 @@ static bool persist_split_usable(int H, int B) {
 extern "C" int fac_lstm_persist_split_ok(int H, int B) { return fac::persist_split_usable(H, B) ? 1 : 0; }
 
 extern "C" int fac_lstm_persist_timeouts(void) { return (int)fac::persist_timeouts(); }
+
+extern "C" int fac_lstm_persist_arm(fac_stream_t stream) {
+  fac::arm_timeout_word((hipStream_t)stream);
+  return fac::timeout_word_armed() ? 1 : 0;
+}
+
+extern "C" int fac_lstm_abort_flag(float* dst, fac_stream_t stream) {
+  using namespace fac;
+  FAC_REQUIRE(dst != nullptr, "lstm_abort_flag: null pointer");
+  hipLaunchKernelGGL(lstm_abort_flag_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, dst);
+  return check_launch("lstm_abort_flag");
+}
+
+extern "C" int fac_mask_flags_if(float* flags, int n, const float* poison, fac_stream_t stream) {
+  using namespace fac;
+  FAC_REQUIRE(flags && poison && n > 0, "mask_flags_if: bad arguments");
+  hipLaunchKernelGGL(mask_flags_if_kernel, dim3((n + 255) / 256 > 64 ? 64 : (n + 255) / 256), dim3(256), 0, (hipStream_t)stream, flags, n, poison);
+  return check_launch("mask_flags_if");
+}
 
 extern "C" int fac_pack_lstm_whh_split(const float* w_hh, void* packed, int H, fac_stream_t stream) {
   using namespace fac;
@@ -840,6 +877,7 @@ extern "C" int fac_lstm_layer_fwd_persist_split(const float* pre, const void* ws
   FAC_REQUIRE(slot >= 0, "lstm_layer_fwd_persist_split: more than %d streams in use", LSTM_SYNC_SLOTS);
   SplitKern kern = split_kernel_for(H);
   FAC_REQUIRE(kern != nullptr, "lstm_layer_fwd_persist_split: no kernel for H=%d", H);
+  arm_timeout_word((hipStream_t)stream);        // (no-op once armed; an un-armed word makes the launch unusable)
   FAC_REQUIRE(persist_split_usable(H, B), "lstm_layer_fwd_persist_split: %d workgroups are not co-resident on this device, or an earlier "
               "resident launch timed out (%u): ask fac_lstm_persist_split_ok first and fall back to fac_lstm_layer_fwd", H / 8, persist_timeouts());
   int rc;
@@ -876,6 +914,7 @@ extern "C" int fac_lstm_layer_fwd_persist(const float* pre, const float* whh16, 
   FAC_REQUIRE(slot >= 0, "lstm_layer_fwd_persist: more than %d streams in use", LSTM_SYNC_SLOTS);
   FwdKern kern = fwd_kernel_for(H, B);
   FAC_REQUIRE(kern != nullptr, "lstm_layer_fwd_persist: no kernel for H=%d", H);
+  arm_timeout_word((hipStream_t)stream);        // (no-op once armed; an un-armed word makes the launch unusable)
   FAC_REQUIRE(persist_usable(H, B), "lstm_layer_fwd_persist: %d workgroups are not co-resident on this device, or an earlier resident "
               "launch timed out (%u): ask fac_lstm_persist_ok first and fall back to fac_lstm_layer_fwd", H / 8, persist_timeouts());
   int rc;
@@ -903,6 +942,7 @@ extern "C" int fac_lstm_layer_bwd_persist(const float* dyT, const float* whh16t,
   float* dgfrag = scratch + 4 * hbuf;
   BwdKern kern = bwd_kernel_for(H, B);
   FAC_REQUIRE(kern != nullptr, "lstm_layer_bwd_persist: no kernel for H=%d", H);
+  arm_timeout_word((hipStream_t)stream);        // (no-op once armed; an un-armed word makes the launch unusable)
   FAC_REQUIRE(persist_usable(H, B), "lstm_layer_bwd_persist: %d workgroups are not co-resident on this device, or an earlier resident "
               "launch timed out (%u)", H / 8, persist_timeouts());
   int rc;

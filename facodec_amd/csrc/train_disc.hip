@@ -60,6 +60,34 @@ __global__ void leaky_quad_kernel(const float4* __restrict__ x, const float4* __
   }
 }
 
+// The same for any pitch / row length (round 6): four consecutive elements per lane with 16-byte accesses; the position of the
+// quad's first element is resolved once (one 32-bit modulo, one division) and walked forward from there -- the element-wise
+// kernels above cost a 64-bit modulo and two divisions per element and ran at 3.2 - 3.5 TB/s (profiles/r06_pmc_train_before.json).
+template <bool BWD>
+__global__ void leaky_quad_any_kernel(const float4* __restrict__ x, const float4* __restrict__ dy, float4* __restrict__ out, float slope,
+                                      int T, int pitch, int valid, int rpg, int vrows, long long n4) {
+  GRID_STRIDE(q, n4) {
+    const float4 xv = x[q];
+    const float4 gv = BWD ? dy[q] : xv;
+    const long long i = 4 * q;
+    int pos = (i >> 31) == 0 ? (int)((unsigned)i % (unsigned)T) : (int)(i % T);
+    int row = pos / pitch;
+    int c = pos - row * pitch;
+    int rr = rpg ? row % rpg : 0;
+    const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, gs[4] = {gv.x, gv.y, gv.z, gv.w};
+    float o[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const bool ok = c < valid && (rpg == 0 || rr < vrows);
+      o[j] = ok ? (xs[j] > 0.f ? gs[j] : gs[j] * slope) : 0.f;
+      ++c; ++pos;
+      if (pos == T) { pos = 0; c = 0; rr = 0; }
+      else if (c == pitch) { c = 0; if (++rr == rpg) rr = 0; }
+    }
+    out[q] = make_float4(o[0], o[1], o[2], o[3]);
+  }
+}
+
 // out[(b*p + j)*pitch + l] = xr[l*p + j] for l < L (zero for L <= l < pitch), xr = x reflect-extended on the right to
 // L*p samples (MPD.pad_to_period + rearrange); rows (b, j) laid one after another with `pitch` columns each
 __global__ void period_fold_kernel(const float* __restrict__ x, float* __restrict__ out, int T, int p, int L, int pitch, long long n) {
@@ -254,6 +282,13 @@ extern "C" int fac_leaky_relu(const float* x, const float* dy, float* out, int64
     float4* o4 = reinterpret_cast<float4*>(out);
     if (dy) L1(leaky_quad_kernel<true>, n4, x4, d4, o4, slope, T > 0 ? T : 1, pitch, valid, rows_per_group, valid_rows, n4);
     else L1(leaky_quad_kernel<false>, n4, x4, d4, o4, slope, T > 0 ? T : 1, pitch, valid, rows_per_group, valid_rows, n4);
+  } else if (pitch != 0 && (n & 3) == 0 && ((reinterpret_cast<unsigned long long>(x) | reinterpret_cast<unsigned long long>(out) |
+                                               reinterpret_cast<unsigned long long>(dy)) & 15) == 0) {
+    const long long n4 = n / 4;
+    const float4 *x4 = reinterpret_cast<const float4*>(x), *d4 = reinterpret_cast<const float4*>(dy);
+    float4* o4 = reinterpret_cast<float4*>(out);
+    if (dy) L1(leaky_quad_any_kernel<true>, n4, x4, d4, o4, slope, T, pitch, valid, rows_per_group, valid_rows, n4);
+    else L1(leaky_quad_any_kernel<false>, n4, x4, d4, o4, slope, T, pitch, valid, rows_per_group, valid_rows, n4);
   } else if (dy) L1(leaky_bwd_kernel, n, x, dy, out, slope, T > 0 ? T : 1, pitch, valid, rows_per_group, valid_rows, (long long)n);
   else L1(leaky_fwd_kernel, n, x, out, slope, T > 0 ? T : 1, pitch, valid, rows_per_group, valid_rows, (long long)n);
   return fac::check_launch("leaky_relu");

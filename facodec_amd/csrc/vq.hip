@@ -109,7 +109,7 @@ __global__ __launch_bounds__(256) void vq_fwd_kernel(VqArgs a, int n_tiles, int 
   extern __shared__ __attribute__((aligned(16))) float sm[];
   float* cbn = sm;                              // [Kc][8]
   float* cc = cbn + a.Kc * VQ_CD;               // [Kc]
-  float* part = cc + a.Kc;                      // [4][8][16]
+  float* part = cc + ((a.Kc + 3) & ~3);         // [4][8][16]; everything behind cc stays 16-byte aligned for any codebook size
   float* zes = part + 4 * VQ_CD * VT;           // [8][16]  z_e
   float* bestv = zes + VQ_CD * VT;              // [16 groups][16]
   int* bestk = reinterpret_cast<int*>(bestv + VG * VT);  // [16][16]
@@ -444,7 +444,7 @@ extern "C" int fac_vq_fwd(const fac_vq_desc* d, fac_stream_t stream) {
   a.b_out = d->b_out; a.mask = d->mask; a.codes = (long long*)d->codes; a.z_e = d->z_e;
   a.loss_part = d->loss_part; a.codes_bs = d->codes_bs;
   a.B = d->B; a.D = d->D; a.T = d->T; a.Kc = d->Kc;
-  const size_t lds = ((size_t)d->Kc * (VQ_CD + 1) + 4 * VQ_CD * VT + VQ_CD * VT + 2 * VG * VT + (size_t)d->D * VQ_CD) * 4;
+  const size_t lds = ((size_t)d->Kc * VQ_CD + ((d->Kc + 3) & ~3) + 4 * VQ_CD * VT + VQ_CD * VT + 2 * VG * VT + (size_t)d->D * VQ_CD) * 4;
   FAC_REQUIRE(lds <= 160 * 1024, "vq_fwd: codebook of %d entries + %d in-proj rows do not fit LDS", d->Kc, d->D);
   static bool attr_set = false;
   if (!attr_set) {

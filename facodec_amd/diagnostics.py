@@ -61,6 +61,68 @@ def check_codes_decidable(codes, fixture):
         sha256=got_sha, sha256_equal=got_sha == sha(ref), sha256_equal_fp64_reference=got_sha == sha(runs["f64"]))
 
 
+# which earlier stages decide the INPUT of stage i (modules/quantize.py:398-417: prosody | content x 2 on the latent, residual x 3 on
+# x - z_p - z_c; inside an RVQ every stage sees the residual the earlier ones left, dac/nn/quantize.py:173-193)
+FEEDS = {0: (), 1: (), 2: (1,), 3: (0, 1, 2), 4: (0, 1, 2, 3), 5: (0, 1, 2, 3, 4)}
+
+
+def check_codes_decidable_noise(codes, fixture, batch=0):
+    """The exact code check with the reference's OWN arithmetic noise in the definition of "decidable" (VERDICT r5 item 5).
+
+    fixture: tests/golden/codec_b32x4_decidable.npz (make_golden_bench.py b32x4_decidable): for each of four 32-clip batches the
+    real reference in fp32 / all threads, fp32 / one thread and fp64, the fp64 run's second-best code and top-2 gap per position, and
+    `noise[batch]` = the largest difference that batch's fp32 runs show against its fp64 run in the margin between those two codes.
+    `decidable` = the three runs agree AND the fp64 gap >= noise[batch]: a position the runs agree on with a smaller gap agrees by
+    luck (the reference's own fp32 rounding could have flipped it), so there either of the fp64 run's two best codes is the
+    reference's answer.  codes: (32, 6, 160) or the three streams FAquantizer.forward_v2 returns, for batch `batch` of the fixture.
+
+    Rule, stage by stage in the order the quantizers run (no tolerance anywhere).  R = the reference runs whose codes equal the
+    product's on every stage feeding this one (FEEDS):
+      * R not empty: the code must be the answer of a run in R -- or, where all three runs agree with an fp64 gap below the batch's
+        noise, the fp64 run's second-best code (a NOISE FLIP; listed with its gap);
+      * R empty because an earlier stage of the frame took a noise flip: nothing the reference computed says what follows (no run
+        went that way) -- counted as that flip's cascade, not compared;
+      * R empty for any other reason: an earlier stage was already wrong; counted as a mismatch as well.
+    -> dict(ok, mismatches, noise_flips [[clip, stage, frame, fp64 gap] ...], cascade_positions, differs_from_fp32 / _fp64, ...)."""
+    if isinstance(codes, (list, tuple)):
+        codes = torch.cat([torch.as_tensor(c) for c in codes], 1)
+    got = torch.as_tensor(codes).cpu().numpy().astype(np.int64)
+    runs = [fixture["codes_" + k][batch].astype(np.int64) for k in REFERENCE_RUNS]
+    agree, dec = fixture["agree"][batch].astype(bool), fixture["decidable"][batch].astype(bool)
+    second, gap = fixture["second_f64"][batch].astype(np.int64), fixture["gap_f64"][batch]
+    assert got.shape == dec.shape, (got.shape, dec.shape)
+    B, n, T = got.shape
+    eq = [got == r for r in runs]                                            # per run (B, n, T)
+    bad = np.zeros((B, n, T), bool)
+    flip = np.zeros((B, n, T), bool)
+    cascade = np.zeros((B, n, T), bool)
+    flipped_upstream = np.zeros((B, n, T), bool)                             # a stage feeding this one took a noise flip
+    for i in range(n):
+        cons = [np.ones((B, T), bool) for _ in runs]
+        for j in FEEDS[i]:
+            cons = [c & e[:, j] for c, e in zip(cons, eq)]
+            flipped_upstream[:, i] |= flip[:, j] | flipped_upstream[:, j]
+        any_cons = cons[0] | cons[1] | cons[2]
+        answered = (cons[0] & eq[0][:, i]) | (cons[1] & eq[1][:, i]) | (cons[2] & eq[2][:, i])
+        all_cons = cons[0] & cons[1] & cons[2]
+        noise_ok = all_cons & agree[:, i] & ~dec[:, i] & (got[:, i] == second[:, i])
+        flip[:, i] = noise_ok & ~answered
+        cascade[:, i] = ~any_cons & flipped_upstream[:, i]
+        bad[:, i] = ~(answered | noise_ok | cascade[:, i])
+    sha = lambda a: hashlib.sha256(a.astype(np.int16).tobytes()).hexdigest()   # noqa: E731
+    flips = [[int(b), int(i), int(t), float(gap[b, i, t])] for b, i, t in np.argwhere(flip)]
+    bad_pos = np.argwhere(bad)
+    return dict(
+        ok=bool(bad.sum() == 0), batch=int(batch), positions=int(dec.size), decidable=int(dec.sum()),
+        noise=float(fixture["noise"][batch]), mismatches=int(bad.sum()), decidable_mismatches=int((bad & dec).sum()),
+        mismatch_positions=bad_pos[:16].tolist(), mismatch_fp64_gaps=[float(gap[tuple(p)]) for p in bad_pos[:16]],
+        noise_flips=flips, cascade_positions=int(cascade.sum()),
+        runs_agree_but_gap_below_noise=int((agree & ~dec).sum()), runs_disagree=int((~agree).sum()),
+        differs_from_fp32=int((~eq[0]).sum()), differs_from_fp64=int((~eq[2]).sum()),
+        differs_from_fp64_positions_and_gaps=[[int(b), int(i), int(t), float(gap[b, i, t])] for b, i, t in np.argwhere(~eq[2])[:8]],
+        equals_run=[k for k, e in zip(REFERENCE_RUNS, eq) if e.all()], sha256=sha(got))
+
+
 class LatentCapture:
     """Context manager: records the projected latents (B, 8 n, T) every ResidualVectorQuantize under `module` returns."""
 

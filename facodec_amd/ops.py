@@ -40,33 +40,6 @@ def _dev(t, what="tensor"):
 
 
 # --------------------------------------------------------------------------------- weights (K6)
-# Timing experiment only (tools/train_ab.py): FAC_EXP_STALE_PACKS=1 memoises the weight-norm scales and packed weight layouts
-# ACROSS steps -- the weights go stale, results are wrong -- to measure what the ~1 500 small scale / pack launches of a train step
-# cost in wall time (the upper bound of what batching them into multi-tensor launches could buy).
-_EXP_STALE_PACKS = os.environ.get("FAC_EXP_STALE_PACKS") == "1"
-_EXP_MEMO = {}
-
-
-def _exp_memo(fn):
-    if not _EXP_STALE_PACKS:
-        return fn
-    import functools
-
-    @functools.wraps(fn)
-    def wrapped(*args, **kw):
-        key = [fn.__name__]
-        for a in list(args) + [kw.get(k) for k in sorted(kw) if k not in ("out", "scale")]:
-            key.append((a.data_ptr(), tuple(a.shape)) if torch.is_tensor(a) else a)
-        key = tuple(key)
-        r = _EXP_MEMO.get(key)
-        if r is None:
-            kw.pop("out", None)
-            r = _EXP_MEMO[key] = fn(*args, **kw)
-        return r
-    return wrapped
-
-
-@_exp_memo
 def wn_scale(v, g):
     """scale[i] = g[i]/||v[i]|| (dac/model/encodec.py:42-51)."""
     v = _dev(v, "weight_v")
@@ -77,7 +50,6 @@ def wn_scale(v, g):
     return scale
 
 
-@_exp_memo
 def pack_conv_weight(v, g=None, out=None, scale=None):
     """(C_out, C_in, K) [+ weight-norm gain g (C_out,1,1)] -> packed (cin_pad(C_in), K, pad32(C_out));
     the rows of the padding channels are written as zeros by the kernel (no separate fill)."""
@@ -95,7 +67,6 @@ def pack_conv_weight(v, g=None, out=None, scale=None):
     return out
 
 
-@_exp_memo
 def pack_convtr_weight(v, g, stride, out=None):
     """ConvTranspose1d (C_in, C_out, 2*stride) -> polyphase packed (stride, cin_pad(C_in), 2, pad32(C_out))."""
     v = _dev(v, "weight")
@@ -127,7 +98,6 @@ def convtr_rows_ok(t_in, stride, causal=True):
     return CONVTR_ROWS and causal and 2 <= stride <= 16 and t_in >= CONVTR_ROWS_MIN_T
 
 
-@_exp_memo
 def pack_convtr_weight_rows(v, g, stride, out=None):
     """ConvTranspose1d (C_in, C_out, 2*stride) -> (cin_pad(C_in), 2, rows) with rows = (channel, phase) pairs in 128-row
     tiles (fac_pack_convtr_w_rows); conv_transpose1d recognises the layout by its 3 dimensions."""
@@ -392,7 +362,6 @@ def gemm_split_strided_ok(c_out, c_in, k, stride, batch, t_out):
             and c_out >= 64 and t_out >= 256 and batch * t_out >= 1024)
 
 
-@_exp_memo
 def pack_gemm_weight_split(v, g=None, out=None, in_stride=1, scale=None):
     """(C_out, C_in, K) [weight-normed with g over dim 0] -> fac_pack_gemm_w_split layout (uint8 buffer); K <= 2, or a strided
     conv's taps (in_stride < K <= 2 * in_stride)."""
@@ -439,7 +408,6 @@ def split2_ok(c_out, k, k1, stride, n_cols):
             and n_cols >= 4096)
 
 
-@_exp_memo
 def pack_conv_weight_split2(v, g=None, k1=0, out=None, scale=None):
     """(C_out <= 32, C_in, K) [weight-normed with g] -> fac_pack_conv_w_split2 layout (uint8 buffer); k1: taps per level."""
     v = _dev(v, "weight")
@@ -455,7 +423,6 @@ def pack_conv_weight_split2(v, g=None, k1=0, out=None, scale=None):
     return out
 
 
-@_exp_memo
 def pack_convtr_weight_rows_split(v, g, stride, out=None):
     """ConvTranspose1d (C_in, C_out, 2*stride) -> split GEMM weights of the all-phases launch: the (channel, phase) rows of
     pack_convtr_weight_rows, each row's (C_in, 2) taps as bf16 planes.  Returns (split buffer, rows)."""
@@ -471,7 +438,6 @@ def pack_convtr_weight_rows_split(v, g, stride, out=None):
     return out, R
 
 
-@_exp_memo
 def pack_conv_weight_split(v, g=None, out=None, scale=None):
     """(C_out, C_in, K) [weight-normed with g] -> split-bf16 layout of fac_pack_conv_w_split (K = 5 / 7; uint8 buffer) or of
     fac_pack_gemm_w_split (K = 1 / 2)."""
@@ -700,12 +666,46 @@ LSTM_PERSIST = os.environ.get("FAC_LSTM_PERSIST", "1") != "0"
 LSTM_PERSIST_MAX_BATCH = int(os.environ.get("FAC_LSTM_PERSIST_MAX_BATCH", "16"))
 
 
+_LSTM_ARMED = set()
+
+
+def _lstm_arm():
+    """The resident kernels' waits give up after 4 s without progress and count that in a host-mapped word the device has to be
+    told about (fac_lstm_persist_arm: one one-thread kernel, once per device, outside any stream capture).  A device whose word is
+    not armed answers fac_lstm_persist_ok = 0, so the word is armed here, eagerly, the first time anybody asks."""
+    dev = torch.cuda.current_device()
+    if dev in _LSTM_ARMED:
+        return
+    if torch.cuda.is_current_stream_capturing():
+        return                                   # not now; the per-step kernels take this call, a later eager call arms
+    if _lib.load().fac_lstm_persist_arm(_stream()):
+        _LSTM_ARMED.add(dev)
+
+
+def lstm_timeouts():
+    """Resident-LSTM waits that gave up in this process so far (host-mapped counter: no synchronisation; it counts what the device
+    has EXECUTED, so a caller that wants the verdict on launches it just queued synchronises first)."""
+    return int(_lib.load().fac_lstm_persist_timeouts())
+
+
+def raise_if_lstm_timed_out(what="resident LSTM launch"):
+    """Results of a resident launch whose wait gave up are meaningless.  Training is protected on the device (optim.FlatAdamW: the
+    abort flag travels with the per-parameter flags and the masked AdamW step steps nothing on ANY rank); this is the host-side
+    report for inference callers and benchmarks, to be called behind a synchronisation point."""
+    n = lstm_timeouts()
+    if n:
+        raise _lib.FacodecHipError(f"{what}: {n} resident-LSTM wait(s) timed out on this device -- the outputs of that launch are "
+                                   "meaningless (later layers use the per-step kernels: fac_lstm_persist_ok answers 0 from now on)")
+
+
 def lstm_persist_ok(H, batch):
     """True when the one-launch-per-layer recurrence (lstm_persist.hip) is used for an (H, batch) zero-initial-state
     layer on this device: H in {512, 1024, 1536}, H/8 workgroups <= CUs, batch <= 16.  The kernels cover batch <= 32
     (two 16-column blocks) but measure no faster than the per-step launches there (profiles/r03_lstm_bench.log)."""
-    return (LSTM_PERSIST and batch is not None and batch <= LSTM_PERSIST_MAX_BATCH and not _ranks_share_a_device()
-            and bool(_lib.load().fac_lstm_persist_ok(int(H), int(batch)))
+    if not (LSTM_PERSIST and batch is not None and batch <= LSTM_PERSIST_MAX_BATCH) or _ranks_share_a_device():
+        return False
+    _lstm_arm()
+    return (bool(_lib.load().fac_lstm_persist_ok(int(H), int(batch)))
             and bool(_lib.load().fac_lstm_persist_stream_ok(_stream())))
 
 
@@ -725,9 +725,11 @@ def lstm_persist_split_ok(H, batch, T=None):
     which need none, take the layer."""
     if T is not None and int(T) * int(H) * 32 * 6 > LSTM_PERSIST_SPLIT_MAX_SCRATCH:
         return False
-    return (LSTM_PERSIST and LSTM_PERSIST_SPLIT and BF16_SPLIT and batch is not None
-            and LSTM_PERSIST_SPLIT_MIN_BATCH <= batch <= 32 and not _ranks_share_a_device()
-            and bool(_lib.load().fac_lstm_persist_split_ok(int(H), int(batch)))
+    if not (LSTM_PERSIST and LSTM_PERSIST_SPLIT and BF16_SPLIT and batch is not None
+            and LSTM_PERSIST_SPLIT_MIN_BATCH <= batch <= 32) or _ranks_share_a_device():
+        return False
+    _lstm_arm()
+    return (bool(_lib.load().fac_lstm_persist_split_ok(int(H), int(batch)))
             and bool(_lib.load().fac_lstm_persist_stream_ok(_stream())))
 
 
@@ -1003,7 +1005,6 @@ def aa_snakebeta(x, alpha_log, beta_log, filter12):
 
 
 # --------------------------------------------------------------------------------- backward of the conv stack
-@_exp_memo
 def flipped_weight(v, g=None, scale=None):
     """(C_out, C_in, K) [weight-normed] -> (C_in, C_out, K) weights of the data-gradient conv (channels swapped, taps flipped),
     one launch (fac_flip_transpose_w)."""
@@ -1016,7 +1017,6 @@ def flipped_weight(v, g=None, scale=None):
     return out
 
 
-@_exp_memo
 def pack_conv_weight_bwd(v, g=None, scale=None):
     """(C_out, C_in, K) [weight-normed] -> packed weights of the bwd-data conv (taps flipped, channels swapped)."""
     v = _dev(v, "weight")
@@ -1029,9 +1029,12 @@ def pack_conv_weight_bwd(v, g=None, scale=None):
     return packed
 
 
-def conv1d_bwd_data(dy, v, g, t_in, stride=1, dilation=1, pad_mode=PAD_REFLECT, causal=True, scale=None):
+def conv1d_bwd_data(dy, v, g, t_in, stride=1, dilation=1, pad_mode=PAD_REFLECT, causal=True, scale=None, allow_view=False):
     """Gradient w.r.t. the input of SConv1d (dac/model/encodec.py:212-228) given dy (B, C_out, T_out).
-    scale: the weight-norm scale g / ||v|| if the caller already has it (the forward computed it)."""
+    scale: the weight-norm scale g / ||v|| if the caller already has it (the forward computed it).
+    allow_view: the caller's consumer takes rows with a stride (snake_bwd_fused): the result may then be the window
+    [pad_left, pad_left + t_in) of the padded gradient rows -- a non-contiguous (B, C, t_in) view, mirrored edge samples added in
+    place (fac_pad_fold_edges) -- instead of a copy (fac_pad_fold_bwd: 8 bytes per element to move the tensor by <= 54 samples)."""
     dy = _dev(dy, "dy")
     if scale is None and g is not None:
         scale = wn_scale(v, g)
@@ -1060,10 +1063,31 @@ def conv1d_bwd_data(dy, v, g, t_in, stride=1, dilation=1, pad_mode=PAD_REFLECT, 
         dy_ext = torch.cat([dy, torch.zeros(B, c_out, 1, device=dy.device)], dim=2)
         dxpad = conv_transpose1d(dy_ext, convtr_weight_for(v, g, stride, dy_ext.shape[-1], batch=B), c_in, stride)
         assert dxpad.shape[-1] == tp, (dxpad.shape, tp)
+    if tp == t_in:
+        return dxpad                                  # no padding (the 1x1 convs): the padded gradient IS the gradient
+    if allow_view and FOLD_IN_PLACE and dxpad.is_contiguous() and (pad_mode == PAD_ZERO or t_in > pad_left + pad_right):
+        if pad_mode == PAD_REFLECT:
+            _lib.check(_lib.load().fac_pad_fold_edges(_ptr(dxpad), B, c_in, t_in, tp, pad_left, _stream()), "fac_pad_fold_edges")
+        return dxpad[:, :, pad_left:pad_left + t_in]
     dx = torch.empty(B, c_in, t_in, device=dy.device, dtype=torch.float32)
     _lib.check(_lib.load().fac_pad_fold_bwd(_ptr(dxpad), _ptr(dx), B, c_in, t_in, tp, pad_left, pad_mode, _stream()),
                "fac_pad_fold_bwd")
     return dx
+
+
+FOLD_IN_PLACE = os.environ.get("FAC_FOLD_IN_PLACE", "1") != "0"
+
+
+def _rows_view(t):
+    """(tensor, row stride) for a (B, C, T) fp32 CUDA tensor whose rows are time-contiguous and evenly spaced (a window of a wider
+    buffer, see conv1d_bwd_data(allow_view=True)); anything else is made contiguous first."""
+    if t is None:
+        return None, 0
+    if (t.is_cuda and t.dtype == torch.float32 and t.dim() == 3 and t.stride(2) == 1 and t.stride(1) >= t.shape[2]
+            and t.stride(0) == t.shape[1] * t.stride(1)):
+        return t, t.stride(1)
+    t = _dev(t, "dy")
+    return t, t.shape[2]
 
 
 def conv1d_bwd_weight(x, dy, k, stride=1, dilation=1, pad_mode=PAD_REFLECT, causal=True, pad_left=None, k1=0, dilation2=0,
@@ -1171,13 +1195,14 @@ def snake_bwd(x, alpha, dy):
 def snake_bwd_fused(x, alpha, dy, add=None, want_bias=False):
     """Snake backward with the fan-in add and the producing conv's bias gradient fused in (fac_snake_bwd_fused):
     dx = add + dy * dsnake/dx, dalpha, [dbias = sum over (b, t) of dx]."""
-    x, dy, add = _dev(x, "x"), _dev(dy, "dy"), _dev(add, "add")
+    x, add = _dev(x, "x"), _dev(add, "add")
+    dy, dy_rs = _rows_view(dy)              # dy may be a window of padded gradient rows (conv1d_bwd_data(allow_view=True))
     B, c, t = x.shape
     dx, dalpha = torch.empty_like(x), torch.empty(c, device=x.device, dtype=torch.float32)
     db = torch.empty(c, device=x.device, dtype=torch.float32) if want_bias else None
     scratch = torch.empty(64 * c, device=x.device, dtype=torch.float32)
-    _lib.check(_lib.load().fac_snake_bwd_fused(_ptr(x), _ptr(alpha), _ptr(dy), _ptr(add), _ptr(dx), _ptr(dalpha), _ptr(db),
-                                               _ptr(scratch), B, c, t, _stream()), "fac_snake_bwd_fused")
+    _lib.check(_lib.load().fac_snake_bwd_fused_rs(_ptr(x), _ptr(alpha), _ptr(dy), dy_rs, _ptr(add), _ptr(dx), _ptr(dalpha), _ptr(db),
+                                                  _ptr(scratch), B, c, t, _stream()), "fac_snake_bwd_fused")
     return dx, dalpha, db
 
 

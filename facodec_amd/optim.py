@@ -109,9 +109,15 @@ class FlatAdamW:
         P = len(self.params)
         self.n, self.data_parallel = n, data_parallel
         self.p = torch.empty(n, device=dev, dtype=torch.float32)
-        self._gx = torch.zeros(n + P, device=dev, dtype=torch.float32)     # gradients | per-parameter flags
+        # gradients | per-parameter flags | one "poison" word: a resident-LSTM wait of some rank gave up during this step
+        # (ops.lstm_timeouts).  The word travels with the flags, and a positive value after the exchange clears every
+        # flag on every rank before the masked AdamW step -- a step whose gradients came out of a bailed-out recurrence is skipped
+        # everywhere, with no host read between backward and step.
+        self._gx = torch.zeros(n + P + 1, device=dev, dtype=torch.float32)
         self.g = self._gx[:n]
-        self._flags = self._gx[n:]
+        self._flags = self._gx[n:n + P]
+        self._flagsx = self._gx[n:]                                        # flags + poison: what the flag collective carries
+        self._poison = self._gx[n + P:]
         self.m = torch.zeros(n, device=dev, dtype=torch.float32)
         self.v = torch.zeros(n, device=dev, dtype=torch.float32)
         self._scratch = torch.empty(1024, device=dev, dtype=torch.float32)
@@ -297,6 +303,8 @@ class FlatAdamW:
             self._flags_cache = torch.tensor(pat, dtype=torch.float32).to(self._gx.device)
             self._flags_pat = pat
         self._flags.copy_(self._flags_cache)
+        if self._gx.is_cuda:
+            _lib.check(_lib.load().fac_lstm_abort_flag(ops._ptr(self._poison), ops._stream()), "fac_lstm_abort_flag")
 
     def _exchanging(self):
         # a single rank has nothing to exchange; FAC_FORCE_ALLREDUCE=1 still issues the collectives (smoke-tests the RCCL path --
@@ -323,7 +331,7 @@ class FlatAdamW:
             self._upload_flags()
             self._flags_final = True
             self._launch_log.append(("flags", where))
-            self._works.append(dist.all_reduce(self._flags, op=dist.ReduceOp.MAX, async_op=True))
+            self._works.append(dist.all_reduce(self._flagsx, op=dist.ReduceOp.MAX, async_op=True))
             return
         if self.g.is_cuda and self._next_bucket < len(self.buckets) and self.buckets[self._next_bucket][0] >= from_param:
             ops.join_side_streams(self.g.device)    # parameter gradients written by chains on side streams (discriminators, heads)
@@ -343,7 +351,7 @@ class FlatAdamW:
         if self._next_bucket == len(self.buckets):
             self._upload_flags()
             self._flags_final = True
-            self._works.append(reduce(self._flags))
+            self._works.append(reduce(self._flagsx))
 
     def _late_gradients(self):
         """Parameters of already launched buckets that were marked after the launch (in-place accumulation into the bound views
@@ -411,9 +419,16 @@ class FlatAdamW:
             self.zero_grad()
 
     def step(self, zero_grad=True, advance_lr=True):
+        self.exchange_for_step()
+        self._step_kernels()
+        self.end_step(zero_grad, advance_lr)
+
+    def _step_kernels(self):
+        """The device side of a step, behind the exchange: poison check (a positive word = some rank's resident LSTM bailed out during
+        this step: every flag is cleared, nothing is stepped anywhere), gradient-norm clip, masked AdamW."""
         lib = _lib.load()
         st = ops._stream()
-        self.exchange_for_step()
+        _lib.check(lib.fac_mask_flags_if(ops._ptr(self._flags), len(self.params), ops._ptr(self._poison), st), "fac_mask_flags_if")
         clip = None
         if self.max_norm is not None:
             _lib.check(lib.fac_grad_norm_clip(ops._ptr(self.g), self.n, self.max_norm, ops._ptr(self._scratch), ops._ptr(self.norm), st),
@@ -423,7 +438,6 @@ class FlatAdamW:
                                              ops._ptr(self._offsets), len(self.params), ops._ptr(self._flags), ops._ptr(self._steps_dev),
                                              ops._ptr(self._bc), self.lr, self.betas[0], self.betas[1], self.eps, self.wd,
                                              ops._ptr(clip), st), "fac_adamw_step_masked")
-        self.end_step(zero_grad, advance_lr)
 
     def scheduler_step(self):
         """ExponentialLR.step(), once per iteration (train.py:372-374)."""

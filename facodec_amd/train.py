@@ -134,6 +134,20 @@ class GeneratorStep:
         return {k: dict(launched=summary(o), buckets=(o.exchange_log[-1] if o.exchange_log else []), n_buckets=len(o.buckets),
                         wait_ms=o.exchange_wait_ms()) for k, o in self.opt.items()}
 
+    _lstm_timeouts_seen = 0
+
+    def _report_lstm_timeouts(self):
+        """Host-side report of resident-LSTM waits that gave up (ops.lstm_timeouts: no synchronisation, so it speaks about steps the
+        device has finished).  The affected step was skipped on every rank by the optimiser's poison word (optim.FlatAdamW) and the
+        LSTM layers run on the per-step kernels from then on; this only makes sure it does not go unnoticed."""
+        from . import ops
+        n = ops.lstm_timeouts() if next(iter(self.opt.values())).p.is_cuda else 0
+        if n > GeneratorStep._lstm_timeouts_seen:
+            import warnings
+            warnings.warn(f"facodec_amd: {n} resident-LSTM wait(s) timed out on this device so far; the step they fell into was skipped "
+                          "by every rank's optimiser (no parameter moved) and the LSTM layers now use the per-step kernels")
+            GeneratorStep._lstm_timeouts_seen = n
+
     def _zero(self, keys):
         """Gradient arenas cleared; `.grad` left unbound so that autograd hands over its gradient tensors and the
         optimiser folds them in with one multi-tensor copy (FlatAdamW.zero_grad).  Under a DistributedDataParallel
@@ -143,6 +157,7 @@ class GeneratorStep:
 
     def forward_backward(self, wave, masks=None, full_waves=None, wave_lens=None):
         m = self.model
+        self._report_lstm_timeouts()
         self._zero(("encoder", "quantizer", "decoder"))
         z = m.encoder(wave)
         outs, _, commitment, codebook, _ = m.quantizer(z, wave, n_c=2, masks=masks, full_waves=full_waves, wave_lens=wave_lens)
@@ -219,6 +234,7 @@ class TrainStep(GeneratorStep):
         logged-only criteria of train.py:296,298 (multi-scale STFT, waveform L1)."""
         from .discriminator import gan_losses
         m, opt = self.model, self.opt
+        self._report_lstm_timeouts()
         self._zero(opt.keys())
         z = m.encoder(wave)
         outs, quantized, commitment, codebook, timbre = m.quantizer(z, wave, n_c=2, masks=masks, full_waves=full_waves,

@@ -276,6 +276,17 @@ int fac_lstm_persist_split_ok(int H, int B);
  * context; from then on fac_lstm_persist_ok / fac_lstm_persist_split_ok answer 0 (callers use the per-step kernels).  Reads a
  * host-mapped counter: no synchronisation. */
 int fac_lstm_persist_timeouts(void);
+/* Tells the current device where that counter lives (one one-thread kernel on `stream`, once per device; refuses inside a stream
+ * capture).  Returns 1 when the device is armed.  An un-armed device answers fac_lstm_persist_ok / _split_ok = 0: a launch whose
+ * waits may give up must be able to report it.  The launch entry points arm by themselves when they can. */
+int fac_lstm_persist_arm(fac_stream_t stream);
+/* Device-side hand-over of "a resident wait of this device has given up": dst[0] = 1.0f / 0.0f, ordered on `stream` (no host
+ * synchronisation).  The optimiser puts the word behind its per-parameter flags, so it crosses the ranks with them, and then
+ * fac_mask_flags_if(flags, n, poison): flags[0..n) = 0 when *poison > 0 -- fac_adamw_step_masked then steps nothing, on every
+ * rank, instead of applying a gradient that came out of a bailed-out recurrence (optimizers.py:72-108 has no counterpart: the
+ * reference's cuDNN LSTM cannot time out). */
+int fac_lstm_abort_flag(float* dst, fac_stream_t stream);
+int fac_mask_flags_if(float* flags, int n, const float* poison, fac_stream_t stream);
 int fac_pack_lstm_whh_split(const float* w_hh, void* packed, int H, fac_stream_t stream);
 int fac_lstm_layer_fwd_persist_split(const float* pre, const void* wsplit, void* hsplit, float* yT, int T, int H, int B, int BP,
                                      fac_stream_t stream);
@@ -404,6 +415,10 @@ int fac_pack_conv_w_bwd(const float* v, const float* scale, float* packed, int C
                         fac_stream_t stream);
 int fac_pad_fold_bwd(const float* dxpad, float* dx, int B, int C, int T, int Tp, int pad_left, int pad_mode,
                      fac_stream_t stream);
+/* fac_pad_fold_bwd in place for reflect padding, edges only: adds every mirrored padded position of dxpad (B, C, Tp) onto the sample
+ * it mirrors (dac/model/encodec.py:96-113 backward); afterwards dx[b][c][j] IS dxpad[b][c][pad_left + j].  Needs T > pad_left +
+ * pad_right.  Zero padding needs no call at all (the window is the gradient). */
+int fac_pad_fold_edges(float* dxpad, int B, int C, int T, int Tp, int pad_left, fac_stream_t stream);
 /* dW (C_out, C_in, K) = sum over (b, t) of dy[b][co][t] * xpad[b][ci][t*stride + k*dilation]; ws: scratch of
  * fac_conv1d_bwd_weight_ws_bytes(...) bytes (partial sums per (b, t) range, added in a fixed order). */
 int64_t fac_conv1d_bwd_weight_ws_bytes(int B, int C_in, int C_out, int T_out, int K);
@@ -439,6 +454,10 @@ int fac_snake_bwd(const float* x, const float* alpha, const float* dy, float* dx
  * that produced x -- NULL: skipped).  scratch: 64*C floats. */
 int fac_snake_bwd_fused(const float* x, const float* alpha, const float* dy, const float* add, float* dx, float* dalpha,
                         float* dbias, float* scratch, int B, int C, int T, fac_stream_t stream);
+/* The same with the rows of dy `dy_row_stride` (>= T) elements apart: dy is then typically the window [pad_left, pad_left + T) of the
+ * padded gradient rows a data-gradient conv wrote, after fac_pad_fold_edges -- no separate un-padding pass over the tensor. */
+int fac_snake_bwd_fused_rs(const float* x, const float* alpha, const float* dy, long long dy_row_stride, const float* add, float* dx,
+                           float* dalpha, float* dbias, float* scratch, int B, int C, int T, fac_stream_t stream);
 /* db[c] = sum over (b, t) of dy; scratch: 32*C floats. */
 int fac_bias_grad(const float* dy, float* db, float* scratch, int B, int C, int T, fac_stream_t stream);
 

@@ -19,7 +19,10 @@ code and arithmetic are untouched, only where its saved activations wait changes
                   fp32 / all threads, fp32 / 1 thread and fp64; per position the three answers, the fp64 top-2 gap, `decidable` =
                   all three agree (b32_decidable() below; + codec_b32_decidable_report.json)
 
-Run:  python tests/golden/make_golden_bench.py [b32] [b32_decidable] [train16]   (about 2 + 25 + 30 minutes on 8 cores, < 60 GB RAM, ~100 GB of /tmp)
+  codec_b32x4_decidable.npz  the same for four batches (seeds 0..3) with the reference's own margin noise in the definition of
+                  `decidable` (b32x4_decidable() below; + codec_b32x4_decidable_report.json; ~12 minutes)
+
+Run:  python tests/golden/make_golden_bench.py [b32] [b32_decidable] [b32x4_decidable] [train16]   (about 2 + 25 + 30 minutes on 8 cores, < 60 GB RAM, ~100 GB of /tmp)
 """
 import hashlib
 import json
@@ -117,7 +120,7 @@ def b32():
 # the three answers, the fp64 run's gap between its best and second-best code (dac/nn/quantize.py:86-91 distance) and the
 # margin each fp32 run saw between those same two codes.  `decidable` = the three runs agree.  Nothing here is tuned to this
 # build: the script never imports facodec_amd beyond the synthetic weights / clips.
-def _run_reference_with_vq_capture(dtype, threads, tag):
+def _run_reference_with_vq_capture(dtype, threads, tag, seed=0):
     build_model, recursive_munch = MG.ref_imports()
     from dac.nn.quantize import VectorQuantize
     torch.set_num_threads(threads)
@@ -129,7 +132,7 @@ def _run_reference_with_vq_capture(dtype, threads, tag):
             for k in ("encoder", "quantizer", "decoder"):
                 synth.load_synthetic(model[k], seed=0, prefix=k + ".")           # fp32-valued weights, exact in fp64
                 model[k].to(dtype).eval()
-            wave = synth.synth_clips(32, 48000, seed=0).to(dtype)
+            wave = synth.synth_clips(32, 48000, seed=seed).to(dtype)
             cap = []                                                               # call order = prosody, content x 2, residual x 3
             hooks = [m.register_forward_hook(lambda mod, args, out: cap.append((mod, out[4].detach().clone(), out[3].detach().clone())))
                      for m in model.quantizer.modules() if isinstance(m, VectorQuantize)]
@@ -210,6 +213,79 @@ def b32_decidable():
     print(json.dumps(report, indent=1))
 
 
+# ------------------------------------------------------------------------------------------------------------------------------
+# The same self-examination of the reference on FOUR batches (seeds 0..3 of synth.synth_clips(32, 48000): 122 880 code indices),
+# and a definition of "decidable" that has the reference's own arithmetic noise in it: per batch, the largest
+# difference the reference's fp32 runs show against its fp64 run in the MARGIN between the fp64 run's two best codes (positions
+# whose upstream stages agree) is that batch's `noise`; a position is decidable iff the three runs agree AND the fp64 top-2 gap is
+# at least that noise.  A position the runs agree on with a smaller gap agrees "by luck rather than by margin": the reference's
+# own fp32 rounding could have flipped it, so either of the fp64 run's two best codes is the reference's answer there.
+def _decidability_of_one_batch(seed, ncpu):
+    runs = {"f32_mt": _run_reference_with_vq_capture(torch.float32, ncpu, f"seed {seed}: fp32, {ncpu} threads", seed),
+            "f32_1t": _run_reference_with_vq_capture(torch.float32, 1, f"seed {seed}: fp32, 1 thread", seed),
+            "f64": _run_reference_with_vq_capture(torch.float64, ncpu, f"seed {seed}: fp64, {ncpu} threads", seed)}
+    B, n, T = runs["f64"]["codes"].shape
+    gap64 = np.zeros((B, n, T), np.float64)
+    second64 = np.zeros((B, n, T), np.int16)
+    margins = {k: np.zeros((B, n, T), np.float64) for k in ("f32_mt", "f32_1t")}
+    for i in range(n):
+        r = runs["f64"]
+        _, d = _pair_margin(r["z_e"][i], r["codebooks"][i], torch.zeros(B, T, dtype=torch.int64), torch.zeros(B, T, dtype=torch.int64))
+        top2 = torch.topk(-d, 2, dim=1)
+        best = top2.indices[:, 0].reshape(B, T)
+        assert torch.equal(best, torch.from_numpy(r["codes"][:, i].astype(np.int64))), i
+        sec = top2.indices[:, 1].reshape(B, T)
+        gap64[:, i] = (top2.values[:, 0] - top2.values[:, 1]).reshape(B, T).numpy()
+        second64[:, i] = sec.numpy()
+        for k in margins:
+            m, _ = _pair_margin(runs[k]["z_e"][i], runs[k]["codebooks"][i], best, sec)
+            margins[k][:, i] = m.numpy()
+    agree = (runs["f32_mt"]["codes"] == runs["f32_1t"]["codes"]) & (runs["f32_mt"]["codes"] == runs["f64"]["codes"])
+    feeds = {0: [], 1: [], 2: [1], 3: [0, 1, 2], 4: [0, 1, 2, 3], 5: [0, 1, 2, 3, 4]}
+    upstream_agree = np.stack([np.all(agree[:, feeds[i]], axis=1) if feeds[i] else np.ones((B, T), bool) for i in range(n)], 1)
+    noise = max(float(np.abs(margins[k] - gap64)[upstream_agree].max()) for k in margins)
+    return runs, gap64, second64, agree, upstream_agree, noise
+
+
+def b32x4_decidable(seeds=(0, 1, 2, 3)):
+    ncpu = os.cpu_count()
+    keep = {k: [] for k in ("codes_f32_mt", "codes_f32_1t", "codes_f64", "second_f64", "gap_f64", "agree", "decidable")}
+    noises, report = [], {"seeds": list(seeds), "batches": []}
+    for seed in seeds:
+        runs, gap64, second64, agree, upstream_agree, noise = _decidability_of_one_batch(seed, ncpu)
+        if seed == 0:
+            held = np.load(os.path.join(HERE, "codec_b32_decidable.npz"))
+            assert all(np.array_equal(runs[k]["codes"], held["codes_" + k]) for k in runs), "seed 0 no longer reproduces codec_b32_decidable.npz"
+        decidable = agree & (gap64 >= noise)
+        for k in ("f32_mt", "f32_1t", "f64"):
+            keep["codes_" + k].append(runs[k]["codes"])
+        keep["second_f64"].append(second64)
+        keep["gap_f64"].append(gap64.astype(np.float32))
+        keep["agree"].append(agree)
+        keep["decidable"].append(decidable)
+        noises.append(noise)
+        below = agree & ~decidable
+        report["batches"].append({
+            "seed": int(seed), "positions": int(agree.size), "runs_agree": int(agree.sum()), "runs_disagree": int((~agree).sum()),
+            "runs_disagree_positions_clip_codebook_frame": np.argwhere(~agree).tolist(),
+            "fp64_gap_where_runs_disagree": [float(gap64[tuple(p)]) for p in np.argwhere(~agree)],
+            "margin_noise_fp32_vs_fp64_max": noise,
+            "agree_but_gap_below_noise": int(below.sum()),
+            "agree_but_gap_below_noise_positions": np.argwhere(below).tolist(),
+            "agree_but_gap_below_noise_fp64_gaps": [float(gap64[tuple(p)]) for p in np.argwhere(below)],
+            "decidable": int(decidable.sum()),
+            "smallest_fp64_gap_among_decidable": float(gap64[decidable].min()),
+            "fp32_runs_bit_identical": bool(np.array_equal(runs["f32_mt"]["codes"], runs["f32_1t"]["codes"])),
+            "fp32_vs_fp64_code_differences": int((runs["f32_mt"]["codes"] != runs["f64"]["codes"]).sum()),
+            "seconds": {k: float(r["seconds"]) for k, r in runs.items()}})
+        print(json.dumps(report["batches"][-1]), flush=True)
+    report["rule"] = ("decidable = the reference's three runs agree AND its fp64 top-2 gap >= the batch's measured fp32-vs-fp64 margin noise; "
+                      "see facodec_amd.diagnostics.check_codes_decidable_noise")
+    np.savez_compressed(os.path.join(HERE, "codec_b32x4_decidable.npz"), seeds=np.array(seeds), noise=np.array(noises, np.float64),
+                        report=np.array(json.dumps(report)), **{k: np.stack(v) for k, v in keep.items()})
+    json.dump(report, open(os.path.join(HERE, "codec_b32x4_decidable_report.json"), "w"), indent=1)
+
+
 def train16():
     model, _ = MGT.build_reference_in_train_mode()
     cfg = dict(B=B16, SEG_FRAMES=160, T_FULL=T_FULL16, WAVE_LENS=WAVE_LENS16, CROP_START=CROP16, DROPOUT_DRAWS=DRAWS16,
@@ -244,5 +320,7 @@ if __name__ == "__main__":
         b32()
     if "b32_decidable" in what:
         b32_decidable()
+    if "b32x4_decidable" in what:
+        b32x4_decidable()
     if "train16" in what:
         train16()

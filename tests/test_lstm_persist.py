@@ -206,3 +206,42 @@ def test_split_resident_layer_replays_in_a_graph(split_ops, cuda):
         graph.replay()
     torch.cuda.synchronize()
     assert torch.equal(out, ref) and torch.isfinite(out2).all()
+
+
+def test_poisoned_step_moves_nothing_and_clean_step_is_unchanged(cuda):
+    """a resident-LSTM wait that gives up leaves meaningless results behind; the optimiser must not apply them.  The
+    abort word rides behind the per-parameter flags (`FlatAdamW._poison`, written by fac_lstm_abort_flag, exchanged with the
+    flags) and a positive value clears every flag in front of the masked AdamW step (fac_mask_flags_if): no parameter, moment or
+    step count moves.  With the word at 0 (this process never timed out) the step is the one torch.optim.AdamW takes."""
+    from facodec_amd import ops as _ops
+    from facodec_amd.optim import FlatAdamW
+    assert _ops.lstm_persist_ok(512, 4) and _ops.lstm_timeouts() == 0         # arms the device's counter word on the way
+    g = _g(11)
+    ref = [torch.randn(33, 7, generator=g).requires_grad_(), torch.randn(19, generator=g).requires_grad_()]
+    ours = [torch.nn.Parameter(r.detach().clone().to(cuda)) for r in ref]
+    opt = FlatAdamW(ours, lr=1e-2)
+    grads = [torch.randn(33, 7, generator=g), torch.randn(19, generator=g)]
+
+    def backward():
+        for p, gr in zip(ours, grads):
+            p.grad.copy_(gr.to(cuda))
+        opt.mark_grads()
+
+    before = [p.detach().clone() for p in ours]
+    backward()
+    opt.exchange_for_step()
+    assert float(opt._poison) == 0.0                    # what the device reports about itself
+    opt._poison.fill_(1.0)                              # ... and what a rank whose recurrence bailed out would have contributed
+    opt._step_kernels()
+    opt.end_step()
+    assert all(torch.equal(a, p.detach()) for a, p in zip(before, ours)) and opt.param_steps == [0, 0]
+    assert float(opt.m.abs().max()) == 0.0 and float(opt.v.abs().max()) == 0.0
+    backward()
+    opt.step()
+    t = torch.optim.AdamW(ref, lr=1e-2, betas=(0.9, 0.98), eps=1e-9, weight_decay=0.1)
+    for r, gr in zip(ref, grads):
+        r.grad = gr.clone()
+    t.step()
+    assert opt.param_steps == [1, 1]
+    for r, p in zip(ref, ours):
+        assert rel(p, r) < 1e-6

@@ -133,6 +133,31 @@ def test_batch32_codes_against_reference_golden(cuda, golden_dir):
     assert abs(float(commit) - float(d["commitment"])) / float(d["commitment"]) < 1e-4
 
 
+def test_four_batches_of_codes_against_reference_golden(cuda, golden_dir):
+    """4 x 32 clips (seeds 0..3; 122 880 code indices) against the real reference's fp32 / fp32-one-thread / fp64
+    runs, with the reference's own fp32-vs-fp64 margin noise in the definition of decidable (tests/golden/codec_b32x4_decidable.npz,
+    facodec_amd.diagnostics.check_codes_decidable_noise): zero allowance on every decidable position; where the reference's own
+    rounding could have flipped the decision, either of its fp64 run's two best codes.  The per-batch report (flips against the fp64
+    and fp32 runs with their fp64 gaps) goes to gpurun_out/codes_four_batches_report.json."""
+    from facodec_amd.diagnostics import check_codes_decidable_noise
+    fx = np.load(os.path.join(golden_dir, "codec_b32x4_decidable.npz"))
+    model = _model(cuda, ("encoder", "quantizer", "decoder"))
+    for k in ("encoder", "quantizer", "decoder"):
+        model[k].eval()
+    report = []
+    for bi, seed in enumerate(fx["seeds"].tolist()):
+        wave = synth.synth_clips(32, 48000, seed=int(seed)).to(cuda)
+        with torch.no_grad():
+            codes = model.quantizer(model.encoder(wave), wave, n_c=2, return_codes=True)[5]
+        v = check_codes_decidable_noise(codes, fx, bi)
+        report.append({k: v[k] for k in ("batch", "ok", "decidable", "noise", "mismatches", "noise_flips", "cascade_positions",
+                                         "differs_from_fp32", "differs_from_fp64", "differs_from_fp64_positions_and_gaps", "equals_run")})
+    os.makedirs("gpurun_out", exist_ok=True)
+    json.dump(report, open("gpurun_out/codes_four_batches_report.json", "w"), indent=1)
+    for r in report:
+        assert r["ok"] and r["mismatches"] == 0, r
+
+
 def test_train_step_batch16_against_reference_golden(cuda, golden_dir):
     """configs[2] at its real per-GPU size against REFERENCE-MADE numbers (tests/golden/train_b16.npz: ONE train.py:188-374
     iteration of the real reference on 16 segments x 2 s cropped from 16 padded utterances, recorded random draws): the 17

@@ -42,6 +42,8 @@ def main():
     n_hops = int(a.minutes * 60 * 24000 // HOP)
     r = benchutil.streaming_soak(model, dev, n_hops, check_minutes=a.check_minutes, streams=a.streams, use_graphs=not a.no_graphs)
     print(json.dumps(dict({"metric": "streaming per-hop latency / RTF"}, **r)))
+    if not r["ok"]:
+        raise SystemExit(f"streaming session drifted from the offline model or produced non-finite output: {r['drift_check']}")
 
 
 if __name__ == "__main__":

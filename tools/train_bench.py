@@ -19,7 +19,37 @@ from facodec_amd.commons import build_model, default_model_params  # noqa: E402
 from facodec_amd.train import GeneratorStep, TrainStep  # noqa: E402
 
 
+def stale_packs():
+    """TIMING EXPERIMENT ONLY (FAC_EXP_STALE_PACKS=1, used through tools/train_ab.py): memoises the weight-norm scales and packed
+    weight layouts ACROSS steps by monkeypatching facodec_amd.ops from here -- the weights go stale, the results are WRONG -- to
+    measure what the ~1 500 small scale / pack launches of a step cost in wall time.  Lives in this tool, not in the
+    product module, so that no environment variable can freeze the weights of a real training run."""
+    import functools
+    from facodec_amd import ops
+    memo = {}
+
+    def wrap(fn):
+        @functools.wraps(fn)
+        def wrapped(*args, **kw):
+            key = [fn.__name__]
+            for a in list(args) + [kw.get(k) for k in sorted(kw) if k not in ("out", "scale")]:
+                key.append((a.data_ptr(), tuple(a.shape)) if torch.is_tensor(a) else a)
+            key = tuple(key)
+            if key not in memo:
+                kw.pop("out", None)
+                memo[key] = fn(*args, **kw)
+            return memo[key]
+        return wrapped
+
+    for name in ("wn_scale", "pack_conv_weight", "pack_convtr_weight", "pack_convtr_weight_rows", "pack_gemm_weight_split",
+                 "pack_conv_weight_split2", "pack_convtr_weight_rows_split", "pack_conv_weight_split"):
+        setattr(ops, name, wrap(getattr(ops, name)))
+    print("[train_bench] FAC_EXP_STALE_PACKS=1: weight scales / packs memoised across steps -- RESULTS ARE WRONG, timing only", file=sys.stderr)
+
+
 def main():
+    if os.environ.get("FAC_EXP_STALE_PACKS") == "1":
+        stale_packs()
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--steps", type=int, default=3)
