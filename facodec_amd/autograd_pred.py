@@ -101,7 +101,7 @@ def predictors(m, quantized, timbre):
               lambda: cnnlstm(m.rev_f0_predictor[1], rev(rin_f0)), lambda: cnnlstm(m.rev_content_predictor[1], rev(rin_ph))]
     if m.use_gr_x_timbre:
         chains.append(lambda: cnnlstm(m.rev_timbre_predictor[1], rev(A.add(A.add(prosody, content), residual))))
-    res = ops.run_chains(chains, content.device, PRED_STREAMS)
+    res = ops.run_chains(chains, content.device, PRED_STREAMS, inputs=[prosody, content, residual, rin_f0, rin_ph, timbre])
     content_pred = res[0][0]
     f0_pred, uv_pred = res[1]
     rev_f0_pred, rev_uv_pred = res[2]

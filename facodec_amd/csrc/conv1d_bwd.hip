@@ -273,6 +273,7 @@ __global__ __launch_bounds__(256) void snake_bwd_fused_kernel(const float* __res
       for (int t = t0 + first; t < t1; t += 256) {
         const long long o = ro + t;
         const float xv = x[o], g = dyr[t];
+        // (libm on purpose: a hand-rolled Cody-Waite sin^2 / sin 2x pair measured SLOWER here, 378 vs 285 us at (16, 192, 24000))
         const float ax = al * xv;
         const float sn = sinf(ax), cs = cosf(ax);
         const float s2 = 2.f * sn * cs;

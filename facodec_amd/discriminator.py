@@ -180,7 +180,7 @@ class Discriminator(nn.Module):
             return [d(x) for d in self.discriminators]
         # heaviest chains first (the spectrogram discriminators, then the period discriminators), round robin over the streams
         order = sorted(range(len(self.discriminators)), key=lambda i: not isinstance(self.discriminators[i], MRD))
-        res = ops.run_chains([lambda d=self.discriminators[i]: d(x) for i in order], x.device, N_STREAMS)
+        res = ops.run_chains([lambda d=self.discriminators[i]: d(x) for i in order], x.device, N_STREAMS, inputs=[x])
         outs = [None] * len(order)
         for i, r in zip(order, res):
             outs[i] = r

@@ -21,8 +21,43 @@ def cin_pad(c):
     return ((c + 47) // 48) * 48
 
 
+# torch.cuda.current_stream() builds a Stream object through five layers of Python (7 us per call, 11 000 calls = 40 ms of host time
+# per train step: tools/tune/host_profile.py, round 6); the raw handle is one C call.  Same value: the current stream of the
+# current device, side-stream contexts included.
+_SLOW_STREAM = os.environ.get("FAC_SLOW_STREAM") == "1"           # A/B switch: torch.cuda.current_stream() as in rounds 1-5
+_RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_GET_DEVICE = getattr(torch._C, "_cuda_getDevice", None)
+
+
+def _raw_stream(device_index=None):
+    """The current HIP stream of the (current) device as an integer handle."""
+    if _RAW_STREAM is not None and _GET_DEVICE is not None and not _SLOW_STREAM:
+        return _RAW_STREAM(_GET_DEVICE() if device_index is None else device_index)
+    return torch.cuda.current_stream(device_index).cuda_stream
+
+
 def _stream():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return C.c_void_p(_raw_stream())
+
+
+_SYNC_H2D = os.environ.get("FAC_SYNC_H2D") == "1"        # A/B switch: the blocking copies of rounds 1-5
+
+
+def h2d(t, device, dtype=None):
+    """Small host tensor (masks, lengths, offsets) -> device WITHOUT blocking the host: through the pinned caching allocator and an
+    asynchronous copy on the current stream.  `t.to(device)` from pageable memory makes the host wait until the device has drained
+    everything queued before it on that stream -- four such copies per train step (the quantizer-dropout masks) cost the step the
+    whole lead of the host over the device and ~11 ms of idle GPU (tools/gpu_idle.py, round 6).  Tensors already on the device
+    only change dtype."""
+    if t.is_cuda:
+        return t if dtype is None or t.dtype == dtype else t.to(dtype)
+    if dtype is not None and t.dtype != dtype:
+        t = t.to(dtype)
+    if torch.device(device).type != "cuda" or _SYNC_H2D:
+        return t.to(device)
+    staged = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+    staged.copy_(t)
+    return staged.to(device, non_blocking=True)
 
 
 def _ptr(t):
@@ -269,11 +304,20 @@ def join_side_streams(device):
                     cur.wait_stream(st)
 
 
-def run_chains(chains, device, n_streams):
+def run_chains(chains, device, n_streams, inputs=()):
     """Independent chains of launches (callables) side by side on up to n_streams side streams that fork from and join the
     caller's stream; returns their results in order.  Kernels with fewer workgroups than CUs (or a partly filled last round)
     then overlap with another chain's kernels; autograd replays every node's backward on the stream of its forward, so the
-    backward passes of the chains overlap the same way."""
+    backward passes of the chains overlap the same way.
+
+    inputs: the tensors the chains READ that were allocated on the caller's stream (nested lists / dicts are walked).  They are
+    recorded on every side stream in use (Tensor.record_stream), because of what happens in BACKWARD: a chain's node saves such a
+    tensor, its backward runs on the side stream, and the moment that backward function returns -- its kernels merely queued --
+    the engine drops the saved tensor; the caching allocator then hands the block to the next allocation on the CALLER's stream,
+    which is not ordered behind the side stream at that point.  Found in round 6 as a flaky 1 - 2 % error in ONE gradient
+    (timbre_encoder.spectral.0.weight: the last backward node of the timbre chain reads the log-mel features, allocated on the main
+    stream and freed right after; tools/tune/race_probe.py, profiles/r06_race_probe.log).  The forward has no such window: the join
+    below orders the caller's stream behind everything the chains queued."""
     n = min(n_streams, len(chains))
     if n <= 1 or device.type != "cuda":
         return [c() for c in chains]
@@ -281,6 +325,7 @@ def run_chains(chains, device, n_streams):
     streams = side_streams(device, n)
     for st in streams:
         st.wait_stream(main)
+        _record_stream(inputs, st)
     outs = []
     for j, c in enumerate(chains):
         with torch.cuda.stream(streams[j % n]):
@@ -307,11 +352,21 @@ def _record_stream(obj, stream):
             _record_stream(o, stream)
 
 
+_CUDA_DEVICES = {}
+
+
+def _cuda_device(index):
+    d = _CUDA_DEVICES.get(index)
+    if d is None:
+        d = _CUDA_DEVICES[index] = torch.device("cuda", index)
+    return d
+
+
 def _conv_workspace(device):
     """Zero-filled scratch handed to every conv launch (fac_conv_desc.ws), used by the split-reduction kernel for launches
     with few output columns: the partial sums live there between the two kernels of a launch, so it belongs to ONE stream
     at a time -- one buffer per (device, registered stream)."""
-    slot = _STREAM_SLOTS.get(torch.cuda.current_stream(device).cuda_stream, 0) if _STREAM_SLOTS else 0
+    slot = _STREAM_SLOTS.get(_raw_stream(device.index), 0) if _STREAM_SLOTS else 0
     key = (device, slot)
     ws = _CONV_WS.get(key)
     if ws is None:
@@ -321,7 +376,7 @@ def _conv_workspace(device):
 
 def _launch_conv(d, what):
     lib = _lib.load()
-    ws = _conv_workspace(torch.device("cuda", torch.cuda.current_device()))
+    ws = _conv_workspace(_cuda_device(_GET_DEVICE() if _GET_DEVICE is not None else torch.cuda.current_device()))
     d.ws, d.ws_bytes = ws.data_ptr(), CONV_WS_BYTES
     if _FLOPS is not None:
         _FLOPS.add(_FLOP_KEY, 2.0 * d.B * d.n_phase * max(1, d.row_phases) * d.C_out * d.T_out * d.C_in * d.K + (2.0 * d.B * d.C_out * d.T_out * d.C_out if d.w_k1 else 0.0))
@@ -1063,9 +1118,9 @@ def conv1d_bwd_data(dy, v, g, t_in, stride=1, dilation=1, pad_mode=PAD_REFLECT, 
         dy_ext = torch.cat([dy, torch.zeros(B, c_out, 1, device=dy.device)], dim=2)
         dxpad = conv_transpose1d(dy_ext, convtr_weight_for(v, g, stride, dy_ext.shape[-1], batch=B), c_in, stride)
         assert dxpad.shape[-1] == tp, (dxpad.shape, tp)
-    if tp == t_in:
+    if tp == t_in and FOLD_IN_PLACE in (1, 2):
         return dxpad                                  # no padding (the 1x1 convs): the padded gradient IS the gradient
-    if allow_view and FOLD_IN_PLACE and dxpad.is_contiguous() and (pad_mode == PAD_ZERO or t_in > pad_left + pad_right):
+    if allow_view and FOLD_IN_PLACE in (1, 3) and dxpad.is_contiguous() and (pad_mode == PAD_ZERO or t_in > pad_left + pad_right):
         if pad_mode == PAD_REFLECT:
             _lib.check(_lib.load().fac_pad_fold_edges(_ptr(dxpad), B, c_in, t_in, tp, pad_left, _stream()), "fac_pad_fold_edges")
         return dxpad[:, :, pad_left:pad_left + t_in]
@@ -1075,7 +1130,8 @@ def conv1d_bwd_data(dy, v, g, t_in, stride=1, dilation=1, pad_mode=PAD_REFLECT, 
     return dx
 
 
-FOLD_IN_PLACE = os.environ.get("FAC_FOLD_IN_PLACE", "1") != "0"
+# 1 (default): both shortcuts; 0: neither (rounds 1-5); 2: only "no padding -> no copy"; 3: only the in-place edge fold + row-stride view
+FOLD_IN_PLACE = int(os.environ.get("FAC_FOLD_IN_PLACE", "1"))
 
 
 def _rows_view(t):
@@ -1118,7 +1174,7 @@ WGRAD_WS_CAP = int(float(os.environ.get("FAC_WGRAD_WS_GB", "6")) * (1 << 30))
 def _wgrad_workspace(device, nbytes):
     """One grow-only buffer per (device, stream): the discriminators' backward passes run on several streams at once
     (discriminator.py), and a launch's operand planes / partial sums must not be overwritten by another stream's launch."""
-    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    key = (device, _raw_stream(device.index))
     ws = _WGRAD_WS.get(key)
     if ws is None or ws.numel() * 4 < nbytes:
         if ws is not None:

@@ -82,7 +82,7 @@ class ResidualVectorQuantize(nn.Module):
             if masks is None:
                 masks = A.draw_quantizer_masks(self.n_codebooks, B, self.quantizer_dropout)
             latents = torch.empty(B, 8 * self.n_codebooks, T, device=z.device, dtype=torch.float32)
-            z_q, codes, commit, cbl = A.rvq(self, z, masks.to(z.device, torch.float32), latents=latents)
+            z_q, codes, commit, cbl = A.rvq(self, z, ops.h2d(masks, z.device, torch.float32), latents=latents)
             return z_q, codes, latents, commit, cbl
         n = self.n_codebooks if n_quantizers is None else min(int(n_quantizers), self.n_codebooks)
         B, D, T = z.shape
@@ -390,7 +390,7 @@ class FAquantizer(nn.Module):
             mk = masks.get(key)
             if mk is None:
                 mk = A.draw_quantizer_masks(rvq.n_codebooks, B, rvq.quantizer_dropout)
-            return mk.to(dev)
+            return ops.h2d(mk, dev)                     # asynchronous: a blocking copy here costs the host its lead over the device
 
         # The same three independent chains as the eval forward, side by side (ops.run_chains; autograd replays each chain's backward
         # on the chain's stream).  The chains are ISSUED one after the other by the host, so the random draws keep their order:
@@ -399,7 +399,7 @@ class FAquantizer(nn.Module):
             if full_waves is None:
                 return AQ.style_encoder(self.timbre_encoder, mel, None, use_dropout=use_drop)
             mel_full = self.to_mel(full_waves)
-            m = sequence_mask(wave_lens.to(dev) // self.hop_length, mel_full.shape[-1]).to(torch.float32).contiguous()
+            m = sequence_mask(ops.h2d(wave_lens, dev) // self.hop_length, mel_full.shape[-1]).to(torch.float32).contiguous()
             return AQ.style_encoder(self.timbre_encoder, mel_full, m, use_dropout=use_drop)
 
         def prosody_chain():
@@ -410,13 +410,14 @@ class FAquantizer(nn.Module):
             return A.rvq(self.prosody_quantizer, f0, qmask("p", self.prosody_quantizer))
 
         timbre, (z_p, codes_p, cm_p, cb_p), (z_c, codes_c, cm_c, cb_c) = ops.run_chains(
-            [timbre_chain, prosody_chain, lambda: A.rvq(self.content_quantizer, x, qmask("c", self.content_quantizer))], dev, QUANT_STREAMS)
+            [timbre_chain, prosody_chain, lambda: A.rvq(self.content_quantizer, x, qmask("c", self.content_quantizer))], dev, QUANT_STREAMS,
+            inputs=[mel, x, full_waves, wave_lens, [v for v in masks.values() if torch.is_tensor(v)]])
         z_r, codes_r, cm_r, cb_r = A.rvq(self.residual_quantizer, A.sub_detached(x, z_p, z_c), qmask("r", self.residual_quantizer))
         res = masks.get("res")
         if res is None:
             res = torch.from_numpy(np.random.choice([0, 1], size=B, p=[self.prob_random_mask_residual,
                                                                        1 - self.prob_random_mask_residual]))
-        res = res.to(device=dev, dtype=torch.float32).contiguous()
+        res = ops.h2d(res, dev, torch.float32).contiguous()
         outs = A.mix_outs(z_p, z_c, z_r, res)
         outs = A.layernorm_affine(outs, A.linear(self.timbre_linear, timbre))
         quantized = [z_p, z_c, z_r]
@@ -441,7 +442,7 @@ class FAquantizer(nn.Module):
             if full_waves is None:
                 return self.timbre_encoder(mel, None)
             mel_full = self.to_mel(full_waves)
-            m = sequence_mask(wave_lens.to(mel_full.device) // self.hop_length, mel_full.shape[-1]).to(torch.float32).contiguous()
+            m = sequence_mask(ops.h2d(wave_lens, mel_full.device) // self.hop_length, mel_full.shape[-1]).to(torch.float32).contiguous()
             return self.timbre_encoder(mel_full, m)
 
         def prosody_chain():
@@ -453,7 +454,7 @@ class FAquantizer(nn.Module):
             return self.prosody_quantizer(f0, 1)
 
         timbre, (z_p, codes_p, _, cm_p, cb_p), (z_c, codes_c, _, cm_c, cb_c) = ops.run_chains(
-            [timbre_chain, prosody_chain, lambda: self.content_quantizer(x, n_c)], x.device, QUANT_STREAMS)
+            [timbre_chain, prosody_chain, lambda: self.content_quantizer(x, n_c)], x.device, QUANT_STREAMS, inputs=[mel, x, full_waves, wave_lens])
         residual_feature = ops.sub2(x, z_p, z_c)
         z_r, codes_r, _, cm_r, cb_r = self.residual_quantizer(residual_feature, 3)
         outs = ops.add(ops.add(z_p, z_c), z_r)

@@ -33,7 +33,8 @@ def crop_segments(waves, mel_input_length, max_frame_len=80, hop=300, starts=Non
         span = torch.tensor([max(n - seg, 0) for n in lens], dtype=torch.float64)
         u = torch.rand(B, generator=generator, dtype=torch.float64)
         starts = torch.minimum((u * span).floor(), (span - 1).clamp_min(0)).to(torch.int64)   # randint(0, len - seg); 0 when equal
-    starts = torch.as_tensor(starts, dtype=torch.int64).to(waves.device)
+    from . import ops
+    starts = ops.h2d(torch.as_tensor(starts, dtype=torch.int64), waves.device)
     wav_seg = AD.CropRows.apply(waves.reshape(B, 1, -1), starts, seg * hop, hop)
     out_extra = [AD.CropRows.apply(e if e.dim() == 3 else e.reshape(B, 1, -1), starts, seg, 1).reshape(*e.shape[:-1], seg) for e in extra]
     return wav_seg, starts, out_extra

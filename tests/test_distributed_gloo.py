@@ -432,3 +432,105 @@ def test_two_rank_unbound_gradients_fold_and_exchange():
         assert torch.allclose(g0[12:17], torch.full((5,), 1.5))                 # 3 on rank 0, nothing on rank 1 -> mean 1.5
         assert torch.equal(g0[17:], torch.zeros(6))
         assert (f0[:2] > 0).all() and f0[2] == 0
+
+
+class _FusedRecurrence(torch.autograd.Function):
+    """h_t = tanh(W h_{t-1} + x_t) over T steps as ONE autograd node (what the resident LSTM launch is to the engine)."""
+
+    @staticmethod
+    def forward(ctx, x, W):
+        hs, h = [], torch.zeros(x.shape[1], W.shape[0])
+        for t in range(x.shape[0]):
+            h = torch.tanh(h @ W.t() + x[t])
+            hs.append(h)
+        out = torch.stack(hs)
+        ctx.save_for_backward(x, W, out)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, W, out = ctx.saved_tensors
+        dx, dW, dh = torch.zeros_like(x), torch.zeros_like(W), torch.zeros(x.shape[1], W.shape[0])
+        for t in reversed(range(x.shape[0])):
+            g = (dout[t] + dh) * (1 - out[t] ** 2)
+            h_prev = out[t - 1] if t > 0 else torch.zeros_like(out[0])
+            dW += g.t() @ h_prev
+            dx[t] = g
+            dh = g @ W
+        return dx, dW
+
+
+class _ChainWithRecurrence(torch.nn.Module):
+    """x -> lin0 -> recurrence (fused node or one node per step) -> lin1 -> lin2, like conv stack -> SLSTM -> conv stack."""
+
+    def __init__(self, fused):
+        super().__init__()
+        self.lin0, self.lin1, self.lin2 = (torch.nn.Linear(8, 8) for _ in range(3))
+        self.W = torch.nn.Parameter(torch.randn(8, 8) * 0.3)
+        self.fused = fused
+
+    def children_in_order(self):
+        return [self.lin0, "rec", self.lin1, self.lin2]
+
+    def forward(self, x, hook=None):          # x (T, B, 8)
+        for k, m in enumerate(self.children_in_order()):
+            if hook is not None:
+                hook(k, x)
+            if m == "rec":
+                if self.fused:
+                    x = _FusedRecurrence.apply(x, self.W)
+                else:                          # the per-step fall-back: T small nodes instead of one
+                    hs, h = [], torch.zeros(x.shape[1], 8)
+                    for t in range(x.shape[0]):
+                        h = torch.tanh(h @ self.W.t() + x[t])
+                        hs.append(h)
+                    x = torch.stack(hs)
+            else:
+                x = torch.tanh(m(x))
+        return x
+
+
+def _fallback_worker(rank, world, port, q):
+    sys.path.insert(0, REPO)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from facodec_amd import benchutil
+    from facodec_amd.optim import FlatAdamW
+    benchutil.init_distributed("gloo")
+    out = {}
+    for mode in ("both_fused", "rank1_falls_back"):
+        torch.manual_seed(0)
+        net = _ChainWithRecurrence(fused=(mode == "both_fused" or rank == 0))
+        params = list(net.lin0.parameters()) + [net.W] + list(net.lin1.parameters()) + list(net.lin2.parameters())
+        opt = FlatAdamW(params, bucket_bytes=280)
+        first = [0, 2, 3, 5]                                    # first parameter index of child k (lin0 | W | lin1 | lin2)
+        events = []
+
+        def hook(k, x, opt=opt, events=events):                 # gradient of the activation entering child k: children k + 1 .. final
+            if x.requires_grad and k + 1 < 4:
+                def fire(g, k=k):
+                    opt.launch_all_reduce(from_param=first[k + 1], from_hook=True)
+                    events.append((k, opt._next_bucket))
+                x.register_hook(fire)
+
+        opt.zero_grad(unbind=True)
+        x = torch.randn(6, 3, 8, generator=torch.Generator().manual_seed(20 + rank)).requires_grad_()
+        net(x, hook).pow(2).sum().backward()
+        opt.exchange_for_step()
+        out[mode] = (opt.g.clone(), list(opt._launch_log), list(events), len(opt.buckets))
+        opt.end_step()
+    q.put(_portable((rank, out)))
+    torch.distributed.destroy_process_group()
+
+
+def test_two_rank_bucket_order_when_one_rank_falls_back_to_per_step_lstm():
+    """a rank whose resident LSTM is unusable (fac_lstm_persist_ok = 0: timeout seen, device shared) runs the
+    recurrence as one node PER STEP instead of one node per layer.  The exchange's launch points are gradient hooks on the
+    activations entering the top-level children, so the graph INSIDE a child must not matter: both ranks issue the same buckets
+    from the same points in the same order, and the averaged gradient equals the run where both ranks use the fused node."""
+    (_, o0), (_, o1) = _run_ranks(_fallback_worker)
+    for mode in ("both_fused", "rank1_falls_back"):
+        assert o0[mode][1] == o1[mode][1] and o0[mode][2] == o1[mode][2], (mode, o0[mode][1], o1[mode][1])
+        assert torch.equal(o0[mode][0], o1[mode][0])
+    assert o0["both_fused"][1] == o0["rank1_falls_back"][1] and o0["both_fused"][2] == o0["rank1_falls_back"][2]
+    assert o0["both_fused"][3] >= 3 and any(w == "hook" for _, w in o0["both_fused"][1])
+    assert torch.allclose(o0["both_fused"][0], o0["rank1_falls_back"][0], atol=1e-6)

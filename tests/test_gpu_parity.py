@@ -1347,6 +1347,42 @@ def test_encoder_backward_against_autograd(O, cuda):
     _grad_parity(enc, sd, lambda s, xx: O.encoder_forward(s, xx, rates=(2, 5, 5, 6), lstm=2), x, cuda, 2e-4)
 
 
+def test_in_place_reflect_fold_is_bit_identical_to_the_unpadding_copy(cuda):
+    """Round 6: the data gradient of a ResidualUnit's k = 7 conv reaches the Snake backward of the producing node as the window
+    [pad_left, pad_left + T) of the padded gradient rows -- mirrored edge samples added in place (fac_pad_fold_edges), rows read
+    with a stride (fac_snake_bwd_fused_rs) -- instead of through an un-padding copy of the whole tensor (fac_pad_fold_bwd).  Same
+    additions in the same order: every gradient of an Encoder backward equals the copying path's bit for bit
+    (FAC_FOLD_IN_PLACE=0), and the view path is the one that runs."""
+    from facodec_amd import ops
+    from facodec_amd.dac_model import Encoder
+
+    def grads(flag):
+        ops.FOLD_IN_PLACE = flag
+        taken = []
+        orig = ops.snake_bwd_fused
+
+        def spy(x, alpha, dy, add=None, want_bias=False):
+            taken.append(bool(dy is not None and not dy.is_contiguous()))
+            return orig(x, alpha, dy, add=add, want_bias=want_bias)
+
+        ops.snake_bwd_fused = spy
+        try:
+            enc = Encoder(d_model=16, strides=[2, 5, 5, 6], d_latent=64, causal=True, lstm=0)
+            synth.load_synthetic(enc, seed=4, prefix="encoder.")
+            enc.to(cuda).train()
+            x = synth.synth_clips(2, 4800, seed=6).to(cuda).requires_grad_()
+            y = enc(x)
+            (y * torch.randn(*y.shape, generator=_g(3)).to(cuda)).sum().backward()
+            return [x.grad.clone()] + [p.grad.clone() for p in enc.parameters()], taken
+        finally:
+            ops.snake_bwd_fused = orig
+            ops.FOLD_IN_PLACE = 1
+
+    (a, took_view), (b, took_copy) = grads(1), grads(0)
+    assert any(took_view) and not any(took_copy)
+    assert len(a) == len(b) and all(torch.equal(u, v) for u, v in zip(a, b))
+
+
 _MEASURED = {}
 
 

@@ -355,6 +355,45 @@ def test_train_step_batch16_linearity_full_size(cuda):
         assert abs(float(out_full["grad_norm"][k]) - n_full) / n_full < 1e-4, k
 
 
+def test_concurrent_quantizer_chains_give_the_serial_gradients_bit_for_bit(cuda):
+    """Round 6: with FAquantizer's three chains on side streams the gradient of ONE parameter (timbre_encoder.spectral.0.weight, the
+    last backward node of the timbre chain) came out 1 - 30 % short on some boxes, run to run -- the node reads the log-mel features,
+    which live in the main stream's allocator pool and are dropped the moment its backward function returns, while its kernels are
+    still queued on the side stream (ops.run_chains now records the chains' inputs on the side streams).  Same kernels, same order
+    within a stream: every key's gradient arena of a B = 8 step must equal the serial run's bit for bit, every time."""
+    from facodec_amd import quantize
+    from facodec_amd.train import TrainStep
+    model = _model(cuda, ("encoder", "quantizer", "decoder", "discriminator"))
+    step = TrainStep(model, lr=0.0)
+    full = synth.synth_clips(16, 48000, seed=4).to(cuda)
+    B = 16
+    ones = lambda n: torch.ones(n, B)   # noqa: E731
+    masks = dict(p=ones(1), c=ones(2), r=torch.cat([ones(2), (torch.arange(B) % 2).float().reshape(1, B)]), res=(torch.arange(B) % 4 != 1).float(),
+                 dropout=False)
+    saved = quantize.QUANT_STREAMS
+
+    def run(lo, hi, streams):
+        quantize.QUANT_STREAMS = streams
+        mk = {k: (v[..., lo:hi].contiguous().to(cuda) if torch.is_tensor(v) else v) for k, v in masks.items()}
+        step(full[lo:hi].contiguous(), masks=mk)
+        return {k: step.opt[k].g.clone() for k in step.opt}
+
+    try:
+        run(0, 16, 3)                                        # the sequence that showed it: a full batch first, then the halves
+        got = [(run(0, 8, 3), run(8, 16, 3)) for _ in range(3)]
+        ref = (run(0, 8, 1), run(8, 16, 1))
+    finally:
+        quantize.QUANT_STREAMS = saved
+    names = [n for n, p in model.quantizer.named_parameters() if p.requires_grad]
+    for pair in got:
+        for h in (0, 1):
+            for k in ref[h]:
+                if not torch.equal(pair[h][k], ref[h][k]):
+                    bad = [names[i] for i, (off, n) in enumerate(step.opt[k].slices)
+                           if not torch.equal(pair[h][k][off:off + n], ref[h][k][off:off + n])] if k == "quantizer" else []
+                    raise AssertionError((k, h, bad[:8], float((pair[h][k] - ref[h][k]).abs().max())))
+
+
 def test_train_step_identical_with_and_without_streaming_kernel():
     """configs[2] at its real size (B = 16 x 2 s), two seeded iterations, once with the streaming k = 1 kernel (forward and
     data gradient of the C <= 384 ResidualUnit tails) and once with FAC_PW=0 (tiled kernel): same summation order, so every loss

@@ -120,7 +120,7 @@ def main():
     add("STFT framing, window 512 hop 128 (K8 / K11)", "stft_frames_kernel", (B, 512, nf), 4 * B * 48000 + 4 * B * 512 * nf,
         lambda: ops.stft_frames(wave, 512, nf, 128, 256, 0))
     spec = torch.randn(B, 2 * 257, nf, device=dev)
-    add("|STFT|^p (K11)", "spec_power_kernel", (B, 257, nf), 12 * B * 257 * nf, lambda: ops.spec_power(spec, 1.0))
+    add("|STFT|^p (K11)", "spec_power_kernel", (B, 257, nf), 12 * B * 257 * nf, lambda: ops.spec_power(spec, 1))
     a_, b_ = torch.rand(B, 80, nf, device=dev) + 0.1, torch.rand(B, 80, nf, device=dev) + 0.1
     outs, scr = torch.zeros(1, device=dev), torch.empty(4096, device=dev)
     add("L1 of log10 mel (K11 reduction)", "reduce_pair_stage1", (B, 80, nf), 8 * B * 80 * nf,

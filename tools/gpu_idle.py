@@ -32,17 +32,19 @@ def main():
         ev = [e for e in ev if e[0] >= t_end - a.tail_ms * 1e6]
     t0 = ev[0][0]
     span = (t_end - t0) / 1e6
-    busy, cur_end, gaps = 0, ev[0][0], []
+    busy, cur_end, gaps, last_name = 0, ev[0][0], [], ev[0][2]
     sum_dur = 0
+    longest = []
     for s, e, n in ev:
         sum_dur += e - s
         if s > cur_end:
             gaps.append((s - cur_end, n))
-            busy += 0
-            cur_end_prev = cur_end
+            longest.append((s - cur_end, round((cur_end - t0) / 1e6, 2), last_name, n))
         if e > cur_end:
             busy += e - max(s, cur_end)
             cur_end = e
+            last_name = n
+    longest.sort(reverse=True)
     idle = span - busy / 1e6
     big = [g for g in gaps if g[0] >= a.gap_us * 1e3]
     behind = collections.Counter()
@@ -57,7 +59,8 @@ def main():
            "overlap_ms (kernels running side by side)": round((sum_dur - busy) / 1e6, 2),
            "idle_ms_by_gap_length": {k: round(v / 1e6, 2) for k, v in hist.items()},
            "gaps": len(gaps), f"gaps_over_{a.gap_us:g}us": len(big),
-           "idle_ms_in_front_of (top 12)": {k: round(v / 1e6, 2) for k, v in behind.most_common(12)}}
+           "idle_ms_in_front_of (top 12)": {k: round(v / 1e6, 2) for k, v in behind.most_common(12)},
+           "longest_gaps [us, at ms, kernel that ended last, kernel that started]": [[round(g / 1e3, 1), at, a_[:48], b_[:48]] for g, at, a_, b_ in longest[:24]]}
     print(json.dumps(res, indent=1))
     if a.out:
         json.dump(res, open(a.out, "w"), indent=1)
