@@ -206,6 +206,7 @@ def train_leg(model, device, rank, world, steps, warmup):
     for k in ("discriminator", "fa_predictors"):
         synth.load_synthetic(model[k], seed=0, prefix=k + ".")
         model[k].to(device)
+    import numpy as np
     step = TrainStep(model, with_predictors=True)
     ref_check = check_train_step_against_reference(step, device)        # first iteration on fresh weights = the fixture's; aborts on a miss
     n_samples = int(CLIP_SECONDS * SAMPLE_RATE)
@@ -218,6 +219,7 @@ def train_leg(model, device, rank, world, steps, warmup):
         # dropout / quantizer-dropout draws (CPU torch.randint, device bernoulli_) come from the default generators: seeded per call,
         # so the losses of the line are reproducible run to run -- same draw sequence for a given (steps, warmup)
         torch.manual_seed(7000 + 100 * rank + calls[0])
+        np.random.seed(7000 + 100 * rank + calls[0])            # the residual mask comes from np.random.choice (modules/quantize.py:420-423)
         calls[0] += 1
         last.update(step(wave, targets=targets))
 

@@ -218,15 +218,21 @@ class FlatAdamW:
         unbind=True (what TrainStep uses): `.grad` is left None for the coming backward, so autograd's AccumulateGrad
         keeps ("steals") each produced gradient tensor instead of launching one add-into-the-view kernel per parameter
         (~800 small launches per step); `launch_all_reduce` / `step` then fold all of them into the arena with one
-        multi-tensor copy and bind the views again."""
+        multi-tensor copy and bind the views again.
+        (Round 6: no `_rebind()` in here any more -- folding foreign gradient tensors into an arena that is zeroed on the next line
+        was ~1 ms of Python per key at the one point of the step where the device has nothing queued, tools/gpu_idle.py.)"""
         self._drain()
-        self._rebind()
         self._gx.zero_()
         self._touched = [False] * len(self.params)
         self._reset_exchange_state()
         if unbind:
             for p in self.params:
                 p.grad = None
+        else:
+            views = self._views
+            for i, p in enumerate(self.params):
+                if p.grad is not views[i]:
+                    p.grad = views[i]
 
     def _reset_exchange_state(self):
         """Nothing of this key is in flight or marked launched: the next `launch_all_reduce` starts from bucket 0 again.  (`step`
@@ -248,25 +254,33 @@ class FlatAdamW:
         src, dst = [], []
         hi = len(self.params) if hi is None else hi
         launched_from = self.buckets[self._next_bucket - 1][0] if self._next_bucket else len(self.params)
+        in_flight = bool(self._works or self._flags_final)
+        params, slices, views, touched = self.params, self.slices, self._views, self._touched
+        # This loop runs once per key and step at the one point where the device has nothing queued (~1 500 parameters: 4.4 ms per step
+        # in round 5's form, tools/tune/host_profile.py).  The arena-residency check costs a third of it and guards against a
+        # module.to() / .float() AFTER the optimiser was built, which does not happen between two steps of a loop: every 16th call.
+        self._rebind_calls = getattr(self, "_rebind_calls", 0) + 1
+        if self._rebind_calls % 16 == 1:
+            for i in range(lo, hi):
+                if params[i].data_ptr() != base_p + 4 * slices[i][0]:
+                    raise RuntimeError("FlatAdamW: a parameter no longer lives in the optimiser's arena (was the module moved or cast "
+                                       "after the optimiser was built?); build FlatAdamW after the model is on its final device")
         for i in range(lo, hi):
-            p, (off, k) = self.params[i], self.slices[i]
-            if p.data_ptr() != base_p + 4 * off:
-                raise RuntimeError("FlatAdamW: a parameter no longer lives in the optimiser's arena (was the module moved or cast after "
-                                   "the optimiser was built?); build FlatAdamW after the model is on its final device")
+            p = params[i]
             g = p.grad
+            v = views[i]
             if g is None:
-                p.grad = self._views[i]
-            elif g.data_ptr() != base_g + 4 * off:            # foreign gradient tensor: fold it in once, then rebind
-                if i >= launched_from and (self._works or self._flags_final):
+                p.grad = v
+            elif g is not v and g.data_ptr() != base_g + 4 * slices[i][0]:     # foreign gradient tensor: fold it in once, then rebind
+                if i >= launched_from and in_flight:
                     raise RuntimeError(f"FlatAdamW: the gradient of parameter {i} arrived after the exchange of its bucket was launched "
                                        "(the launch point is too early for this graph; FAC_EARLY_EXCHANGE=0 launches after backward)")
-                src.append(g.detach())
-                dst.append(self._views[i])
-                p.grad = self._views[i]
-                self._touched[i] = True
+                src.append(g)
+                dst.append(v)
+                p.grad = v
+                touched[i] = True
         if src:
-            same = all(a.dtype == b.dtype and a.device == b.device and a.is_contiguous() for a, b in zip(src, dst))
-            if same and hasattr(torch, "_foreach_copy_"):
+            if hasattr(torch, "_foreach_copy_"):            # (takes its slow path by itself for tensors that differ in dtype / layout)
                 torch._foreach_copy_(dst, src)
             else:
                 for a, b in zip(src, dst):

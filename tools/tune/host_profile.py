@@ -39,6 +39,35 @@ def main():
     torch.cuda.synchronize()
     t_all = (time.perf_counter() - t0) / 3
     print(f"host enqueue time per step {1e3 * t_host:.1f} ms; wall per step incl. device {1e3 * t_all:.1f} ms", flush=True)
+    # host time of the bookkeeping at the step boundary (the device is nearly idle there: tools/gpu_idle.py shows one 3.6 - 4.3 ms gap per step)
+    import collections
+    from facodec_amd import optim, train
+    acc = collections.Counter()
+
+    def timed(cls, name):
+        orig = getattr(cls, name)
+
+        def wrapped(*a, **k):
+            t = time.perf_counter()
+            try:
+                return orig(*a, **k)
+            finally:
+                acc[cls.__name__ + "." + name] += time.perf_counter() - t
+        setattr(cls, name, wrapped)
+        return orig
+
+    saved = [(c, n, timed(c, n)) for c, n in ((train.GeneratorStep, "_zero"), (optim.FlatAdamW, "_rebind"), (optim.FlatAdamW, "zero_grad"),
+                                              (optim.FlatAdamW, "step"), (optim.FlatAdamW, "exchange_for_step"), (optim.FlatAdamW, "end_step"),
+                                              (optim.FlatAdamW, "_upload_flags"), (train.GeneratorStep, "_report_lstm_timeouts"))]
+    t0 = time.perf_counter()
+    for _ in range(3):
+        step(wave, targets=targets)
+    t_host = (time.perf_counter() - t0) / 3
+    torch.cuda.synchronize()
+    print(f"host enqueue {1e3 * t_host:.1f} ms per step; of it (ms per step, nested calls counted in their parents too):",
+          {k: round(1e3 * v / 3, 2) for k, v in sorted(acc.items(), key=lambda kv: -kv[1])}, flush=True)
+    for c, n, o in saved:
+        setattr(c, n, o)
     torch.autograd.set_multithreading_enabled(False)
     pr = cProfile.Profile()
     pr.enable()
