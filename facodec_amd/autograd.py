@@ -51,7 +51,12 @@ class _Conv(Function):
         else:
             wp, ws = ops.pack_conv_weight(vd, gd, scale=sc), None
         ctx.scale = sc
-        y = ops.conv1d(x.detach(), wp, v.shape[0], k, bias=bias.detach() if bias is not None else None,
+        xin = x.detach()
+        if ws is not None and stride > 1 and dilation == 1:
+            # split GEMM over the phase sub-signals: plane inputs where the pass pays for itself (ops.p8_prepass; round 6: the training
+            # launches take the same pre-pass as the inference ones -- same bf16 operands in the same order, same bits)
+            xin = ops.p8_prepass(xin, 2.0 * v.shape[0] * k / (4.0 * stride))
+        y = ops.conv1d(xin, wp, v.shape[0], k, bias=bias.detach() if bias is not None else None,
                        stride=stride, dilation=dilation, pad_mode=pad_mode, causal=causal, act=act, w_split=ws)
         ctx.cfg = cfg
         ctx.save_for_backward(x, v, g, bias, y if act == ops.ACT_TANH else None)
@@ -83,8 +88,11 @@ class _ConvTr(Function):
     @staticmethod
     def forward(ctx, x, v, g, bias, stride):
         vd, gd = v.detach(), (g.detach() if g is not None else None)
-        y = ops.conv_transpose1d(x.detach(), ops.convtr_weight_for(vd, gd, stride, x.shape[-1], batch=x.shape[0]), v.shape[1], stride,
-                                 bias=bias.detach() if bias is not None else None)
+        wt = ops.convtr_weight_for(vd, gd, stride, x.shape[-1], batch=x.shape[0])
+        xin = x.detach()
+        if isinstance(wt, tuple):                     # all-phases launch on the split GEMM kernel: 2 s C_out MACs per input sample
+            xin = ops.p8_prepass(xin, 2.0 * v.shape[1] * 2 * stride / 4.0)
+        y = ops.conv_transpose1d(xin, wt, v.shape[1], stride, bias=bias.detach() if bias is not None else None)
         ctx.stride = stride
         ctx.save_for_backward(x, v, g, bias)
         return y
@@ -239,7 +247,10 @@ class _LSTM(Function):
             w_ih, w_hh, b_ih, b_hh = (p.detach() for p in params[4 * l: 4 * l + 4])
             with ops.flop_scale(B / BP):
                 use_split = ops.gemm_split_ok(4 * H, H, 1, T * BP)
-                pre = ops.conv1d(inp.view(1, H, T * BP), None if use_split else ops.pack_conv_weight(w_ih), 4 * H, 1,
+                sig = inp.view(1, H, T * BP)
+                if use_split:
+                    sig = ops.p8_prepass(sig, 2.0 * 4 * H / 4.0)
+                pre = ops.conv1d(sig, None if use_split else ops.pack_conv_weight(w_ih), 4 * H, 1,
                                  bias=ops.add(b_ih, b_hh), pad_left=0, t_out=T * BP, pad_mode=ops.PAD_ZERO,
                                  w_split=ops.pack_gemm_weight_split(w_ih) if use_split else None)
                 gates = torch.empty(4 * H, T, BP, device=x.device)

@@ -41,7 +41,10 @@ class PlainConv(Function):
         else:
             wp, ws = ops.pack_conv_weight(vd, gd, scale=sc), None
         ctx.scale = sc
-        y = ops.conv1d(x.detach(), wp, v.shape[0], k, bias=bias.detach() if bias is not None else None,
+        xin = x.detach()
+        if ws is not None and not k1 and stride > 1 and ops.gemm_split_strided_ok(v.shape[0], c_in, k, stride, B, t_out):
+            xin = ops.p8_prepass(xin, 2.0 * v.shape[0] * k / (4.0 * stride))      # (5, 1) stride-3 convs on the split GEMM kernel
+        y = ops.conv1d(xin, wp, v.shape[0], k, bias=bias.detach() if bias is not None else None,
                        stride=stride, pad_left=pad, pad_mode=ops.PAD_ZERO, t_out=t_out, w_split=ws, k1=k1, dilation2=dil2)
         ctx.cfg = (k, stride, pad, t_in, t_out, k1, dil2, max_off)
         ctx.save_for_backward(x, v, g, bias)
@@ -63,8 +66,11 @@ class PlainConv(Function):
                 # polyphase transposed conv (no zero-inserted columns: 1.2x the useful flops for k = 5, s = 3 instead of 3x)
                 v6 = torch.cat([vd, vd.new_zeros(c_out, c_in, 2 * stride - k)], dim=2) if k < 2 * stride else vd
                 dy_ext = torch.cat([dy, dy.new_zeros(B, c_out, 1)], dim=2)
+                wt = ops.convtr_weight_for(v6, gd, stride, dy_ext.shape[-1], batch=B)
+                if isinstance(wt, tuple):
+                    dy_ext = ops.p8_prepass(dy_ext, 2.0 * c_in * 2 * stride / 4.0)
                 with ops.flop_scale(k / (2.0 * stride)):      # the zero taps that pad k to 2 * stride are not algorithmic work
-                    dxp = ops.conv_transpose1d(dy_ext, ops.convtr_weight_for(v6, gd, stride, dy_ext.shape[-1], batch=B), c_in, stride)
+                    dxp = ops.conv_transpose1d(dy_ext, wt, c_in, stride)
                 if dxp.shape[-1] < pad + t_in:
                     dxp = torch.cat([dxp, dxp.new_zeros(B, c_in, pad + t_in - dxp.shape[-1])], dim=2)
                 dx = dxp[:, :, pad:pad + t_in].contiguous()

@@ -15,6 +15,7 @@
 // Reference semantics: torch autograd through dac/model/encodec.py SConv1d / dac/nn/layers.py snake (checked
 // against autograd of the CPU oracle in tests/test_gpu_parity.py).
 #include "conv1d_mfma.h"
+#include <stdlib.h>
 
 namespace fac {
 
@@ -298,6 +299,64 @@ __global__ __launch_bounds__(256) void snake_bwd_fused_kernel(const float* __res
   }
 }
 
+// The same kernel on 16-byte accesses (round 6): T % 4 == 0, x / add / dx rows 16-byte aligned, dy rows 8-byte aligned (a window of
+// padded rows starts an even number of samples into its row).  A lane owns four consecutive steps: four independent sin / cos
+// evaluations and 40 bytes of loads in flight per trip instead of one and 12 -- the scalar kernel ran at 4.1 TB/s against the
+// 6 - 7 of the LeakyReLU kernels on the same tensors (profiles/r06_hbm_kernels.json).  Slices are cut in quads; partial sums are
+// per-lane chains over its quads, then the same fixed-order tree.
+__global__ __launch_bounds__(256) void snake_bwd_fused_v4_kernel(const float* __restrict__ x, const float* __restrict__ alpha,
+                                                                 const float* __restrict__ dy, const float* __restrict__ add,
+                                                                 float* __restrict__ dx, float* __restrict__ part,
+                                                                 float* __restrict__ part2, int B, int C, int T, long long dy_rs) {
+  __shared__ float red[2][256];
+  const int c = blockIdx.x, sl = blockIdx.y, tid = threadIdx.x;
+  const float al = alpha[c], ae = al + 1e-9f;
+  const int T4 = T >> 2;
+  const long long n = (long long)B * T4;                       // quads of this channel
+  const long long per = (n + RED_NS - 1) / RED_NS;
+  const long long lo = sl * per, hi = lo + per < n ? lo + per : n;
+  float s = 0.f, sb = 0.f;
+  if (lo < hi) {
+    const int b_lo = (int)(lo / T4), b_hi = (int)((hi - 1) / T4);
+    for (int b = b_lo; b <= b_hi; ++b) {
+      const long long base = (long long)b * T4;
+      const int q0 = (int)(lo > base ? lo - base : 0);
+      const int q1 = (int)(hi < base + T4 ? hi - base : T4);
+      const long long ro = ((long long)b * C + c) * T;
+      const float* dyr = dy + ((long long)b * C + c) * dy_rs;
+      for (int q = q0 + tid; q < q1; q += 256) {
+        const float4 xv = *reinterpret_cast<const float4*>(x + ro + 4 * q);
+        const float2 g0 = *reinterpret_cast<const float2*>(dyr + 4 * q), g1 = *reinterpret_cast<const float2*>(dyr + 4 * q + 2);
+        float4 av = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (add) av = *reinterpret_cast<const float4*>(add + ro + 4 * q);
+        const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, gs[4] = {g0.x, g0.y, g1.x, g1.y}, as[4] = {av.x, av.y, av.z, av.w};
+        float d[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float ax = al * xs[j];
+          const float sn = sinf(ax), cs = cosf(ax);
+          const float s2 = 2.f * sn * cs;
+          d[j] = gs[j] * (1.f + al * s2 / ae) + as[j];
+          s += gs[j] * (xs[j] * s2 * ae - sn * sn) / (ae * ae);
+          sb += d[j];
+        }
+        *reinterpret_cast<float4*>(dx + ro + 4 * q) = make_float4(d[0], d[1], d[2], d[3]);
+      }
+    }
+  }
+  red[0][tid] = s;
+  red[1][tid] = sb;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (tid < o) { red[0][tid] += red[0][tid + o]; red[1][tid] += red[1][tid + o]; }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    part[c * RED_NS + sl] = red[0][0];
+    if (part2) part2[c * RED_NS + sl] = red[1][0];
+  }
+}
+
 // db[c] = sum over (b, t) of dy: workgroup (c, slice) sums its contiguous share of the flattened (b, t) range -- walked clip by
 // clip (no per-element division), 16 bytes per lane where the rows allow it, four independent partial sums per thread -- and a
 // second pass adds the RED_NS slices in fixed order.
@@ -489,8 +548,14 @@ extern "C" int fac_snake_bwd_fused_rs(const float* x, const float* alpha, const 
   using namespace fac;
   FAC_REQUIRE(x && alpha && dy && dx && dalpha && scratch && B > 0 && C > 0 && T > 0 && dy_row_stride >= T, "snake_bwd_fused: bad arguments");
   float* part2 = dbias ? scratch + (long long)RED_NS * C : nullptr;
-  hipLaunchKernelGGL(snake_bwd_fused_kernel, dim3(C, RED_NS), dim3(256), 0, (hipStream_t)stream, x, alpha, dy, add, dx, scratch, part2,
-                     B, C, T, dy_row_stride);
+  static const bool v4_on = !(getenv("FAC_SNAKE_BWD_V4") && getenv("FAC_SNAKE_BWD_V4")[0] == '0');
+  auto al = [](const void* p, unsigned m) { return (reinterpret_cast<unsigned long long>(p) & m) == 0; };
+  if (v4_on && (T & 3) == 0 && (dy_row_stride & 1) == 0 && al(x, 15) && al(dx, 15) && (!add || al(add, 15)) && al(dy, 7))
+    hipLaunchKernelGGL(snake_bwd_fused_v4_kernel, dim3(C, RED_NS), dim3(256), 0, (hipStream_t)stream, x, alpha, dy, add, dx, scratch,
+                       part2, B, C, T, dy_row_stride);
+  else
+    hipLaunchKernelGGL(snake_bwd_fused_kernel, dim3(C, RED_NS), dim3(256), 0, (hipStream_t)stream, x, alpha, dy, add, dx, scratch, part2,
+                       B, C, T, dy_row_stride);
   hipLaunchKernelGGL(channel_reduce_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, scratch, dalpha, C);
   if (dbias)
     hipLaunchKernelGGL(channel_reduce_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, part2, dbias, C);

@@ -257,16 +257,12 @@ class FlatAdamW:
         in_flight = bool(self._works or self._flags_final)
         params, slices, views, touched = self.params, self.slices, self._views, self._touched
         # This loop runs once per key and step at the one point where the device has nothing queued (~1 500 parameters: 4.4 ms per step
-        # in round 5's form, tools/tune/host_profile.py).  The arena-residency check costs a third of it and guards against a
-        # module.to() / .float() AFTER the optimiser was built, which does not happen between two steps of a loop: every 16th call.
-        self._rebind_calls = getattr(self, "_rebind_calls", 0) + 1
-        if self._rebind_calls % 16 == 1:
-            for i in range(lo, hi):
-                if params[i].data_ptr() != base_p + 4 * slices[i][0]:
-                    raise RuntimeError("FlatAdamW: a parameter no longer lives in the optimiser's arena (was the module moved or cast "
-                                       "after the optimiser was built?); build FlatAdamW after the model is on its final device")
+        # in round 5's form, tools/tune/host_profile.py): locals instead of attribute chains, no detach(), no per-tensor layout test.
         for i in range(lo, hi):
             p = params[i]
+            if p.data_ptr() != base_p + 4 * slices[i][0]:
+                raise RuntimeError("FlatAdamW: a parameter no longer lives in the optimiser's arena (was the module moved or cast after "
+                                   "the optimiser was built?); build FlatAdamW after the model is on its final device")
             g = p.grad
             v = views[i]
             if g is None:
