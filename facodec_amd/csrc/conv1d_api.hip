@@ -202,7 +202,7 @@ extern "C" int fac_conv1d_variant(const fac_conv_desc* d, char* name, int name_l
     a.y_tstride = d->y_tstride; a.res = d->res; a.y2 = d->y2; a.w1 = d->w_k1; a.w_batched = d->w_batched; a.y = d->y; a.B = d->B;
     a.T_out = d->T_out; a.K1 = d->K1 > 0 ? d->K1 : d->K;
     if (conv_thin_ok(a, d->ws, d->ws_bytes)) {
-      if (name && name_len > 0) snprintf(name, name_len, "conv1d_thin_kernel (VALU, C_out<=2, split channels)");
+      if (name && name_len > 0) snprintf(name, name_len, "conv1d_thin_kernel (VALU, C_out<=8, split channels)");
       return 13;
     }
   }

@@ -282,12 +282,17 @@ __global__ __launch_bounds__(256) void conv1d_thin_sum_kernel(ConvArgs a, const 
   }
 }
 
+// Round 6: the same kernel pair for up to EIGHT output channels (1 <= K <= 2 taps; C_out 3 .. 8): the data gradient of the quantizers'
+// out-projections (1024 -> 8 over 16 x 160 frames, dac/nn/quantize.py:46-53 backward) ran on the 32 x 256 MFMA tile -- 16 workgroups
+// each walking all 1 024 channels, 225 us for 42 MFLOP and 10.5 MB (0.2 TFLOP/s; six such launches per train step).
+static int thin_co(int C_out) { return C_out <= 1 ? 1 : C_out <= 2 ? 2 : C_out <= 4 ? 4 : 8; }
+
 bool conv_thin_ok(const ConvArgs& a, const void* ws, long long ws_bytes) {
-  if (!(a.C_out <= 2 && a.C_in >= 2 * THIN_CC && a.K <= THIN_KMAX && a.stride == 1 && a.n_phase == 1 && a.phase_shift == 0 &&
+  if (!((a.C_out <= 2 || (a.C_out <= 8 && a.K <= 2 && !a.alpha_in)) && a.C_in >= 2 * THIN_CC && a.K <= THIN_KMAX && a.stride == 1 && a.n_phase == 1 && a.phase_shift == 0 &&
         a.y_tstride == 1 && !a.res && !a.y2 && !a.w1 && !a.w_batched && a.y && ws && a.B <= 65535 && !conv_two_level(a)))
     return false;
   const long long chunks = (a.C_in + THIN_CC - 1) / THIN_CC;
-  return chunks <= 65535 && ws_bytes >= chunks * a.B * 2 * a.T_out * (long long)sizeof(float);
+  return chunks <= 65535 && ws_bytes >= chunks * a.B * thin_co(a.C_out) * a.T_out * (long long)sizeof(float);
 }
 
 int conv_dispatch_thin(ConvArgs& a, void* ws, hipStream_t s) {
@@ -296,12 +301,22 @@ int conv_dispatch_thin(ConvArgs& a, void* ws, hipStream_t s) {
   dim3 grid((a.T_out + THIN_TT - 1) / THIN_TT, chunks, a.B);
   const long long n = (long long)a.B * a.C_out * a.T_out;
   const int rb = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
-  if (a.C_out == 1) {
-    hipLaunchKernelGGL(conv1d_thin_part_kernel<1>, grid, dim3(THIN_TT), 0, s, a, part);
-    hipLaunchKernelGGL(conv1d_thin_sum_kernel<1>, dim3(rb), dim3(256), 0, s, a, part, chunks);
-  } else {
-    hipLaunchKernelGGL(conv1d_thin_part_kernel<2>, grid, dim3(THIN_TT), 0, s, a, part);
-    hipLaunchKernelGGL(conv1d_thin_sum_kernel<2>, dim3(rb), dim3(256), 0, s, a, part, chunks);
+  switch (thin_co(a.C_out)) {
+    case 1:
+      hipLaunchKernelGGL(conv1d_thin_part_kernel<1>, grid, dim3(THIN_TT), 0, s, a, part);
+      hipLaunchKernelGGL(conv1d_thin_sum_kernel<1>, dim3(rb), dim3(256), 0, s, a, part, chunks);
+      break;
+    case 2:
+      hipLaunchKernelGGL(conv1d_thin_part_kernel<2>, grid, dim3(THIN_TT), 0, s, a, part);
+      hipLaunchKernelGGL(conv1d_thin_sum_kernel<2>, dim3(rb), dim3(256), 0, s, a, part, chunks);
+      break;
+    case 4:
+      hipLaunchKernelGGL(conv1d_thin_part_kernel<4>, grid, dim3(THIN_TT), 0, s, a, part);
+      hipLaunchKernelGGL(conv1d_thin_sum_kernel<4>, dim3(rb), dim3(256), 0, s, a, part, chunks);
+      break;
+    default:
+      hipLaunchKernelGGL(conv1d_thin_part_kernel<8>, grid, dim3(THIN_TT), 0, s, a, part);
+      hipLaunchKernelGGL(conv1d_thin_sum_kernel<8>, dim3(rb), dim3(256), 0, s, a, part, chunks);
   }
   return check_launch("conv1d_thin");
 }

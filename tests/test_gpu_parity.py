@@ -78,6 +78,10 @@ CONV_CASES = [
     # one / two output channels, too few tiles for the VALU kernel: channel-split partial sums + fixed-order sum
     (1, 1024, 1, 9001, 3, 1, 1, False, False, False, 0, "zero"),
     (2, 300, 2, 1500, 5, 1, 2, True, True, False, 1, "reflect"),
+    # three to eight output channels over many input channels, 1 - 2 taps (round 6: the quantizer out-projections' data gradient)
+    (16, 1024, 8, 160, 1, 1, 1, False, False, False, 0, "zero"),
+    (3, 520, 5, 333, 2, 1, 1, False, True, False, 0, "zero"),
+    (2, 256, 4, 700, 1, 1, 1, False, False, False, 1, "zero"),
 ]
 
 
