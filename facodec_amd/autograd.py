@@ -52,6 +52,17 @@ class _Conv(Function):
             wp, ws = ops.pack_conv_weight(vd, gd, scale=sc), None
         ctx.scale = sc
         xin = x.detach()
+        n_out = -(-x.shape[-1] // stride)
+        if (stride > 1 and dilation == 1 and causal and pad_mode == ops.PAD_REFLECT and act == ops.ACT_NONE and x.shape[-1] % stride == 0
+                and x.shape[-1] > stride and ops.flat_strided_ok(v.shape[0], v.shape[1], k, stride, x.shape[0], n_out)):
+            # short clips (the 160-frame latent rate): every clip reflect-padded on the left by k - s = s samples (the causal padding
+            # of dac/model/encodec.py:212-222; T % s == 0: no right padding), all of them as one signal on the split GEMM kernel
+            y = ops.conv1d_flat_strided(torch.nn.functional.pad(xin, (stride, 0), mode="reflect"),
+                                        ops.pack_gemm_weight_split(vd, gd, in_stride=stride, scale=sc), v.shape[0], k, stride,
+                                        bias=bias.detach() if bias is not None else None)
+            ctx.cfg = cfg
+            ctx.save_for_backward(x, v, g, bias, None)
+            return y
         if ws is not None and stride > 1 and dilation == 1:
             # split GEMM over the phase sub-signals: plane inputs where the pass pays for itself (ops.p8_prepass; round 6: the training
             # launches take the same pre-pass as the inference ones -- same bf16 operands in the same order, same bits)
@@ -88,6 +99,13 @@ class _ConvTr(Function):
     @staticmethod
     def forward(ctx, x, v, g, bias, stride):
         vd, gd = v.detach(), (g.detach() if g is not None else None)
+        ctx.stride = stride
+        ctx.save_for_backward(x, v, g, bias)
+        if ops.flat_convtr_ok(v.shape[0], v.shape[1], stride, x.shape[0], x.shape[-1] + 1):
+            # short clips: a zero column in front of every clip (the x[t - 1] of its first frame), one flattened signal; the s output
+            # samples of that column are dropped
+            xz = torch.nn.functional.pad(x.detach(), (1, 0))
+            return ops.conv_transpose1d_flat(xz, vd, gd, stride, bias=bias.detach() if bias is not None else None)[:, :, stride:].contiguous()
         wt = ops.convtr_weight_for(vd, gd, stride, x.shape[-1], batch=x.shape[0])
         xin = x.detach()
         if isinstance(wt, tuple):                     # all-phases launch on the split GEMM kernel: 2 s C_out MACs per input sample

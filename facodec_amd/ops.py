@@ -682,6 +682,54 @@ def conv_transpose1d(x, w_packed, c_out, stride, bias=None, alpha_in=None, out=N
     return (out, y2) if alpha_y2 is not None else out
 
 
+# Short clips on the split GEMM kernel as ONE flattened signal (layers.SConv1d._run_flat / SConvTranspose1d.run, round 4, inference):
+# the same trick for the TRAINING launches (round 6).  Per-clip column tiles of that kernel would be half empty at the 160-frame
+# latent rate, so those launches (the encoder's last downsampling conv, the decoder's first ConvTranspose1d, and their data
+# gradients) fell to the fp32 128 x 160 tile at 38 - 63 TFLOP/s (profiles/r06_train_layers_serial.log: 3.9 ms per step).
+FLAT_TRAIN = os.environ.get("FAC_FLAT_TRAIN", "1") != "0"
+
+
+def flat_strided_ok(c_out, c_in, k, s, batch, n_out):
+    """A k = 2 s strided conv over `batch` clips of n_out outputs each, too short for per-clip tiles but long enough as one signal."""
+    return (FLAT_TRAIN and k == 2 * s and s > 1 and n_out < 256 and not gemm_split_strided_ok(c_out, c_in, k, s, batch, n_out)
+            and gemm_split_strided_ok(c_out, c_in, k, s, 1, batch * (n_out + 1) - 1))
+
+
+def conv1d_flat_strided(xp, w_split, c_out, k, s, bias=None):
+    """xp (B, C_in, (n + 1) s): every clip already carries its s columns of padding (reflected on the left for the causal forward
+    conv, zeros on the right for the data gradient of a transposed conv).  The clips are laid one after another as ONE signal and
+    the strided conv runs WITHOUT padding: output column b (n + 1) + t is output t of clip b (same products, same order as the
+    per-clip launch), plus one junk column per clip where the window straddles two clips, dropped on the way back -> (B, C_out, n)."""
+    B, c_in, L = xp.shape
+    n = L // s - 1
+    xf = xp.permute(1, 0, 2).reshape(1, c_in, B * L)
+    t_out = B * (n + 1) - 1
+    xf = p8_prepass(xf, 2.0 * c_out * k / (4.0 * s))
+    y = conv1d(xf, None, c_out, k, bias=bias, stride=s, pad_left=0, pad_mode=PAD_ZERO, t_out=t_out, w_split=w_split)
+    full = torch.empty(c_out, B * (n + 1), device=y.device, dtype=y.dtype)
+    full[:, :t_out] = y[0]
+    return full.reshape(c_out, B, n + 1)[:, :, :n].permute(1, 0, 2).contiguous()
+
+
+def flat_convtr_ok(c_in, c_out, s, batch, t_cols):
+    """An all-phases ConvTranspose1d launch over `batch` clips of t_cols input columns each (incl. their zero column), short clips."""
+    return (FLAT_TRAIN and t_cols < 256 and not convtr_split_ok(c_in, c_out, s, batch, t_cols)
+            and convtr_split_ok(c_in, c_out, s, 1, batch * t_cols))
+
+
+def conv_transpose1d_flat(xz, v, g, s, bias=None):
+    """xz (B, C_in, T'): clips that already hold their zero column (in FRONT for the forward transposed conv: the x[t - 1] of a
+    clip's first frame; at the END for the data gradient of a strided conv, where it is the next clip's x[t - 1] as well).  One
+    signal of B T' columns through the all-phases split-GEMM launch -> (B, C_out, T' s): per clip exactly the per-clip launch's
+    output (y[t s + p] = W[p] x[t] + W[p + s] x[t - 1])."""
+    B, c_in, T1 = xz.shape
+    c_out = v.shape[1]
+    xf = xz.permute(1, 0, 2).reshape(1, c_in, B * T1)
+    xf = p8_prepass(xf, 2.0 * c_out * 2 * s / 4.0)
+    y = conv_transpose1d(xf, pack_convtr_weight_rows_split(v, g, s), c_out, s, bias=bias, causal=True)
+    return y.reshape(c_out, B, T1 * s).permute(1, 0, 2).contiguous()
+
+
 def snake(x, alpha, out=None):
     x = _dev(x, "x")
     B, c, t = x.shape
@@ -1116,7 +1164,10 @@ def conv1d_bwd_data(dy, v, g, t_in, stride=1, dilation=1, pad_mode=PAD_REFLECT, 
         if k != 2 * stride or dilation != 1:
             raise NotImplementedError("strided bwd_data is built for the model's k = 2*stride convs")
         dy_ext = torch.cat([dy, torch.zeros(B, c_out, 1, device=dy.device)], dim=2)
-        dxpad = conv_transpose1d(dy_ext, convtr_weight_for(v, g, stride, dy_ext.shape[-1], batch=B), c_in, stride)
+        if flat_convtr_ok(c_out, c_in, stride, B, t_out + 1):      # short clips: one flattened signal (the trailing zero column of a
+            dxpad = conv_transpose1d_flat(dy_ext, v, g, stride)    # clip is the x[t - 1] of the next clip's first frame)
+        else:
+            dxpad = conv_transpose1d(dy_ext, convtr_weight_for(v, g, stride, dy_ext.shape[-1], batch=B), c_in, stride)
         assert dxpad.shape[-1] == tp, (dxpad.shape, tp)
     if tp == t_in and FOLD_IN_PLACE in (1, 2):
         return dxpad                                  # no padding (the 1x1 convs): the padded gradient IS the gradient
@@ -1281,6 +1332,8 @@ def conv_transpose1d_bwd(x, dy, v, g, stride):
     if gemm_split_strided_ok(c_in, c_out, k, stride, B, t_in):     # the strided conv of dy on the split GEMM kernel
         dx = conv1d(dy, None, c_in, k, stride=stride, pad_left=0, pad_mode=PAD_ZERO, t_out=t_in,
                     w_split=pack_gemm_weight_split(v, g, in_stride=stride))
+    elif flat_strided_ok(c_in, c_out, k, stride, B, t_in):         # short clips: zeros on the right of every clip, one flattened signal
+        dx = conv1d_flat_strided(torch.nn.functional.pad(dy, (0, stride)), pack_gemm_weight_split(v, g, in_stride=stride), c_in, k, stride)
     else:
         dx = conv1d(dy, pack_conv_weight(v, g), c_in, k, stride=stride, pad_left=0, pad_mode=PAD_ZERO, t_out=t_in)
     dw = torch.empty(c_in, c_out, k, device=x.device, dtype=torch.float32)

@@ -1387,6 +1387,56 @@ def test_in_place_reflect_fold_is_bit_identical_to_the_unpadding_copy(cuda):
     assert len(a) == len(b) and all(torch.equal(u, v) for u, v in zip(a, b))
 
 
+def test_short_clip_training_convs_run_flattened(cuda):
+    """Round 6: at the 160-frame latent rate the training launches of the encoder's last strided conv and the decoder's first
+    ConvTranspose1d (forward AND data gradient) run as ONE flattened signal on the split GEMM kernel (ops.conv1d_flat_strided /
+    conv_transpose1d_flat) instead of per clip on the fp32 128 x 160 tile.  Same mathematical products: outputs and gradients
+    within 1e-5 of the per-clip path (FAC_FLAT_TRAIN=0), and the flattened launch is the one that runs."""
+    from facodec_amd import autograd as A
+    from facodec_amd import ops
+    from facodec_amd.layers import SConv1d, SConvTranspose1d
+    g = _g(12)
+    B = 16
+    down = SConv1d(128, 256, kernel_size=12, stride=6, causal=True, norm="weight_norm").to(cuda)
+    up = SConvTranspose1d(256, 128, kernel_size=12, stride=6, causal=True, norm="weight_norm").to(cuda)
+    x = torch.randn(B, 128, 960, generator=g).to(cuda)
+    r1 = torch.randn(B, 256, 160, generator=g).to(cuda)
+    r2 = torch.randn(B, 128, 960, generator=g).to(cuda)
+
+    def run(flag):
+        ops.FLAT_TRAIN = flag
+        names = []
+        orig = ops._launch_conv
+
+        def spy(d, what):
+            buf = ops.C.create_string_buffer(96)
+            ops._lib.load().fac_conv1d_variant(ops.C.byref(d), buf, 96)
+            names.append((d.B, buf.value.decode()[:28]))
+            orig(d, what)
+
+        ops._launch_conv = spy
+        try:
+            xi = x.clone().requires_grad_()
+            y = A.conv(down, xi)
+            z = A.conv_tr(up, y)
+            ((y * r1).sum() + (z * r2).sum()).backward()
+            grads = [xi.grad.clone()] + [p.grad.clone() for m in (down, up) for p in m.parameters()]
+            for m in (down, up):
+                for p in m.parameters():
+                    p.grad = None
+            return y.detach(), z.detach(), grads, names
+        finally:
+            ops._launch_conv = orig
+            ops.FLAT_TRAIN = True
+
+    y1, z1, g1, n1 = run(True)
+    y0, z0, g0, n0 = run(False)
+    assert sum(1 for b, n in n1 if b == 1 and "gemm_split" in n) >= 4 and not any(b == 1 for b, n in n0)       # fwd x 2, data gradient x 2
+    assert rel(y1, y0) < 1e-5 and rel(z1, z0) < 1e-5
+    for a, b in zip(g1, g0):
+        assert rel(a, b) < 1e-5
+
+
 _MEASURED = {}
 
 
