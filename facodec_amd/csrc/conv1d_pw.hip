@@ -146,8 +146,13 @@ __global__ __launch_bounds__(PW_WAVES * 64, 4) void conv1d_pw_kernel(ConvArgs a,
         if (a.act != FAC_ACT_NONE) v = apply_act_slow(v, a.act);
         v += rv[m & 1][r];
         if (ok) {
+#ifdef FAC_PW_NT_STORES
+          if (yp) __builtin_nontemporal_store(v, yp + (long long)row * a.y_cs);
+          if (y2p) __builtin_nontemporal_store(snake_apply(v, prm[3 * CO + row], prm[4 * CO + row]), y2p + (long long)row * a.y_cs);
+#else
           if (yp) yp[(long long)row * a.y_cs] = v;
           if (y2p) y2p[(long long)row * a.y_cs] = snake_apply(v, prm[3 * CO + row], prm[4 * CO + row]);
+#endif
         }
       }
     }
