@@ -780,7 +780,7 @@ def compact_line(out, detail=None):
     cb = out.get("cpu_baseline")
     if cb:
         line["cpu_baseline"] = pick(cb, "value", "unit", "cores", "kind", "pinned_cpus")
-        line["cpu_baseline"]["sample"] = cb["sample"][:160]
+        line["cpu_baseline"]["sample"] = cb["sample"][:96]
         if "train" in cb:
             line["cpu_baseline"]["train"] = pick(cb["train"], "value", "unit", "ms_per_step", "cores", "kind")
     st = out.get("streaming")
@@ -810,7 +810,7 @@ def compact_line(out, detail=None):
         t["roofline"] = pick(r, "bound", "kernel", "achieved", "peak", "unit", "frac", "launches_per_step", "avg_launch_us", "whole_step_tflops",
                              "whole_step_frac_of_split_peak")
         t["roofline"]["kernel"] = r["kernel"][:48]
-        t["roofline"]["top"] = {k[:36]: [v["launches_per_step"], v["tflops"], v["ms_per_step"]] for k, v in list(r["all_variants"].items())[:7]}
+        t["roofline"]["top"] = {k[:30]: [v["launches_per_step"], v["tflops"], v["ms_per_step"]] for k, v in list(r["all_variants"].items())[:6]}
         line["train_step"] = t
     line["lstm_timeouts"] = out.get("lstm_timeouts", 0)
     line["detail"] = detail
