@@ -506,6 +506,7 @@ struct WkArgs {
   int n_tt, tiles_per_split;
   int MT;                    // 128-row tiles per workgroup (1 or 2)
   int gx, gy, gz, per_xcd;   // logical grid (row tiles, column-block quads, (b, t) slices) and workgroups per XCD (0: plain 3-D grid)
+  int narrow_rows;           // 1: a row tile with <= 32 real output channels runs the one-row-block wave layout (FAC_WGRAD_NARROW=0: off)
 };
 
 __device__ __forceinline__ void wk_barrier() {
@@ -733,6 +734,63 @@ __global__ __launch_bounds__((4 * MT + 4) * 64, MT == 1 ? 2 : 1) void conv1d_wgr
   int poff[WS_TT / 16];
 #pragma unroll
   for (int ks = 0; ks < WS_TT / 16; ++ks) poff[ks] = ((ks * 2 + kq) ^ sw) * 16;
+
+  if constexpr (MT == 1) {
+    // ---- at most 32 real output channels in this row tile (round 6: the multi-resolution discriminator's 32-channel stacks and
+    // the 1-channel output convs -- 75 + of the step's 227 weight gradients): three quarters of the 128 x 128 tile's MFMAs
+    // multiplied padding rows.  The four MFMA waves share the ONE real 32-row block and take 32 columns each (wave w: columns
+    // [32 w, 32 w + 32) of the tile): 24 MFMAs per 16-step slab instead of 96; the staging waves and the barrier protocol are
+    // untouched.  Two accumulators per wave (products 0 / 2 / 4 and 1 / 3 / 5) so that consecutive MFMAs do not depend on each other.
+    if (a.narrow_rows && a.C_out - co0 <= 32) {
+      const int aoff1 = l31 * WK_ROWB;
+      const int boff1 = A_OPND + (wave * 32 + l31) * WK_ROWB;
+      f32x16 acc_a, acc_b;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { acc_a[r] = 0.f; acc_b[r] = 0.f; }
+      bf16x8 A1[2][3], B1[2][3];
+      auto ld1 = [&](const unsigned char* st, int ks, bf16x8 (&Ad)[3], bf16x8 (&Bd)[3]) {
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+          Ad[p] = *reinterpret_cast<const bf16x8*>(st + aoff1 + p * A_PLANE + poff[ks]);
+          Bd[p] = *reinterpret_cast<const bf16x8*>(st + boff1 + p * WK_PLANE + poff[ks]);
+        }
+      };
+      wk_barrier();   // stage 0 staged
+      for (int base = 0; base < n_chunks; base += NST) {
+#pragma unroll
+        for (int i = 0; i < NST; ++i) {
+          const int chunk = base + i;
+          if (chunk < n_chunks) {
+            const unsigned char* st = sm + i * STAGE;
+            ld1(st, 0, A1[0], B1[0]);
+#pragma unroll
+            for (int ks = 0; ks < WS_TT / 16; ++ks) {
+              if (ks + 1 < WS_TT / 16) ld1(st, ks + 1, A1[(ks + 1) & 1], B1[(ks + 1) & 1]);
+              __builtin_amdgcn_sched_barrier(0);
+              constexpr int TA[6] = {1, 2, 0, 1, 0, 0}, TB[6] = {1, 0, 2, 0, 1, 0};     // smallest terms first
+#pragma unroll
+              for (int q = 0; q < 6; q += 2) {
+                acc_a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1[ks & 1][TA[q]], B1[ks & 1][TB[q]], acc_a, 0, 0, 0);
+                acc_b = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1[ks & 1][TA[q + 1]], B1[ks & 1][TB[q + 1]], acc_b, 0, 0, 0);
+              }
+              __builtin_amdgcn_sched_barrier(0);
+            }
+            wk_barrier();
+          }
+        }
+      }
+      float* pz1 = a.part + (long long)z * a.C_out * a.NBk * 32;
+      const int gb = gb0 + wave;
+      if (gb < a.NBk) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int co = co0 + (r & 3) + 8 * (r >> 2) + 4 * kq;
+          if (co < a.C_out) pz1[((long long)co * a.NBk + gb) * 32 + l31] = acc_a[r] + acc_b[r];
+        }
+      }
+      return;
+    }
+  }
 
   f32x16 acc[2][2];
 #pragma unroll
@@ -1009,6 +1067,8 @@ static int bwd_weight_split_impl(const float* x, const float* dy, float* dw, flo
       const bool xcd_order = xcd_env >= 0 ? xcd_env == 1 : S >= 5;
       const bool ksplit = k.MT == 1 && (ksp_env >= 0 ? ksp_env == 1
                                                      : (k.K == 7 && k.K2 == 1 && stride == 1 && (long long)grid.x * grid.y <= 256 && S >= 4));
+      static const bool narrow_on = !(getenv("FAC_WGRAD_NARROW") && getenv("FAC_WGRAD_NARROW")[0] == '0');
+      k.narrow_rows = narrow_on ? 1 : 0;
       k.gx = (int)grid.x; k.gy = (int)grid.y; k.gz = (int)grid.z; k.per_xcd = 0;
       if (xcd_order) {
         const long long total = (long long)grid.x * grid.y * grid.z;
