@@ -216,7 +216,8 @@ __global__ __launch_bounds__(256) void snake_bwd_kernel(const float* __restrict_
   const int c = blockIdx.x, sl = blockIdx.y, tid = threadIdx.x;
   const float al = alpha[c], ae = al + 1e-9f;
   const long long n = (long long)B * T;
-  const long long per = (n + RED_NS - 1) / RED_NS;
+  const int ns = gridDim.y;                     // slices in use (<= RED_NS), see fac_bias_grad
+  const long long per = (n + ns - 1) / ns;
   const long long lo = sl * per, hi = lo + per < n ? lo + per : n;
   float s = 0.f;
   if (lo < hi) {                                    // clip by clip: no per-element index division
@@ -246,6 +247,7 @@ __global__ __launch_bounds__(256) void snake_bwd_kernel(const float* __restrict_
     __syncthreads();
   }
   if (tid == 0) part[c * RED_NS + sl] = red[0];
+  if (sl == 0 && tid > 0 && tid < RED_NS && tid >= ns) part[c * RED_NS + tid] = 0.f;
 }
 
 // The same backward with the neighbours fused in: dx = add + dy * dsnake/dx (the other gradient of a tensor with two consumers --
@@ -259,7 +261,8 @@ __global__ __launch_bounds__(256) void snake_bwd_fused_kernel(const float* __res
   const int c = blockIdx.x, sl = blockIdx.y, tid = threadIdx.x;
   const float al = alpha[c], ae = al + 1e-9f;
   const long long n = (long long)B * T;
-  const long long per = (n + RED_NS - 1) / RED_NS;
+  const int ns = gridDim.y;                     // slices in use (<= RED_NS), see fac_bias_grad
+  const long long per = (n + ns - 1) / ns;
   const long long lo = sl * per, hi = lo + per < n ? lo + per : n;
   float s = 0.f, sb = 0.f;
   if (lo < hi) {
@@ -297,6 +300,10 @@ __global__ __launch_bounds__(256) void snake_bwd_fused_kernel(const float* __res
     part[c * RED_NS + sl] = red[0][0];
     if (part2) part2[c * RED_NS + sl] = red[1][0];
   }
+  if (sl == 0 && tid > 0 && tid < RED_NS && tid >= ns) {      // unused slices of this channel's rows
+    part[c * RED_NS + tid] = 0.f;
+    if (part2) part2[c * RED_NS + tid] = 0.f;
+  }
 }
 
 // The same kernel on 16-byte accesses (round 6): T % 4 == 0, x / add / dx rows 16-byte aligned, dy rows 8-byte aligned (a window of
@@ -313,7 +320,8 @@ __global__ __launch_bounds__(256) void snake_bwd_fused_v4_kernel(const float* __
   const float al = alpha[c], ae = al + 1e-9f;
   const int T4 = T >> 2;
   const long long n = (long long)B * T4;                       // quads of this channel
-  const long long per = (n + RED_NS - 1) / RED_NS;
+  const int ns = gridDim.y;                     // slices in use (<= RED_NS), see fac_bias_grad
+  const long long per = (n + ns - 1) / ns;
   const long long lo = sl * per, hi = lo + per < n ? lo + per : n;
   float s = 0.f, sb = 0.f;
   if (lo < hi) {
@@ -355,6 +363,10 @@ __global__ __launch_bounds__(256) void snake_bwd_fused_v4_kernel(const float* __
     part[c * RED_NS + sl] = red[0][0];
     if (part2) part2[c * RED_NS + sl] = red[1][0];
   }
+  if (sl == 0 && tid > 0 && tid < RED_NS && tid >= ns) {      // unused slices of this channel's rows
+    part[c * RED_NS + tid] = 0.f;
+    if (part2) part2[c * RED_NS + tid] = 0.f;
+  }
 }
 
 // db[c] = sum over (b, t) of dy: workgroup (c, slice) sums its contiguous share of the flattened (b, t) range -- walked clip by
@@ -363,8 +375,9 @@ __global__ __launch_bounds__(256) void snake_bwd_fused_v4_kernel(const float* __
 __global__ __launch_bounds__(256) void bias_grad_kernel(const float* __restrict__ dy, float* __restrict__ part, int B, int C, int T) {
   __shared__ float red[256];
   const int c = blockIdx.x, sl = blockIdx.y, tid = threadIdx.x;
+  const int ns = gridDim.y;                     // slices in use (<= RED_NS): small tensors get few, the rest of the row is zero-filled
   const long long n = (long long)B * T;
-  const long long per = (n + RED_NS - 1) / RED_NS;
+  const long long per = (n + ns - 1) / ns;
   const long long lo = sl * per, hi = lo + per < n ? lo + per : n;
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
   if (lo < hi) {
@@ -406,6 +419,7 @@ __global__ __launch_bounds__(256) void bias_grad_kernel(const float* __restrict_
     __syncthreads();
   }
   if (tid == 0) part[c * RED_NS + sl] = red[0];
+  if (sl == 0 && tid > 0 && tid < RED_NS && tid >= ns) part[c * RED_NS + tid] = 0.f;      // unused slices of this channel's row
 }
 
 __global__ void channel_reduce_kernel(const float* __restrict__ part, float* __restrict__ out, int C) {
@@ -534,11 +548,17 @@ extern "C" int fac_weight_norm_bwd(const float* v, const float* g, const float* 
   return fac::check_launch("weight_norm_bwd");
 }
 
+// slices of the (b, t) range per channel for the reduction kernels above: one per ~8 K work items, at most RED_NS
+static unsigned red_slices(long long items) {
+  long long ns = (items + 8191) / 8192;
+  return (unsigned)(ns < 1 ? 1 : (ns > fac::RED_NS ? fac::RED_NS : ns));
+}
+
 extern "C" int fac_snake_bwd(const float* x, const float* alpha, const float* dy, float* dx, float* dalpha, float* scratch,
                              int B, int C, int T, fac_stream_t stream) {
   using namespace fac;
   FAC_REQUIRE(x && alpha && dy && dx && dalpha && scratch && B > 0 && C > 0 && T > 0, "snake_bwd: bad arguments");
-  hipLaunchKernelGGL(snake_bwd_kernel, dim3(C, RED_NS), dim3(256), 0, (hipStream_t)stream, x, alpha, dy, dx, scratch, B, C, T);
+  hipLaunchKernelGGL(snake_bwd_kernel, dim3(C, red_slices((long long)B * T)), dim3(256), 0, (hipStream_t)stream, x, alpha, dy, dx, scratch, B, C, T);
   hipLaunchKernelGGL(channel_reduce_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, scratch, dalpha, C);
   return check_launch("snake_bwd");
 }
@@ -551,11 +571,11 @@ extern "C" int fac_snake_bwd_fused_rs(const float* x, const float* alpha, const 
   static const bool v4_on = !(getenv("FAC_SNAKE_BWD_V4") && getenv("FAC_SNAKE_BWD_V4")[0] == '0');
   auto al = [](const void* p, unsigned m) { return (reinterpret_cast<unsigned long long>(p) & m) == 0; };
   if (v4_on && (T & 3) == 0 && (dy_row_stride & 1) == 0 && al(x, 15) && al(dx, 15) && (!add || al(add, 15)) && al(dy, 7))
-    hipLaunchKernelGGL(snake_bwd_fused_v4_kernel, dim3(C, RED_NS), dim3(256), 0, (hipStream_t)stream, x, alpha, dy, add, dx, scratch,
-                       part2, B, C, T, dy_row_stride);
+    hipLaunchKernelGGL(snake_bwd_fused_v4_kernel, dim3(C, red_slices((long long)B * T / 4)), dim3(256), 0, (hipStream_t)stream, x, alpha, dy, add,
+                       dx, scratch, part2, B, C, T, dy_row_stride);
   else
-    hipLaunchKernelGGL(snake_bwd_fused_kernel, dim3(C, RED_NS), dim3(256), 0, (hipStream_t)stream, x, alpha, dy, add, dx, scratch, part2,
-                       B, C, T, dy_row_stride);
+    hipLaunchKernelGGL(snake_bwd_fused_kernel, dim3(C, red_slices((long long)B * T)), dim3(256), 0, (hipStream_t)stream, x, alpha, dy, add, dx,
+                       scratch, part2, B, C, T, dy_row_stride);
   hipLaunchKernelGGL(channel_reduce_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, scratch, dalpha, C);
   if (dbias)
     hipLaunchKernelGGL(channel_reduce_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, part2, dbias, C);
@@ -570,7 +590,9 @@ extern "C" int fac_snake_bwd_fused(const float* x, const float* alpha, const flo
 extern "C" int fac_bias_grad(const float* dy, float* db, float* scratch, int B, int C, int T, fac_stream_t stream) {
   using namespace fac;
   FAC_REQUIRE(dy && db && scratch && B > 0 && C > 0 && T > 0, "bias_grad: bad arguments");
-  hipLaunchKernelGGL(bias_grad_kernel, dim3(C, RED_NS), dim3(256), 0, (hipStream_t)stream, dy, scratch, B, C, T);
+  // one slice per ~8 K elements of a channel (round 6: (C, 32) workgroups for a (16, 1024, 160) tensor were 32 768 workgroups of
+  // 256 threads for 2.6 M elements -- 50 us; 43 such launches per train step)
+  hipLaunchKernelGGL(bias_grad_kernel, dim3(C, red_slices((long long)B * T)), dim3(256), 0, (hipStream_t)stream, dy, scratch, B, C, T);
   hipLaunchKernelGGL(channel_reduce_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, scratch, db, C);
   return check_launch("bias_grad");
 }

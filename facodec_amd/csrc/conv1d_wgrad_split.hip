@@ -121,7 +121,7 @@ __global__ __launch_bounds__(256) void split_planes_rowsum_kernel(const float* _
                                                                   long long plane_bytes) {
   __shared__ float red[256];
   const long long row = blockIdx.y;
-  const int uq = blockIdx.x * 256 + threadIdx.x;            // 8-step piece of the row
+  const int uq = blockIdx.x * blockDim.x + threadIdx.x;     // 8-step piece of the row (blockDim.x = 256, or 64 for rows of <= 512 steps)
   const float* xr = src + row * T;
   float sum = 0.f;
   if (uq * 8 < U) {
@@ -146,7 +146,7 @@ __global__ __launch_bounds__(256) void split_planes_rowsum_kernel(const float* _
   }
   red[threadIdx.x] = sum;
   __syncthreads();
-  for (int o = 128; o > 0; o >>= 1) {
+  for (int o = blockDim.x >> 1; o > 0; o >>= 1) {
     if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
     __syncthreads();
   }
@@ -1034,8 +1034,9 @@ static int bwd_weight_split_impl(const float* x, const float* dy, float* dw, flo
       if (db != nullptr && (long long)B * C_out <= 65535) {
         const int n_chunks = (k.UA + 2047) / 2048;
         float* rs = reinterpret_cast<float*>(bp + ws_align(3 * k.b_plane_bytes));
-        hipLaunchKernelGGL(split_planes_rowsum_kernel, dim3(n_chunks, B * C_out), dim3(256), 0, st, dy, ap, rs, T_out, k.UA, n_chunks,
-                           k.a_plane_bytes);
+        // short rows (the 160-frame layers: 20 pieces of 8 steps per row) get one wave per row instead of 256 threads of which 236 idle
+        hipLaunchKernelGGL(split_planes_rowsum_kernel, dim3(n_chunks, B * C_out), dim3(k.UA <= 512 ? 64 : 256), 0, st, dy, ap, rs, T_out, k.UA,
+                           n_chunks, k.a_plane_bytes);
         hipLaunchKernelGGL(bias_from_rowsums_kernel, dim3((C_out + 255) / 256), dim3(256), 0, st, rs, db, B, C_out, n_chunks);
         db = nullptr;
       } else {
