@@ -11,6 +11,7 @@ LIB_PATH = os.environ.get("FAC_LIB_PATH", os.path.join(_HERE, "libfacodec_hip.so
 
 PAD_ZERO, PAD_REFLECT = 0, 1
 ACT_NONE, ACT_TANH, ACT_MISH, ACT_LOG_MEL = 0, 1, 2, 3
+ACT_GATE, ACT_WN_RES_SKIP = 4, 5          # epilogues of the few-column split-reduction launches only (facodec_hip.h)
 
 _p = C.c_void_p
 _i = C.c_int

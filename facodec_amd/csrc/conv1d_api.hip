@@ -29,6 +29,7 @@ unsigned long long* g_conv_dbg = nullptr;
 // One or two output channels, plain stride-1 conv with nothing but bias / activation in the epilogue.
 // (it parallelises over (batch, 1024-step tile) only: with fewer than ~128 such tiles -- the period discriminators' 1024 -> 1
 // output conv over one row-concatenated signal -- the MFMA tile is 10x faster despite wasting 31 of its 32 rows)
+static const bool NARROW_TWO_LEVEL = !(getenv("FAC_NARROW_TWO_LEVEL") && getenv("FAC_NARROW_TWO_LEVEL")[0] == '0');
 static bool narrow_ok(const fac_conv_desc* d) {
   return d->C_out <= 2 && d->stride == 1 && d->n_phase == 1 && d->phase_shift == 0 && d->y_tstride == 1 && !d->res && !d->y2 &&
          !d->w_batched && d->y && (long long)d->B <= 65535 && (long long)d->B * ((d->T_out + 1023) / 1024) >= 128;
@@ -43,7 +44,7 @@ extern "C" void fac_debug_set_buffer(void* p) { fac::g_conv_dbg = (unsigned long
 extern "C" int fac_conv1d_fwd(const fac_conv_desc* d, fac_stream_t stream) {
   using namespace fac;
   FAC_REQUIRE(d && (d->x || d->x_p8) && (d->w || d->w_split) && (d->y || d->y2 || d->y2_p8), "conv1d: null pointer");
-  FAC_REQUIRE(!d->y2 || d->alpha_y2, "conv1d: y2 needs alpha_y2");
+  FAC_REQUIRE(!d->y2 || d->alpha_y2 || d->act == FAC_ACT_WN_RES_SKIP, "conv1d: y2 needs alpha_y2");
   FAC_REQUIRE(d->B > 0 && d->C_in > 0 && d->C_out > 0 && d->T_in > 0 && d->T_out > 0,
               "conv1d: bad shape B=%d C_in=%d C_out=%d T_in=%d T_out=%d", d->B, d->C_in, d->C_out,
               d->T_in, d->T_out);
@@ -97,6 +98,11 @@ extern "C" int fac_conv1d_fwd(const fac_conv_desc* d, fac_stream_t stream) {
     FAC_REQUIRE(ok, "conv1d: P8 operands given but the launch does not run on a kernel that takes them (K=%d stride=%d C_in=%d columns=%lld)",
                 d->K, d->stride, d->C_in, (long long)d->B * d->T_out);
   }
+  if (d->act == FAC_ACT_GATE || d->act == FAC_ACT_WN_RES_SKIP) {    // epilogues of the split-reduction kernel only
+    FAC_REQUIRE(d->w && !d->w_k1 && !d->x_p8 && !conv_two_level(a) && conv_skinny_ok(a, d->ws, d->ws_bytes),
+                "conv1d: FAC_ACT_GATE / FAC_ACT_WN_RES_SKIP exist only for few-column launches (B * T_out <= 640) with a workspace");
+    return conv_dispatch_skinny(a, d->ws, d->ws_bytes, s);
+  }
   if (d->w_k1) return conv_dispatch_fused_ru(a, s);
   a.gflat = 0;
   a.grt = 0;
@@ -127,7 +133,7 @@ extern "C" int fac_conv1d_fwd(const fac_conv_desc* d, fac_stream_t stream) {
               "conv1d: shape does not qualify for a split-bf16 kernel (K=%d stride=%d C_in=%d C_out=%d columns=%lld) and no fp32 "
               "weights were given", d->K, d->stride, d->C_in, d->C_out, (long long)d->B * d->T_out);
   if (!two_level && conv_skinny_ok(a, d->ws, d->ws_bytes)) return conv_dispatch_skinny(a, d->ws, d->ws_bytes, s);
-  if (!two_level && narrow_ok(d)) return conv_dispatch_narrow(a, s);
+  if (narrow_ok(d) && (!two_level || (NARROW_TWO_LEVEL && (a.KV - 1) * a.dil <= 64))) return conv_dispatch_narrow(a, s);
   if (conv_thin_ok(a, d->ws, d->ws_bytes)) return conv_dispatch_thin(a, d->ws, s);   // C_out <= 2 without enough tiles for narrow
   if (conv_cin1_ok(a)) return conv_dispatch_cin1(a, s);
   static const bool pw_on = !(getenv("FAC_PW") && getenv("FAC_PW")[0] == '0');
@@ -192,9 +198,12 @@ extern "C" int fac_conv1d_variant(const fac_conv_desc* d, char* name, int name_l
       return 10;
     }
   }
-  if (!(d->K1 > 0 && d->K1 < d->K) && narrow_ok(d)) {
-    if (name && name_len > 0) snprintf(name, name_len, "conv1d_narrow_kernel (VALU, C_out<=2)");
-    return 9;
+  {
+    const bool two = d->K1 > 0 && d->K1 < d->K;
+    if (narrow_ok(d) && (!two || (NARROW_TWO_LEVEL && (d->K1 - 1) * d->dilation <= 64))) {
+      if (name && name_len > 0) snprintf(name, name_len, two ? "conv1d_narrow_kernel (VALU, C_out<=2, two-level taps)" : "conv1d_narrow_kernel (VALU, C_out<=2)");
+      return 9;
+    }
   }
   {
     ConvArgs a{};

@@ -5,6 +5,10 @@
 // Rows are padded to a multiple of 4 floats so that a thread's window starts 16-byte aligned: for dilation 1 and K <= 9 the
 // window is three ds_read_b128 (lanes 16 B apart: conflict-free); element-wise reads at a 16-byte lane stride are 4-way bank
 // conflicts, which made the 96 -> 1 layer LDS-bound at 1.6 TB/s of input.
+// Two-level taps (fac_conv_desc.K1: the (3, k) Conv2d layers of the multi-resolution discriminator over a row-concatenated
+// signal) run as K / K1 VIRTUAL channels per real one, each the same input row read k2 * dilation2 columns further on (ConvArgs.K2v):
+// the 32 -> 1 output conv and the 32 -> 2 data gradient of the first layer then are plain 96-channel, 3- / 9-tap convs here
+// instead of 32-row MFMA tiles with 1 or 2 live rows (round 6: 213 -> ~90 us per launch for the first layer's data gradient).
 #include "conv1d_mfma.h"
 
 namespace fac {
@@ -15,7 +19,9 @@ constexpr int NARROW_CIC = 8;
 template <int CO>
 __global__ __launch_bounds__(256) void conv1d_narrow_kernel(ConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
-  const int K = a.K, dil = a.dil;
+  const int K = a.KV, dil = a.dil;                  // taps per (virtual) channel
+  const int CV = a.CV, K2v = a.K2v;
+  const bool two = K2v > 1;                         // two-level taps: zero padding only (fac_conv1d_fwd)
   const int halo = (K - 1) * dil;
   const int XW = (NARROW_TT + halo + 3) & ~3;
   float* xs = sm;                                   // [CIC][XW]
@@ -41,7 +47,8 @@ __global__ __launch_bounds__(256) void conv1d_narrow_kernel(ConvArgs a) {
     int idx = -1;
     if (c < XW) {
       const int tin = t0 - a.pad_left + c;
-      if (a.pad_mode == FAC_PAD_REFLECT) idx = reflect_index(tin, a.T_in, a.T_ext);
+      if (two) idx = tin;                          // the virtual channel's shift comes on top: bounds are checked per row
+      else if (a.pad_mode == FAC_PAD_REFLECT) idx = reflect_index(tin, a.T_in, a.T_ext);
       else idx = (tin >= 0 && tin < a.T_in) ? tin : -1;
     }
     s_idx[sl] = idx;
@@ -50,21 +57,31 @@ __global__ __launch_bounds__(256) void conv1d_narrow_kernel(ConvArgs a) {
   auto load_chunk = [&](int ci0) {
 #pragma unroll
     for (int r = 0; r < NARROW_CIC; ++r) {
-      const int ci = ci0 + r;                      // uniform
+      const int vc = ci0 + r;                      // uniform
+      const int ci = two ? vc / K2v : vc;
+      const int off = two ? (vc - ci * K2v) * a.dil2 : 0;
       const float* xrow = xg + (long long)ci * a.x_cs;
 #pragma unroll
-      for (int sl = 0; sl < SPR; ++sl) v[r][sl] = (ci < a.C_in && s_idx[sl] >= 0) ? xrow[s_idx[sl]] : 0.f;
+      for (int sl = 0; sl < SPR; ++sl) {
+        int idx = s_idx[sl];
+        bool ok = idx >= 0;
+        if (two) {
+          idx += off;
+          ok = sl * 256 + tid < XW && idx >= 0 && idx < a.T_in;
+        }
+        v[r][sl] = (vc < CV && ok) ? xrow[idx] : 0.f;
+      }
     }
   };
   load_chunk(0);
 
-  for (int ci0 = 0; ci0 < a.C_in; ci0 += NARROW_CIC) {
+  for (int ci0 = 0; ci0 < CV; ci0 += NARROW_CIC) {
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < NARROW_CIC; ++r) {
-      const int ci = ci0 + r;
-      const bool sn = a.alpha_in != nullptr && ci < a.C_in;
-      const float al = sn ? a.alpha_in[ci] : 0.f;
+      const int vc = ci0 + r;
+      const bool sn = a.alpha_in != nullptr && vc < CV;
+      const float al = sn ? a.alpha_in[two ? vc / K2v : vc] : 0.f;
       const float inv = sn ? snake_inv(al) : 0.f;
 #pragma unroll
       for (int sl = 0; sl < SPR; ++sl) {
@@ -75,11 +92,11 @@ __global__ __launch_bounds__(256) void conv1d_narrow_kernel(ConvArgs a) {
     for (int i = tid; i < NARROW_CIC * K * CO; i += 256) {
       const int r = i / (K * CO), rem = i - r * (K * CO);
       const int k = rem / CO, c = rem - k * CO;
-      const int ci = ci0 + r;
-      ws[i] = ci < a.C_in ? a.w[((long long)ci * K + k) * a.C_out_pad + c] : 0.f;
+      const int vc = ci0 + r;                      // row (vc * KV + k) of the packed weights IS row (ci * K + k2 * K1 + k)
+      ws[i] = vc < CV ? a.w[((long long)vc * K + k) * a.C_out_pad + c] : 0.f;
     }
     __syncthreads();
-    if (ci0 + NARROW_CIC < a.C_in) load_chunk(ci0 + NARROW_CIC);
+    if (ci0 + NARROW_CIC < CV) load_chunk(ci0 + NARROW_CIC);
     if (dil == 1 && K <= 9) {
 #pragma unroll 2
       for (int r = 0; r < NARROW_CIC; ++r) {
@@ -322,10 +339,10 @@ int conv_dispatch_thin(ConvArgs& a, void* ws, hipStream_t s) {
 }
 
 int conv_dispatch_narrow(ConvArgs& a, hipStream_t s) {
-  const int XW = (NARROW_TT + (a.K - 1) * a.dil + 3) & ~3;
-  const size_t lds = ((size_t)NARROW_CIC * XW + (size_t)NARROW_CIC * a.K * 2) * sizeof(float);
-  if (lds > 64 * 1024 || (a.K - 1) * a.dil > 64) {
-    set_error("conv1d(narrow): receptive field too wide (K=%d dil=%d)", a.K, a.dil);
+  const int XW = (NARROW_TT + (a.KV - 1) * a.dil + 3) & ~3;
+  const size_t lds = ((size_t)NARROW_CIC * XW + (size_t)NARROW_CIC * a.KV * 2) * sizeof(float);
+  if (lds > 64 * 1024 || (a.KV - 1) * a.dil > 64) {
+    set_error("conv1d(narrow): receptive field too wide (K=%d dil=%d)", a.KV, a.dil);
     return FAC_ERR_ARG;
   }
   dim3 grid((a.T_out + NARROW_TT - 1) / NARROW_TT, a.B);

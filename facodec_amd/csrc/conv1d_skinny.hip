@@ -16,7 +16,10 @@
 //     again without fences -- write-through (sc1) partial tiles, `s_waitcnt vmcnt(0)`, a relaxed per-tile ticket, the last
 //     workgroup of a tile reading the S slices back with sc1 loads: bit-identical, but the streaming hop went from p50 1.24 to
 //     1.69 ms: one workgroup pulling S x 16 KB past the L2 costs more than the dependent launch it saves.  Two launches it is.)
-//   * the epilogue is the tiled kernel's: bias, Snake, activation, residual, pre-activated second output.
+//   * the epilogue is the tiled kernel's: bias, Snake, activation, residual, pre-activated second output -- plus the two
+//     WaveNet epilogues of the streaming hop (round 6: a hop is ~170 dependent launches on its longer chain, so every
+//     elementwise launch folded into a reduction kernel is ~6 us of the 1.2 ms): FAC_ACT_GATE (tanh x sigmoid of the two
+//     channel halves, modules/commons.py:113-120) and FAC_ACT_WN_RES_SKIP (modules/wavenet.py:159-165).
 #include "conv1d_mfma.h"
 
 namespace fac {
@@ -41,6 +44,17 @@ __device__ __forceinline__ void skinny_emit(const ConvArgs& a, int e, float v, i
   if (co >= a.C_out || c2 >= ncol) return;
   const int b2 = c2 / a.T_out, t2 = c2 - b2 * a.T_out;
   v += a.bias ? a.bias[co] : 0.f;
+  if (a.act == FAC_ACT_WN_RES_SKIP) {        // first half: x += rs (res = x, may alias y); second half: out (= y2) += rs
+    const int half = a.C_out >> 1;
+    if (co < half) {
+      const long long o = (long long)b2 * a.y_bs + (long long)co * a.y_cs + t2;
+      a.y[o] = __fadd_rn(a.res[o], v);
+    } else {
+      const long long o = (long long)b2 * a.y_bs + (long long)(co - half) * a.y_cs + t2;
+      a.y2[o] = __fadd_rn(a.y2[o], v);
+    }
+    return;
+  }
   if (a.alpha_out) { const float al = a.alpha_out[co]; v = snake_apply(v, al, snake_inv(al)); }
   if (a.act != FAC_ACT_NONE) v = apply_act_slow(v, a.act);
   const long long o = (long long)b2 * a.y_bs + (long long)co * a.y_cs + (long long)t2 * a.y_tstride + phase;
@@ -49,6 +63,8 @@ __device__ __forceinline__ void skinny_emit(const ConvArgs& a, int e, float v, i
   if (a.y2) { const float al2 = a.alpha2[co]; a.y2[o] = snake_apply(v, al2, snake_inv(al2)); }
 }
 
+// U = weight rows a wave has in flight per round trip (one float4 + one B value per lane each)
+template <int U>
 __global__ __launch_bounds__(256) void conv1d_skinny_kernel(ConvArgs a, SkinnyGeom g, float* __restrict__ part) {
   extern __shared__ __attribute__((aligned(16))) float red[];   // [4 waves][4 m][16 r][64 lanes]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -85,7 +101,6 @@ __global__ __launch_bounds__(256) void conv1d_skinny_kernel(ConvArgs a, SkinnyGe
     for (int i = 0; i < 16; ++i) acc[m][i] = 0.f;
 
   int jp = r / K, k = r - jp * K;
-  constexpr int U = 8;
   while (r < r_end) {
     float4 av[U];
     float bv[U];
@@ -164,6 +179,57 @@ __global__ __launch_bounds__(256) void conv1d_skinny_reduce_kernel(ConvArgs a, S
   skinny_emit(a, 4 * e4 + 3, sum.w, co0, cb, phase, ncol);
 }
 
+// FAC_ACT_GATE: channel co of the first half of the output channels and co + C_out / 2 live in two tiles; one thread adds the
+// S partial sums of both (slice order, as above) and writes tanh(a) * sigmoid(b) -- gate_kernel's arithmetic (misc.hip) on the
+// values the plain reduction would have written.  C_out / 2 is a multiple of the 128-row tile, S > 1.
+__global__ __launch_bounds__(256) void conv1d_skinny_reduce_gate_kernel(ConvArgs a, SkinnyGeom g, const float* __restrict__ part) {
+  const int half_tiles = g.co_tiles >> 1;
+  const int pair = blockIdx.x >> 2, quarter = blockIdx.x & 3;
+  const int zi = pair / half_tiles;
+  const int ct = pair - zi * half_tiles;
+  const int co0 = ct * SK_CO;
+  const int cb = zi % g.n_cb;
+  const int ncol = a.B * a.T_out;
+  const int e4 = quarter * 256 + threadIdx.x;
+  const int half = a.C_out >> 1;
+  float4 sums[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int tile = zi * g.co_tiles + ct + h * half_tiles;
+    const float4* base = reinterpret_cast<const float4*>(part) + (long long)tile * g.S * 1024 + e4;
+    float4 pv[SK_MAX_S];
+#pragma unroll
+    for (int s = 0; s < SK_MAX_S; ++s) pv[s] = s < g.S ? base[(long long)s * 1024] : make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 sum = pv[0];
+#pragma unroll
+    for (int s = 1; s < SK_MAX_S; ++s) {
+      if (s < g.S) { sum.x += pv[s].x; sum.y += pv[s].y; sum.z += pv[s].z; sum.w += pv[s].w; }
+    }
+    sums[h] = sum;
+  }
+  const float va[4] = {sums[0].x, sums[0].y, sums[0].z, sums[0].w}, vb[4] = {sums[1].x, sums[1].y, sums[1].z, sums[1].w};
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int e = 4 * e4 + j;
+    const int ln = e & 63, ri = (e >> 6) & 15, m = e >> 10;
+    const int co = co0 + 4 * ((ri & 3) + 8 * (ri >> 2) + 4 * (ln >> 5)) + m;
+    const int c2 = cb * 32 + (ln & 31);
+    if (co >= half || c2 >= ncol) continue;
+    const int b2 = c2 / a.T_out, t2 = c2 - b2 * a.T_out;
+    const float ta = va[j] + (a.bias ? a.bias[co] : 0.f), sa = vb[j] + (a.bias ? a.bias[co + half] : 0.f);
+    a.y[(long long)b2 * a.y_bs + (long long)co * a.y_cs + t2] = __fmul_rn(tanhf(ta), sigmoid_f(sa));
+  }
+}
+
+// tuning knobs (tools/tune/skinny_probe.py): workgroups aimed at, fewest (ci-pair, tap) rows per slice, rows in flight per wave
+static int skinny_env(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return v && v[0] ? atoi(v) : dflt;
+}
+static const int kSkinnyWgs = skinny_env("FAC_SKINNY_WGS", 512);
+static const int kSkinnyMinRows = skinny_env("FAC_SKINNY_MIN_ROWS", 32);
+static const int kSkinnyU = skinny_env("FAC_SKINNY_U", 8);
+
 static SkinnyGeom skinny_geom(const ConvArgs& a, int* n_tiles) {
   SkinnyGeom g;
   g.rows = (cin_pad_dev(a.C_in) / 2) * a.K;
@@ -171,9 +237,9 @@ static SkinnyGeom skinny_geom(const ConvArgs& a, int* n_tiles) {
   g.n_cb = (ncol + 31) / 32;
   g.co_tiles = (a.C_out + SK_CO - 1) / SK_CO;
   const int tiles = g.co_tiles * g.n_cb * a.n_phase;
-  int S = (512 + tiles - 1) / tiles;                      // ~2 workgroups per CU
+  int S = (kSkinnyWgs + tiles - 1) / tiles;               // ~2 workgroups per CU
   if (tiles >= 128) S = 1;                                // enough tiles already: skip the reduce kernel
-  const int max_s = g.rows / 32 > 0 ? g.rows / 32 : 1;    // >= 8 rows per wave
+  const int max_s = g.rows / kSkinnyMinRows > 0 ? g.rows / kSkinnyMinRows : 1;    // >= 8 rows per wave
   if (S > max_s) S = max_s;
   if (S > SK_MAX_S) S = SK_MAX_S;
   if (S < 1) S = 1;
@@ -191,6 +257,10 @@ bool conv_skinny_ok(const ConvArgs& a, const void* ws, long long ws_bytes) {
   if (rows < 24) return false;                          // too little to split: the tiled kernel is fine
   int tiles;
   const SkinnyGeom g = skinny_geom(a, &tiles);
+  if (a.act == FAC_ACT_GATE && (g.S < 2 || a.C_out % (2 * SK_CO) != 0 || a.n_phase != 1 || a.y_tstride != 1 || a.alpha_out || a.res ||
+                                a.y2 || !a.y)) return false;
+  if (a.act == FAC_ACT_WN_RES_SKIP && (a.C_out % 2 != 0 || a.n_phase != 1 || a.y_tstride != 1 || a.alpha_out || !a.res || !a.y2 || !a.y))
+    return false;
   return ws_bytes >= (long long)tiles * g.S * 16384;
 }
 
@@ -200,13 +270,23 @@ int conv_dispatch_skinny(ConvArgs& a, void* ws, long long ws_bytes, hipStream_t 
   (void)ws_bytes;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv1d_skinny_kernel),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv1d_skinny_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv1d_skinny_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv1d_skinny_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
     attr_set = true;
   }
   float* part = reinterpret_cast<float*>(ws);
-  hipLaunchKernelGGL(conv1d_skinny_kernel, dim3(g.co_tiles, g.S, g.n_cb * a.n_phase), dim3(256), 65536, s, a, g, part);
-  if (g.S > 1)
+  const dim3 grid(g.co_tiles, g.S, g.n_cb * a.n_phase);
+  const int per_wave = (g.rows_per_slice + 3) / 4;
+  if (kSkinnyU >= 32 && per_wave > 16)
+    hipLaunchKernelGGL(conv1d_skinny_kernel<32>, grid, dim3(256), 65536, s, a, g, part);
+  else if (kSkinnyU >= 16 && per_wave > 8)
+    hipLaunchKernelGGL(conv1d_skinny_kernel<16>, grid, dim3(256), 65536, s, a, g, part);
+  else
+    hipLaunchKernelGGL(conv1d_skinny_kernel<8>, grid, dim3(256), 65536, s, a, g, part);
+  if (a.act == FAC_ACT_GATE)
+    hipLaunchKernelGGL(conv1d_skinny_reduce_gate_kernel, dim3(tiles * 2), dim3(256), 0, s, a, g, part);
+  else if (g.S > 1)
     hipLaunchKernelGGL(conv1d_skinny_reduce_kernel, dim3(tiles * 4), dim3(256), 0, s, a, g, part);
   return check_launch("conv1d_skinny");
 }

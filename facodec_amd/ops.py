@@ -9,7 +9,7 @@ import os
 import torch
 
 from . import _lib
-from ._lib import ConvDesc, VqDesc, PAD_REFLECT, PAD_ZERO, ACT_NONE, ACT_TANH, ACT_MISH, ACT_LOG_MEL  # noqa: F401
+from ._lib import ConvDesc, VqDesc, PAD_REFLECT, PAD_ZERO, ACT_NONE, ACT_TANH, ACT_MISH, ACT_LOG_MEL, ACT_GATE, ACT_WN_RES_SKIP  # noqa: F401
 
 
 def pad32(n):
@@ -574,12 +574,14 @@ def p8_prepass(x, flop_per_in_byte):
 
 def conv1d(x, w_packed, c_out, k, bias=None, stride=1, dilation=1, pad_left=None, pad_mode=PAD_REFLECT,
            t_out=None, alpha_in=None, alpha_out=None, res=None, act=ACT_NONE, out=None, causal=True,
-           alpha_y2=None, want_y=True, w_k1=None, bias_k1=None, w_split=None, k1=0, dilation2=0):
+           alpha_y2=None, want_y=True, w_k1=None, bias_k1=None, w_split=None, k1=0, dilation2=0, skip_acc=None):
     """Fused conv (see fac_conv1d_fwd).  x (B, C_in, T).  With pad_left=None the SConv1d padding
     rule is applied (causal: everything on the left; non-causal: asymmetric split).
     k1 / dilation2: two-level taps (tap k = k2 * k1 + k1' reads offset k2 * dilation2 + k1' * dilation), see fac_conv_desc.
     alpha_y2: also produce y2 = snake(y, alpha_y2) (returned as (y, y2); y is None if not want_y).
-    w_k1 / bias_k1: fused ResidualUnit tail -- y = w_k1 * snake(conv + bias, alpha_out) + bias_k1 + res."""
+    w_k1 / bias_k1: fused ResidualUnit tail -- y = w_k1 * snake(conv + bias, alpha_out) + bias_k1 + res.
+    act=ACT_GATE / ACT_WN_RES_SKIP (streaming hops only, facodec_hip.h): the output has c_out / 2 channels; ACT_WN_RES_SKIP adds
+    the first half of the channels to `res` (-> out, which may be res itself) and the second half onto `skip_acc` in place."""
     x_p8 = x if isinstance(x, P8) else None
     if x_p8 is not None:
         B, c_in, t_in = x_p8.shape
@@ -596,9 +598,13 @@ def conv1d(x, w_packed, c_out, k, bias=None, stride=1, dilation=1, pad_left=None
     if t_out is None:
         raise ValueError("t_out required with explicit pad_left")
     cp = w_packed.shape[-1] if w_packed is not None else pad32(c_out)
+    c_y = c_out // 2 if act in (ACT_GATE, ACT_WN_RES_SKIP) else c_out
     if out is None and want_y:
-        out = torch.empty(B, c_out, t_out, device=dev_, dtype=torch.float32)
+        out = torch.empty(B, c_y, t_out, device=dev_, dtype=torch.float32)
     y2 = torch.empty(B, c_out, t_out, device=dev_, dtype=torch.float32) if alpha_y2 is not None else None
+    if act == ACT_WN_RES_SKIP:
+        assert skip_acc is not None and skip_acc.is_contiguous() and skip_acc.shape == out.shape and alpha_y2 is None
+        y2 = skip_acc
     res = _dev(res, "res")
     d = ConvDesc()
     d.bias = bias.data_ptr() if bias is not None else None
@@ -617,13 +623,19 @@ def conv1d(x, w_packed, c_out, k, bias=None, stride=1, dilation=1, pad_left=None
     d.bias_k1 = bias_k1.data_ptr() if bias_k1 is not None else None
     d.w_split = w_split.data_ptr() if w_split is not None else None
     d.x_bs, d.x_cs = (x.stride(0), x.stride(1)) if x_p8 is None else (c_in * t_in, t_in)
-    d.y_bs, d.y_cs = c_out * t_out, t_out
+    d.y_bs, d.y_cs = c_y * t_out, t_out
     d.B, d.C_in, d.T_in, d.C_out, d.C_out_pad, d.T_out = B, c_in, t_in, c_out, cp, t_out
     d.K, d.stride, d.dilation, d.pad_left, d.pad_mode = k, stride, dilation, pad_left, pad_mode
     d.n_phase, d.y_tstride, d.act, d.w_batched, d.w_bs = 1, 1, act, 0, 0
     d.K1, d.dilation2 = k1, dilation2
     _launch_conv(d, "fac_conv1d_fwd")
     return (out, y2) if alpha_y2 is not None else out
+
+
+# Streaming hops: the WaveNet's elementwise launches folded into the reduction kernels of its convs (FAC_STREAM_FOLD=0: separate
+# launches, the round-5 hop; bit-identical either way -- tests/test_gpu_parity.py::test_streaming_folded_epilogues_are_bit_identical)
+STREAM_FOLD = os.environ.get("FAC_STREAM_FOLD", "1") != "0"
+SKINNY_MAX_COLS = 640
 
 
 def conv_transpose1d(x, w_packed, c_out, stride, bias=None, alpha_in=None, out=None, alpha_y2=None, causal=True,

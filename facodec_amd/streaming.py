@@ -321,10 +321,23 @@ class _QuantizerStream:
                        pad_mode=ops.PAD_ZERO, t_out=n)
         wn = q.melspec_encoder
         out = torch.zeros_like(h)
+        fold = ops.STREAM_FOLD and h.shape[0] * n <= ops.SKINNY_MAX_COLS
         for i in range(wn.n_layers):                       # WN.forward, modules/wavenet.py:138-166
-            a = _conv(wn.in_layers[i], self.wn_taps[i], h)
-            rs = wn.res_skip_layers[i].run(ops.gate_tanh_sigmoid(a))
-            ops.wn_res_skip_(rs, h, out, last=(i == wn.n_layers - 1))
+            last = i == wn.n_layers - 1
+            if not fold:
+                a = _conv(wn.in_layers[i], self.wn_taps[i], h)
+                rs = wn.res_skip_layers[i].run(ops.gate_tanh_sigmoid(a))
+                ops.wn_res_skip_(rs, h, out, last=last)
+                continue
+            # the same arithmetic with the gate and the residual / skip adds as epilogues of the two convs' reduction kernels
+            acts = _conv(wn.in_layers[i], self.wn_taps[i], h, act=ops.ACT_GATE)
+            rsl = wn.res_skip_layers[i]
+            w = rsl.w
+            if last:
+                ops.conv1d(acts, w.packed(), w.c_out, 1, bias=w.bias, pad_left=0, pad_mode=ops.PAD_ZERO, t_out=n, res=out, out=out)
+            else:
+                ops.conv1d(acts, w.packed(), w.c_out, 1, bias=w.bias, pad_left=0, pad_mode=ops.PAD_ZERO, t_out=n, res=h, out=h,
+                           skip_acc=out, act=ops.ACT_WN_RES_SKIP)
         f0_feat = q.melspec_linear2.run(out)
         z_p, codes_p = self._rvq(q.prosody_quantizer, f0_feat, 1)
         z_c, codes_c = self._rvq(q.content_quantizer, x, n_c)

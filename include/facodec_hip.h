@@ -38,6 +38,15 @@ typedef void* fac_stream_t; /* hipStream_t */
 #define FAC_ACT_TANH 1  /* nn.Tanh, dac/model/dac.py:159 */
 #define FAC_ACT_MISH 2  /* x*tanh(softplus(x)), modules/style_encoder.py:6-10 */
 #define FAC_ACT_LOG_MEL 3 /* (log(1e-5+x)+4)/4, modules/quantize.py:241 */
+/* The two epilogues of a WaveNet layer (modules/wavenet.py:138-166), taken only by the few-column split-reduction launches of
+ * the streaming hop (B * T_out <= 640; fac_conv1d_fwd fails for any other shape -- there the elementwise kernels
+ * fac_gate_tanh_sigmoid / fac_wn_res_skip do the same arithmetic):
+ *   FAC_ACT_GATE        : y (B, C_out / 2, T) = tanh(c[:, :C_out/2]) * sigmoid(c[:, C_out/2:]) of c = conv + bias
+ *                         (fused_add_tanh_sigmoid_multiply without conditioning, modules/commons.py:113-120); C_out % 256 == 0.
+ *   FAC_ACT_WN_RES_SKIP : c = conv + bias; y (B, C_out / 2, T) = res + c[:, :C_out/2] (res may be y itself) and
+ *                         y2 (B, C_out / 2, T) += c[:, C_out/2:] (no alpha_y2; y2 is the running skip sum). */
+#define FAC_ACT_GATE 4
+#define FAC_ACT_WN_RES_SKIP 5
 
 /* ABI version; bumped whenever a signature changes. */
 int fac_version(void);

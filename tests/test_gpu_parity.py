@@ -1021,6 +1021,43 @@ def test_streaming_matches_offline(full_model, cuda, use_graphs):
     assert rel(torch.cat(got_wave, -1), y) < E2E_TOL
 
 
+def _run_session(m, wave, timbre, n_hops, use_graphs=True):
+    from facodec_amd.streaming import HOP, StreamingCodec
+    sess = StreamingCodec(m, timbre, n_c=2, use_graphs=use_graphs)
+    outs = [sess.prime(wave[:, :, :4800])]
+    for h in range(n_hops):
+        o = sess.push(wave[:, :, 4800 + h * HOP: 4800 + (h + 1) * HOP])
+        outs.append({k: ([c.clone() for c in v] if isinstance(v, list) else (v.clone() if torch.is_tensor(v) else v)) for k, v in o.items()})
+    outs.append(sess.finish())
+    return outs
+
+
+def test_streaming_folded_epilogues_are_bit_identical(full_model, cuda, ops, monkeypatch):
+    """Round 6: the hop's elementwise launches folded into its convs' reduction kernels (WaveNet gate and residual / skip adds,
+    FAC_ACT_GATE / FAC_ACT_WN_RES_SKIP) and the left-context buffers written by their producers -- every code and every output
+    sample equals the hop built from separate launches (FAC_STREAM_FOLD=0), graphs on, over three periods."""
+    from facodec_amd.streaming import HOP
+    m = full_model
+    n_hops = 15
+    wave = synth.synth_clips(2, 4800 + n_hops * HOP, seed=12).to(cuda)
+    with torch.no_grad():
+        timbre = m.quantizer(m.encoder(wave), wave, n_c=2)[4]
+        monkeypatch.setattr(ops, "STREAM_FOLD", False)
+        ref = _run_session(m, wave, timbre, n_hops)
+        monkeypatch.setattr(ops, "STREAM_FOLD", True)
+        got = _run_session(m, wave, timbre, n_hops)
+    n_frames = 0
+    for r, g in zip(ref, got):
+        assert r["frame0"] == g["frame0"] and (r["codes"] is None) == (g["codes"] is None)
+        if r["codes"] is None:
+            continue
+        n_frames += r["codes"][0].shape[-1]
+        for a, b in zip(r["codes"], g["codes"]):
+            assert torch.equal(a, b)
+        assert torch.equal(r["wave"], g["wave"])
+    assert n_frames == (4800 + n_hops * HOP) // 300
+
+
 def test_stream_push_kernel(ops, cuda):
     g = _g(3)
     buf = torch.zeros(2, 3, 10 + 7, device=cuda)

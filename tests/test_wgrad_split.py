@@ -185,3 +185,43 @@ def test_two_level_conv_is_conv2d(sf, kf, F0, P, T, cuda):
         dw = wc.grad.cpu().reshape(co, ci, 3, kf)
         assert float((dw.double() - wr.grad).abs().max() / wr.grad.abs().max()) < 1e-5, split
         assert float((bc.grad.cpu().double() - r.sum((0, 2, 3))).abs().max()) < 1e-3
+
+
+@pytest.mark.parametrize("ci,co,kf,sf,F0,P,T", [(2, 32, 9, 1, 129, 144, 480), (32, 1, 3, 1, 129, 144, 480), (2, 32, 9, 2, 129, 144, 480)])
+def test_two_level_convs_with_one_or_two_live_channels_run_on_the_narrow_kernel(ci, co, kf, sf, F0, P, T, cuda):
+    """Round 6: the multi-resolution discriminator's 32 -> 1 output conv (forward) and the 2-channel data gradient of its first
+    layer (dac/model/discriminator.py:110-121) are two-level-tap convs with one or two output channels: VALU kernel over
+    3 x C_in virtual channels (conv1d_narrow.hip) instead of a 32-row MFMA tile.  Forward and data gradient against conv2d in fp64."""
+    from facodec_amd import autograd_disc as AD
+    g = torch.Generator().manual_seed(5 + ci + kf)
+    B, pf = 2, kf // 2
+    x4 = torch.randn(B, ci, T, F0, generator=g)
+    w = torch.randn(co, ci, 3, kf, generator=g) * 0.2
+    bias = torch.randn(co, generator=g)
+    xr = x4.double().requires_grad_()
+    y_ref = F.conv2d(xr, w.double(), bias.double(), stride=(1, sf), padding=(1, pf))
+    F1 = y_ref.shape[-1]
+    r = torch.randn(*y_ref.shape, generator=g).double()
+    (y_ref * r).sum().backward()
+    P_out = P // sf
+    cat = torch.zeros(ci, B, T + 1, P)
+    cat[:, :, :T, :F0] = x4.permute(1, 0, 2, 3)
+    rc = torch.zeros(co, B, T + 1, P_out)
+    rc[:, :, :T, :F1] = r.permute(1, 0, 2, 3).float()
+    xc = cat.reshape(1, ci, -1).to(cuda).requires_grad_()
+    wc = w.reshape(co, ci, 3 * kf).to(cuda).requires_grad_()
+    bc = bias.to(cuda).requires_grad_()
+    prof = ops.ConvLaunchProfile()
+    ops.set_conv_profile(prof)
+    try:
+        y = AD.PlainConv.apply(xc, wc, None, bc, 3 * kf, sf, P + pf, (kf, P))
+        (y * rc.reshape(1, co, -1).to(cuda)).sum().backward()
+        torch.cuda.synchronize()
+    finally:
+        ops.set_conv_profile(None)
+    if sf == 1:          # (the strided first layers' data gradient is a zero-inserted stride-1 conv as well; forward with stride stays on its tile)
+        assert any("narrow" in k and "two-level" in k for k in prof.summary()), prof.summary().keys()
+    yv = y.detach().cpu().reshape(co, B, T + 1, P_out)[:, :, :T, :F1].permute(1, 0, 2, 3)
+    assert float((yv.double() - y_ref.detach()).abs().max() / y_ref.detach().abs().max()) < 1e-5
+    dx = xc.grad.cpu().reshape(ci, B, T + 1, P)[:, :, :T, :F0].permute(1, 0, 2, 3)
+    assert float((dx.double() - xr.grad).abs().max() / xr.grad.abs().max()) < 1e-5
