@@ -108,6 +108,7 @@ SIGNATURES = {
     "fac_grad_norm_clip": (_i, [_p, _i64, _f, _p, _p, _p]),
     "fac_adamw_step": (_i, [_p, _p, _p, _p, _i64, _f, _f, _f, _f, _f, _i64, _p, _p]),
     "fac_logdiff_rms_bwd": (_i, [_p, _p, _p, _i, _i, _i, _f, _f, _i, _p]),
+    "fac_gather_copy": (_i, [_p, _p, _p, _i, _p]),
     "fac_adamw_step_masked": (_i, [_p, _p, _p, _p, _i64, _p, _i, _p, _p, _p, _f, _f, _f, _f, _f, _p, _p]),
     "fac_gate_bwd": (_i, [_p, _p, _p, _i, _i, _i, _p]),
     "fac_mish_fwd": (_i, [_p, _p, _i64, _p]),

@@ -25,6 +25,7 @@ new tensor to `p.grad` is folded into the arena and marked by `gather_grads()` /
 pre-bound view (`p.grad.copy_(...)`, `p.grad.add_(...)`) is invisible to both -- call `mark_grads()` (all parameters, or
 the ones given) after writing gradients that way, otherwise those parameters are skipped like `grad is None`.
 """
+import ctypes
 import os
 
 import torch
@@ -93,6 +94,35 @@ class NativeRccl:
         t.record_stream(self.stream)
         self.calls += 1
         return _NativeWork(done)
+
+
+GATHER_COPY = os.environ.get("FAC_GATHER_COPY", "1") != "0"
+
+
+def _fold(dst, src):
+    """dst[j].copy_(src[j]) for all j.  On the GPU: fac_gather_copy (a few launches, ~0.1 ms of host time for 300 tensors) for the
+    contiguous fp32 pairs; torch._foreach_copy_ (measured 17 us of host time per tensor, a hipMemcpyAsync for every second one)
+    for whatever is left, on the CPU, and with FAC_GATHER_COPY=0."""
+    rest_d, rest_s = dst, src
+    if GATHER_COPY and dst[0].is_cuda:
+        ok = [s.is_cuda and s.dtype == torch.float32 and d.dtype == torch.float32 and s.is_contiguous() and d.is_contiguous()
+              and s.numel() == d.numel() and s.numel() > 0 for d, s in zip(dst, src)]
+        fd = [d for d, k in zip(dst, ok) if k]
+        fs = [s for s, k in zip(src, ok) if k]
+        if fd:
+            n = len(fd)
+            ps = (ctypes.c_void_p * n)(*[s.data_ptr() for s in fs])
+            pd = (ctypes.c_void_p * n)(*[d.data_ptr() for d in fd])
+            ne = (ctypes.c_int64 * n)(*[s.numel() for s in fs])
+            _lib.check(_lib.load().fac_gather_copy(ps, pd, ne, n, ops._stream()), "fac_gather_copy")
+        rest_d = [d for d, k in zip(dst, ok) if not k]
+        rest_s = [s for s, k in zip(src, ok) if not k]
+    if rest_d:
+        if hasattr(torch, "_foreach_copy_"):                # (takes its slow path by itself for tensors that differ in dtype / layout)
+            torch._foreach_copy_(rest_d, rest_s)
+        else:
+            for a, b in zip(rest_s, rest_d):
+                b.copy_(a)
 
 
 class FlatAdamW:
@@ -276,11 +306,7 @@ class FlatAdamW:
                 p.grad = v
                 touched[i] = True
         if src:
-            if hasattr(torch, "_foreach_copy_"):            # (takes its slow path by itself for tensors that differ in dtype / layout)
-                torch._foreach_copy_(dst, src)
-            else:
-                for a, b in zip(src, dst):
-                    b.copy_(a)
+            _fold(dst, src)
 
     def gather_grads(self, mark_all=False):
         """Compatibility with callers that assign `.grad` tensors by hand: folds them into the arena (no-op for views).

@@ -340,6 +340,10 @@ int fac_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, floa
 int fac_adamw_step_masked(float* p, const float* g, float* m, float* v, int64_t n, const int64_t* offsets, int n_params,
                           const float* flags, int32_t* steps, float* bc, float lr, float beta1, float beta2, float eps,
                           float weight_decay, const float* clip, fac_stream_t stream);
+/* dst[j][0..n[j]) = src[j][0..n[j]) for `count` fp32 tensors (host arrays of device pointers and element counts), a few launches
+ * for all of them: folds the gradient tensors autograd produced into the optimiser's flat gradient arena (the arena is what
+ * train.py:362-374's clip_grad_norm_ + optimizer.step() read). */
+int fac_gather_copy(const void* const* src, void* const* dst, const int64_t* n, int count, fac_stream_t stream);
 /* Training path of the FA-quantizer's side branches (modules/wavenet.py gate, modules/style_encoder.py Mish / GLU /
  * masked mean, modules/attentions.py attention): elementwise backward kernels, and attention with the probability
  * matrix P (B, H, T, T) kept in HBM so that dropout on it and the softmax backward are row kernels.

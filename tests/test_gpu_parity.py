@@ -1595,6 +1595,37 @@ def test_flat_adamw_matches_torch(cuda):
         assert rel(o, r) < 1e-5
 
 
+def test_gather_copy_folds_many_tensors_bit_exactly(cuda, monkeypatch):
+    """fac_gather_copy (the fold of autograd's gradient tensors into the optimiser arena): 300 tensors -- one element to several
+    workgroups' worth, odd lengths, destinations at element offsets that are not 16-byte aligned, non-contiguous and fp64 sources
+    (left to torch) -- land exactly where `copy_` puts them, and nothing else of the arena changes."""
+    from facodec_amd import optim
+    g = _g(5)
+    sizes = [1, 2, 3, 5, 64, 255, 1023, 4097, 8192, 8193, 70001] * 27 + [3, 1 << 20, 7]
+    assert len(sizes) == 300
+    arena = torch.full((sum(sizes) + 64,), -7.0, device=cuda)
+    ref = arena.clone()
+    dst, src, off = [], [], 5                       # first destination starts 20 bytes into the arena
+    for j, n in enumerate(sizes):
+        d = arena[off:off + n]
+        if j % 50 == 7:
+            s_ = torch.randn(n, 2, generator=g).to(cuda)[:, 0]            # non-contiguous
+        elif j % 50 == 9:
+            s_ = torch.randn(n, generator=g).double().to(cuda)           # another dtype
+        else:
+            s_ = torch.randn(n, generator=g).to(cuda)
+        ref[off:off + n].copy_(s_)
+        dst.append(d)
+        src.append(s_)
+        off += n
+    optim._fold(dst, src)
+    assert torch.equal(arena, ref)
+    arena2 = torch.full_like(arena, -7.0)
+    monkeypatch.setattr(optim, "GATHER_COPY", False)
+    optim._fold([arena2[d.storage_offset():d.storage_offset() + d.numel()] for d in dst], src)
+    assert torch.equal(arena2, ref)
+
+
 def test_generator_step_gradients_against_autograd(O, cuda):
     """encoder -> FA-quantizer (training mode, fixed dropout masks) -> decoder -> 15 mel + 0.25 commitment + codebook:
     gradients of every trained parameter (timbre encoder and prosody WaveNet included; Bernoulli dropouts off for the

@@ -49,7 +49,7 @@ def main():
         g[2] += fl
     tot = sum(g[1] for g in groups.values())
     print("B C_in C_out T_out K K1 s d d2 ph rp kernel | launches  ms  TFLOP/s      (sum %.1f ms)" % tot)
-    for key, (n, ms, fl) in sorted(groups.items(), key=lambda kv: -kv[1][1])[:70]:
+    for key, (n, ms, fl) in sorted(groups.items(), key=lambda kv: -kv[1][1])[:int(os.environ.get("FAC_LAYERS_TOP", "70"))]:
         print("%3d %5d %5d %8d %2d %2d %d %d %5d %d %d %-44s | %3d %8.3f %7.1f" % (*key, n, ms, fl / ms / 1e9))
 
 
