@@ -221,8 +221,136 @@ __global__ __launch_bounds__(256) void conv1d_skinny_reduce_gate_kernel(ConvArgs
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// One to four output columns and a small weight matrix (the frame-rate layers of a streaming hop at B = 1: the prosody WaveNet,
+// the mel projections -- tools/tune/hop_layers.py): ONE launch.  The two-kernel scheme above costs such a conv 10 - 13 us of the
+// hop's graph whatever its size (dependent launch + the partial tiles' round trip through memory), a single small kernel ~6 us.
+// Output channels are split across workgroups (8 per workgroup: two float4 of the packed (row, co) weights), every workgroup walks
+// ALL (ci, tap) rows, one row per thread and step, VALU FMAs against the <= 4 column values; the 256 threads' 8 x 4 partial sums
+// meet in LDS in a fixed order (32-thread groups, then the 8 groups).  The layouts the 32-column MFMA tile wastes (1 - 2 live
+// columns of 32) do not exist here.  Epilogue as above, FAC_ACT_GATE included (the workgroup then owns channels c .. c + 3 of BOTH halves).
+// CO = 8 output channels per workgroup (two float4 per weight row), or 4 where 8 would leave fewer than 256 workgroups walking
+// more than ~100 KB of weights each (one workgroup streams at ~1/100 of the chip's bandwidth).
+template <int CO>
+__global__ __launch_bounds__(256) void conv1d_gemv_kernel(ConvArgs a) {
+  constexpr int GV_CO = CO;
+  __shared__ float red[256 * 33];
+  __shared__ float fin[8][32];
+  __shared__ float tot[32];
+  const int tid = threadIdx.x;
+  const int K = a.K, CP = a.C_out_pad;
+  const int ncol = a.B * a.T_out;
+  const bool gate = a.act == FAC_ACT_GATE;
+  const int half = a.C_out >> 1;
+  // workgroups i, i + 8, i + 16 ... share an XCD (and its L2): give them NEIGHBOURING channel groups, so that the 128-byte lines of a
+  // weight row (four groups of 32 bytes) are fetched into one L2 instead of four
+  const int nb = gridDim.x, per = nb >> 3;
+  const int wg = (nb & 7) == 0 ? (blockIdx.x & 7) * per + (blockIdx.x >> 3) : blockIdx.x;
+  const int coA = gate ? 4 * wg : GV_CO * wg;
+  const int coB = gate ? half + 4 * wg : coA + 4;
+  const bool okA = coA < CP, okB = (CO == 8 || gate) && coB < CP;
+  const int rows = a.C_in * K;
+  const bool reflect = a.pad_mode == FAC_PAD_REFLECT;
+  // column c -> (b, first input index)
+  int xoff[4], tin0[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const int cc = c < ncol ? c : 0;
+    const int b = cc / a.T_out, t = cc - b * a.T_out;
+    xoff[c] = b;                     // batch index (the offset itself may exceed 32 bits)
+    tin0[c] = t * a.stride - a.pad_left;
+  }
+  float acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc[i][c] = 0.f;
+#pragma unroll 4
+  for (int r = tid; r < rows; r += 256) {
+    const int ci = r / K, k = r - ci * K;
+    const float* wr = a.w + (long long)r * CP;
+    const float4 wa = okA ? *reinterpret_cast<const float4*>(wr + coA) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 wb = okB ? *reinterpret_cast<const float4*>(wr + coB) : make_float4(0.f, 0.f, 0.f, 0.f);
+    float xv[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      int tin = tin0[c] + k * a.dil;
+      if (reflect) tin = reflect_index(tin, a.T_in, a.T_ext);
+      xv[c] = (c < ncol && tin >= 0 && tin < a.T_in) ? a.x[(long long)xoff[c] * a.x_bs + (long long)ci * a.x_cs + tin] : 0.f;
+    }
+    const float w8[8] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w};
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) acc[i][c] = fmaf(w8[i], xv[c], acc[i][c]);
+  }
+  // ---- 256 threads x 32 values -> 32 values, fixed order
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) red[tid * 33 + i * 4 + c] = acc[i][c];
+  __syncthreads();
+  {
+    const int v = tid & 31, grp = tid >> 5;
+    float sum = 0.f;
+    for (int j = 0; j < 32; ++j) sum += red[(grp * 32 + j) * 33 + v];
+    fin[grp][v] = sum;
+  }
+  __syncthreads();
+  if (tid < 32) {
+    float sum = fin[0][tid];
+#pragma unroll
+    for (int gq = 1; gq < 8; ++gq) sum += fin[gq][tid];
+    const int i = tid >> 2;
+    const int co = i < 4 ? coA + i : coB + (i - 4);
+    tot[tid] = sum + ((a.bias && co < a.C_out && (i < 4 || okB)) ? a.bias[co] : 0.f);
+  }
+  __syncthreads();
+  if (tid >= 32) return;
+  const int i = tid >> 2, c = tid & 3;
+  if (c >= ncol || (i >= 4 && !okB)) return;
+  const int co = i < 4 ? coA + i : coB + (i - 4);
+  if (co >= a.C_out) return;
+  const int b2 = c / a.T_out, t2 = c - b2 * a.T_out;
+  float v = tot[tid];
+  if (gate) {
+    if (i >= 4) return;
+    a.y[(long long)b2 * a.y_bs + (long long)co * a.y_cs + t2] = __fmul_rn(tanhf(v), sigmoid_f(tot[tid + 16]));
+    return;
+  }
+  if (a.act == FAC_ACT_WN_RES_SKIP) {
+    if (co < half) {
+      const long long o = (long long)b2 * a.y_bs + (long long)co * a.y_cs + t2;
+      a.y[o] = __fadd_rn(a.res[o], v);
+    } else {
+      const long long o = (long long)b2 * a.y_bs + (long long)(co - half) * a.y_cs + t2;
+      a.y2[o] = __fadd_rn(a.y2[o], v);
+    }
+    return;
+  }
+  if (a.alpha_out) { const float al = a.alpha_out[co]; v = snake_apply(v, al, snake_inv(al)); }
+  if (a.act != FAC_ACT_NONE) v = apply_act_slow(v, a.act);
+  const long long o = (long long)b2 * a.y_bs + (long long)co * a.y_cs + t2;
+  if (a.res) v += a.res[o];
+  if (a.y) a.y[o] = v;
+  if (a.y2) { const float al2 = a.alpha2[co]; a.y2[o] = snake_apply(v, al2, snake_inv(al2)); }
+}
+
+static int skinny_env(const char* name, int dflt);
+// 8 or 4 channels per workgroup, or 0: not a shape for this kernel
+static int gemv_co(const ConvArgs& a) {
+  static const bool on = skinny_env("FAC_GEMV", 1) != 0;
+  static const long long max_wg = (long long)skinny_env("FAC_GEMV_MAX_WG_KB", 100) * 1024;   // weights one workgroup may walk
+  if (!on || (long long)a.B * a.T_out > 4 || a.n_phase != 1 || a.y_tstride != 1) return 0;
+  if (a.act == FAC_ACT_GATE) return a.C_out % 8 == 0 && (long long)a.C_in * a.K * 32 <= max_wg ? 8 : 0;
+  const long long row_bytes8 = (long long)a.C_in * a.K * 32;
+  if (row_bytes8 <= max_wg * 3 / 4 || (a.C_out + 7) / 8 >= 256) return row_bytes8 <= max_wg ? 8 : (row_bytes8 / 2 <= max_wg ? 4 : 0);
+  return row_bytes8 / 2 <= max_wg ? 4 : 0;
+}
+static bool gemv_ok(const ConvArgs& a) { return gemv_co(a) != 0; }
+
 // tuning knobs (tools/tune/skinny_probe.py): workgroups aimed at, fewest (ci-pair, tap) rows per slice, rows in flight per wave
-static int skinny_env(const char* name, int dflt) {
+static int skinny_env(const char* name, int dflt) {   // (declared above for gemv_ok)
   const char* v = getenv(name);
   return v && v[0] ? atoi(v) : dflt;
 }
@@ -257,14 +385,20 @@ bool conv_skinny_ok(const ConvArgs& a, const void* ws, long long ws_bytes) {
   if (rows < 24) return false;                          // too little to split: the tiled kernel is fine
   int tiles;
   const SkinnyGeom g = skinny_geom(a, &tiles);
-  if (a.act == FAC_ACT_GATE && (g.S < 2 || a.C_out % (2 * SK_CO) != 0 || a.n_phase != 1 || a.y_tstride != 1 || a.alpha_out || a.res ||
-                                a.y2 || !a.y)) return false;
+  if (a.act == FAC_ACT_GATE && (((g.S < 2 || a.C_out % (2 * SK_CO) != 0) && !gemv_ok(a)) || a.n_phase != 1 || a.y_tstride != 1 ||
+                                a.alpha_out || a.res || a.y2 || !a.y)) return false;
   if (a.act == FAC_ACT_WN_RES_SKIP && (a.C_out % 2 != 0 || a.n_phase != 1 || a.y_tstride != 1 || a.alpha_out || !a.res || !a.y2 || !a.y))
     return false;
   return ws_bytes >= (long long)tiles * g.S * 16384;
 }
 
 int conv_dispatch_skinny(ConvArgs& a, void* ws, long long ws_bytes, hipStream_t s) {
+  if (const int co = gemv_co(a)) {
+    const int wgs = a.act == FAC_ACT_GATE ? (a.C_out / 2 + 3) / 4 : (a.C_out + co - 1) / co;
+    if (co == 8) hipLaunchKernelGGL(conv1d_gemv_kernel<8>, dim3(wgs), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(conv1d_gemv_kernel<4>, dim3(wgs), dim3(256), 0, s, a);
+    return check_launch("conv1d_gemv");
+  }
   int tiles;
   const SkinnyGeom g = skinny_geom(a, &tiles);
   (void)ws_bytes;

@@ -624,6 +624,10 @@ def conv1d(x, w_packed, c_out, k, bias=None, stride=1, dilation=1, pad_left=None
     d.w_split = w_split.data_ptr() if w_split is not None else None
     d.x_bs, d.x_cs = (x.stride(0), x.stride(1)) if x_p8 is None else (c_in * t_in, t_in)
     d.y_bs, d.y_cs = c_y * t_out, t_out
+    if out is not None and (out.stride(0), out.stride(1)) != (d.y_bs, d.y_cs) and out.shape[0] * out.shape[1] > 1:
+        # a time-contiguous view of a wider buffer as the output (streaming: the LSTM pre-activations of the real batch columns)
+        assert out.stride(2) == 1 and y2 is None and res is None and out.shape == (B, c_y, t_out)
+        d.y_bs, d.y_cs = out.stride(0), out.stride(1)
     d.B, d.C_in, d.T_in, d.C_out, d.C_out_pad, d.T_out = B, c_in, t_in, c_out, cp, t_out
     d.K, d.stride, d.dilation, d.pad_left, d.pad_mode = k, stride, dilation, pad_left, pad_mode
     d.n_phase, d.y_tstride, d.act, d.w_batched, d.w_bs = 1, 1, act, 0, 0

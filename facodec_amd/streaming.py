@@ -32,6 +32,7 @@ from . import ops
 from .dac_model import FUSED_RU_CHANNELS, DecoderBlock, EncoderBlock
 from .layers import ConvWeights
 
+LSTM_REAL_COLUMNS = os.environ.get("FAC_STREAM_LSTM_REAL_COLUMNS", "1") != "0"     # _LSTMState.run
 HOP = 480            # samples per streaming hop (20 ms @ 24 kHz)
 FRAME = 300          # encoder hop (prod of strides 2*5*5*6)
 PERIOD = 2400        # lcm(HOP, FRAME): 5 hops = 8 frames
@@ -99,6 +100,7 @@ class _LSTMState:
         self.bias = [ops.add(getattr(p, f"bias_ih_l{l}").detach(), getattr(p, f"bias_hh_l{l}").detach()) for l in range(L)]
         self.whh = [ops.pack_lstm_whh(getattr(p, f"weight_hh_l{l}").detach()) for l in range(L)]
         self.c = [0]             # steps taken
+        self._pre = {}           # (layer, T) -> zero-initialised (4H, T, BP) pre-activation buffer, real batch columns rewritten per hop
         sess._counters.append(self)
 
     def run(self, x, alpha_out):
@@ -106,9 +108,20 @@ class _LSTMState:
         B, H, T = x.shape
         inp = ops.lstm_to_time_major(x)
         BP = inp.shape[2]
+        few = LSTM_REAL_COLUMNS and T * B <= 4 and B < BP
         for l in range(len(self.state)):
-            pre = ops.conv1d(inp.view(1, H, T * BP), self.w_ih[l], 4 * H, 1, bias=self.bias[l], pad_left=0,
-                             t_out=T * BP, pad_mode=ops.PAD_ZERO)
+            if few:
+                # The recurrence kernel wants the batch padded to 32 columns; the input projection does not: as T "clips" of B
+                # columns (views of the time-major buffers) it is a 1 - 4 column conv on the single-launch kernel instead of a
+                # 32 T column one whose other columns are padding (33 -> 10 us per layer of the decoder's LSTM, tools/tune/hop_layers.py)
+                pre = self._pre.get((l, T))
+                if pre is None:
+                    pre = self._pre[(l, T)] = torch.zeros(4 * H, T, BP, device=x.device)
+                ops.conv1d(inp.view(H, T, BP).permute(1, 0, 2)[:, :, :B], self.w_ih[l], 4 * H, 1, bias=self.bias[l], pad_left=0,
+                           t_out=B, pad_mode=ops.PAD_ZERO, out=pre.permute(1, 0, 2)[:, :, :B])
+            else:
+                pre = ops.conv1d(inp.view(1, H, T * BP), self.w_ih[l], 4 * H, 1, bias=self.bias[l], pad_left=0,
+                                 t_out=T * BP, pad_mode=ops.PAD_ZERO).view(4 * H, T, BP)
             inp = ops.lstm_layer(pre.view(4 * H, T, BP), self.whh[l], H, state=self.state[l], step0=self.c[0])
         self.c[0] += T
         return ops.lstm_from_time_major(inp, x if self.m.skip else None, B, alpha_out)

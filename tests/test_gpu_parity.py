@@ -82,6 +82,12 @@ CONV_CASES = [
     (16, 1024, 8, 160, 1, 1, 1, False, False, False, 0, "zero"),
     (3, 520, 5, 333, 2, 1, 1, False, True, False, 0, "zero"),
     (2, 256, 4, 700, 1, 1, 1, False, False, False, 1, "zero"),
+    # one to four output columns, small weight matrix (round 6: the streaming hop's frame-rate layers on the single-launch VALU kernel)
+    (1, 256, 512, 2, 5, 1, 1, False, False, False, 0, "zero"),
+    (2, 256, 512, 2, 1, 1, 1, False, True, True, 0, "zero"),
+    (1, 1025, 80, 1, 1, 1, 1, False, False, False, 1, "zero"),
+    (1, 37, 45, 3, 5, 1, 2, False, True, True, 0, "reflect"),
+    (4, 20, 256, 1, 1, 1, 1, False, False, False, 0, "zero"),
 ]
 
 
@@ -110,6 +116,36 @@ def test_conv1d_against_oracle(case, O, ops, cuda):
                     res=r.to(cuda) if res else None, act=act)
     assert yg.shape == y.shape
     assert rel(yg, y) < OP_TOL
+
+
+@pytest.mark.parametrize("B,T", [(1, 1), (1, 2), (2, 2), (3, 2)])
+def test_wavenet_layer_epilogues_in_the_conv_match_the_elementwise_kernels(B, T, ops, cuda):
+    """FAC_ACT_GATE / FAC_ACT_WN_RES_SKIP (the gate and the residual / skip adds of a WaveNet layer, modules/wavenet.py:138-166, as
+    epilogues of its two convs in a streaming hop) against conv + fac_gate_tanh_sigmoid / fac_wn_res_skip, bit for bit, plus the
+    pre-activated second output on the same few-column launches; B * T <= 4 takes the single-launch kernel, B * T = 6 the
+    split-reduction pair."""
+    g = _g(17 + B + T)
+    H = 256
+    h = torch.randn(B, H, T + 4, generator=g).to(cuda)
+    w_in = ops.pack_conv_weight((torch.randn(2 * H, H, 5, generator=g) / (5 * H) ** 0.5).to(cuda))
+    b_in = (torch.randn(2 * H, generator=g) * 0.1).to(cuda)
+    w_rs = ops.pack_conv_weight((torch.randn(2 * H, H, 1, generator=g) / H ** 0.5).to(cuda))
+    b_rs = (torch.randn(2 * H, generator=g) * 0.1).to(cuda)
+    kw = dict(pad_left=0, pad_mode=ops.PAD_ZERO, t_out=T)
+    a = ops.conv1d(h, w_in, 2 * H, 5, bias=b_in, **kw)
+    acts_ref = ops.gate_tanh_sigmoid(a)
+    acts = ops.conv1d(h, w_in, 2 * H, 5, bias=b_in, act=ops.ACT_GATE, **kw)
+    assert acts.shape == (B, H, T) and torch.equal(acts, acts_ref)
+    x0 = torch.randn(B, H, T, generator=g).to(cuda)
+    out0 = torch.randn(B, H, T, generator=g).to(cuda)
+    x_ref, out_ref = x0.clone(), out0.clone()
+    ops.wn_res_skip_(ops.conv1d(acts, w_rs, 2 * H, 1, bias=b_rs, **kw), x_ref, out_ref, last=False)
+    x_got, out_got = x0.clone(), out0.clone()
+    ops.conv1d(acts, w_rs, 2 * H, 1, bias=b_rs, res=x_got, out=x_got, skip_acc=out_got, act=ops.ACT_WN_RES_SKIP, **kw)
+    assert torch.equal(x_got, x_ref) and torch.equal(out_got, out_ref)
+    al = (1 + 0.2 * torch.rand(2 * H, generator=g)).to(cuda)
+    y, y2 = ops.conv1d(acts, w_rs, 2 * H, 1, bias=b_rs, alpha_y2=al, **kw)
+    assert torch.equal(y, ops.conv1d(acts, w_rs, 2 * H, 1, bias=b_rs, **kw)) and rel(y2, ops.snake(y, al)) < 1e-6
 
 
 @pytest.mark.parametrize("B,ci,co,T,s", [(2, 256, 128, 160, 6), (2, 128, 64, 333, 5), (1, 192, 96, 1000, 2), (1, 24, 12, 7, 5)])
