@@ -251,6 +251,8 @@ __global__ __launch_bounds__(256) void conv1d_gemv_kernel(ConvArgs a) {
   const bool okA = coA < CP, okB = (CO == 8 || gate) && coB < CP;
   const int rows = a.C_in * K;
   const bool reflect = a.pad_mode == FAC_PAD_REFLECT;
+  const int phase = blockIdx.y;        // polyphase ConvTranspose1d: weights of phase p, outputs at t * y_tstride + p
+  const float* wbase = a.w + (long long)phase * cin_pad_dev(a.C_in) * K * CP;
   // column c -> (b, first input index)
   int xoff[4], tin0[4];
 #pragma unroll
@@ -268,7 +270,7 @@ __global__ __launch_bounds__(256) void conv1d_gemv_kernel(ConvArgs a) {
 #pragma unroll 4
   for (int r = tid; r < rows; r += 256) {
     const int ci = r / K, k = r - ci * K;
-    const float* wr = a.w + (long long)r * CP;
+    const float* wr = wbase + (long long)r * CP;
     const float4 wa = okA ? *reinterpret_cast<const float4*>(wr + coA) : make_float4(0.f, 0.f, 0.f, 0.f);
     const float4 wb = okB ? *reinterpret_cast<const float4*>(wr + coB) : make_float4(0.f, 0.f, 0.f, 0.f);
     float xv[4];
@@ -318,6 +320,7 @@ __global__ __launch_bounds__(256) void conv1d_gemv_kernel(ConvArgs a) {
     a.y[(long long)b2 * a.y_bs + (long long)co * a.y_cs + t2] = __fmul_rn(tanhf(v), sigmoid_f(tot[tid + 16]));
     return;
   }
+  const long long o = (long long)b2 * a.y_bs + (long long)co * a.y_cs + (long long)t2 * a.y_tstride + phase;
   if (a.act == FAC_ACT_WN_RES_SKIP) {
     if (co < half) {
       const long long o = (long long)b2 * a.y_bs + (long long)co * a.y_cs + t2;
@@ -330,7 +333,6 @@ __global__ __launch_bounds__(256) void conv1d_gemv_kernel(ConvArgs a) {
   }
   if (a.alpha_out) { const float al = a.alpha_out[co]; v = snake_apply(v, al, snake_inv(al)); }
   if (a.act != FAC_ACT_NONE) v = apply_act_slow(v, a.act);
-  const long long o = (long long)b2 * a.y_bs + (long long)co * a.y_cs + t2;
   if (a.res) v += a.res[o];
   if (a.y) a.y[o] = v;
   if (a.y2) { const float al2 = a.alpha2[co]; a.y2[o] = snake_apply(v, al2, snake_inv(al2)); }
@@ -339,12 +341,16 @@ __global__ __launch_bounds__(256) void conv1d_gemv_kernel(ConvArgs a) {
 static int skinny_env(const char* name, int dflt);
 // 8 or 4 channels per workgroup, or 0: not a shape for this kernel
 static int gemv_co(const ConvArgs& a) {
-  static const bool on = skinny_env("FAC_GEMV", 1) != 0;
+  const bool on = skinny_env("FAC_GEMV", 1) != 0;            // (read per launch: tools/tune/stream_ab_inproc.py flips it between sessions)
   static const long long max_wg = (long long)skinny_env("FAC_GEMV_MAX_WG_KB", 100) * 1024;   // weights one workgroup may walk
-  if (!on || (long long)a.B * a.T_out > 4 || a.n_phase != 1 || a.y_tstride != 1) return 0;
-  if (a.act == FAC_ACT_GATE) return a.C_out % 8 == 0 && (long long)a.C_in * a.K * 32 <= max_wg ? 8 : 0;
+  if (!on || (long long)a.B * a.T_out > 4 || a.phase_shift != 0) return 0;
+  if (a.act == FAC_ACT_GATE || a.act == FAC_ACT_WN_RES_SKIP) {
+    if (a.n_phase != 1 || a.y_tstride != 1) return 0;
+    if (a.act == FAC_ACT_GATE) return a.C_out % 8 == 0 && (long long)a.C_in * a.K * 32 <= max_wg ? 8 : 0;
+  }
   const long long row_bytes8 = (long long)a.C_in * a.K * 32;
-  if (row_bytes8 <= max_wg * 3 / 4 || (a.C_out + 7) / 8 >= 256) return row_bytes8 <= max_wg ? 8 : (row_bytes8 / 2 <= max_wg ? 4 : 0);
+  if (row_bytes8 <= max_wg * 3 / 4 || (long long)((a.C_out + 7) / 8) * a.n_phase >= 256)
+    return row_bytes8 <= max_wg ? 8 : (row_bytes8 / 2 <= max_wg ? 4 : 0);
   return row_bytes8 / 2 <= max_wg ? 4 : 0;
 }
 static bool gemv_ok(const ConvArgs& a) { return gemv_co(a) != 0; }
@@ -367,7 +373,10 @@ static SkinnyGeom skinny_geom(const ConvArgs& a, int* n_tiles) {
   const int tiles = g.co_tiles * g.n_cb * a.n_phase;
   int S = (kSkinnyWgs + tiles - 1) / tiles;               // ~2 workgroups per CU
   if (tiles >= 128) S = 1;                                // enough tiles already: skip the reduce kernel
-  const int max_s = g.rows / kSkinnyMinRows > 0 ? g.rows / kSkinnyMinRows : 1;    // >= 8 rows per wave
+  // >= 8 rows per wave; >= 4 for the short reductions (k = 1 with <= 512 channels: otherwise one workgroup per tile, a handful of
+  // workgroups on the chip and the whole epilogue in them -- 17 -> 10 us for the 64- / 96-channel ResidualUnit tails of a hop)
+  const int min_rows = g.rows <= 256 ? (kSkinnyMinRows < 16 ? kSkinnyMinRows : 16) : kSkinnyMinRows;
+  const int max_s = g.rows / min_rows > 0 ? g.rows / min_rows : 1;
   if (S > max_s) S = max_s;
   if (S > SK_MAX_S) S = SK_MAX_S;
   if (S < 1) S = 1;
@@ -395,8 +404,8 @@ bool conv_skinny_ok(const ConvArgs& a, const void* ws, long long ws_bytes) {
 int conv_dispatch_skinny(ConvArgs& a, void* ws, long long ws_bytes, hipStream_t s) {
   if (const int co = gemv_co(a)) {
     const int wgs = a.act == FAC_ACT_GATE ? (a.C_out / 2 + 3) / 4 : (a.C_out + co - 1) / co;
-    if (co == 8) hipLaunchKernelGGL(conv1d_gemv_kernel<8>, dim3(wgs), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(conv1d_gemv_kernel<4>, dim3(wgs), dim3(256), 0, s, a);
+    if (co == 8) hipLaunchKernelGGL(conv1d_gemv_kernel<8>, dim3(wgs, a.n_phase), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(conv1d_gemv_kernel<4>, dim3(wgs, a.n_phase), dim3(256), 0, s, a);
     return check_launch("conv1d_gemv");
   }
   int tiles;

@@ -319,17 +319,15 @@ class _QuantizerStream:
             return None
         return self.z_fifo.window(f0, n).contiguous()
 
-    def run(self, n_c, final=False, x=None):
-        """Quantizes the frames whose look-ahead is complete -> (outs, [codes_p, codes_c, codes_r]) or None.
-        x: their latents if `take_latents` already copied them out."""
+    def prosody(self, final=False):
+        """The branch of the frames whose look-ahead is complete that depends on the WAVEFORM only (log-mel -> 1x1 -> WaveNet -> 1x1 ->
+        prosody RVQ, modules/quantize.py:398-413) -> (n, z_p, codes_p) or None."""
         q = self.q
         f0 = self.c[0]
         n = self.frames_ready(self.wave.c[0], final) - f0
         if n <= 0:
             return None
         mel = self._mel(f0, n, final)
-        if x is None:
-            x = self.z_fifo.window(f0, n).contiguous()
         h = ops.conv1d(mel[:, :20], q.melspec_linear.w.packed(), 256, 1, bias=q.melspec_linear.w.bias, pad_left=0,
                        pad_mode=ops.PAD_ZERO, t_out=n)
         wn = q.melspec_encoder
@@ -353,11 +351,32 @@ class _QuantizerStream:
                            skip_acc=out, act=ops.ACT_WN_RES_SKIP)
         f0_feat = q.melspec_linear2.run(out)
         z_p, codes_p = self._rvq(q.prosody_quantizer, f0_feat, 1)
-        z_c, codes_c = self._rvq(q.content_quantizer, x, n_c)
+        return n, z_p, codes_p
+
+    def content(self, n_c, x):
+        """Content RVQ of the due latents (modules/quantize.py:415-420): depends on the latents only."""
+        return self._rvq(self.q.content_quantizer, x, n_c)
+
+    def rest(self, x, pros, cont):
+        """Residual RVQ of what the first two leave, sum, timbre-conditioned LayerNorm (modules/quantize.py:422-453)."""
+        q = self.q
+        n, z_p, codes_p = pros
+        z_c, codes_c = cont
         z_r, codes_r = self._rvq(q.residual_quantizer, ops.sub2(x, z_p, z_c), 3)
         outs = ops.layernorm_c_affine(ops.add(ops.add(z_p, z_c), z_r), self.style)
         self.c[0] += n
         return outs, [codes_p, codes_c, codes_r]
+
+    def run(self, n_c, final=False, x=None):
+        """Quantizes the frames whose look-ahead is complete -> (outs, [codes_p, codes_c, codes_r]) or None.
+        x: their latents if `take_latents` already copied them out."""
+        f0 = self.c[0]
+        pros = self.prosody(final)
+        if pros is None:
+            return None
+        if x is None:
+            x = self.z_fifo.window(f0, pros[0]).contiguous()
+        return self.rest(x, pros, self.content(n_c, x))
 
 
 class StreamingCodec:

@@ -162,6 +162,23 @@ def test_conv_transpose_against_oracle(B, ci, co, T, s, O, ops, cuda):
     assert yg.shape == y.shape and rel(yg, y) < OP_TOL
 
 
+@pytest.mark.parametrize("B,ci,co,T,s", [(1, 1536, 768, 2, 6), (1, 256, 128, 1, 6), (2, 128, 60, 2, 5), (1, 24, 12, 3, 2), (1, 768, 384, 12, 5)])
+def test_conv_transpose_with_few_columns(B, ci, co, T, s, O, ops, cuda):
+    """The polyphase ConvTranspose1d on 1 - 4 input frames (the streaming hop's first upsampling layer at B = 1: the single-launch
+    VALU kernel, one workgroup row per phase) and on 12 (split-reduction pair), with the pre-activated second output."""
+    g = _g(60 + s + T)
+    x = torch.randn(B, ci, T, generator=g)
+    v = torch.randn(ci, co, 2 * s, generator=g) / (ci * 2) ** 0.5
+    gg = torch.rand(ci, 1, 1, generator=g) + 0.5
+    b = torch.randn(co, generator=g) * 0.1
+    al = 1 + 0.2 * torch.rand(co, generator=g)
+    y = O.sconvtr1d(x, O.weight_norm_weight(v, gg), b, s, causal=True)
+    wp = ops.pack_convtr_weight(v.to(cuda), gg.to(cuda), s)
+    yg, y2 = ops.conv_transpose1d(x.to(cuda), wp, co, s, bias=b.to(cuda), alpha_y2=al.to(cuda))
+    assert yg.shape == y.shape and rel(yg, y) < OP_TOL
+    assert rel(y2, O.snake(y, al.view(1, -1, 1))) < OP_TOL
+
+
 @pytest.mark.parametrize("B,ci,co,T,s", [(2, 192, 96, 1000, 2), (2, 96, 40, 777, 5), (1, 128, 64, 1333, 6), (3, 64, 22, 512, 3)])
 def test_conv_transpose_all_phases_launch(B, ci, co, T, s, O, ops, cuda):
     """The all-phases-per-workgroup ConvTranspose1d (fac_conv_desc.row_phases: (channel, phase) rows, phases interleaved
@@ -1082,16 +1099,17 @@ def test_streaming_folded_epilogues_are_bit_identical(full_model, cuda, ops, mon
         ref = _run_session(m, wave, timbre, n_hops)
         monkeypatch.setattr(ops, "STREAM_FOLD", True)
         got = _run_session(m, wave, timbre, n_hops)
-    n_frames = 0
-    for r, g in zip(ref, got):
-        assert r["frame0"] == g["frame0"] and (r["codes"] is None) == (g["codes"] is None)
-        if r["codes"] is None:
-            continue
-        n_frames += r["codes"][0].shape[-1]
-        for a, b in zip(r["codes"], g["codes"]):
-            assert torch.equal(a, b)
-        assert torch.equal(r["wave"], g["wave"])
-    assert n_frames == (4800 + n_hops * HOP) // 300
+    for other in (got,):
+        n_frames = 0
+        for r, g in zip(ref, other):
+            assert r["frame0"] == g["frame0"] and (r["codes"] is None) == (g["codes"] is None)
+            if r["codes"] is None:
+                continue
+            n_frames += r["codes"][0].shape[-1]
+            for a, b in zip(r["codes"], g["codes"]):
+                assert torch.equal(a, b)
+            assert torch.equal(r["wave"], g["wave"])
+        assert n_frames == (4800 + n_hops * HOP) // 300
 
 
 def test_stream_push_kernel(ops, cuda):
