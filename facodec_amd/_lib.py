@@ -31,6 +31,7 @@ class ConvDesc(C.Structure):
         ("w_batched", C.c_int32), ("w_bs", _i64), ("ws", _p), ("ws_bytes", _i64), ("w_split", _p),
         ("K1", C.c_int32), ("dilation2", C.c_int32), ("row_phases", C.c_int32),
         ("x_p8", _p), ("x_p8_plane_bytes", _i64), ("y2_p8", _p), ("y2_p8_plane_bytes", _i64),
+        ("pw_split", C.c_int32),
     ]
 
 

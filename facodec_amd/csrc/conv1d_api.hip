@@ -137,6 +137,7 @@ extern "C" int fac_conv1d_fwd(const fac_conv_desc* d, fac_stream_t stream) {
   if (conv_thin_ok(a, d->ws, d->ws_bytes)) return conv_dispatch_thin(a, d->ws, s);   // C_out <= 2 without enough tiles for narrow
   if (conv_cin1_ok(a)) return conv_dispatch_cin1(a, s);
   static const bool pw_on = !(getenv("FAC_PW") && getenv("FAC_PW")[0] == '0');
+  if (pw_on && d->pw_split && conv_pw_ok(a) && conv_pws_ok(a)) return conv_dispatch_pws(a, s);   // k = 1 tails at C <= 192 on the bf16 pipe
   if (pw_on && conv_pw_ok(a)) return conv_dispatch_pw(a, s);
   switch (select_variant(d)) {
     case 0: return conv_dispatch_128x32(a, s);
@@ -226,6 +227,11 @@ extern "C" int fac_conv1d_variant(const fac_conv_desc* d, char* name, int name_l
     }
     a.K = d->K; a.pad_left = d->pad_left; a.T_in = d->T_in; a.C_out_pad = d->C_out_pad; a.w = d->w;
     static const bool pw_on = !(getenv("FAC_PW") && getenv("FAC_PW")[0] == '0');
+    a.x_p8 = reinterpret_cast<const unsigned char*>(d->x_p8);
+    if (pw_on && d->pw_split && conv_pw_ok(a) && conv_pws_ok(a)) {
+      if (name && name_len > 0) snprintf(name, name_len, "conv1d_pws_kernel (k=1 streaming, W planes in LDS, bf16x3 split, fp32-grade)");
+      return 17;
+    }
     if (pw_on && conv_pw_ok(a)) {
       if (name && name_len > 0) snprintf(name, name_len, "conv1d_pw_kernel (k=1 streaming, W in LDS)");
       return 14;

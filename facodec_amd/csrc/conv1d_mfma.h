@@ -817,6 +817,8 @@ int conv_dispatch_gsplit(ConvArgs& a, hipStream_t s);
 bool conv_bsplit_ok(const ConvArgs& a);
 bool conv_bsplit_p8_ok(const ConvArgs& a);   // ... and the launch takes a P8 input (wide shape: C_in >= 64, C_in % 16 == 0)
 int conv_dispatch_bsplit(ConvArgs& a, hipStream_t s);
+bool conv_pws_ok(const ConvArgs& a);
+int conv_dispatch_pws(ConvArgs& a, hipStream_t s);
 bool conv_skinny_ok(const ConvArgs& a, const void* ws, long long ws_bytes);
 int conv_dispatch_skinny(ConvArgs& a, void* ws, long long ws_bytes, hipStream_t s);
 

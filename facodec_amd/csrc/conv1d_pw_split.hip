@@ -1,0 +1,255 @@
+// The streaming k = 1 kernel of conv1d_pw.hip on the bf16 matrix pipe (round 6): the ResidualUnit tails at C <= 192
+// (dac/model/dac.py:33-42) with both operands split into three bf16 planes (hi + mid + lo == value exactly; six products,
+// smallest first, fp32 accumulate -- the "fp32-grade" arithmetic of conv1d_bsplit.hip / conv1d_gemm_split.hip).
+// Same skeleton as conv1d_pw.hip -- weights resident in LDS for the life of the workgroup, a wave owns 32 columns x 32 MBW
+// output channels at a time, B operand straight from global memory through a register ring, epilogue in the C/D layout with
+// bias / Snake / residual / y / y2 -- but:
+//   * the weights are split ONCE in the prologue into the A-fragment order of v_mfma_f32_32x32x16_bf16
+//     ([K step of 16][32-row block][plane][lane][8 bf16]: one ds_read_b128 per fragment, conflict-free), 6 bytes per weight:
+//     96 output channels x 192 inputs = 108 KB, so C = 192 runs as two slices of 96 (as C = 256 / 384 do on the fp32 kernel);
+//   * a K step is 16 input channels: lane (kq, l31) loads x[16 s + 8 kq + j][t0 + l31], j = 0..7 (two full 128-byte lines per
+//     instruction, as before), splits the eight values in registers and feeds 6 x MBW MFMAs of 32 cycles -- 2.7 x fewer
+//     matrix-pipe cycles than the 8 x MBW fp32 MFMAs of 64 cycles for the same 16 channels (C = 192: 288 fp32 MFMAs per block
+//     and wave were 37 us per round of the chip against 33 us of HBM time).
+#include "conv1d_mfma.h"
+
+namespace fac {
+
+typedef __bf16 pws_bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ void pws_split3(float x, __bf16& h, __bf16& m, __bf16& l) {
+  h = (__bf16)x;
+  const float r1 = x - (float)h;
+  m = (__bf16)r1;
+  l = (__bf16)(r1 - (float)m);
+}
+
+// MBW: accumulator blocks per wave; NSPLIT: waves sharing a column block (C_out slice = 32 * MBW * NSPLIT); WAVES per workgroup;
+// D: K steps of 16 input channels in flight per wave (C_in % (16 D) == 0)
+template <int MBW, int NSPLIT, int WAVES, int D>
+__global__ __launch_bounds__(WAVES * 64) void conv1d_pws_kernel(ConvArgs a, int nblk, int n_items) {
+  constexpr int CO = 32 * MBW * NSPLIT;
+  constexpr int NB = CO / 32;                                  // 32-row blocks of the slice
+  extern __shared__ __attribute__((aligned(16))) unsigned char pws_sm[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, kq = lane >> 5;
+  const int S16 = a.C_in >> 4;
+  const int n_slices = a.C_out / CO;
+  const int slice = (blockIdx.x >> 3) % n_slices;
+  const int wg = (blockIdx.x & 7) + 8 * (blockIdx.x / (8 * n_slices));
+  const int n_wg = gridDim.x / n_slices;
+  const int co_base = slice * CO;
+  float* prm_all = reinterpret_cast<float*>(pws_sm + (size_t)S16 * NB * 3 * 1024);
+  {
+    const int n_frag = S16 * NB * 64;                          // one (K step, block, lane) = 8 weights = three 16-byte stores
+    for (int i = tid; i < n_frag; i += WAVES * 64) {
+      const int ln = i & 63, rest = i >> 6;
+      const int mb = rest % NB, s = rest / NB;
+      const int co = co_base + 32 * mb + (ln & 31);
+      const int ci0 = 16 * s + 8 * (ln >> 5);
+      pws_bf16x8 h, m, l;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        __bf16 a0, a1, a2;
+        pws_split3(a.w[(long long)(ci0 + j) * a.C_out_pad + co], a0, a1, a2);
+        h[j] = a0; m[j] = a1; l[j] = a2;
+      }
+      unsigned char* dst = pws_sm + ((size_t)(s * NB + mb) * 3) * 1024 + ln * 16;
+      *reinterpret_cast<pws_bf16x8*>(dst) = h;
+      *reinterpret_cast<pws_bf16x8*>(dst + 1024) = m;
+      *reinterpret_cast<pws_bf16x8*>(dst + 2048) = l;
+    }
+    for (int i = tid; i < CO; i += WAVES * 64) {
+      const int co = co_base + i;
+      prm_all[i] = a.bias ? a.bias[co] : 0.f;
+      prm_all[CO + i] = a.alpha_out ? a.alpha_out[co] : 0.f;
+      prm_all[2 * CO + i] = a.alpha_out ? snake_inv(a.alpha_out[co]) : 0.f;
+      prm_all[3 * CO + i] = a.y2 ? a.alpha2[co] : 0.f;
+      prm_all[4 * CO + i] = a.y2 ? snake_inv(a.alpha2[co]) : 0.f;
+    }
+  }
+  __syncthreads();
+  const int half = NSPLIT == 2 ? (wave & 1) : 0;
+  const int co0 = half * 32 * MBW;
+  const int mb0 = half * MBW;                                  // first 32-row block of this wave
+  const float* prm = prm_all + co0 + 4 * kq;
+  const long long xs = a.x_cs;
+  const unsigned char* Al = pws_sm + (size_t)mb0 * 3 * 1024 + lane * 16;   // fragment (s, m, p): Al[((s NB + m) 3 + p) 1024]
+  const int stride_items = n_wg * (WAVES / NSPLIT);
+
+  auto item_ptr = [&](int it, long long& yoff, bool& ok) -> const float* {
+    const int b = it / nblk;
+    const int t = (it - b * nblk) * 32 + l31;
+    ok = t < a.T_out;
+    const int tc = ok ? t : a.T_out - 1;
+    yoff = (long long)b * a.y_bs + (long long)(co_base + co0 + 4 * kq) * a.y_cs + tc;
+    return a.x + (long long)b * a.x_bs + (long long)(8 * kq) * a.x_cs + tc;
+  };
+
+  int item = wg * (WAVES / NSPLIT) + (wave / NSPLIT);
+  if (item >= n_items) return;
+  long long yoff;
+  bool ok;
+  const float* xp = item_ptr(item, yoff, ok);
+  float xr[D][8];                                              // D K steps (16 D input channels) in flight
+#pragma unroll
+  for (int q = 0; q < D; ++q)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) xr[q][j] = xp[(long long)(16 * q + j) * xs];
+
+  for (;;) {
+    f32x16 acc[MBW];
+#pragma unroll
+    for (int m = 0; m < MBW; ++m)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+    const float* rp = a.res ? a.res + yoff : nullptr;
+    float rv[16];                                              // ONE residual block in flight (registers: 3 waves per SIMD)
+    auto ld_res = [&](int m) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) rv[r] = rp ? rp[(long long)(m * 32 + (r & 3) + 8 * (r >> 2)) * a.y_cs] : 0.f;
+    };
+    const int nxt = item + stride_items;
+    const bool more = nxt < n_items;
+    long long yoff_n = yoff;
+    bool ok_n = ok;
+    const float* xn = more ? item_ptr(nxt, yoff_n, ok_n) : xp;
+
+    for (int s0 = 0; s0 < S16; s0 += D) {
+      const bool last = s0 + D >= S16;
+      if (last) ld_res(0);                                     // the first residual block rides along with the last trip
+#pragma unroll
+      for (int q = 0; q < D; ++q) {
+        const int s = s0 + q;
+        pws_bf16x8 B[3];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          __bf16 b0, b1, b2;
+          pws_split3(xr[q][j], b0, b1, b2);
+          B[0][j] = b0; B[1][j] = b1; B[2][j] = b2;
+        }
+        // refill this slot with K step s + D (the next block's first rows during the last trip)
+        const float* src = last ? xn + (long long)(16 * q) * xs : xp + (long long)(16 * (s + D)) * xs;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) xr[q][j] = src[(long long)j * xs];
+        const unsigned char* as = Al + (size_t)s * NB * 3 * 1024;
+#pragma unroll
+        for (int m = 0; m < MBW; ++m) {
+          const pws_bf16x8 A0 = *reinterpret_cast<const pws_bf16x8*>(as + (m * 3 + 0) * 1024);
+          const pws_bf16x8 A1 = *reinterpret_cast<const pws_bf16x8*>(as + (m * 3 + 1) * 1024);
+          const pws_bf16x8 A2 = *reinterpret_cast<const pws_bf16x8*>(as + (m * 3 + 2) * 1024);
+          // smallest terms first (as conv1d_gemm_split.hip): mid*mid, lo*hi, hi*lo, mid*hi, hi*mid, hi*hi
+          acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, B[1], acc[m], 0, 0, 0);
+          acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A2, B[0], acc[m], 0, 0, 0);
+          acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0, B[2], acc[m], 0, 0, 0);
+          acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, B[0], acc[m], 0, 0, 0);
+          acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0, B[1], acc[m], 0, 0, 0);
+          acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0, B[0], acc[m], 0, 0, 0);
+        }
+      }
+    }
+
+    float* yp = a.y ? a.y + yoff : nullptr;
+    float* y2p = a.y2 ? a.y2 + yoff : nullptr;
+#pragma unroll
+    for (int m = 0; m < MBW; ++m) {
+      // values first (they consume the residual block), then the next block's residual loads, then this block's stores: the
+      // loads are in front of the stores in the memory queue, so waiting for them does not wait for the stores to drain
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m * 32 + (r & 3) + 8 * (r >> 2);
+        float v = acc[m][r] + prm[row];
+        if (a.alpha_out) v = snake_apply(v, prm[CO + row], prm[2 * CO + row]);
+        if (a.act != FAC_ACT_NONE) v = apply_act_slow(v, a.act);
+        acc[m][r] = v + rv[r];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (m + 1 < MBW) ld_res(m + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      if (ok) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = m * 32 + (r & 3) + 8 * (r >> 2);
+          const float v = acc[m][r];
+          if (yp) yp[(long long)row * a.y_cs] = v;
+          if (y2p) y2p[(long long)row * a.y_cs] = snake_apply(v, prm[3 * CO + row], prm[4 * CO + row]);
+        }
+      }
+    }
+    if (!more) break;
+    item = nxt;
+    xp = xn;
+    yoff = yoff_n;
+    ok = ok_n;
+  }
+}
+
+// C -> output channels per weight slice (the slice's three planes, 6 bytes per weight, must fit the LDS)
+static int pws_slice_channels(int C) {
+  switch (C) {
+    case 64: case 96: case 128: return C;
+    case 192: return 96;
+    case 256: case 384: return 64;
+    default: return 0;
+  }
+}
+
+static int pws_env(const char* name) {
+  const char* v = getenv(name);
+  return v ? atoi(v) : 0;
+}
+
+bool conv_pws_ok(const ConvArgs& a) {
+  static const bool on = !(getenv("FAC_PW_SPLIT") && getenv("FAC_PW_SPLIT")[0] == '0');
+  static const int max_c = pws_env("FAC_PWS_MAX_C") ? pws_env("FAC_PWS_MAX_C") : 384;
+  if (!on || !(a.K == 1 && a.stride == 1 && a.n_phase == 1 && a.phase_shift == 0 && a.y_tstride == 1 && a.pad_left == 0 && !a.alpha_in &&
+               !a.w1 && !a.w_batched && !conv_two_level(a) && a.T_in >= a.T_out && a.C_in == a.C_out && !a.x_p8))
+    return false;
+  const int co = pws_slice_channels(a.C_out);
+  if (!co || a.C_out_pad != a.C_out || a.C_out > max_c) return false;
+  // enough column blocks that every wave slot of a 256-CU chip walks at least two of them
+  const long long items = (long long)a.B * ((a.T_out + 31) / 32);
+  const int nsplit = co == 128 ? 2 : 1;
+  const long long slots = (256 / (a.C_out / co)) * (12 / nsplit);
+  return items >= 2 * slots;
+}
+
+template <int MBW, int NSPLIT, int WAVES, int D>
+static int pws_launch(ConvArgs& a, hipStream_t s) {
+  const int nblk = (a.T_out + 31) / 32;
+  const long long n_items = (long long)a.B * nblk;
+  if (n_items > 0x7fffffffll) {
+    set_error("conv1d(pointwise, split): too many column blocks (%lld)", n_items);
+    return FAC_ERR_ARG;
+  }
+  constexpr int CO = 32 * MBW * NSPLIT;
+  const size_t lds = (size_t)(a.C_in / 16) * (CO / 32) * 3 * 1024 + 5 * CO * sizeof(float);
+  auto kern = conv1d_pws_kernel<MBW, NSPLIT, WAVES, D>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  constexpr int per_wg = WAVES / NSPLIT;
+  const int n_slices = a.C_out / CO;
+  long long groups = 256 / (8 * n_slices);
+  const long long need = (n_items + 8 * per_wg - 1) / (8 * per_wg);
+  if (groups > need) groups = need;
+  if (groups < 1) groups = 1;
+  hipLaunchKernelGGL(kern, dim3((unsigned)(groups * 8 * n_slices)), dim3(WAVES * 64), lds, s, a, nblk, (int)n_items);
+  return check_launch("conv1d_pw_split");
+}
+
+// 12 waves (three per SIMD, <= 168 registers): measured against 16 (spills) and 8 on the forward's six layer shapes
+// (profiles/r06_pws_ab.log)
+int conv_dispatch_pws(ConvArgs& a, hipStream_t s) {
+  static const int d_env = pws_env("FAC_PWS_D");               // experiment: K steps in flight
+  switch (pws_slice_channels(a.C_out)) {
+    case 64: return d_env == 2 ? pws_launch<2, 1, 12, 2>(a, s) : pws_launch<2, 1, 12, 4>(a, s);   // C = 64; C = 256 / 384 in slices of 64
+    case 128: return d_env == 2 ? pws_launch<2, 2, 12, 2>(a, s) : pws_launch<2, 2, 12, 4>(a, s);
+    default: return d_env == 2 ? pws_launch<3, 1, 12, 2>(a, s) : pws_launch<3, 1, 12, 3>(a, s);   // C = 96; C = 192 in two slices of 96
+  }
+}
+
+}  // namespace fac

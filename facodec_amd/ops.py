@@ -632,6 +632,7 @@ def conv1d(x, w_packed, c_out, k, bias=None, stride=1, dilation=1, pad_left=None
     d.K, d.stride, d.dilation, d.pad_left, d.pad_mode = k, stride, dilation, pad_left, pad_mode
     d.n_phase, d.y_tstride, d.act, d.w_batched, d.w_bs = 1, 1, act, 0, 0
     d.K1, d.dilation2 = k1, dilation2
+    d.pw_split = 1 if (BF16_SPLIT and PW_SPLIT and k == 1) else 0
     _launch_conv(d, "fac_conv1d_fwd")
     return (out, y2) if alpha_y2 is not None else out
 
@@ -703,6 +704,8 @@ def conv_transpose1d(x, w_packed, c_out, stride, bias=None, alpha_in=None, out=N
 # latent rate, so those launches (the encoder's last downsampling conv, the decoder's first ConvTranspose1d, and their data
 # gradients) fell to the fp32 128 x 160 tile at 38 - 63 TFLOP/s (profiles/r06_train_layers_serial.log: 3.9 ms per step).
 FLAT_TRAIN = os.environ.get("FAC_FLAT_TRAIN", "1") != "0"
+# k = 1 ResidualUnit tails at C <= 192 on the bf16 pipe inside the streaming kernel (conv1d_pw_split.hip); 0: fp32 MFMAs (rounds 2-5)
+PW_SPLIT = os.environ.get("FAC_PW_SPLIT", "1") != "0"
 
 
 def flat_strided_ok(c_out, c_in, k, s, batch, n_out):

@@ -173,6 +173,10 @@ typedef struct fac_conv_desc {
   int64_t x_p8_plane_bytes;
   void* y2_p8;
   int64_t y2_p8_plane_bytes;
+  /* Optional (0 = off): the k = 1 streaming kernel (C_in == C_out in {64, 96, 128, 192}, many columns) may split BOTH operands into
+   * three bf16 planes inside the kernel (weights once per workgroup, inputs per load) and run on the bf16 matrix pipe with fp32-grade
+   * results, instead of fp32 MFMAs.  Needs only `w`.  The host side sets it wherever it hands `w_split` to the other layers. */
+  int32_t pw_split;
 } fac_conv_desc;
 
 int fac_conv1d_fwd(const fac_conv_desc* d, fac_stream_t stream);

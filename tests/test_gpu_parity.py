@@ -230,11 +230,15 @@ def test_conv_second_output_is_snake_of_first(O, ops, cuda):
     assert none_y is None and torch.equal(y2b, y2)
 
 
+@pytest.mark.parametrize("split", [False, True])
 @pytest.mark.parametrize("C,T,B", [(64, 4101, 64), (96, 4101, 64), (128, 4099, 32), (192, 4100, 32), (256, 2100, 64), (384, 1101, 64)])
-def test_pointwise_streaming_kernel(C, T, B, O, ops, cuda):
-    """k = 1 ResidualUnit tail on the streaming kernel (conv1d_pw.hip: weights resident in LDS, inputs straight from global
-    memory): bias + residual + second Snake output, ragged last column block, against the oracle and BIT-EQUAL to the tiled
-    kernel (same summation order); then the data-gradient form (no bias / residual, transposed weights)."""
+def test_pointwise_streaming_kernel(C, T, B, split, O, ops, cuda, monkeypatch):
+    """k = 1 ResidualUnit tail on the streaming kernels (weights resident in LDS, inputs straight from global memory): bias +
+    residual + second Snake output, ragged last column block, against the oracle; then the data-gradient form (no bias /
+    residual, transposed weights).  split=False: conv1d_pw.hip, fp32 MFMAs, BIT-EQUAL to the tiled kernel (same summation
+    order).  split=True (the default policy): C <= 192 on conv1d_pw_split.hip (both operands as three bf16 planes split inside
+    the kernel, fp32-grade), wider layers unchanged."""
+    monkeypatch.setattr(ops, "PW_SPLIT", split)
     g = _g(C + T)
     x = torch.randn(B, C, T, generator=g)
     w = torch.randn(C, C, 1, generator=g) / C ** 0.5
@@ -247,16 +251,23 @@ def test_pointwise_streaming_kernel(C, T, B, O, ops, cuda):
     ops.set_conv_profile(prof)
     try:
         y, y2 = ops.conv1d(x.to(cuda), wp, C, 1, bias=b.to(cuda), res=r.to(cuda), alpha_y2=a2.to(cuda))
-        # few columns: the same layer on the tiled kernel (the streaming kernel wants a chip's worth of column blocks)
+        # few columns: the same layer on the tiled kernel (the streaming kernels want a chip's worth of column blocks)
         n = 3
         y_t, y2_t = ops.conv1d(x[:n].to(cuda), wp, C, 1, bias=b.to(cuda), res=r[:n].to(cuda), alpha_y2=a2.to(cuda))
         dx = ops.conv1d(x.to(cuda), ops.pack_conv_weight_bwd(w.to(cuda)), C, 1, pad_left=0, pad_mode=ops.PAD_ZERO, t_out=T)
     finally:
         ops.set_conv_profile(None)
     names = [rec[0] for rec in prof.records]
-    assert names[0].startswith("conv1d_pw_kernel") and names[2].startswith("conv1d_pw_kernel") and "pw" not in names[1], names
+    want = "conv1d_pws_kernel" if split else "conv1d_pw_kernel"
+    assert names[0].startswith(want) and names[2].startswith(want) and "pw" not in names[1], names
     assert rel(y, y_ref) < OP_TOL and rel(y2, O.snake(y_ref, a2.view(1, -1, 1))) < OP_TOL
-    assert torch.equal(y_t, y[:n]) and torch.equal(y2_t, y2[:n])
+    if want == "conv1d_pw_kernel":
+        assert torch.equal(y_t, y[:n]) and torch.equal(y2_t, y2[:n])
+    else:
+        # fp32-grade: as close to the fp64 answer as the fp32 tile is (the split drops only the lo*lo, lo*mid and mid*lo products)
+        y64 = torch.einsum("oc,bct->bot", w[:, :, 0].double(), x[:n].double()) + b.double().view(1, -1, 1) + r[:n].double()
+        e_split, e_tile = rel(y[:n].double(), y64), rel(y_t.double(), y64)
+        assert e_split < 2e-6 and e_split < 4 * e_tile + 1e-7, (e_split, e_tile)
     assert rel(dx, torch.einsum("oc,bot->bct", w[:, :, 0], x)) < OP_TOL
 
 
