@@ -112,6 +112,9 @@ extern "C" int fac_conv1d_fwd(const fac_conv_desc* d, fac_stream_t stream) {
     return conv_dispatch_bsplit2(a, s);
   }
   FAC_REQUIRE(!conv_two_level(a) || d->w, "conv1d: two-level taps outside the split kernel's shapes need fp32 weights");
+  static const bool pw_on = !(getenv("FAC_PW") && getenv("FAC_PW")[0] == '0');
+  // stride-2 layers with few channels (weights resident in LDS as bf16 planes, inputs streamed): conv1d_pw_split.hip
+  if (pw_on && d->pw_split && d->w && conv_pwt_ok(a)) return conv_dispatch_pwt(a, s);
   // 1- / 2-tap convs with split weights in the GEMM layout (fac_pack_gemm_w_split): the bf16 matrix pipe, fp32-grade
   if (d->w_split && (d->K <= 2 || (d->stride > 1 && d->K <= 2 * d->stride)) && conv_gsplit_ok(a) &&
       !conv_skinny_ok(a, d->ws, d->ws_bytes)) {
@@ -136,7 +139,6 @@ extern "C" int fac_conv1d_fwd(const fac_conv_desc* d, fac_stream_t stream) {
   if (narrow_ok(d) && (!two_level || (NARROW_TWO_LEVEL && (a.KV - 1) * a.dil <= 64))) return conv_dispatch_narrow(a, s);
   if (conv_thin_ok(a, d->ws, d->ws_bytes)) return conv_dispatch_thin(a, d->ws, s);   // C_out <= 2 without enough tiles for narrow
   if (conv_cin1_ok(a)) return conv_dispatch_cin1(a, s);
-  static const bool pw_on = !(getenv("FAC_PW") && getenv("FAC_PW")[0] == '0');
   if (pw_on && d->pw_split && conv_pw_ok(a) && conv_pws_ok(a)) return conv_dispatch_pws(a, s);   // k = 1 tails at C <= 192 on the bf16 pipe
   if (pw_on && conv_pw_ok(a)) return conv_dispatch_pw(a, s);
   switch (select_variant(d)) {
@@ -161,6 +163,18 @@ extern "C" int fac_conv1d_variant(const fac_conv_desc* d, char* name, int name_l
   if (d->w_k1) {
     if (name && name_len > 0) snprintf(name, name_len, "conv1d_mfma_kernel<C/32,1,1,4,7,fused RU> Cx128");
     return 7;
+  }
+  if (d->pw_split && d->w && !(getenv("FAC_PW") && getenv("FAC_PW")[0] == '0')) {
+    ConvArgs a{};
+    a.K = d->K; a.K1 = d->K1 > 0 ? d->K1 : d->K; a.stride = d->stride; a.dil = d->dilation; a.rp = d->row_phases > 1 ? d->row_phases : 1;
+    a.pad_left = d->pad_left; a.pad_mode = d->pad_mode; a.w = d->w; a.x = d->x; a.n_phase = d->n_phase; a.phase_shift = d->phase_shift;
+    a.y_tstride = d->y_tstride; a.alpha_in = d->alpha_in; a.alpha_out = d->alpha_out; a.act = d->act; a.res = d->res; a.w1 = d->w_k1;
+    a.w_batched = d->w_batched; a.x_p8 = reinterpret_cast<const unsigned char*>(d->x_p8); a.y2_p8 = reinterpret_cast<unsigned char*>(d->y2_p8);
+    a.C_in = d->C_in; a.C_out = d->C_out; a.C_out_pad = d->C_out_pad; a.y_cs = d->y_cs; a.y_bs = d->y_bs; a.B = d->B; a.T_out = d->T_out;
+    if (conv_pwt_ok(a)) {
+      if (name && name_len > 0) snprintf(name, name_len, "conv1d_pwt_kernel<%d taps> (streaming, W planes in LDS, bf16x3 split, fp32-grade)", d->K);
+      return 18;
+    }
   }
   if (d->w_split && d->C_out <= 32) {
     ConvArgs a{};

@@ -819,6 +819,8 @@ bool conv_bsplit_p8_ok(const ConvArgs& a);   // ... and the launch takes a P8 in
 int conv_dispatch_bsplit(ConvArgs& a, hipStream_t s);
 bool conv_pws_ok(const ConvArgs& a);
 int conv_dispatch_pws(ConvArgs& a, hipStream_t s);
+bool conv_pwt_ok(const ConvArgs& a);        // streaming kernel with taps: stride-2 ConvTranspose1d (all phases) / k = 4 stride-2 conv, few channels
+int conv_dispatch_pwt(ConvArgs& a, hipStream_t s);
 bool conv_skinny_ok(const ConvArgs& a, const void* ws, long long ws_bytes);
 int conv_dispatch_skinny(ConvArgs& a, void* ws, long long ws_bytes, hipStream_t s);
 

@@ -185,6 +185,180 @@ __global__ __launch_bounds__(WAVES * 64) void conv1d_pws_kernel(ConvArgs a, int 
   }
 }
 
+// ---- the same streaming skeleton for two small-channel layers with TAPS (round 6): the causal ConvTranspose1d 192 -> 96 of the
+// decoder's last block (stride 2: two taps, all output phases as rows -- weights of fac_pack_convtr_w_rows) and the encoder's first
+// downsampling conv 64 -> 128 (k = 4, stride 2 -- weights of fac_pack_conv_w), dac/model/dac.py:45-66,107-128, plus the data
+// gradients of each (which are the other one's shape).  On the tiled split GEMM kernel these ran at 72 / 79 TFLOP/s-eq for
+// 1.2 - 1.8 GB of traffic (1.56 / 0.64 ms at B = 32: six 32-channel stages per 128 x 128 tile, then a 128 KB epilogue).  Here the
+// contraction index is the VIRTUAL channel v = ci * KT + k (exactly the row order of both packed weight layouts), X_v[u] =
+// x[ci][u * S + k - pad_left]; 64 output rows per workgroup slice (C_in * KT <= 384 virtual channels: 147 KB of planes), the
+// slices of one column-block set on one XCD as above.  RP = 2: rows are (channel, phase) pairs, phase fastest -- the two phases
+// of a channel sit in neighbouring accumulator registers of one lane, so the interleave is an 8-byte store.
+template <int KT, int S, int RP, int WAVES, int D>
+__global__ __launch_bounds__(WAVES * 64) void conv1d_pwt_kernel(ConvArgs a, int nblk, int n_items) {
+  constexpr int MBW = 2, CO = 64, NB = 2;
+  constexpr int CPS = 16 / KT;                                 // real channels per K step
+  constexpr int CPL = 8 / KT;                                  // real channels per lane and K step
+  extern __shared__ __attribute__((aligned(16))) unsigned char pws_sm[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, kq = lane >> 5;
+  const int S16 = (a.C_in * KT) >> 4;
+  const int n_slices = (a.C_out * RP) / CO;
+  const int slice = (blockIdx.x >> 3) % n_slices;
+  const int wg = (blockIdx.x & 7) + 8 * (blockIdx.x / (8 * n_slices));
+  const int n_wg = gridDim.x / n_slices;
+  const int row_base = slice * CO;
+  float* prm_all = reinterpret_cast<float*>(pws_sm + (size_t)S16 * NB * 3 * 1024);
+  {
+    const int n_frag = S16 * NB * 64;
+    for (int i = tid; i < n_frag; i += WAVES * 64) {
+      const int ln = i & 63, rest = i >> 6;
+      const int mb = rest % NB, s = rest / NB;
+      const int row = row_base + 32 * mb + (ln & 31);
+      const int v0 = 16 * s + 8 * (ln >> 5);
+      pws_bf16x8 h, m, l;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        __bf16 a0, a1, a2;
+        pws_split3(a.w[(long long)(v0 + j) * a.C_out_pad + row], a0, a1, a2);
+        h[j] = a0; m[j] = a1; l[j] = a2;
+      }
+      unsigned char* dst = pws_sm + ((size_t)(s * NB + mb) * 3) * 1024 + ln * 16;
+      *reinterpret_cast<pws_bf16x8*>(dst) = h;
+      *reinterpret_cast<pws_bf16x8*>(dst + 1024) = m;
+      *reinterpret_cast<pws_bf16x8*>(dst + 2048) = l;
+    }
+    for (int i = tid; i < CO; i += WAVES * 64) {
+      const int ch = (row_base + i) / RP;
+      prm_all[i] = a.bias ? a.bias[ch] : 0.f;
+      prm_all[CO + i] = a.y2 ? a.alpha2[ch] : 0.f;
+      prm_all[2 * CO + i] = a.y2 ? snake_inv(a.alpha2[ch]) : 0.f;
+    }
+  }
+  __syncthreads();
+  const float* prm = prm_all + 4 * kq;
+  const long long xs = a.x_cs;
+  const unsigned char* Al = pws_sm + lane * 16;
+  const int stride_items = n_wg * WAVES;
+
+  // per item: the KT column offsets of this lane's output column (reflected / clamped) and 1 / 0 factors for zero padding
+  struct Cols { int off[KT]; float f[KT]; };
+  auto item_ptr = [&](int it, long long& yoff, bool& ok, Cols& c) -> const float* {
+    const int b = it / nblk;
+    const int u = (it - b * nblk) * 32 + l31;
+    ok = u < a.T_out;
+    const int uc = ok ? u : a.T_out - 1;
+#pragma unroll
+    for (int k = 0; k < KT; ++k) {
+      const int t = uc * S + k - a.pad_left;
+      int j;
+      if (a.pad_mode == FAC_PAD_REFLECT) j = reflect_index(t, a.T_in, a.T_ext);
+      else j = (t >= 0 && t < a.T_in) ? t : -1;
+      c.off[k] = j < 0 ? 0 : j;
+      c.f[k] = j < 0 ? 0.f : 1.f;
+    }
+    // row (row_base + 4 kq + local row) of the output; RP == 2: channel (row / 2), columns 2 u + phase
+    yoff = (long long)b * a.y_bs + (long long)((row_base + 4 * kq) / RP) * a.y_cs + (long long)uc * RP;
+    return a.x + (long long)b * a.x_bs + (long long)(CPL * kq) * xs;
+  };
+
+  int item = wg * WAVES + wave;
+  if (item >= n_items) return;
+  long long yoff;
+  bool ok;
+  Cols cc;
+  const float* xp = item_ptr(item, yoff, ok, cc);
+  float xr[D][8];
+#pragma unroll
+  for (int q = 0; q < D; ++q)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) xr[q][j] = xp[(long long)(CPS * q + j / KT) * xs + cc.off[j % KT]];
+
+  for (;;) {
+    f32x16 acc[MBW];
+#pragma unroll
+    for (int m = 0; m < MBW; ++m)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+    const int nxt = item + stride_items;
+    const bool more = nxt < n_items;
+    long long yoff_n = yoff;
+    bool ok_n = ok;
+    Cols cn = cc;
+    const float* xn = more ? item_ptr(nxt, yoff_n, ok_n, cn) : xp;
+
+    for (int s0 = 0; s0 < S16; s0 += D) {
+      const bool last = s0 + D >= S16;
+#pragma unroll
+      for (int q = 0; q < D; ++q) {
+        const int s = s0 + q;
+        pws_bf16x8 B[3];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          __bf16 b0, b1, b2;
+          pws_split3(xr[q][j] * cc.f[j % KT], b0, b1, b2);
+          B[0][j] = b0; B[1][j] = b1; B[2][j] = b2;
+        }
+        if (last) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) xr[q][j] = xn[(long long)(CPS * q + j / KT) * xs + cn.off[j % KT]];
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) xr[q][j] = xp[(long long)(CPS * (s + D) + j / KT) * xs + cc.off[j % KT]];
+        }
+        const unsigned char* as = Al + (size_t)s * NB * 3 * 1024;
+#pragma unroll
+        for (int m = 0; m < MBW; ++m) {
+          const pws_bf16x8 A0 = *reinterpret_cast<const pws_bf16x8*>(as + (m * 3 + 0) * 1024);
+          const pws_bf16x8 A1 = *reinterpret_cast<const pws_bf16x8*>(as + (m * 3 + 1) * 1024);
+          const pws_bf16x8 A2 = *reinterpret_cast<const pws_bf16x8*>(as + (m * 3 + 2) * 1024);
+          acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, B[1], acc[m], 0, 0, 0);
+          acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A2, B[0], acc[m], 0, 0, 0);
+          acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0, B[2], acc[m], 0, 0, 0);
+          acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, B[0], acc[m], 0, 0, 0);
+          acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0, B[1], acc[m], 0, 0, 0);
+          acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0, B[0], acc[m], 0, 0, 0);
+        }
+      }
+    }
+
+    if (ok) {
+      float* yp = a.y ? a.y + yoff : nullptr;
+      float* y2p = a.y2 ? a.y2 + yoff : nullptr;
+#pragma unroll
+      for (int m = 0; m < MBW; ++m) {
+        if (RP == 2) {
+#pragma unroll
+          for (int r = 0; r < 16; r += 2) {
+            const int row = m * 32 + (r & 3) + 8 * (r >> 2);   // even: phases 0 / 1 of channel (row_base + 4 kq + row) / 2
+            const float v0 = acc[m][r] + prm[row], v1 = acc[m][r + 1] + prm[row + 1];
+            const long long o = (long long)(row >> 1) * a.y_cs;
+            if (yp) *reinterpret_cast<float2*>(yp + o) = make_float2(v0, v1);
+            if (y2p)
+              *reinterpret_cast<float2*>(y2p + o) = make_float2(snake_apply(v0, prm[CO + row], prm[2 * CO + row]),
+                                                                snake_apply(v1, prm[CO + row + 1], prm[2 * CO + row + 1]));
+          }
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = m * 32 + (r & 3) + 8 * (r >> 2);
+            const float v = acc[m][r] + prm[row];
+            if (yp) yp[(long long)row * a.y_cs] = v;
+            if (y2p) y2p[(long long)row * a.y_cs] = snake_apply(v, prm[CO + row], prm[2 * CO + row]);
+          }
+        }
+      }
+    }
+    if (!more) break;
+    item = nxt;
+    xp = xn;
+    yoff = yoff_n;
+    ok = ok_n;
+    cc = cn;
+  }
+}
+
 // C -> output channels per weight slice (the slice's three planes, 6 bytes per weight, must fit the LDS)
 static int pws_slice_channels(int C) {
   switch (C) {
@@ -250,6 +424,58 @@ int conv_dispatch_pws(ConvArgs& a, hipStream_t s) {
     case 128: return d_env == 2 ? pws_launch<2, 2, 12, 2>(a, s) : pws_launch<2, 2, 12, 4>(a, s);
     default: return d_env == 2 ? pws_launch<3, 1, 12, 2>(a, s) : pws_launch<3, 1, 12, 3>(a, s);   // C = 96; C = 192 in two slices of 96
   }
+}
+
+// the two tap shapes of conv1d_pwt_kernel: 1 = all-phases ConvTranspose1d with stride 2 (K = 2, row_phases = 2), 2 = k = 4 stride-2 conv
+static int pwt_shape(const ConvArgs& a) {
+  if (a.K == 2 && a.stride == 1 && a.rp == 2 && a.pad_left == 1 && a.pad_mode == FAC_PAD_ZERO) return 1;
+  if (a.K == 4 && a.stride == 2 && a.rp == 1) return 2;
+  return 0;
+}
+
+bool conv_pwt_ok(const ConvArgs& a) {
+  static const bool on = !(getenv("FAC_PW_TAPS") && getenv("FAC_PW_TAPS")[0] == '0') &&
+                         !(getenv("FAC_PW_SPLIT") && getenv("FAC_PW_SPLIT")[0] == '0');
+  if (!on || !pwt_shape(a) || !a.w || !a.x) return false;
+  if (!(a.dil == 1 && a.n_phase == 1 && a.phase_shift == 0 && a.y_tstride == 1 && !a.alpha_in && !a.alpha_out && a.act == FAC_ACT_NONE &&
+        !a.res && !a.w1 && !a.w_batched && !conv_two_level(a) && !a.x_p8 && !a.y2_p8))
+    return false;
+  const int kv = a.C_in * a.K, rows = a.C_out * a.rp;
+  if (kv % 64 != 0 || kv > 384 || rows % 64 != 0 || rows > a.C_out_pad) return false;
+  if (a.rp == 2 && ((a.y_cs | a.y_bs) & 1)) return false;      // 8-byte stores
+  const long long items = (long long)a.B * ((a.T_out + 31) / 32);
+  return items >= 2 * (256 / (rows / 64)) * 12;
+}
+
+template <int KT, int S, int RP, int D>
+static int pwt_launch(ConvArgs& a, hipStream_t s) {
+  constexpr int WAVES = 12;
+  const int nblk = (a.T_out + 31) / 32;
+  const long long n_items = (long long)a.B * nblk;
+  if (n_items > 0x7fffffffll) {
+    set_error("conv1d(streaming, taps): too many column blocks (%lld)", n_items);
+    return FAC_ERR_ARG;
+  }
+  const size_t lds = (size_t)(a.C_in * KT / 16) * 2 * 3 * 1024 + 3 * 64 * sizeof(float);
+  auto kern = conv1d_pwt_kernel<KT, S, RP, WAVES, D>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  const int n_slices = a.C_out * RP / 64;
+  long long groups = 256 / (8 * n_slices);
+  const long long need = (n_items + 8 * WAVES - 1) / (8 * WAVES);
+  if (groups > need) groups = need;
+  if (groups < 1) groups = 1;
+  hipLaunchKernelGGL(kern, dim3((unsigned)(groups * 8 * n_slices)), dim3(WAVES * 64), lds, s, a, nblk, (int)n_items);
+  return check_launch("conv1d_pw_taps");
+}
+
+int conv_dispatch_pwt(ConvArgs& a, hipStream_t s) {
+  static const int d_env = pws_env("FAC_PWS_D");
+  if (pwt_shape(a) == 1) return d_env == 4 ? pwt_launch<2, 1, 2, 4>(a, s) : pwt_launch<2, 1, 2, 2>(a, s);
+  return d_env == 4 ? pwt_launch<4, 2, 1, 4>(a, s) : pwt_launch<4, 2, 1, 2>(a, s);
 }
 
 }  // namespace fac

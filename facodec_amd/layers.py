@@ -144,6 +144,10 @@ class SConv1d(nn.Module):
               and not (PW_TAILS_TO_384 and w.c_in == w.c_out and w.c_in in (256, 384) and x.shape[0] * x.shape[-1] >= 65536)):
             # (the C = 256 / 384 ResidualUnit tails stay on the streaming k = 1 kernel: -0.7 ms per B = 32 forward, round 4)
             split = w.packed_split()          # 1x1 with many channels: split-bf16 GEMM (conv1d_gemm_split.hip)
+        elif (self.stride == 2 and alpha_in is None and alpha_out is None and res is None and act == ops.ACT_NONE and self.dilation == 1
+              and isinstance(x, torch.Tensor)
+              and ops.pw_taps_ok(w.c_in, w.c_out, self.kernel_size, 2, False, x.shape[0], -(-x.shape[-1] // 2))):
+            pass                              # few channels: the streaming kernel with taps takes the fp32 pack (fac_conv_desc.pw_split)
         elif (self.stride > 1 and alpha_in is None and self.dilation == 1
               and ops.gemm_split_strided_ok(w.c_out, w.c_in, self.kernel_size, self.stride, x.shape[0], -(-x.shape[-1] // self.stride))):
             split = w.packed_split_strided(self.stride)     # downsampling conv: 2 taps over `stride` phase sub-signals
@@ -238,7 +242,10 @@ class SConvTranspose1d(nn.Module):
 
     def run(self, x, alpha_in=None, alpha_y2=None):
         w = self.w
-        if ops.convtr_split_ok(w.c_in, w.c_out, self.stride, x.shape[0], x.shape[-1], self.causal, alpha_in):
+        if (self.causal and alpha_in is None and isinstance(x, torch.Tensor)
+                and ops.pw_taps_ok(w.c_in, w.c_out, 2 * self.stride, self.stride, True, x.shape[0], x.shape[-1])):
+            wp = w.packed_rows()              # stride 2, few channels: the streaming kernel with taps (conv1d_pw_split.hip)
+        elif ops.convtr_split_ok(w.c_in, w.c_out, self.stride, x.shape[0], x.shape[-1], self.causal, alpha_in):
             wp = w.packed_rows_split()
             x = ops.p8_prepass(x, 2.0 * w.c_out * 2 * self.stride / 4.0)      # all output phases as GEMM rows: 2 s C_out MACs per input sample
         elif (FLAT_SHORT_CLIPS and not torch.is_grad_enabled() and x.shape[-1] < 256

@@ -632,7 +632,7 @@ def conv1d(x, w_packed, c_out, k, bias=None, stride=1, dilation=1, pad_left=None
     d.K, d.stride, d.dilation, d.pad_left, d.pad_mode = k, stride, dilation, pad_left, pad_mode
     d.n_phase, d.y_tstride, d.act, d.w_batched, d.w_bs = 1, 1, act, 0, 0
     d.K1, d.dilation2 = k1, dilation2
-    d.pw_split = 1 if (BF16_SPLIT and PW_SPLIT and k == 1) else 0
+    d.pw_split = 1 if (BF16_SPLIT and PW_SPLIT and (k == 1 or (PW_TAPS and k == 4 and stride == 2))) else 0
     _launch_conv(d, "fac_conv1d_fwd")
     return (out, y2) if alpha_y2 is not None else out
 
@@ -695,6 +695,7 @@ def conv_transpose1d(x, w_packed, c_out, stride, bias=None, alpha_in=None, out=N
         if not causal or has_history:
             raise _lib.FacodecHipError("the all-phases ConvTranspose1d launch is causal and offline only")
         d.n_phase, d.y_tstride, d.phase_shift, d.row_phases = 1, 1, 0, stride
+        d.pw_split = 1 if (BF16_SPLIT and PW_SPLIT and PW_TAPS and not split_rows and stride == 2) else 0
     _launch_conv(d, "fac_conv1d_fwd(convtr)")
     return (out, y2) if alpha_y2 is not None else out
 
@@ -706,6 +707,22 @@ def conv_transpose1d(x, w_packed, c_out, stride, bias=None, alpha_in=None, out=N
 FLAT_TRAIN = os.environ.get("FAC_FLAT_TRAIN", "1") != "0"
 # k = 1 ResidualUnit tails at C <= 192 on the bf16 pipe inside the streaming kernel (conv1d_pw_split.hip); 0: fp32 MFMAs (rounds 2-5)
 PW_SPLIT = os.environ.get("FAC_PW_SPLIT", "1") != "0"
+
+
+# stride-2 layers with few channels on the streaming kernel with taps (conv1d_pw_split.hip, conv1d_pwt_kernel); follows PW_SPLIT
+PW_TAPS = os.environ.get("FAC_PW_TAPS", "1") != "0"
+
+
+def pw_taps_ok(c_in, c_out, k, stride, transposed, batch, t_out):
+    """Mirror of conv_pwt_ok: the causal ConvTranspose1d with stride 2 (all output phases as rows, fp32 weights of
+    pack_convtr_weight_rows) or a k = 4 stride-2 conv (fp32 weights of pack_conv_weight) whose C_in * taps <= 384 virtual channels
+    fit the LDS as bf16 planes for 64 output rows; t_out = output columns per clip at the INPUT rate (transposed) / output rate."""
+    if not (BF16_SPLIT and PW_SPLIT and PW_TAPS and stride == 2):
+        return False
+    taps, rows = (2, 2 * c_out) if transposed else (4, c_out)
+    if k != 4 or (c_in * taps) % 64 or c_in * taps > 384 or rows % 64:
+        return False
+    return batch * ((t_out + 31) // 32) >= 2 * (256 // (rows // 64)) * 12
 
 
 def flat_strided_ok(c_out, c_in, k, s, batch, n_out):

@@ -271,6 +271,66 @@ def test_pointwise_streaming_kernel(C, T, B, split, O, ops, cuda, monkeypatch):
     assert rel(dx, torch.einsum("oc,bot->bct", w[:, :, 0], x)) < OP_TOL
 
 
+@pytest.mark.parametrize("B,T", [(32, 4101), (64, 2050)])
+def test_streaming_taps_kernel_conv_transpose_stride2(B, T, O, ops, cuda, monkeypatch):
+    """The decoder's last ConvTranspose1d (192 -> 96, stride 2: dac/model/dac.py:107-128) on the streaming kernel with taps
+    (conv1d_pw_split.hip, conv1d_pwt_kernel: both phases as rows, 8-byte interleaved stores), bias + pre-activated second output,
+    ragged last column block, against the oracle and against the tiled all-phases launch; and the data-gradient shape of the
+    encoder's first downsampling conv (128 -> 64, stride 2)."""
+    for ci, co in ((192, 96), (128, 64)):
+        g = _g(ci + T)
+        x = torch.randn(B, ci, T, generator=g)
+        v = torch.randn(ci, co, 4, generator=g) / (ci * 2) ** 0.5
+        gg = torch.rand(ci, 1, 1, generator=g) + 0.5
+        b = torch.randn(co, generator=g) * 0.1
+        al = 1 + 0.2 * torch.rand(co, generator=g)
+        y_ref = O.sconvtr1d(x, O.weight_norm_weight(v, gg), b, 2, causal=True)
+        assert ops.pw_taps_ok(ci, co, 4, 2, True, B, T)
+        wp = ops.pack_convtr_weight_rows(v.to(cuda), gg.to(cuda), 2)
+        prof = ops.ConvLaunchProfile()
+        ops.set_conv_profile(prof)
+        try:
+            y, y2 = ops.conv_transpose1d(x.to(cuda), wp, co, 2, bias=b.to(cuda), alpha_y2=al.to(cuda))
+            monkeypatch.setattr(ops, "PW_TAPS", False)
+            yt, y2t = ops.conv_transpose1d(x.to(cuda), wp, co, 2, bias=b.to(cuda), alpha_y2=al.to(cuda))
+            monkeypatch.setattr(ops, "PW_TAPS", True)
+        finally:
+            ops.set_conv_profile(None)
+        names = [rec[0] for rec in prof.records]
+        assert names[0].startswith("conv1d_pwt_kernel") and "pwt" not in names[1], names
+        assert y.shape == y_ref.shape and rel(y, y_ref) < OP_TOL and rel(y2, O.snake(y_ref, al.view(1, -1, 1))) < OP_TOL
+        assert rel(y, yt) < 2e-6 and rel(y2, y2t) < 2e-6
+
+
+@pytest.mark.parametrize("B,T", [(32, 8203), (64, 4100), (32, 8201)])
+def test_streaming_taps_kernel_strided_conv(B, T, O, ops, cuda, monkeypatch):
+    """The encoder's first downsampling conv (64 -> 128, k = 4, stride 2, causal reflect padding: dac/model/dac.py:45-66) and the
+    data-gradient shape of the decoder's last ConvTranspose1d (96 -> 192) on the streaming kernel with taps; odd lengths exercise
+    the extra right padding of dac/model/encodec.py:212-228."""
+    for ci, co in ((64, 128), (96, 192)):
+        g = _g(ci + T)
+        x = torch.randn(B, ci, T, generator=g)
+        w = torch.randn(co, ci, 4, generator=g) / (ci * 4) ** 0.5
+        b = torch.randn(co, generator=g) * 0.1
+        al = 1 + 0.2 * torch.rand(co, generator=g)
+        y_ref = O.sconv1d(x, w, b, stride=2, causal=True)
+        assert ops.pw_taps_ok(ci, co, 4, 2, False, B, y_ref.shape[-1])
+        wp = ops.pack_conv_weight(w.to(cuda))
+        prof = ops.ConvLaunchProfile()
+        ops.set_conv_profile(prof)
+        try:
+            y, y2 = ops.conv1d(x.to(cuda), wp, co, 4, bias=b.to(cuda), stride=2, alpha_y2=al.to(cuda))
+            monkeypatch.setattr(ops, "PW_TAPS", False)
+            yt = ops.conv1d(x.to(cuda), wp, co, 4, bias=b.to(cuda), stride=2)
+            monkeypatch.setattr(ops, "PW_TAPS", True)
+        finally:
+            ops.set_conv_profile(None)
+        names = [rec[0] for rec in prof.records]
+        assert names[0].startswith("conv1d_pwt_kernel") and "pwt" not in names[1], names
+        assert y.shape == y_ref.shape and rel(y, y_ref) < OP_TOL and rel(y2, O.snake(y_ref, al.view(1, -1, 1))) < OP_TOL
+        assert rel(y, yt) < 2e-6
+
+
 def test_first_conv_two_outputs(O, ops, cuda):
     """Encoder input conv (1 -> 64, k = 7: dac/model/dac.py:84) with the pre-activated second output, ragged length (scalar
     tail stores) and the y2-only form."""

@@ -50,3 +50,28 @@ for (C, T) in shapes:
     gb = 4 * 4.0 * B * C * T / 1e9
     print(f"C={C} T={T} B={B}: fp32 {min(res[False]):.3f} ms ({gb / min(res[False]):.2f} TB/s) err {errs[False]:.2e} | "
           f"split {min(res[True]):.3f} ms ({gb / min(res[True]):.2f} TB/s) err {errs[True]:.2e} | D={os.environ.get('FAC_PWS_D', 'default')}", flush=True)
+
+# ---- stride-2 layers with few channels: streaming kernel with taps against the tiled split GEMM kernel (the layers' own routing)
+from facodec_amd import layers
+with torch.no_grad():
+    for kind, ci, co, T in (("convtr", 192, 96, 24000), ("conv", 64, 128, 48000), ("convtr", 128, 64, 24000), ("conv", 96, 192, 48000)):
+        torch.manual_seed(ci)
+        if kind == "convtr":
+            m = layers.SConvTranspose1d(ci, co, 4, stride=2, causal=True, norm="weight_norm").to(dev)
+        else:
+            m = layers.SConv1d(ci, co, 4, stride=2, causal=True, norm="weight_norm").to(dev)
+        m.w.freeze_packed = True
+        x = torch.randn(B, ci, T, device=dev)
+        a2 = torch.ones(co, device=dev)
+        res, outs = {}, {}
+        for rep in range(2):
+            for taps in (False, True):
+                ops.PW_TAPS = taps
+                res.setdefault(taps, []).append(timed(lambda: m.run(x, alpha_y2=a2)))
+                outs[taps] = m.run(x, alpha_y2=a2)[0]
+        err = float((outs[True] - outs[False]).abs().max() / outs[False].abs().max())
+        t_out = T * 2 if kind == "convtr" else T // 2
+        gb = 4.0 * B * (ci * T + 2 * co * t_out) / 1e9
+        fl = 2.0 * B * co * ci * (2 if kind == "convtr" else 4) * t_out
+        print(f"{kind} {ci}->{co} s2 T_in={T} B={B}: tiled {min(res[False]):.3f} ms ({fl / min(res[False]) / 1e9:.0f} TF-eq) | "
+              f"streaming taps {min(res[True]):.3f} ms ({fl / min(res[True]) / 1e9:.0f} TF-eq, {gb / min(res[True]):.2f} TB/s) | max diff {err:.1e}", flush=True)
