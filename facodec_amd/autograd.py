@@ -25,7 +25,7 @@ _LSTM_BWD_FUSED = _os.environ.get("FAC_LSTM_BWD_FUSED", "1") != "0"
 
 def _split_ok(c_out, c_in, k, stride, x):
     if k == 1 and stride == 1:          # 1x1 with many channels: split-bf16 GEMM (conv1d_gemm_split.hip)
-        return ops.gemm_split_ok(c_out, c_in, 1, x.shape[0] * x.shape[-1])
+        return ops.gemm_split_ok(c_out, c_in, 1, x.shape[0] * x.shape[-1]) and not ops.pw_split_tail_ok(c_in, c_out, x.shape[0] * x.shape[-1])
     if k in (3, 5):                     # WaveNet / style-encoder k = 5, encoder output conv k = 3: enough channels only
         return (ops.BF16_SPLIT and stride == 1 and c_in % 16 == 0 and c_in >= 64 and c_out % 16 == 0 and c_out > 32
                 and x.shape[0] * x.shape[-1] > 640)
@@ -44,7 +44,10 @@ class _Conv(Function):
         k, stride, dilation, pad_mode, causal, act = cfg
         vd, gd = v.detach(), (g.detach() if g is not None else None)
         sc = ops.wn_scale(vd, gd) if gd is not None else None          # g / ||v||: once per forward, re-used by the backward
-        if stride > 1 and dilation == 1 and ops.gemm_split_strided_ok(v.shape[0], v.shape[1], k, stride, x.shape[0], -(-x.shape[-1] // stride)):
+        if (stride == 2 and dilation == 1 and act == ops.ACT_NONE
+                and ops.pw_taps_ok(v.shape[1], v.shape[0], k, 2, False, x.shape[0], -(-x.shape[-1] // 2))):
+            wp, ws = ops.pack_conv_weight(vd, gd, scale=sc), None        # few channels: the streaming kernel with taps takes the fp32 pack
+        elif stride > 1 and dilation == 1 and ops.gemm_split_strided_ok(v.shape[0], v.shape[1], k, stride, x.shape[0], -(-x.shape[-1] // stride)):
             wp, ws = None, ops.pack_gemm_weight_split(vd, gd, in_stride=stride, scale=sc)     # downsampling conv on the split GEMM kernel
         elif _split_ok(v.shape[0], v.shape[1], k, stride, x):       # k = 7 / k = 1 convs: fp32-grade split on the bf16 pipe
             wp, ws = None, ops.pack_conv_weight_split(vd, gd, scale=sc)

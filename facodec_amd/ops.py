@@ -157,6 +157,8 @@ def convtr_split_ok(c_in, c_out, stride, batch, t_in, causal=True, alpha_in=None
 def convtr_weight_for(v, g, stride, t_in, causal=True, batch=1, alpha_in=None):
     """The packed weights conv_transpose1d wants for an input of `batch` clips of t_in columns: (split GEMM buffer, rows) for the
     bf16-pipe launch, the fp32 rows layout (opt-in) or the polyphase layout."""
+    if causal and alpha_in is None and pw_taps_ok(v.shape[0], v.shape[1], 2 * stride, stride, True, batch, t_in):
+        return pack_convtr_weight_rows(v, g, stride)          # stride 2, few channels: the streaming kernel with taps
     if convtr_split_ok(v.shape[0], v.shape[1], stride, batch, t_in, causal, alpha_in):
         return pack_convtr_weight_rows_split(v, g, stride)
     return pack_convtr_weight_rows(v, g, stride) if convtr_rows_ok(t_in, stride, causal) else pack_convtr_weight(v, g, stride)
@@ -709,6 +711,12 @@ FLAT_TRAIN = os.environ.get("FAC_FLAT_TRAIN", "1") != "0"
 PW_SPLIT = os.environ.get("FAC_PW_SPLIT", "1") != "0"
 
 
+def pw_split_tail_ok(c_in, c_out, cols):
+    """C = 256 / 384 ResidualUnit tails (and their data gradients) of the TRAINING step on the streaming bf16-plane kernel instead
+    of the split GEMM kernel (round 6: 0.29 -> 0.2 ms per launch at 16 x 4800 columns)."""
+    return BF16_SPLIT and PW_SPLIT and c_in == c_out and c_in in (256, 384) and cols >= 65536
+
+
 # stride-2 layers with few channels on the streaming kernel with taps (conv1d_pw_split.hip, conv1d_pwt_kernel); follows PW_SPLIT
 PW_TAPS = os.environ.get("FAC_PW_TAPS", "1") != "0"
 
@@ -1190,7 +1198,7 @@ def conv1d_bwd_data(dy, v, g, t_in, stride=1, dilation=1, pad_mode=PAD_REFLECT, 
         wt = flipped_weight(v, g, scale)                                   # (C_in, C_out, K) = weights of the bwd conv
         dxpad = conv1d(dy, None, c_in, k, dilation=dilation, pad_left=(k - 1) * dilation, pad_mode=PAD_ZERO, t_out=tp,
                        w_split=pack_conv_weight_split(wt))
-    elif stride == 1 and k == 1 and gemm_split_ok(c_in, c_out, 1, B * tp):
+    elif stride == 1 and k == 1 and gemm_split_ok(c_in, c_out, 1, B * tp) and not pw_split_tail_ok(c_in, c_out, B * tp):
         w = rows_fma(v, scale) if g is not None else v                    # 1x1: the transposed GEMM on the bf16 pipe
         dxpad = conv1d(dy, None, c_in, 1, pad_left=0, pad_mode=PAD_ZERO, t_out=tp, w_split=pack_gemm_weight_split_t(w))
     elif stride == 1:
@@ -1365,7 +1373,9 @@ def conv_transpose1d_bwd(x, dy, v, g, stride):
     B, c_in, t_in = x.shape
     c_out, k = v.shape[1], v.shape[2]
     assert k == 2 * stride and dy.shape == (B, c_out, t_in * stride)
-    if gemm_split_strided_ok(c_in, c_out, k, stride, B, t_in):     # the strided conv of dy on the split GEMM kernel
+    if pw_taps_ok(c_out, c_in, k, stride, False, B, t_in):         # stride 2, few channels: the streaming kernel with taps (fp32 pack)
+        dx = conv1d(dy, pack_conv_weight(v, g), c_in, k, stride=stride, pad_left=0, pad_mode=PAD_ZERO, t_out=t_in)
+    elif gemm_split_strided_ok(c_in, c_out, k, stride, B, t_in):   # the strided conv of dy on the split GEMM kernel
         dx = conv1d(dy, None, c_in, k, stride=stride, pad_left=0, pad_mode=PAD_ZERO, t_out=t_in,
                     w_split=pack_gemm_weight_split(v, g, in_stride=stride))
     elif flat_strided_ok(c_in, c_out, k, stride, B, t_in):         # short clips: zeros on the right of every clip, one flattened signal

@@ -395,18 +395,27 @@ def test_concurrent_quantizer_chains_give_the_serial_gradients_bit_for_bit(cuda)
 
 
 def test_train_step_identical_with_and_without_streaming_kernel():
-    """configs[2] at its real size (B = 16 x 2 s), two seeded iterations, once with the streaming k = 1 kernel (forward and
-    data gradient of the C <= 384 ResidualUnit tails) and once with FAC_PW=0 (tiled kernel): same summation order, so every loss
-    and every gradient norm must agree to the last bit.  Separate processes: the switch is read once per process."""
+    """configs[2] at its real size (B = 16 x 2 s), two seeded iterations: with the fp32 streaming k = 1 kernel (forward and data
+    gradient of the C <= 384 ResidualUnit tails; FAC_PW_SPLIT=0) and with FAC_PW=0 (tiled kernel) the summation order is the same,
+    so every loss and every gradient norm must agree to the last bit.  The default policy (round 6: the same layers and the two
+    stride-2 layers with few channels on the bf16-plane streaming kernels of conv1d_pw_split.hip) is fp32-grade, not bit-equal:
+    losses within 1e-4, gradient norms within 5e-4 of the fp32 run (measured: 6e-8 / 2e-5 on the first iteration).  Separate processes: the switches are read once per process."""
     import json
     import subprocess
     import sys
     script = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "tune", "pw_check.py")
     outs = []
-    for flag in ("0", "1"):
-        env = dict(os.environ, FAC_PW=flag)
+    for extra in ({"FAC_PW": "0", "FAC_PW_SPLIT": "0"}, {"FAC_PW": "1", "FAC_PW_SPLIT": "0"}, {}):
+        env = dict(os.environ, **extra)
+        if not extra:
+            env.pop("FAC_PW", None)
+            env.pop("FAC_PW_SPLIT", None)
         r = subprocess.run([sys.executable, script, "2"], env=env, capture_output=True, text=True, timeout=900)
         assert r.returncode == 0, r.stderr[-2000:]
         line = [ln for ln in r.stdout.splitlines() if ln.startswith("PW=")][-1]
         outs.append(json.loads(line.split(" ", 1)[1]))
     assert outs[0] == outs[1], outs
+    for (loss_a, mel_a, gn_a), (loss_b, mel_b, gn_b) in zip(outs[1], outs[2]):
+        assert abs(loss_a - loss_b) <= 1e-4 * abs(loss_a) and abs(mel_a - mel_b) <= 1e-4 * abs(mel_a), outs
+        for k in gn_a:
+            assert abs(gn_a[k] - gn_b[k]) <= 5e-4 * abs(gn_a[k]), (k, outs)
