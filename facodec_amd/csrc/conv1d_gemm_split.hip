@@ -44,6 +44,19 @@ __device__ __forceinline__ void gs_split3(float x, __bf16& h, __bf16& m, __bf16&
   l = (__bf16)(r1 - (float)m);
 }
 
+// XOR swizzle of the INPUT planes (round 6).  The weights keep slot = piece ^ ((row >> 2) & 3): they reach the LDS by DMA and are only
+// read.  The inputs are also WRITTEN by ds_write_b128 (fp32 inputs, split in the staging waves), and a 16-byte store is serviced in
+// groups of 8 consecutive lanes = 8 consecutive rows over a 128-byte bank window (two rows): with (row >> 2) & 3 rows r and r + 2 of
+// a group share their banks -- every staging store took two LDS passes (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE 0.13 - 0.27 on this
+// kernel, 0.00 on the others: profiles/r06_pmc_train.json).  f = bit 2 | (bit 1 ^ bit 3) << 1 keeps the fragment reads (16-lane groups
+// {0-3, 12-15, 20-27} / {4-11, 16-19, 28-31} over a 256-byte window, rows shifted by the tap) conflict-free and makes 8 aligned
+// consecutive rows hit 8 different 16-byte slots (exhaustive search over the GF(2)-linear maps of the row bits: tools/tune/lds_swizzle_search.py).
+#ifdef FAC_GS_OLD_SWZ   // tuning builds: the swizzle of rounds 3 - 5
+__device__ __forceinline__ int gs_xswz(int row) { return (row >> 2) & 3; }
+#else
+__device__ __forceinline__ int gs_xswz(int row) { return ((row >> 2) & 1) | ((((row >> 1) ^ (row >> 3)) & 1) << 1); }
+#endif
+
 __device__ __forceinline__ void gs_barrier() {
   asm volatile("" ::: "memory");
   __builtin_amdgcn_s_barrier();
@@ -168,7 +181,7 @@ __global__ __launch_bounds__(512, 2) void conv1d_gemm_split_kernel(ConvArgs a) {
         const int row = blk * 16 + (lane >> 2);
         b_plane[j] = plane;
         b_row[j] = row;
-        b_piece[j] = (lane & 3) ^ ((row >> 2) & 3);
+        b_piece[j] = (lane & 3) ^ gs_xswz(row);
         b_lds[j] = A_BYTES + plane * GS_BPL + blk * 1024;
         b_live[j] = row < GS_XR;                                   // rows past the plane's LDS allocation must not be written
         unsigned off = zero_off;
@@ -240,10 +253,13 @@ __global__ __launch_bounds__(512, 2) void conv1d_gemm_split_kernel(ConvArgs a) {
     bool u_ok[GS_NU], u_in[GS_NU];
 #pragma unroll
     for (int j = 0; j < GS_NU; ++j) {
+      // units 0 .. 511: (group, column) = (unit / 128, unit % 128) -- 8 consecutive lanes are 8 aligned consecutive rows of one
+      // group (conflict-free stores, gs_xswz); the K - 1 halo columns of the four groups are units 512 ..
       const int unit = j * 256 + sl;
-      const int g = unit / (GS_COLS + K - 1), c = unit - g * (GS_COLS + K - 1);
-      u_ok[j] = g < 4;                                       // a unit that exists in the staged window
-      u_lds[j] = c * GS_RB + ((g ^ ((c >> 2) & 3)) * 16);
+      const int g = unit < 4 * GS_COLS ? unit >> 7 : (unit - 4 * GS_COLS) / (K > 1 ? K - 1 : 1);
+      const int c = unit < 4 * GS_COLS ? unit & (GS_COLS - 1) : GS_COLS + (unit - 4 * GS_COLS) % (K > 1 ? K - 1 : 1);
+      u_ok[j] = unit < 4 * (GS_COLS + K - 1);                // a unit that exists in the staged window
+      u_lds[j] = c * GS_RB + ((g ^ gs_xswz(c)) * 16);
       long long off = 0;
       bool in = false;
       if (flat) {                                            // K == 1: flattened (clip, time) columns, no halo
@@ -386,7 +402,7 @@ __global__ __launch_bounds__(512, 2) void conv1d_gemm_split_kernel(ConvArgs a) {
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
         const int row = nh * 64 + l31 + k;
-        boff[k][ks] = A_BYTES + row * GS_RB + (((ks * 2 + kq) ^ ((row >> 2) & 3)) * 16);
+        boff[k][ks] = A_BYTES + row * GS_RB + (((ks * 2 + kq) ^ gs_xswz(row)) * 16);
       }
 
     f32x16 acc[2][2];
@@ -408,7 +424,7 @@ __global__ __launch_bounds__(512, 2) void conv1d_gemm_split_kernel(ConvArgs a) {
 #pragma unroll
       for (int p = 0; p < 3; ++p)
 #pragma unroll
-        for (int n = 0; n < 2; ++n)     // rows 32 apart: (row >> 2) & 3 is unchanged, the swizzle of block n = that of block 0
+        for (int n = 0; n < 2; ++n)     // rows 32 apart: gs_xswz(row) is unchanged, the swizzle of block n = that of block 0
           Bf[n][p] = *reinterpret_cast<const bf16x8*>(st + boff[k][ks] + p * GS_BPL + n * 32 * GS_RB);
     };
 
