@@ -1,4 +1,4 @@
-// The streaming k = 1 kernel of conv1d_pw.hip on the bf16 matrix pipe (round 6): the ResidualUnit tails at C <= 192
+// The streaming k = 1 kernel of conv1d_pw.hip on the bf16 matrix pipe (round 6): the ResidualUnit tails at C = 64 .. 384
 // (dac/model/dac.py:33-42) with both operands split into three bf16 planes (hi + mid + lo == value exactly; six products,
 // smallest first, fp32 accumulate -- the "fp32-grade" arithmetic of conv1d_bsplit.hip / conv1d_gemm_split.hip).
 // Same skeleton as conv1d_pw.hip -- weights resident in LDS for the life of the workgroup, a wave owns 32 columns x 32 MBW
@@ -6,11 +6,14 @@
 // bias / Snake / residual / y / y2 -- but:
 //   * the weights are split ONCE in the prologue into the A-fragment order of v_mfma_f32_32x32x16_bf16
 //     ([K step of 16][32-row block][plane][lane][8 bf16]: one ds_read_b128 per fragment, conflict-free), 6 bytes per weight:
-//     96 output channels x 192 inputs = 108 KB, so C = 192 runs as two slices of 96 (as C = 256 / 384 do on the fp32 kernel);
+//     96 output channels x 192 inputs = 108 KB, so C = 192 runs as two slices of 96 and C = 256 / 384 as four / six slices of 64
+//     (the slices of one column-block set sit on one XCD: the input rows come from HBM once, from that XCD's L2 afterwards);
 //   * a K step is 16 input channels: lane (kq, l31) loads x[16 s + 8 kq + j][t0 + l31], j = 0..7 (two full 128-byte lines per
 //     instruction, as before), splits the eight values in registers and feeds 6 x MBW MFMAs of 32 cycles -- 2.7 x fewer
 //     matrix-pipe cycles than the 8 x MBW fp32 MFMAs of 64 cycles for the same 16 channels (C = 192: 288 fp32 MFMAs per block
 //     and wave were 37 us per round of the chip against 33 us of HBM time).
+// Measured at B = 32 (profiles/r06_pws_ab.log, fp32 kernel -> this one): C = 64 0.37 -> 0.32 ms, 96 0.63 -> 0.47, 128 0.46 -> 0.34,
+// 192 0.87 -> 0.57, 256 0.30 -> 0.21, 384 0.60 -> 0.40; error against fp64 as small as the fp32 kernel's (2 - 5e-7 of the largest value).
 #include "conv1d_mfma.h"
 
 namespace fac {
@@ -369,19 +372,13 @@ static int pws_slice_channels(int C) {
   }
 }
 
-static int pws_env(const char* name) {
-  const char* v = getenv(name);
-  return v ? atoi(v) : 0;
-}
-
 bool conv_pws_ok(const ConvArgs& a) {
   static const bool on = !(getenv("FAC_PW_SPLIT") && getenv("FAC_PW_SPLIT")[0] == '0');
-  static const int max_c = pws_env("FAC_PWS_MAX_C") ? pws_env("FAC_PWS_MAX_C") : 384;
   if (!on || !(a.K == 1 && a.stride == 1 && a.n_phase == 1 && a.phase_shift == 0 && a.y_tstride == 1 && a.pad_left == 0 && !a.alpha_in &&
                !a.w1 && !a.w_batched && !conv_two_level(a) && a.T_in >= a.T_out && a.C_in == a.C_out && !a.x_p8))
     return false;
   const int co = pws_slice_channels(a.C_out);
-  if (!co || a.C_out_pad != a.C_out || a.C_out > max_c) return false;
+  if (!co || a.C_out_pad != a.C_out) return false;
   // enough column blocks that every wave slot of a 256-CU chip walks at least two of them
   const long long items = (long long)a.B * ((a.T_out + 31) / 32);
   const int nsplit = co == 128 ? 2 : 1;
@@ -415,14 +412,13 @@ static int pws_launch(ConvArgs& a, hipStream_t s) {
   return check_launch("conv1d_pw_split");
 }
 
-// 12 waves (three per SIMD, <= 168 registers): measured against 16 (spills) and 8 on the forward's six layer shapes
-// (profiles/r06_pws_ab.log)
+// 12 waves (three per SIMD, <= 168 registers; 16 spill, 8 lose 10 - 30 %) and 4 / 3 K steps in flight per wave (2 / 3 accumulator
+// blocks), measured on the forward's six layer shapes: profiles/r06_pws_ab.log
 int conv_dispatch_pws(ConvArgs& a, hipStream_t s) {
-  static const int d_env = pws_env("FAC_PWS_D");               // experiment: K steps in flight
   switch (pws_slice_channels(a.C_out)) {
-    case 64: return d_env == 2 ? pws_launch<2, 1, 12, 2>(a, s) : pws_launch<2, 1, 12, 4>(a, s);   // C = 64; C = 256 / 384 in slices of 64
-    case 128: return d_env == 2 ? pws_launch<2, 2, 12, 2>(a, s) : pws_launch<2, 2, 12, 4>(a, s);
-    default: return d_env == 2 ? pws_launch<3, 1, 12, 2>(a, s) : pws_launch<3, 1, 12, 3>(a, s);   // C = 96; C = 192 in two slices of 96
+    case 64: return pws_launch<2, 1, 12, 4>(a, s);      // C = 64; C = 256 / 384 in slices of 64
+    case 128: return pws_launch<2, 2, 12, 4>(a, s);
+    default: return pws_launch<3, 1, 12, 3>(a, s);      // C = 96; C = 192 in two slices of 96
   }
 }
 
@@ -473,9 +469,8 @@ static int pwt_launch(ConvArgs& a, hipStream_t s) {
 }
 
 int conv_dispatch_pwt(ConvArgs& a, hipStream_t s) {
-  static const int d_env = pws_env("FAC_PWS_D");
-  if (pwt_shape(a) == 1) return d_env == 4 ? pwt_launch<2, 1, 2, 4>(a, s) : pwt_launch<2, 1, 2, 2>(a, s);
-  return d_env == 4 ? pwt_launch<4, 2, 1, 4>(a, s) : pwt_launch<4, 2, 1, 2>(a, s);
+  if (pwt_shape(a) == 1) return pwt_launch<2, 1, 2, 2>(a, s);
+  return pwt_launch<4, 2, 1, 2>(a, s);
 }
 
 }  // namespace fac

@@ -707,7 +707,7 @@ def conv_transpose1d(x, w_packed, c_out, stride, bias=None, alpha_in=None, out=N
 # latent rate, so those launches (the encoder's last downsampling conv, the decoder's first ConvTranspose1d, and their data
 # gradients) fell to the fp32 128 x 160 tile at 38 - 63 TFLOP/s (profiles/r06_train_layers_serial.log: 3.9 ms per step).
 FLAT_TRAIN = os.environ.get("FAC_FLAT_TRAIN", "1") != "0"
-# k = 1 ResidualUnit tails at C <= 192 on the bf16 pipe inside the streaming kernel (conv1d_pw_split.hip); 0: fp32 MFMAs (rounds 2-5)
+# k = 1 ResidualUnit tails at C = 64 .. 384 on the bf16 pipe inside the streaming kernel (conv1d_pw_split.hip); 0: fp32 MFMAs (rounds 2-5)
 PW_SPLIT = os.environ.get("FAC_PW_SPLIT", "1") != "0"
 
 

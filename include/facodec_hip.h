@@ -173,9 +173,12 @@ typedef struct fac_conv_desc {
   int64_t x_p8_plane_bytes;
   void* y2_p8;
   int64_t y2_p8_plane_bytes;
-  /* Optional (0 = off): the k = 1 streaming kernel (C_in == C_out in {64, 96, 128, 192}, many columns) may split BOTH operands into
-   * three bf16 planes inside the kernel (weights once per workgroup, inputs per load) and run on the bf16 matrix pipe with fp32-grade
-   * results, instead of fp32 MFMAs.  Needs only `w`.  The host side sets it wherever it hands `w_split` to the other layers. */
+  /* Optional (0 = off): launches the streaming kernels take (weights resident in LDS, inputs straight from global memory) may
+   * split BOTH operands into three bf16 planes inside the kernel (weights once per workgroup, inputs per load) and run on the
+   * bf16 matrix pipe with fp32-grade results instead of fp32 MFMAs: k = 1 with C_in == C_out in {64, 96, 128, 192, 256, 384} and
+   * many columns; with fp32 weights `w` of fac_pack_convtr_w_rows also the all-phases ConvTranspose1d with stride 2 (row_phases
+   * = 2), and with `w` of fac_pack_conv_w the k = 4 stride-2 conv, each with C_in * taps <= 384 (conv1d_pw_split.hip).  Needs only
+   * `w`; ignored elsewhere.  The host side sets it wherever it hands `w_split` to the other layers. */
   int32_t pw_split;
 } fac_conv_desc;
 
