@@ -99,47 +99,85 @@ __global__ __launch_bounds__(256) void attn_probs_kernel(const float* __restrict
   for (int t2 = tid; t2 < T; t2 += 256) pr[t2] = sc[t2] / sum;
 }
 
-// o[b][h*dk+d][t1] = sum_t2 P[t1][t2] v[d][t2]
-__global__ void attn_pv_kernel(const float* __restrict__ P, const float* __restrict__ v, float* __restrict__ o, int H, int dk, int T, long long n) {
-  GRID_STRIDE(i, n) {
-    const int t1 = (int)(i % T);
-    const long long r = i / T;            // (b*H + h)*dk + d
-    const long long bh = r / dk;
-    const float* pr = P + (bh * T + t1) * T;
-    const float* vr = v + r * T;
-    float s = 0.f;
-    for (int t2 = 0; t2 < T; ++t2) s = fmaf(pr[t2], vr[t2], s);
-    o[i] = s;
+// The five small matrix products of the attention (o = P v, dv, dP, dq, dk) as ONE tiled kernel (round 6; the per-output
+// kernels of rounds 3 - 5 walked P / dS rows T floats apart from neighbouring lanes: 0.62 ms each for 0.1 GFLOP at T = 188):
+//   C[n][m] = [scale *] sum_k A(m, k) B(n, k),  k ascending, one fmaf per term -- the naive kernels' order, so the same bits.
+// Each operand is either k-contiguous (element (r, k) at r * T + k) or row-contiguous (at k * T + r); a 64 (m) x 16 (n) tile per
+// workgroup, k in chunks of 32 through LDS (coalesced loads along whichever index is contiguous), lane = m, wave = 4 of the n.
+struct AttnGemm {
+  const float* A;
+  const float* B;
+  float* C;
+  long long a_bs, b_bs, c_bs;   // batch strides (one (clip, head) per blockIdx.z)
+  int M, N, K, T;               // T: the row pitch of both operands
+  float scale;
+  int use_scale;
+};
+
+template <bool A_KC, bool B_KC>
+__global__ __launch_bounds__(256) void attn_gemm_kernel(AttnGemm g) {
+  __shared__ float As[32][65];
+  __shared__ float Bs[16][33];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int m0 = blockIdx.x * 64, n0 = blockIdx.y * 16;
+  const float* A = g.A + (long long)blockIdx.z * g.a_bs;
+  const float* B = g.B + (long long)blockIdx.z * g.b_bs;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int k0 = 0; k0 < g.K; k0 += 32) {
+    const int kc = g.K - k0 < 32 ? g.K - k0 : 32;
+    if (A_KC) {
+      const int kk = tid & 31, mm = tid >> 5;
+#pragma unroll
+      for (int p = 0; p < 8; ++p) {
+        const int m = mm + 8 * p;
+        As[kk][m] = (m0 + m < g.M && kk < kc) ? A[(long long)(m0 + m) * g.T + k0 + kk] : 0.f;
+      }
+    } else {
+      const int mm = tid & 63, kk = tid >> 6;
+#pragma unroll
+      for (int p = 0; p < 8; ++p) {
+        const int k = kk + 4 * p;
+        As[k][mm] = (m0 + mm < g.M && k < kc) ? A[(long long)(k0 + k) * g.T + m0 + mm] : 0.f;
+      }
+    }
+    if (B_KC) {
+      const int kk = tid & 31, nn = tid >> 5;
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+        const int n = nn + 8 * p;
+        Bs[n][kk] = (n0 + n < g.N && kk < kc) ? B[(long long)(n0 + n) * g.T + k0 + kk] : 0.f;
+      }
+    } else {
+      const int nn = tid & 15, kk = tid >> 4;
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+        const int k = kk + 16 * p;
+        Bs[nn][k] = (n0 + nn < g.N && k < kc) ? B[(long long)(k0 + k) * g.T + n0 + nn] : 0.f;
+      }
+    }
+    __syncthreads();
+    for (int kk = 0; kk < kc; ++kk) {
+      const float a = As[kk][lane];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[j] = fmaf(a, Bs[4 * wave + j][kk], acc[j]);
+    }
+    __syncthreads();
+  }
+  const int m = m0 + lane;
+  if (m >= g.M) return;
+  float* C = g.C + (long long)blockIdx.z * g.c_bs;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int n = n0 + 4 * wave + j;
+    if (n < g.N) C[(long long)n * g.M + m] = g.use_scale ? acc[j] * g.scale : acc[j];
   }
 }
 
-// dV[d][t2] = sum_t1 P[t1][t2] dO[d][t1]
-__global__ void attn_dv_kernel(const float* __restrict__ P, const float* __restrict__ dO, float* __restrict__ dv, int H, int dk, int T, long long n) {
-  GRID_STRIDE(i, n) {
-    const int t2 = (int)(i % T);
-    const long long r = i / T;
-    const long long bh = r / dk;
-    const float* pb = P + bh * T * T + t2;
-    const float* dr = dO + r * T;
-    float s = 0.f;
-    for (int t1 = 0; t1 < T; ++t1) s = fmaf(pb[(long long)t1 * T], dr[t1], s);
-    dv[i] = s;
-  }
-}
-
-// dP[t1][t2] = sum_d dO[d][t1] v[d][t2]
-__global__ void attn_dp_kernel(const float* __restrict__ dO, const float* __restrict__ v, float* __restrict__ dP, int H, int dk, int T, long long n) {
-  GRID_STRIDE(i, n) {
-    const int t2 = (int)(i % T);
-    const long long r = i / T;
-    const int t1 = (int)(r % T);
-    const long long bh = r / T;
-    const float* dob = dO + bh * dk * T + t1;
-    const float* vb = v + bh * dk * T + t2;
-    float s = 0.f;
-    for (int d = 0; d < dk; ++d) s = fmaf(dob[(long long)d * T], vb[(long long)d * T], s);
-    dP[i] = s;
-  }
+template <bool A_KC, bool B_KC>
+static void attn_gemm(const float* A, const float* B, float* C, long long a_bs, long long b_bs, long long c_bs, int M, int N, int K, int T,
+                      int batch, float scale, int use_scale, hipStream_t s) {
+  AttnGemm g{A, B, C, a_bs, b_bs, c_bs, M, N, K, T, scale, use_scale};
+  hipLaunchKernelGGL((attn_gemm_kernel<A_KC, B_KC>), dim3((M + 63) / 64, (N + 15) / 16, batch), dim3(256), 0, s, g);
 }
 
 // softmax backward per row: dS = P * (dP - sum(dP * P)); masked entries carry no gradient.  In place on dP.
@@ -162,35 +200,6 @@ __global__ __launch_bounds__(256) void attn_softmax_bwd_kernel(const float* __re
     float g = pr[t2] * (dr[t2] - s);
     if (mask && m1 * mask[(long long)b * T + t2] == 0.f) g = 0.f;
     dr[t2] = g;
-  }
-}
-
-// dQ[d][t1] = scale * sum_t2 dS[t1][t2] k[d][t2];  dK[d][t2] = scale * sum_t1 dS[t1][t2] q[d][t1]
-__global__ void attn_dq_kernel(const float* __restrict__ dS, const float* __restrict__ k, float* __restrict__ dq, int H, int dk, int T, long long n) {
-  const float scale = 1.0f / sqrtf((float)dk);
-  GRID_STRIDE(i, n) {
-    const int t1 = (int)(i % T);
-    const long long r = i / T;
-    const long long bh = r / dk;
-    const float* sr = dS + (bh * T + t1) * T;
-    const float* kr = k + r * T;
-    float s = 0.f;
-    for (int t2 = 0; t2 < T; ++t2) s = fmaf(sr[t2], kr[t2], s);
-    dq[i] = s * scale;
-  }
-}
-
-__global__ void attn_dk_kernel(const float* __restrict__ dS, const float* __restrict__ q, float* __restrict__ dk_, int H, int dk, int T, long long n) {
-  const float scale = 1.0f / sqrtf((float)dk);
-  GRID_STRIDE(i, n) {
-    const int t2 = (int)(i % T);
-    const long long r = i / T;
-    const long long bh = r / dk;
-    const float* sb = dS + bh * T * T + t2;
-    const float* qr = q + r * T;
-    float s = 0.f;
-    for (int t1 = 0; t1 < T; ++t1) s = fmaf(sb[(long long)t1 * T], qr[t1], s);
-    dk_[i] = s * scale;
   }
 }
 
@@ -248,8 +257,9 @@ extern "C" int fac_attention_probs(const float* q, const float* k, const float* 
 
 extern "C" int fac_attention_pv(const float* P, const float* v, float* o, int B, int H, int dk, int T, fac_stream_t stream) {
   FAC_REQUIRE(P && v && o && B > 0 && H > 0 && dk > 0 && T > 0, "attention_pv: bad arguments");
-  const long long n = (long long)B * H * dk * T;
-  LAUNCH1(attn_pv_kernel, n, P, v, o, H, dk, T, n);
+  FAC_REQUIRE((long long)B * H <= 65535, "attention_pv: B * heads too large");
+  // o[d][t1] = sum_t2 P[t1][t2] v[d][t2]:  m = t1, n = d, k = t2
+  fac::attn_gemm<true, true>(P, v, o, (long long)T * T, (long long)dk * T, (long long)dk * T, T, dk, T, T, B * H, 1.f, 0, (hipStream_t)stream);
   return fac::check_launch("attention_pv");
 }
 
@@ -259,9 +269,12 @@ extern "C" int fac_attention_pv(const float* P, const float* v, float* o, int B,
 extern "C" int fac_attention_bwd_pv(const float* P_used, const float* v, const float* dO, float* dv, float* dP, int B, int H,
                                     int dk, int T, fac_stream_t stream) {
   FAC_REQUIRE(P_used && v && dO && dv && dP && B > 0 && H > 0 && dk > 0 && T > 0, "attention_bwd_pv: bad arguments");
-  const long long n = (long long)B * H * dk * T, np = (long long)B * H * T * T;
-  LAUNCH1(attn_dv_kernel, n, P_used, dO, dv, H, dk, T, n);
-  LAUNCH1(attn_dp_kernel, np, dO, v, dP, H, dk, T, np);
+  FAC_REQUIRE((long long)B * H <= 65535, "attention_bwd_pv: B * heads too large");
+  const long long tt = (long long)T * T, dt = (long long)dk * T;
+  // dv[d][t2] = sum_t1 P[t1][t2] dO[d][t1]:  m = t2, n = d, k = t1 (P row-contiguous in m)
+  fac::attn_gemm<false, true>(P_used, dO, dv, tt, dt, dt, T, dk, T, T, B * H, 1.f, 0, (hipStream_t)stream);
+  // dP[t1][t2] = sum_d dO[d][t1] v[d][t2]:  m = t2, n = t1, k = d (both operands row-contiguous)
+  fac::attn_gemm<false, false>(v, dO, dP, dt, dt, tt, T, T, dk, T, B * H, 1.f, 0, (hipStream_t)stream);
   return fac::check_launch("attention_bwd_pv");
 }
 
@@ -269,8 +282,11 @@ extern "C" int fac_attention_bwd_qk(const float* P, float* dP, const float* q, c
                                     float* dk_, int B, int H, int dk, int T, fac_stream_t stream) {
   FAC_REQUIRE(P && dP && q && k && dq && dk_ && B > 0 && H > 0 && dk > 0 && T > 0, "attention_bwd_qk: bad arguments");
   hipLaunchKernelGGL(fac::attn_softmax_bwd_kernel, dim3((unsigned)((long long)B * H * T)), dim3(256), 0, (hipStream_t)stream, P, dP, mask, H, T);
-  const long long n = (long long)B * H * dk * T;
-  LAUNCH1(attn_dq_kernel, n, dP, k, dq, H, dk, T, n);
-  LAUNCH1(attn_dk_kernel, n, dP, q, dk_, H, dk, T, n);
+  FAC_REQUIRE((long long)B * H <= 65535, "attention_bwd_qk: B * heads too large");
+  const long long tt = (long long)T * T, dt = (long long)dk * T;
+  const float scale = 1.0f / sqrtf((float)dk);
+  // dq[d][t1] = scale * sum_t2 dS[t1][t2] k[d][t2];  dk[d][t2] = scale * sum_t1 dS[t1][t2] q[d][t1]
+  fac::attn_gemm<true, true>(dP, k, dq, tt, dt, dt, T, dk, T, T, B * H, scale, 1, (hipStream_t)stream);
+  fac::attn_gemm<false, true>(dP, q, dk_, tt, dt, dt, T, dk, T, T, B * H, scale, 1, (hipStream_t)stream);
   return fac::check_launch("attention_bwd_qk");
 }

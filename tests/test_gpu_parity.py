@@ -488,6 +488,42 @@ def test_style_encoder_and_wavenet_against_oracle(O, cuda):
     assert rel(outw, refw) < OP_TOL
 
 
+@pytest.mark.parametrize("B,H,dk,T", [(4, 2, 256, 188), (2, 2, 256, 1300), (3, 2, 128, 70)])
+def test_attention_kernels_against_torch(B, H, dk, T, cuda):
+    """The StyleEncoder's 2-head self-attention (modules/attentions.py:168-199) at the benchmark's frame count (188 per 2 s clip),
+    at a length whose V tile no longer fits the LDS next to the scores (rows read in place) and at a ragged one: the inference
+    kernel (V rows staged through LDS, round 6) and the training Function (probabilities materialised; o = P v, dv, dP, dq, dk on
+    the tiled attn_gemm_kernel) against torch's softmax attention and its autograd, fp64."""
+    from facodec_amd import ops
+    from facodec_amd.autograd_quant import _Attention
+    g = _g(B + T)
+    q, k, v = (torch.randn(B, H * dk, T, generator=g) for _ in range(3))
+    mask = torch.ones(B, T)
+    mask[0, T - 17:] = 0
+
+    def ref(q, k, v):
+        qh, kh, vh = (t.double().view(B, H, dk, T).transpose(2, 3) for t in (q, k, v))          # (B, H, T, dk)
+        sc = qh @ kh.transpose(2, 3) / dk ** 0.5
+        m2 = (mask.unsqueeze(1) * mask.unsqueeze(2)).unsqueeze(1)
+        sc = sc.masked_fill(m2 == 0, -1e4)
+        return (torch.softmax(sc, -1) @ vh).transpose(2, 3).reshape(B, H * dk, T)
+
+    qd, kd, vd = (t.clone().requires_grad_(True) for t in (q, k, v))
+    o_ref = ref(qd, kd, vd)
+    w = torch.randn(B, H * dk, T, generator=g)
+    o_ref.backward(w.double())
+    out = ops.attention(q.to(cuda), k.to(cuda), v.to(cuda), mask.to(cuda), H)
+    assert rel(out, o_ref) < OP_TOL
+    if T > 1000:
+        return
+    qc, kc, vc = (t.to(cuda).requires_grad_(True) for t in (q, k, v))
+    o = _Attention.apply(qc, kc, vc, mask.to(cuda), H, None, 1.0)
+    assert rel(o, o_ref) < OP_TOL
+    o.backward(w.to(cuda))
+    for a, b in ((qc, qd), (kc, kd), (vc, vd)):
+        assert rel(a.grad, b.grad) < 2e-5
+
+
 def test_small_encoder_decoder_vs_reference_golden(cuda, golden_dir):
     from facodec_amd.dac_model import Decoder, Encoder
     d = np.load(os.path.join(golden_dir, "small_layers.npz"))
