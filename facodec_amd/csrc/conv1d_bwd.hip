@@ -655,36 +655,65 @@ __global__ __launch_bounds__(256) void vq_codebook_grad_kernel(const float* __re
 // LayerNorm over channels + per-clip affine (modules/quantize.py:444-449): out = xhat * gamma_b + beta_b.
 // Column kernel: dx; row kernel: dgamma / dbeta (sums over time, one workgroup per (b, c)).
 __global__ __launch_bounds__(256) void layernorm_c_bwd_x_kernel(const float* __restrict__ x, const float* __restrict__ style,
-                                                                const float* __restrict__ dout, float* __restrict__ dx, int C,
-                                                                int T) {
+                                                                const float* __restrict__ dout, float* __restrict__ dx,
+                                                                float* __restrict__ stats, int C, int T) {
   __shared__ float red[4][4][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int b = blockIdx.y, t = blockIdx.x * 64 + lane;
   const bool tv = t < T;
-  const float* xb = x + (long long)b * C * T + t;
-  const float* db = dout + (long long)b * C * T + t;
+  const float* xb = x + (long long)b * C * T + (tv ? t : T - 1);
+  const float* db = dout + (long long)b * C * T + (tv ? t : T - 1);
   const float* gm = style + (long long)b * 2 * C;
+  // Round 6: loads go out 16 at a time per chain (they were C / 4 dependent round trips per lane: 288 us for 10 MB), and the
+  // column statistics the row kernel needs are written from here (a separate single-wave kernel recomputed them in 217 us).
+  constexpr int U = 16;
   float s = 0.f;
-  for (int c = wave; c < C; c += 4) s += tv ? xb[(long long)c * T] : 0.f;
+  for (int c0 = wave; c0 < C; c0 += 4 * U) {
+    float buf[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) buf[u] = c0 + 4 * u < C ? xb[(long long)(c0 + 4 * u) * T] : 0.f;
+#pragma unroll
+    for (int u = 0; u < U; ++u) s += tv ? buf[u] : 0.f;
+  }
   red[0][wave][lane] = s;
   __syncthreads();
   const float mean = ((red[0][0][lane] + red[0][1][lane]) + (red[0][2][lane] + red[0][3][lane])) / (float)C;
   float vs = 0.f;
-  for (int c = wave; c < C; c += 4) {
-    const float d = tv ? xb[(long long)c * T] - mean : 0.f;
-    vs = fmaf(d, d, vs);
+  for (int c0 = wave; c0 < C; c0 += 4 * U) {
+    float buf[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) buf[u] = c0 + 4 * u < C ? xb[(long long)(c0 + 4 * u) * T] : mean;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const float d = tv ? buf[u] - mean : 0.f;
+      vs = fmaf(d, d, vs);
+    }
   }
   red[1][wave][lane] = vs;
   __syncthreads();
   const float var = ((red[1][0][lane] + red[1][1][lane]) + (red[1][2][lane] + red[1][3][lane])) / (float)C;
   const float rstd = 1.0f / sqrtf(var + 1e-5f);
+  if (tv && wave == 0) {
+    stats[((long long)b * T + t) * 2] = mean;
+    stats[((long long)b * T + t) * 2 + 1] = rstd;
+  }
   float s1 = 0.f, s2 = 0.f;          // sum of dxhat, sum of dxhat * xhat
-  for (int c = wave; c < C; c += 4) {
-    if (!tv) break;
-    const float xh = (xb[(long long)c * T] - mean) * rstd;
-    const float dxh = db[(long long)c * T] * gm[c];
-    s1 += dxh;
-    s2 = fmaf(dxh, xh, s2);
+  for (int c0 = wave; c0 < C; c0 += 4 * U) {
+    float bx[U], bd[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const bool in = c0 + 4 * u < C;
+      bx[u] = in ? xb[(long long)(c0 + 4 * u) * T] : mean;
+      bd[u] = in ? db[(long long)(c0 + 4 * u) * T] * gm[c0 + 4 * u] : 0.f;
+    }
+    if (tv) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const float xh = (bx[u] - mean) * rstd;
+        s1 += bd[u];
+        s2 = fmaf(bd[u], xh, s2);
+      }
+    }
   }
   red[2][wave][lane] = s1;
   red[3][wave][lane] = s2;
@@ -693,6 +722,7 @@ __global__ __launch_bounds__(256) void layernorm_c_bwd_x_kernel(const float* __r
   const float m2 = ((red[3][0][lane] + red[3][1][lane]) + (red[3][2][lane] + red[3][3][lane])) / (float)C;
   if (!tv) return;
   float* ob = dx + (long long)b * C * T + t;
+#pragma unroll 8
   for (int c = wave; c < C; c += 4) {
     const float xh = (xb[(long long)c * T] - mean) * rstd;
     const float dxh = db[(long long)c * T] * gm[c];
@@ -700,22 +730,7 @@ __global__ __launch_bounds__(256) void layernorm_c_bwd_x_kernel(const float* __r
   }
 }
 
-// stats[b][t] = (mean, rstd) recomputed per column would cost C reads per element: instead the row kernel takes the
-// normalised tensor xhat it needs from a scratch written by ... nothing: it recomputes mean / rstd per column too
-// (C is 1024 and T small on this path; the quantizer runs at frame rate).
-__global__ __launch_bounds__(64) void layernorm_c_stats_kernel(const float* __restrict__ x, float* __restrict__ stats, int C, int T) {
-  const int b = blockIdx.y, t = blockIdx.x * 64 + threadIdx.x;
-  if (t >= T) return;
-  const float* xb = x + (long long)b * C * T + t;
-  float s = 0.f;
-  for (int c = 0; c < C; ++c) s += xb[(long long)c * T];
-  const float mean = s / (float)C;
-  float vs = 0.f;
-  for (int c = 0; c < C; ++c) { const float d = xb[(long long)c * T] - mean; vs = fmaf(d, d, vs); }
-  stats[((long long)b * T + t) * 2] = mean;
-  stats[((long long)b * T + t) * 2 + 1] = 1.0f / sqrtf(vs / (float)C + 1e-5f);
-}
-
+// dgamma / dbeta: sums over time, one workgroup per (b, c); the column statistics come from layernorm_c_bwd_x_kernel.
 __global__ __launch_bounds__(64) void layernorm_c_bwd_style_kernel(const float* __restrict__ x, const float* __restrict__ stats,
                                                                    const float* __restrict__ dout, float* __restrict__ dstyle,
                                                                    int C, int T) {
@@ -766,8 +781,7 @@ extern "C" int fac_layernorm_c_affine_bwd(const float* x, const float* style, co
                                           float* stats, int B, int C, int T, fac_stream_t stream) {
   using namespace fac;
   FAC_REQUIRE(x && style && dout && dx && dstyle && stats && B > 0 && C > 0 && T > 0, "layernorm_c_affine_bwd: bad arguments");
-  hipLaunchKernelGGL(layernorm_c_bwd_x_kernel, dim3((T + 63) / 64, B), dim3(256), 0, (hipStream_t)stream, x, style, dout, dx, C, T);
-  hipLaunchKernelGGL(layernorm_c_stats_kernel, dim3((T + 63) / 64, B), dim3(64), 0, (hipStream_t)stream, x, stats, C, T);
+  hipLaunchKernelGGL(layernorm_c_bwd_x_kernel, dim3((T + 63) / 64, B), dim3(256), 0, (hipStream_t)stream, x, style, dout, dx, stats, C, T);
   hipLaunchKernelGGL(layernorm_c_bwd_style_kernel, dim3(C, B), dim3(64), 0, (hipStream_t)stream, x, stats, dout, dstyle, C, T);
   return check_launch("layernorm_c_affine_bwd");
 }

@@ -10,8 +10,17 @@ constexpr int SUMSQ_BLOCKS = 1024;
 
 __global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* __restrict__ g, long long n, float* __restrict__ part) {
   __shared__ float red[256];
-  float s = 0.f;
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) s = fmaf(g[i], g[i], s);
+  // 16-byte loads, four independent sums per lane (round 6: the scalar loop with one dependent fmaf chain ran at 1.5 TB/s); the
+  // order is fixed by (n, grid), so the norm is reproducible run to run
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  const long long n4 = (reinterpret_cast<unsigned long long>(g) & 15) == 0 ? n >> 2 : 0;
+  const float4* g4 = reinterpret_cast<const float4*>(g);
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+    const float4 q = g4[i];
+    s0 = fmaf(q.x, q.x, s0); s1 = fmaf(q.y, q.y, s1); s2 = fmaf(q.z, q.z, s2); s3 = fmaf(q.w, q.w, s3);
+  }
+  for (long long i = 4 * n4 + (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) s0 = fmaf(g[i], g[i], s0);
+  const float s = (s0 + s1) + (s2 + s3);
   red[threadIdx.x] = s;
   __syncthreads();
   for (int o = 128; o > 0; o >>= 1) {
@@ -84,6 +93,8 @@ __global__ __launch_bounds__(256) void adamw_masked_kernel(float* __restrict__ p
                                                            float eps, float wd, const float* __restrict__ clip) {
   const float gs = clip ? clip[1] : 1.f;
   const long long n_chunks = (n + ADAMW_CHUNK - 1) / ADAMW_CHUNK;
+  const bool aligned16 = ((reinterpret_cast<unsigned long long>(p) | reinterpret_cast<unsigned long long>(g) |
+                           reinterpret_cast<unsigned long long>(m) | reinterpret_cast<unsigned long long>(v)) & 15) == 0;
   for (long long c = blockIdx.x; c < n_chunks; c += gridDim.x) {
     const long long base = c * ADAMW_CHUNK;
     // parameter that owns the chunk's first element: largest j with off[j] <= base (uniform over the workgroup)
@@ -95,6 +106,36 @@ __global__ __launch_bounds__(256) void adamw_masked_kernel(float* __restrict__ p
     int j = lo;
     long long next = off[j + 1];
     float bc1 = bc[2 * j], bc2s = bc[2 * j + 1];
+    if (next >= base + ADAMW_CHUNK && base + ADAMW_CHUNK <= n && aligned16) {
+      // the whole chunk belongs to parameter j (all but ~1 500 of the ~70 000 chunks): 16-byte accesses, the same arithmetic per
+      // element (round 6: the 4-byte form ran at 2.2 TB/s of its 28 B per element)
+      if (bc1 == 0.f) continue;
+#pragma unroll
+      for (int k = 0; k < ADAMW_CHUNK / 1024; ++k) {
+        const long long i = base + k * 1024 + 4 * threadIdx.x;
+        const float4 g4 = *reinterpret_cast<const float4*>(g + i);
+        float4 p4 = *reinterpret_cast<const float4*>(p + i);
+        float4 m4 = *reinterpret_cast<const float4*>(m + i);
+        float4 v4 = *reinterpret_cast<const float4*>(v + i);
+        const float gv[4] = {g4.x, g4.y, g4.z, g4.w};
+        float pv[4] = {p4.x, p4.y, p4.z, p4.w}, mv[4] = {m4.x, m4.y, m4.z, m4.w}, vv[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float gi = gv[e] * gs;
+          float pi = pv[e] * (1.f - lr * wd);
+          const float mi = b1 * mv[e] + (1.f - b1) * gi;
+          const float vi = b2 * vv[e] + (1.f - b2) * gi * gi;
+          mv[e] = mi;
+          vv[e] = vi;
+          pi -= (lr / bc1) * mi / (sqrtf(vi) / bc2s + eps);
+          pv[e] = pi;
+        }
+        *reinterpret_cast<float4*>(m + i) = make_float4(mv[0], mv[1], mv[2], mv[3]);
+        *reinterpret_cast<float4*>(v + i) = make_float4(vv[0], vv[1], vv[2], vv[3]);
+        *reinterpret_cast<float4*>(p + i) = make_float4(pv[0], pv[1], pv[2], pv[3]);
+      }
+      continue;
+    }
 #pragma unroll
     for (int k = 0; k < ADAMW_CHUNK / 256; ++k) {
       const long long i = base + k * 256 + threadIdx.x;
