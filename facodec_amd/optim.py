@@ -191,6 +191,7 @@ class FlatAdamW:
         self.exchange_log = []                                # per step: [(bucket, "hook" | "end"), ...]  ([] = nothing exchanged)
         self._launch_log = []
         self.time_exchange, self._wait_events = False, None
+        self._ptr_cache = None                                # (parameter arena base, gradient arena base, per-parameter addresses)
 
     def _mark(self, i):
         """Post-accumulate hook: fires on EVERY accumulation into parameter i (a tied parameter, a module used twice in one graph, a
@@ -281,32 +282,60 @@ class FlatAdamW:
         [lo, hi): only these parameters (a bucket about to be launched).  A foreign gradient on a parameter whose bucket is
         ALREADY in flight means the bucket was launched before its gradients were final: that is an error, not a fold."""
         base_p, base_g = self.p.data_ptr(), self.g.data_ptr()
-        src, dst = [], []
         hi = len(self.params) if hi is None else hi
         launched_from = self.buckets[self._next_bucket - 1][0] if self._next_bucket else len(self.params)
         in_flight = bool(self._works or self._flags_final)
-        params, slices, views, touched = self.params, self.slices, self._views, self._touched
-        # This loop runs once per key and step at the one point where the device has nothing queued (~1 500 parameters: 4.4 ms per step
-        # in round 5's form, tools/tune/host_profile.py): locals instead of attribute chains, no detach(), no per-tensor layout test.
+        params, views, touched = self.params, self._views, self._touched
+        # This loop runs once per key and step at the one point where the device has nothing queued (tools/gpu_idle.py: one 3.5 - 4.4 ms
+        # gap per step; tools/tune/host_profile.py: 4.2 ms of it in here for ~1 500 parameters in round 6's first form).  Every torch
+        # call costs 0.15 - 0.5 us, so: parameter / view addresses are cached (the arenas never move), and what autograd guarantees
+        # about a gradient (device, dtype and shape of its parameter) is not re-tested per tensor -- only its layout is.
+        cache = self._ptr_cache
+        if cache is None or cache[0] != base_p or cache[1] != base_g:
+            cache = self._ptr_cache = (base_p, base_g, [base_p + 4 * o for o, _ in self.slices], [base_g + 4 * o for o, _ in self.slices])
+        pptr, vptr = cache[2], cache[3]
+        idx, src, sptr = [], [], []
         for i in range(lo, hi):
             p = params[i]
-            if p.data_ptr() != base_p + 4 * slices[i][0]:
+            if p.data_ptr() != pptr[i]:
                 raise RuntimeError("FlatAdamW: a parameter no longer lives in the optimiser's arena (was the module moved or cast after "
                                    "the optimiser was built?); build FlatAdamW after the model is on its final device")
             g = p.grad
             v = views[i]
             if g is None:
                 p.grad = v
-            elif g is not v and g.data_ptr() != base_g + 4 * slices[i][0]:     # foreign gradient tensor: fold it in once, then rebind
-                if i >= launched_from and in_flight:
-                    raise RuntimeError(f"FlatAdamW: the gradient of parameter {i} arrived after the exchange of its bucket was launched "
-                                       "(the launch point is too early for this graph; FAC_EARLY_EXCHANGE=0 launches after backward)")
-                src.append(g)
-                dst.append(v)
-                p.grad = v
-                touched[i] = True
+            elif g is not v:
+                gp = g.data_ptr()
+                if gp != vptr[i]:                      # foreign gradient tensor: fold it in once, then rebind
+                    if i >= launched_from and in_flight:
+                        raise RuntimeError(f"FlatAdamW: the gradient of parameter {i} arrived after the exchange of its bucket was launched "
+                                           "(the launch point is too early for this graph; FAC_EARLY_EXCHANGE=0 launches after backward)")
+                    idx.append(i)
+                    src.append(g)
+                    sptr.append(gp)
+                    p.grad = v
+                    touched[i] = True
         if src:
-            _fold(dst, src)
+            self._fold_into_views(idx, src, sptr, vptr)
+
+    def _fold_into_views(self, idx, src, sptr, vptr):
+        """views[i].copy_(g) for the stolen gradient tensors: contiguous ones on the GPU through fac_gather_copy with the cached view
+        addresses (one table entry per tensor, no per-tensor torch calls beyond the layout test); the rest as `_fold` does."""
+        views, slices = self._views, self.slices
+        if not (GATHER_COPY and self.g.is_cuda):
+            _fold([views[i] for i in idx], src)
+            return
+        ok = [g.is_contiguous() and slices[i][1] > 0 for i, g in zip(idx, src)]
+        if not all(ok):
+            _fold([views[i] for i, k in zip(idx, ok) if not k], [g for g, k in zip(src, ok) if not k])
+            idx = [i for i, k in zip(idx, ok) if k]
+            sptr = [q for q, k in zip(sptr, ok) if k]
+        n = len(idx)
+        if n:
+            ps = (ctypes.c_void_p * n)(*sptr)
+            pd = (ctypes.c_void_p * n)(*[vptr[i] for i in idx])
+            ne = (ctypes.c_int64 * n)(*[slices[i][1] for i in idx])
+            _lib.check(_lib.load().fac_gather_copy(ps, pd, ne, n, ops._stream()), "fac_gather_copy")
 
     def gather_grads(self, mark_all=False):
         """Compatibility with callers that assign `.grad` tensors by hand: folds them into the arena (no-op for views).
