@@ -58,6 +58,13 @@ SIGNATURES = {
     "fac_pack_gemm_w_split": (_i, [_p, _i64, _i64, _i64, _p, _p, _i, _i, _i, _i, _p]),
     "fac_pack_conv_w_split": (_i, [_p, _p, _p, _i, _i, _i, _p]),
     "fac_flip_transpose_w": (_i, [_p, _p, _p, _i, _i, _i, _p]),
+    "fac_prep_begin": (_i, []),
+    "fac_prep_set_phase": (_i, [_i]),
+    "fac_prep_abort": (_i, []),
+    "fac_prep_end": (_i, []),
+    "fac_prep_replay": (_i, [_i, _p]),
+    "fac_prep_info": (_i, [_i, _p, _p]),
+    "fac_prep_free": (_i, [_i]),
     "fac_pack_conv_w_bwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
     "fac_pad_fold_bwd": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "fac_conv1d_bwd_weight_ws_bytes": (_i64, [_i, _i, _i, _i, _i]),

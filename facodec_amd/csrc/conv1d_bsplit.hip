@@ -26,6 +26,7 @@
 #include "conv1d_mfma.h"
 #include <type_traits>
 #include "inflight_regs.h"
+#include "prep_batch.h"
 
 namespace fac {
 
@@ -73,10 +74,10 @@ __host__ __device__ constexpr int bs_slots(int K, int G) { return (G * K + 1) & 
 
 // v (C_out, C_in, K) [* scale per C_out] -> split layout described above.  One thread per (tile, stage, half
 // slot, co): 8 input channels -> three 16-byte pieces.
-__global__ void pack_conv_split_kernel(const float* __restrict__ v, const float* __restrict__ scale,
-                                       bf16x8* __restrict__ out, int C_out, int C_in, int K, int G, int H, int n_st,
-                                       long long n) {
-  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (long long)gridDim.x * blockDim.x) {
+__device__ __forceinline__ void pack_conv_split_body(const float* __restrict__ v, const float* __restrict__ scale,
+                                                     bf16x8* __restrict__ out, int C_out, int C_in, int K, int G, int H, int n_st,
+                                                     long long n, int vb, int vg) {
+  for (long long idx = (long long)vb * 256 + threadIdx.x; idx < n; idx += (long long)vg * 256) {
     const int co = (int)(idx % BS_CO);
     long long r = idx / BS_CO;
     const int hs = (int)(r % H);          // half slot -> (ci group, tap)
@@ -104,6 +105,24 @@ __global__ void pack_conv_split_kernel(const float* __restrict__ v, const float*
     out[((base + 1) * H + hs) * BS_CO + co] = m;
     out[((base + 2) * H + hs) * BS_CO + co] = l;
   }
+}
+
+__global__ __launch_bounds__(256) void pack_conv_split_kernel(const float* __restrict__ v, const float* __restrict__ scale,
+                                                              bf16x8* __restrict__ out, int C_out, int C_in, int K, int G, int H,
+                                                              int n_st, long long n) {
+  pack_conv_split_body(v, scale, out, C_out, C_in, K, G, H, n_st, n, blockIdx.x, gridDim.x);
+}
+
+__global__ __launch_bounds__(256) void bsplit_batch_kernel(const PrepJob* __restrict__ jobs, const int* __restrict__ first, int njobs) {
+  const int j = prep_find_job(first, njobs, blockIdx.x);
+  const PrepJob& J = jobs[j];
+  pack_conv_split_body(static_cast<const float*>(J.a), static_cast<const float*>(J.b), static_cast<bf16x8*>(J.out), J.i[0], J.i[1],
+                       J.i[2], J.i[3], J.i[4], J.i[5], J.n, blockIdx.x - first[j], J.nblocks);
+}
+
+int prep_launch_bsplit(const PrepJob* jobs, const int* first, int njobs, int total, hipStream_t s) {
+  hipLaunchKernelGGL(bsplit_batch_kernel, dim3(total), dim3(256), 0, s, jobs, first, njobs);
+  return check_launch("bsplit_batch");
 }
 
 template <int KT, int G, int NMW, int NSW>
@@ -912,6 +931,11 @@ extern "C" int fac_pack_conv_w_split(const float* v, const float* scale, void* o
   const int n_ct = (C_out + BS_CO - 1) / BS_CO, n_st = (C_in + 8 * G - 1) / (8 * G), H = bs_slots(K, G);
   const long long n = (long long)n_ct * n_st * H * BS_CO;
   const int blocks = (int)((n + 255) / 256 < 65535 ? (n + 255) / 256 : 65535);
+  if (prep_recording()) {
+    PrepJob j{}; j.a = v; j.b = scale; j.out = out; j.kind = PK_CONV_SPLIT; j.nblocks = blocks; j.n = n;
+    j.i[0] = C_out; j.i[1] = C_in; j.i[2] = K; j.i[3] = G; j.i[4] = H; j.i[5] = n_st;
+    return prep_record(PU_BSPLIT, j);
+  }
   hipLaunchKernelGGL(pack_conv_split_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, v, scale,
                      reinterpret_cast<bf16x8*>(out), C_out, C_in, K, G, H, n_st, n);
   return check_launch("pack_conv_w_split");

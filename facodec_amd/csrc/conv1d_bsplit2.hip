@@ -19,6 +19,7 @@
 //   epilogue by all eight waves from an fp32 tile in LDS (bias, activation, residual), 16-byte stores.
 #include "conv1d_mfma.h"
 #include "inflight_regs.h"
+#include "prep_batch.h"
 
 namespace fac {
 
@@ -39,9 +40,10 @@ __host__ __device__ constexpr int b2_slots(int K1) { return (K1 + 1) & ~1; }
 
 // v (C_out, CV, K1) [* scale per C_out] (CV = C_in * K2 virtual channels, contiguous (K2, K1) taps per real channel) ->
 // [co tile of 32][chunk of 8 cv][plane][tap slot][32 co][8 cv] bf16.  One thread per (tile, chunk, slot, co).
-__global__ void pack_conv_split2_kernel(const float* __restrict__ v, const float* __restrict__ scale, bf16x8* __restrict__ out,
-                                        int C_out, int CV, int K1, int H, int n_ch, long long n) {
-  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (long long)gridDim.x * blockDim.x) {
+__device__ __forceinline__ void pack_conv_split2_body(const float* __restrict__ v, const float* __restrict__ scale,
+                                                      bf16x8* __restrict__ out, int C_out, int CV, int K1, int H, int n_ch, long long n,
+                                                      int vb, int vg) {
+  for (long long idx = (long long)vb * 256 + threadIdx.x; idx < n; idx += (long long)vg * 256) {
     const int co = (int)(idx % B2_CO);
     long long r = idx / B2_CO;
     const int k = (int)(r % H);
@@ -68,6 +70,24 @@ __global__ void pack_conv_split2_kernel(const float* __restrict__ v, const float
     out[((base + 1) * H + k) * B2_CO + co] = m;
     out[((base + 2) * H + k) * B2_CO + co] = l;
   }
+}
+
+__global__ __launch_bounds__(256) void pack_conv_split2_kernel(const float* __restrict__ v, const float* __restrict__ scale,
+                                                               bf16x8* __restrict__ out, int C_out, int CV, int K1, int H, int n_ch,
+                                                               long long n) {
+  pack_conv_split2_body(v, scale, out, C_out, CV, K1, H, n_ch, n, blockIdx.x, gridDim.x);
+}
+
+__global__ __launch_bounds__(256) void bsplit2_batch_kernel(const PrepJob* __restrict__ jobs, const int* __restrict__ first, int njobs) {
+  const int j = prep_find_job(first, njobs, blockIdx.x);
+  const PrepJob& J = jobs[j];
+  pack_conv_split2_body(static_cast<const float*>(J.a), static_cast<const float*>(J.b), static_cast<bf16x8*>(J.out), J.i[0], J.i[1],
+                        J.i[2], J.i[3], J.i[4], J.n, blockIdx.x - first[j], J.nblocks);
+}
+
+int prep_launch_bsplit2(const PrepJob* jobs, const int* first, int njobs, int total, hipStream_t s) {
+  hipLaunchKernelGGL(bsplit2_batch_kernel, dim3(total), dim3(256), 0, s, jobs, first, njobs);
+  return check_launch("bsplit2_batch");
 }
 
 // KT: taps per virtual channel (K1);  S: stride (1 or 2);  XU: (64-column block) staging units per staging wave
@@ -422,6 +442,11 @@ extern "C" int fac_pack_conv_w_split2(const float* v, const float* scale, void* 
   const int n_ct = (C_out + B2_CO - 1) / B2_CO, n_ch = (CV + 7) / 8, H = b2_slots(K1);
   const long long n = (long long)n_ct * n_ch * H * B2_CO;
   const int blocks = (int)((n + 255) / 256 < 65535 ? (n + 255) / 256 : 65535);
+  if (prep_recording()) {
+    PrepJob j{}; j.a = v; j.b = scale; j.out = out; j.kind = PK_CONV_SPLIT2; j.nblocks = blocks; j.n = n;
+    j.i[0] = C_out; j.i[1] = CV; j.i[2] = K1; j.i[3] = H; j.i[4] = n_ch;
+    return prep_record(PU_BSPLIT2, j);
+  }
   hipLaunchKernelGGL(pack_conv_split2_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, v, scale,
                      reinterpret_cast<bf16x8*>(out), C_out, CV, K1, H, n_ch, n);
   return check_launch("pack_conv_w_split2");

@@ -15,16 +15,18 @@
 // Reference semantics: torch autograd through dac/model/encodec.py SConv1d / dac/nn/layers.py snake (checked
 // against autograd of the CPU oracle in tests/test_gpu_parity.py).
 #include "conv1d_mfma.h"
+#include "prep_batch.h"
 #include <stdlib.h>
 
 namespace fac {
 
 // packed[(co*K + k')*CP + ci] = v[co][ci][K-1-k'] * scale[co]   (rows co < C_out; the buffer is zero-filled by
 // the caller up to fac_cin_pad(C_out) rows and CP = pad32(C_in) columns)
-__global__ void pack_conv_bwd_kernel(const float* __restrict__ v, const float* __restrict__ scale,
-                                     float* __restrict__ packed, int C_out, int C_in, int K, int CP, long long n) {
+__device__ __forceinline__ void pack_conv_bwd_body(const float* __restrict__ v, const float* __restrict__ scale,
+                                                   float* __restrict__ packed, int C_out, int C_in, int K, int CP, long long n,
+                                                   int vb, int vg) {
   // n covers the whole padded buffer (cin_pad(C_out) rows x K x CP columns): padding rows / columns are written as zeros
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+  for (long long i = (long long)vb * 256 + threadIdx.x; i < n; i += (long long)vg * 256) {
     const int ci = (int)(i % CP);
     const long long r = i / CP;
     const int kp = (int)(r % K);
@@ -36,6 +38,23 @@ __global__ void pack_conv_bwd_kernel(const float* __restrict__ v, const float* _
     }
     packed[i] = w;
   }
+}
+
+__global__ __launch_bounds__(256) void pack_conv_bwd_kernel(const float* __restrict__ v, const float* __restrict__ scale,
+                                                            float* __restrict__ packed, int C_out, int C_in, int K, int CP, long long n) {
+  pack_conv_bwd_body(v, scale, packed, C_out, C_in, K, CP, n, blockIdx.x, gridDim.x);
+}
+
+__global__ __launch_bounds__(256) void bwd_batch_kernel(const PrepJob* __restrict__ jobs, const int* __restrict__ first, int njobs) {
+  const int j = prep_find_job(first, njobs, blockIdx.x);
+  const PrepJob& J = jobs[j];
+  pack_conv_bwd_body(static_cast<const float*>(J.a), static_cast<const float*>(J.b), static_cast<float*>(J.out), J.i[0], J.i[1], J.i[2],
+                     J.i[3], J.n, blockIdx.x - first[j], J.nblocks);
+}
+
+int prep_launch_bwd(const PrepJob* jobs, const int* first, int njobs, int total, hipStream_t s) {
+  hipLaunchKernelGGL(bwd_batch_kernel, dim3(total), dim3(256), 0, s, jobs, first, njobs);
+  return check_launch("bwd_batch");
 }
 
 // dx[b][c][j] = dxpad[pad_left + j] (+ the gradients of the padded positions that mirror sample j)
@@ -458,6 +477,11 @@ extern "C" int fac_pack_conv_w_bwd(const float* v, const float* scale, float* pa
               "pack_conv_w_bwd: bad arguments");
   const long long n = (long long)cin_pad_dev(C_out) * K * C_in_pad;     // the whole padded buffer
   const int blocks = (int)((n + 255) / 256 < 65535 ? (n + 255) / 256 : 65535);
+  if (prep_recording()) {
+    PrepJob j{}; j.a = v; j.b = scale; j.out = packed; j.kind = PK_CONV_BWD; j.nblocks = blocks; j.n = n;
+    j.i[0] = C_out; j.i[1] = C_in; j.i[2] = K; j.i[3] = C_in_pad;
+    return prep_record(PU_BWD, j);
+  }
   hipLaunchKernelGGL(pack_conv_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, v, scale, packed, C_out, C_in,
                      K, C_in_pad, n);
   return check_launch("pack_conv_w_bwd");

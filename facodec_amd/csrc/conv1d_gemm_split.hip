@@ -21,6 +21,7 @@
 //   epilogue by all eight waves from an fp32 tile in LDS (bias, Snake / activation, residual, second pre-activated output,
 //   row_phases interleave), 16-byte stores of contiguous runs.
 #include "conv1d_mfma.h"
+#include "prep_batch.h"
 
 namespace fac {
 
@@ -68,10 +69,10 @@ __device__ __forceinline__ void gs_barrier() {
 // Input stride S > 1 (strided conv, K_total <= 2 S): chunk = (32 real channels, input phase p), p fastest; its K = 2 taps are
 // k = p and k = S + p (zero when >= K_total) -- the conv over the phase-p sub-signal x[S u + p].
 // One thread per (tile, chunk, tap, row, piece): three 16-byte stores.
-__global__ __launch_bounds__(256) void pack_gemm_split_kernel(const float* __restrict__ v, long long rs, long long cs, long long ks,
-                                                              const float* __restrict__ row_scale, unsigned char* __restrict__ out,
-                                                              int R, int C_in, int K, int n_ch, int S, int K_total, long long n) {
-  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < n; idx += (long long)gridDim.x * 256) {
+__device__ __forceinline__ void pack_gemm_split_body(const float* __restrict__ v, long long rs, long long cs, long long ks,
+                                                     const float* __restrict__ row_scale, unsigned char* __restrict__ out,
+                                                     int R, int C_in, int K, int n_ch, int S, int K_total, long long n, int vb, int vg) {
+  for (long long idx = (long long)vb * 256 + threadIdx.x; idx < n; idx += (long long)vg * 256) {
     const int piece = (int)(idx & 3);
     const int row = (int)((idx >> 2) & 127);
     long long r2 = idx >> 9;
@@ -101,6 +102,25 @@ __global__ __launch_bounds__(256) void pack_gemm_split_kernel(const float* __res
     *reinterpret_cast<bf16x8*>(base + (long long)K * GS_APL) = m;
     *reinterpret_cast<bf16x8*>(base + (long long)2 * K * GS_APL) = l;
   }
+}
+
+__global__ __launch_bounds__(256) void pack_gemm_split_kernel(const float* __restrict__ v, long long rs, long long cs, long long ks,
+                                                              const float* __restrict__ row_scale, unsigned char* __restrict__ out,
+                                                              int R, int C_in, int K, int n_ch, int S, int K_total, long long n) {
+  pack_gemm_split_body(v, rs, cs, ks, row_scale, out, R, C_in, K, n_ch, S, K_total, n, blockIdx.x, gridDim.x);
+}
+
+__global__ __launch_bounds__(256) void gsplit_batch_kernel(const PrepJob* __restrict__ jobs, const int* __restrict__ first, int njobs) {
+  const int j = prep_find_job(first, njobs, blockIdx.x);
+  const PrepJob& J = jobs[j];
+  pack_gemm_split_body(static_cast<const float*>(J.a), J.l[0], J.l[1], J.l[2], static_cast<const float*>(J.b),
+                       static_cast<unsigned char*>(J.out), J.i[0], J.i[1], J.i[2], J.i[3], J.i[4], J.i[5], J.n, blockIdx.x - first[j],
+                       J.nblocks);
+}
+
+int prep_launch_gsplit(const PrepJob* jobs, const int* first, int njobs, int total, hipStream_t s) {
+  hipLaunchKernelGGL(gsplit_batch_kernel, dim3(total), dim3(256), 0, s, jobs, first, njobs);
+  return check_launch("gsplit_batch");
 }
 
 template <int K>
@@ -658,6 +678,12 @@ extern "C" int fac_pack_gemm_w_split(const float* v, int64_t row_stride, int64_t
   const int n_tiles = (R + GS_ROWS - 1) / GS_ROWS, n_ch = ((C_in + GS_CI - 1) / GS_CI) * S;
   const long long n = (long long)n_tiles * n_ch * Kt * GS_ROWS * 4;
   const int blocks = (int)((n + 255) / 256 < 65535 ? (n + 255) / 256 : 65535);
+  if (prep_recording()) {
+    PrepJob j{}; j.a = v; j.b = row_scale; j.out = out; j.kind = PK_GEMM_SPLIT; j.nblocks = blocks; j.n = n;
+    j.l[0] = row_stride; j.l[1] = ci_stride; j.l[2] = k_stride;
+    j.i[0] = R; j.i[1] = C_in; j.i[2] = Kt; j.i[3] = n_ch; j.i[4] = S; j.i[5] = K;
+    return prep_record(PU_GSPLIT, j);
+  }
   hipLaunchKernelGGL(pack_gemm_split_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, v, (long long)row_stride,
                      (long long)ci_stride, (long long)k_stride, row_scale, reinterpret_cast<unsigned char*>(out), R, C_in, Kt, n_ch, S, K, n);
   return check_launch("pack_gemm_w_split");

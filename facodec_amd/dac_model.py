@@ -20,6 +20,7 @@ from torch import nn
 
 from . import autograd as A
 from . import ops
+from .wprep import cached_forward
 from .layers import SConv1d, SConvTranspose1d, SLSTM, Snake1d
 
 
@@ -147,6 +148,7 @@ class Encoder(nn.Module):
                 x = A.slstm(m, x)
         return A.conv(mods[-1], A.snake(mods[-2], x))
 
+    @cached_forward
     def forward(self, x):
         if self.training:
             return self._forward_train(x)
@@ -236,6 +238,7 @@ class Decoder(nn.Module):
                 x = A.slstm(m, x)
         return A.conv(mods[-2], xa, act=ops.ACT_TANH)
 
+    @cached_forward
     def forward(self, x):
         if self.training:
             return self._forward_train(x)

@@ -19,6 +19,7 @@ from torch import nn
 
 from . import autograd_disc as AD
 from . import losses, ops
+from .wprep import cached_forward
 
 BANDS = ((0.0, 0.1), (0.1, 0.25), (0.25, 0.5), (0.5, 0.75), (0.75, 1.0))
 
@@ -186,10 +187,12 @@ class Discriminator(nn.Module):
             outs[i] = r
         return outs
 
+    @cached_forward
     def forward_internal(self, x):
         """The 8 lists of internal-layout maps (row-concatenated MPD signals, (B*T, C, F) MRD rows)."""
         return self._run_all(self.preprocess(x))
 
+    @cached_forward
     def forward(self, x):
         B = x.shape[0]
         maps = self._run_all(self.preprocess(x))

@@ -9,6 +9,7 @@ import os
 import torch
 
 from . import _lib
+from .wprep import prepared
 from ._lib import ConvDesc, VqDesc, PAD_REFLECT, PAD_ZERO, ACT_NONE, ACT_TANH, ACT_MISH, ACT_LOG_MEL, ACT_GATE, ACT_WN_RES_SKIP  # noqa: F401
 
 
@@ -75,16 +76,18 @@ def _dev(t, what="tensor"):
 
 
 # --------------------------------------------------------------------------------- weights (K6)
-def wn_scale(v, g):
+@prepared
+def wn_scale(v, g, out=None):
     """scale[i] = g[i]/||v[i]|| (dac/model/encodec.py:42-51)."""
     v = _dev(v, "weight_v")
     g = _dev(g, "weight_g")
     n = v.shape[0]
-    scale = torch.empty(n, device=v.device, dtype=torch.float32)
+    scale = out if out is not None else torch.empty(n, device=v.device, dtype=torch.float32)
     _lib.check(_lib.load().fac_wn_scale(_ptr(v), _ptr(g), _ptr(scale), n, v.numel() // n, _stream()), "fac_wn_scale")
     return scale
 
 
+@prepared
 def pack_conv_weight(v, g=None, out=None, scale=None):
     """(C_out, C_in, K) [+ weight-norm gain g (C_out,1,1)] -> packed (cin_pad(C_in), K, pad32(C_out));
     the rows of the padding channels are written as zeros by the kernel (no separate fill)."""
@@ -102,6 +105,7 @@ def pack_conv_weight(v, g=None, out=None, scale=None):
     return out
 
 
+@prepared
 def pack_convtr_weight(v, g, stride, out=None):
     """ConvTranspose1d (C_in, C_out, 2*stride) -> polyphase packed (stride, cin_pad(C_in), 2, pad32(C_out))."""
     v = _dev(v, "weight")
@@ -133,6 +137,7 @@ def convtr_rows_ok(t_in, stride, causal=True):
     return CONVTR_ROWS and causal and 2 <= stride <= 16 and t_in >= CONVTR_ROWS_MIN_T
 
 
+@prepared
 def pack_convtr_weight_rows(v, g, stride, out=None):
     """ConvTranspose1d (C_in, C_out, 2*stride) -> (cin_pad(C_in), 2, rows) with rows = (channel, phase) pairs in 128-row
     tiles (fac_pack_convtr_w_rows); conv_transpose1d recognises the layout by its 3 dimensions."""
@@ -419,6 +424,7 @@ def gemm_split_strided_ok(c_out, c_in, k, stride, batch, t_out):
             and c_out >= 64 and t_out >= 256 and batch * t_out >= 1024)
 
 
+@prepared
 def pack_gemm_weight_split(v, g=None, out=None, in_stride=1, scale=None):
     """(C_out, C_in, K) [weight-normed with g over dim 0] -> fac_pack_gemm_w_split layout (uint8 buffer); K <= 2, or a strided
     conv's taps (in_stride < K <= 2 * in_stride)."""
@@ -465,6 +471,7 @@ def split2_ok(c_out, k, k1, stride, n_cols):
             and n_cols >= 4096)
 
 
+@prepared
 def pack_conv_weight_split2(v, g=None, k1=0, out=None, scale=None):
     """(C_out <= 32, C_in, K) [weight-normed with g] -> fac_pack_conv_w_split2 layout (uint8 buffer); k1: taps per level."""
     v = _dev(v, "weight")
@@ -480,6 +487,7 @@ def pack_conv_weight_split2(v, g=None, k1=0, out=None, scale=None):
     return out
 
 
+@prepared
 def pack_convtr_weight_rows_split(v, g, stride, out=None):
     """ConvTranspose1d (C_in, C_out, 2*stride) -> split GEMM weights of the all-phases launch: the (channel, phase) rows of
     pack_convtr_weight_rows, each row's (C_in, 2) taps as bf16 planes.  Returns (split buffer, rows)."""
@@ -495,13 +503,14 @@ def pack_convtr_weight_rows_split(v, g, stride, out=None):
     return out, R
 
 
+@prepared
 def pack_conv_weight_split(v, g=None, out=None, scale=None):
     """(C_out, C_in, K) [weight-normed with g] -> split-bf16 layout of fac_pack_conv_w_split (K = 5 / 7; uint8 buffer) or of
     fac_pack_gemm_w_split (K = 1 / 2)."""
     v = _dev(v, "weight")
     c_out, c_in, k = v.shape
     if k <= 2:
-        return pack_gemm_weight_split(v, g, out, scale=scale)
+        return pack_gemm_weight_split(v, g, out=out, scale=scale)
     lib = _lib.load()
     if scale is None and g is not None:
         scale = wn_scale(v, g)
@@ -1152,23 +1161,26 @@ def aa_snakebeta(x, alpha_log, beta_log, filter12):
 
 
 # --------------------------------------------------------------------------------- backward of the conv stack
-def flipped_weight(v, g=None, scale=None):
+@prepared
+def flipped_weight(v, g=None, scale=None, out=None):
     """(C_out, C_in, K) [weight-normed] -> (C_in, C_out, K) weights of the data-gradient conv (channels swapped, taps flipped),
     one launch (fac_flip_transpose_w)."""
     v = _dev(v, "weight")
     c_out, c_in, k = v.shape
     if scale is None and g is not None:
         scale = wn_scale(v, g)
-    out = torch.empty(c_in, c_out, k, device=v.device, dtype=torch.float32)
+    if out is None:
+        out = torch.empty(c_in, c_out, k, device=v.device, dtype=torch.float32)
     _lib.check(_lib.load().fac_flip_transpose_w(_ptr(v), _ptr(scale), _ptr(out), c_out, c_in, k, _stream()), "fac_flip_transpose_w")
     return out
 
 
-def pack_conv_weight_bwd(v, g=None, scale=None):
+@prepared
+def pack_conv_weight_bwd(v, g=None, scale=None, out=None):
     """(C_out, C_in, K) [weight-normed] -> packed weights of the bwd-data conv (taps flipped, channels swapped)."""
     v = _dev(v, "weight")
     c_out, c_in, k = v.shape
-    packed = torch.empty(cin_pad(c_out), k, pad32(c_in), device=v.device, dtype=torch.float32)
+    packed = out if out is not None else torch.empty(cin_pad(c_out), k, pad32(c_in), device=v.device, dtype=torch.float32)
     if scale is None and g is not None:
         scale = wn_scale(v, g)
     _lib.check(_lib.load().fac_pack_conv_w_bwd(_ptr(v), _ptr(scale), _ptr(packed), c_out, c_in, k, pad32(c_in), _stream()),

@@ -21,6 +21,7 @@ import torch
 from torch import nn
 
 from . import dsp, ops
+from .wprep import cached_forward
 from .layers import ConvWeights, SConv1d, _uniform_
 
 
@@ -426,6 +427,7 @@ class FAquantizer(nn.Module):
             return outs, quantized, commitment, codebook, timbre, [codes_p, codes_c, codes_r]
         return outs, quantized, commitment, codebook, timbre
 
+    @cached_forward
     def forward(self, x, wave_segments, n_c=1, n_t=2, full_waves=None, wave_lens=None, return_codes=False, masks=None):
         if self.training:
             return self._forward_train(x, wave_segments, full_waves, wave_lens, return_codes, masks)

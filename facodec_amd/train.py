@@ -169,7 +169,34 @@ class GeneratorStep:
         loss.backward()
         return dict(loss=loss.detach(), mel=mel.detach(), commitment=commitment.detach(), codebook=codebook.detach())
 
+    def _weight_caches(self):
+        """wprep.WeightCache per side: the weight-norm scales and packed layouts of every conv re-materialised as a few launches at
+        the start of the step (and, for the discriminator, again after its optimiser step) instead of ~1 700 small ones inside it."""
+        wc = self.__dict__.get("_wc")
+        if wc is None:
+            from . import wprep
+            wc = self._wc = {}
+            if wprep.ENABLED and next(iter(self.opt.values())).p.is_cuda:
+                gen = [p for k, o in self.opt.items() if k != "discriminator" for p in o.params]
+                wc["gen"] = wprep.WeightCache(gen, "generator side")
+                if "discriminator" in self.opt:
+                    wc["disc"] = wprep.WeightCache(list(self.opt["discriminator"].params), "discriminator")
+        return wc
+
+    def _in_weight_regions(self, fn, *a, **kw):
+        caches = list(self._weight_caches().values())
+        for c in caches:
+            c.begin()
+        try:
+            return fn(*a, **kw)
+        finally:
+            for c in caches:
+                c.end()
+
     def __call__(self, wave, masks=None, full_waves=None, wave_lens=None):
+        return self._in_weight_regions(self._step, wave, masks, full_waves, wave_lens)
+
+    def _step(self, wave, masks=None, full_waves=None, wave_lens=None):
         out = self.forward_backward(wave, masks, full_waves, wave_lens)
         for k in ("decoder", "quantizer", "encoder"):
             self.opt[k].launch_all_reduce()
@@ -230,6 +257,9 @@ class TrainStep(GeneratorStep):
         return total, t
 
     def __call__(self, wave, masks=None, targets=None, full_waves=None, wave_lens=None, log_losses=False):
+        return self._in_weight_regions(self._step, wave, masks, targets, full_waves, wave_lens, log_losses)
+
+    def _step(self, wave, masks=None, targets=None, full_waves=None, wave_lens=None, log_losses=False):
         """wave (B, 1, T) the cropped segments; full_waves (B, T_full) / wave_lens (B,) the whole utterances for the timbre
         encoder (train.py:266-269); targets: predictor targets (with_predictors); log_losses: also evaluate the two
         logged-only criteria of train.py:296,298 (multi-scale STFT, waveform L1)."""
@@ -268,6 +298,10 @@ class TrainStep(GeneratorStep):
             pred_total, terms = self.predictor_losses(preds, rev, targets)
             extra.update({k: v.detach() for k, v in terms.items()})
         opt["discriminator"].step(zero_grad=False)
+        wc = self._weight_caches().get("disc")
+        if wc is not None and wc.depth == 1:                  # the generator step sees the UPDATED discriminator (train.py:292-300)
+            wc.end()
+            wc.begin()
         # ---- generator step (:295-374): the discriminator is only differentiated w.r.t. its input
         for p in opt["discriminator"].params:
             p.requires_grad_(False)

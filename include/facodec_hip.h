@@ -420,6 +420,24 @@ int fac_stream_push(float* buf, const float* src, int64_t rows, int64_t cap, int
  * v (C_out, C_in, K)[co][ci][K-1-k] * scale[co] (scale: fac_wn_scale or NULL).  Pack the result with fac_pack_conv_w_split* . */
 int fac_flip_transpose_w(const float* v, const float* scale, float* out, int C_out, int C_in, int K, fac_stream_t stream);
 
+/* Batched weight preparation (round 6).  The reference's weight_norm recomputes w = g * v / ||v|| in a pre-forward hook of every
+ * conv (dac/model/encodec.py:42-51, dac/nn/layers.py:9-14); here that is one small launch per tensor and layout (fac_wn_scale, then
+ * fac_pack_*): ~290 launches of a configs[1] forward, ~1 700 of a train step.  Between fac_prep_begin() and fac_prep_end() the calling
+ * thread's fac_wn_scale, fac_pack_conv_w, fac_pack_convtr_w, fac_pack_convtr_w_rows, fac_flip_transpose_w, fac_pack_conv_w_split,
+ * fac_pack_gemm_w_split, fac_pack_conv_w_split2 and fac_pack_conv_w_bwd calls are RECORDED (arguments checked, nothing launched) under
+ * the phase set by fac_prep_set_phase (0 at begin; a job that reads another job's output needs a higher phase).  fac_prep_end() uploads
+ * the job tables and returns a plan id (>= 0; negative = error code).  fac_prep_replay() re-runs every job of the plan from the CURRENT
+ * contents of its input tensors -- one launch per (phase, kernel family), phases in order -- with the arithmetic of the single launches
+ * (same device functions: results are bit-identical).  The pointers recorded must stay valid for the life of the plan.  fac_prep_free()
+ * requires that no replay of the plan is still executing. */
+int fac_prep_begin(void);
+int fac_prep_set_phase(int phase);
+int fac_prep_abort(void);
+int fac_prep_end(void);
+int fac_prep_replay(int plan, fac_stream_t stream);
+int fac_prep_info(int plan, int* n_jobs, int* n_launches);
+int fac_prep_free(int plan);
+
 /* ------------------------------------------------------------------------------------------
  * Backward of the conv stack (first kernels of the training step; autograd semantics of
  * dac/model/encodec.py SConv1d / SConvTranspose1d, dac/nn/layers.py snake, weight_norm).
