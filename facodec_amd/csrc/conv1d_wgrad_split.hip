@@ -26,6 +26,7 @@
 // Partial tiles of the S slices are added in slice order by wgrad_split_reduce_kernel (deterministic).
 #include "conv1d_mfma.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace fac {
 
@@ -634,35 +635,44 @@ __global__ __launch_bounds__((4 * MT + 4) * 64, MT == 1 ? 2 : 1) void conv1d_wgr
     // stage's (A lo, B lo, A hi, B hi) fragments while the last four products run.  The stage barrier sits right behind the point
     // where every fragment of the stage is in registers, i.e. in FRONT of those four products: the next stage's first two products
     // never wait for LDS.
+    //
+    // Round 6 (second form of the narrow-rows idea below): a row tile with at most 64 / 96 REAL output channels -- every C = 64 layer,
+    // the second row tile of the C = 192 layers, the C = 96 layers -- splits its waves over the COLUMNS instead: wave (nh, kh) takes
+    // the MB = 2 / 3 real 32-row blocks x columns [64 nh, 64 nh + 64) x its k half, 24 / 36 MFMAs per stage instead of 48 of which
+    // half / a quarter multiplied clamped duplicate rows.  Same staging, same barriers, same product order per accumulator, same
+    // (kh = 0) + (kh = 1) exchange: every dW element is the same sum in the same order as in the row-split layout.
+    auto ksp_body = [&](auto mb_tag, auto nb_tag, auto cs_tag) {
+    constexpr int MB = decltype(mb_tag)::value, NB = decltype(nb_tag)::value;
+    constexpr bool CS = decltype(cs_tag)::value;     // waves split over columns (true) or over rows (false)
     const int l31 = lane & 31, kq = lane >> 5;
-    const int mh = wave >> 1, kh = wave & 1;
+    const int wh = wave >> 1, kh = wave & 1;
     const int sw = (l31 >> 2) & 3;
     const int po = ((kh * 2 + kq) ^ sw) * 16;
-    const int aoff = (mh * 64 + l31) * WK_ROWB + po;
-    const int boff = A_OPND + l31 * WK_ROWB + po;
-    f32x16 acc[2][4];
+    const int aoff = ((CS ? 0 : wh * 64) + l31) * WK_ROWB + po;
+    const int boff = A_OPND + ((CS ? wh * 64 : 0) + l31) * WK_ROWB + po;
+    f32x16 acc[MB][NB];
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
+    for (int m = 0; m < MB; ++m)
 #pragma unroll
-      for (int n = 0; n < 4; ++n)
+      for (int n = 0; n < NB; ++n)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
     // fragment sets: Ahi / Bhi alternate between two register sets (the current stage's stay live to its last product);
     // lo and mid fragments are re-used in place
-    bf16x8 Ahi[2][2], Bhi[2][4], Amid[2], Bmid[4], Alo[2], Blo[4];
-    auto rd_a = [&](const unsigned char* st, int plane, bf16x8 (&d)[2]) {
+    bf16x8 Ahi[2][MB], Bhi[2][NB], Amid[MB], Bmid[NB], Alo[MB], Blo[NB];
+    auto rd_a = [&](const unsigned char* st, int plane, bf16x8 (&d)[MB]) {
 #pragma unroll
-      for (int m = 0; m < 2; ++m) d[m] = *reinterpret_cast<const bf16x8*>(st + aoff + plane * A_PLANE + m * 32 * WK_ROWB);
+      for (int m = 0; m < MB; ++m) d[m] = *reinterpret_cast<const bf16x8*>(st + aoff + plane * A_PLANE + m * 32 * WK_ROWB);
     };
-    auto rd_b = [&](const unsigned char* st, int plane, bf16x8 (&d)[4]) {
+    auto rd_b = [&](const unsigned char* st, int plane, bf16x8 (&d)[NB]) {
 #pragma unroll
-      for (int n = 0; n < 4; ++n) d[n] = *reinterpret_cast<const bf16x8*>(st + boff + plane * WK_PLANE + n * 32 * WK_ROWB);
+      for (int n = 0; n < NB; ++n) d[n] = *reinterpret_cast<const bf16x8*>(st + boff + plane * WK_PLANE + n * 32 * WK_ROWB);
     };
-    auto mm = [&](const bf16x8 (&x)[2], const bf16x8 (&y)[4]) {
+    auto mm = [&](const bf16x8 (&x)[MB], const bf16x8 (&y)[NB]) {
 #pragma unroll
-      for (int m = 0; m < 2; ++m)
+      for (int m = 0; m < MB; ++m)
 #pragma unroll
-        for (int n = 0; n < 4; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x[m], y[n], acc[m][n], 0, 0, 0);
+        for (int n = 0; n < NB; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x[m], y[n], acc[m][n], 0, 0, 0);
     };
     wk_barrier();   // stage 0 staged
     rd_a(sm, 2, Alo); rd_b(sm, 0, Bhi[0]); rd_a(sm, 0, Ahi[0]); rd_b(sm, 2, Blo);
@@ -694,34 +704,42 @@ __global__ __launch_bounds__((4 * MT + 4) * 64, MT == 1 ? 2 : 1) void conv1d_wgr
         }
       }
     }
-    // the two k halves of each 64-row block: kh = 1 parks its sums in LDS (all three stages are free: the DMA waves issue nothing
+    // the two k halves of each wave pair: kh = 1 parks its sums in LDS (all three stages are free: the DMA waves issue nothing
     // past the last chunk and every MFMA wave is past its last fragment read), kh = 0 adds them and stores the partial dW
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    float* ex = reinterpret_cast<float*>(sm) + mh * (8 * 16 * 64);       // [m][n][r][lane] per 64-row block: 32 KB
+    float* ex = reinterpret_cast<float*>(sm) + wh * (8 * 16 * 64);       // [m][n][r][lane] per wave pair: at most 32 KB
     if (kh == 1) {
 #pragma unroll
-      for (int m = 0; m < 2; ++m)
+      for (int m = 0; m < MB; ++m)
 #pragma unroll
-        for (int n = 0; n < 4; ++n)
+        for (int n = 0; n < NB; ++n)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) ex[((m * 4 + n) * 16 + r) * 64 + lane] = acc[m][n][r];
+          for (int r = 0; r < 16; ++r) ex[((m * NB + n) * 16 + r) * 64 + lane] = acc[m][n][r];
     }
     __syncthreads();
     if (kh == 1) return;
     float* pz = a.part + (long long)z * a.C_out * a.NBk * 32;
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
+    for (int m = 0; m < MB; ++m)
 #pragma unroll
-      for (int n = 0; n < 4; ++n) {
-        const int gb = gb0 + n;
+      for (int n = 0; n < NB; ++n) {
+        const int gb = gb0 + (CS ? wh * 2 : 0) + n;
         if (gb >= a.NBk) continue;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int co = co0 + mh * 64 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * kq;
-          const float v = acc[m][n][r] + ex[((m * 4 + n) * 16 + r) * 64 + lane];
+          const int co = co0 + (CS ? 0 : wh * 64) + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * kq;
+          const float v = acc[m][n][r] + ex[((m * NB + n) * 16 + r) * 64 + lane];
           if (co < a.C_out) pz[((long long)co * a.NBk + gb) * 32 + l31] = v;
         }
       }
+    };
+    using i2 = std::integral_constant<int, 2>;
+    using i3 = std::integral_constant<int, 3>;
+    using i4 = std::integral_constant<int, 4>;
+    const int real_rows = a.C_out - co0;
+    if (a.narrow_rows && real_rows <= 64) ksp_body(i2(), i2(), std::true_type());
+    else if (a.narrow_rows && real_rows <= 96) ksp_body(i3(), i2(), std::true_type());
+    else ksp_body(i2(), i4(), std::false_type());
     return;
   }
 
@@ -788,6 +806,72 @@ __global__ __launch_bounds__((4 * MT + 4) * 64, MT == 1 ? 2 : 1) void conv1d_wgr
           if (co < a.C_out) pz1[((long long)co * a.NBk + gb) * 32 + l31] = acc_a[r] + acc_b[r];
         }
       }
+      return;
+    }
+    // ---- 33 .. 96 real output channels (C = 64 / 96 layers, the second row tile of the C = 192 layers; round 6): the same column
+    // split with R = 2 / 3 row blocks per wave -- wave w: R x 32 rows x columns [32 w, 32 w + 32), 6 R MFMAs per 16-step slab
+    // instead of 24 of which a half / a quarter multiplied clamped duplicate rows.  One accumulator per (row block, column block)
+    // and the product order of the 64 x 64 layout: the same sums in the same order, bit for bit.
+    auto colsplit = [&](auto r_tag) {
+      constexpr int R = decltype(r_tag)::value;
+      const int aoff1 = l31 * WK_ROWB;
+      const int boff1 = A_OPND + (wave * 32 + l31) * WK_ROWB;
+      f32x16 accr[R];
+#pragma unroll
+      for (int m = 0; m < R; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accr[m][r] = 0.f;
+      bf16x8 A1[2][R][3], B1[2][3];
+      auto ld1 = [&](const unsigned char* st, int ks, bf16x8 (&Ad)[R][3], bf16x8 (&Bd)[3]) {
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+#pragma unroll
+          for (int m = 0; m < R; ++m) Ad[m][p] = *reinterpret_cast<const bf16x8*>(st + aoff1 + p * A_PLANE + m * 32 * WK_ROWB + poff[ks]);
+          Bd[p] = *reinterpret_cast<const bf16x8*>(st + boff1 + p * WK_PLANE + poff[ks]);
+        }
+      };
+      wk_barrier();   // stage 0 staged
+      for (int base = 0; base < n_chunks; base += NST) {
+#pragma unroll
+        for (int i = 0; i < NST; ++i) {
+          const int chunk = base + i;
+          if (chunk < n_chunks) {
+            const unsigned char* st = sm + i * STAGE;
+            ld1(st, 0, A1[0], B1[0]);
+#pragma unroll
+            for (int ks = 0; ks < WS_TT / 16; ++ks) {
+              if (ks + 1 < WS_TT / 16) ld1(st, ks + 1, A1[(ks + 1) & 1], B1[(ks + 1) & 1]);
+              __builtin_amdgcn_sched_barrier(0);
+              constexpr int TA[6] = {1, 2, 0, 1, 0, 0}, TB[6] = {1, 0, 2, 0, 1, 0};     // smallest terms first
+#pragma unroll
+              for (int q = 0; q < 6; ++q)
+#pragma unroll
+                for (int m = 0; m < R; ++m)
+                  accr[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1[ks & 1][m][TA[q]], B1[ks & 1][TB[q]], accr[m], 0, 0, 0);
+              __builtin_amdgcn_sched_barrier(0);
+            }
+            wk_barrier();
+          }
+        }
+      }
+      float* pzr = a.part + (long long)z * a.C_out * a.NBk * 32;
+      const int gb = gb0 + wave;
+      if (gb < a.NBk) {
+#pragma unroll
+        for (int m = 0; m < R; ++m)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int co = co0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * kq;
+            if (co < a.C_out) pzr[((long long)co * a.NBk + gb) * 32 + l31] = accr[m][r];
+          }
+      }
+    };
+    if (a.narrow_rows && a.C_out - co0 <= 64) {
+      colsplit(std::integral_constant<int, 2>());
+      return;
+    }
+    if (a.narrow_rows && a.C_out - co0 <= 96) {
+      colsplit(std::integral_constant<int, 3>());
       return;
     }
   }

@@ -62,6 +62,12 @@ CASES = [
     (2, 16, 32, 200, 7, 1, 1, 6, ops.PAD_REFLECT),
     (3, 80, 130, 257, 7, 1, 3, 18, ops.PAD_REFLECT),
     (2, 40, 96, 301, 3, 1, 1, 1, ops.PAD_ZERO),
+    # round 6: row tiles with 33 .. 96 real output channels run column-split wave layouts (k-split kernel: k = 7; 64 x 64 kernel: the rest)
+    (2, 192, 192, 500, 7, 1, 9, 54, ops.PAD_REFLECT),
+    (2, 192, 192, 500, 1, 1, 1, 0, ops.PAD_ZERO),
+    (2, 64, 64, 900, 1, 1, 1, 0, ops.PAD_ZERO),
+    (2, 96, 96, 900, 1, 1, 1, 0, ops.PAD_ZERO),
+    (2, 64, 224, 640, 4, 2, 1, 2, ops.PAD_REFLECT),
 ]
 
 
@@ -225,3 +231,20 @@ def test_two_level_convs_with_one_or_two_live_channels_run_on_the_narrow_kernel(
     assert float((yv.double() - y_ref.detach()).abs().max() / y_ref.detach().abs().max()) < 1e-5
     dx = xc.grad.cpu().reshape(ci, B, T + 1, P)[:, :, :T, :F0].permute(1, 0, 2, 3)
     assert float((dx.double() - xr.grad).abs().max() / xr.grad.abs().max()) < 1e-5
+
+
+def test_column_split_wave_layouts_are_bit_identical_to_the_row_split():
+    """Row tiles with 33 .. 96 real output channels (every C = 64 / 96 layer, the second row tile of the C = 192 layers): the waves split
+    over the columns and multiply only real rows -- the same sums in the same order as the row-split layout that multiplies clamped
+    duplicates (FAC_WGRAD_NARROW=0).  Separate processes: the switch is read once."""
+    import json
+    import os
+    import subprocess
+    import sys
+    script = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "tune", "wgrad_narrow_check.py")
+    outs = []
+    for val in ("0", "1"):
+        r = subprocess.run([sys.executable, script], env=dict(os.environ, FAC_WGRAD_NARROW=val), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("WGN ")][-1][4:]))
+    assert outs[0] == outs[1] and len(outs[0]) == 9, outs

@@ -20,6 +20,8 @@ SHAPES = [
     ("dec RU 192 k1 T24000", B, 192, 192, 24000, 1, 1, 1, 0, ops.PAD_ZERO),
     ("dec RU 96 k7 T48000", B, 96, 96, 48000, 7, 1, 1, 6, ops.PAD_REFLECT),
     ("enc RU 64 k7 T48000", B, 64, 64, 48000, 7, 1, 1, 6, ops.PAD_REFLECT),
+    ("enc RU 64 k1 T48000", B, 64, 64, 48000, 1, 1, 1, 0, ops.PAD_ZERO),
+    ("dec RU 96 k1 T48000", B, 96, 96, 48000, 1, 1, 1, 0, ops.PAD_ZERO),
     ("enc RU 128 k7 T24000", B, 128, 128, 24000, 7, 1, 1, 6, ops.PAD_REFLECT),
     ("enc RU 512 k7 T960", B, 512, 512, 960, 7, 1, 1, 6, ops.PAD_REFLECT),
     ("dec in 1024->1536 k7 T160", B, 1024, 1536, 160, 7, 1, 1, 6, ops.PAD_REFLECT),
