@@ -178,9 +178,9 @@ class GeneratorStep:
             wc = self._wc = {}
             if wprep.ENABLED and next(iter(self.opt.values())).p.is_cuda:
                 gen = [p for k, o in self.opt.items() if k != "discriminator" for p in o.params]
-                wc["gen"] = wprep.WeightCache(gen, "generator side")
+                wc["gen"] = wprep.WeightCache(gen, "generator side", any_thread=True)
                 if "discriminator" in self.opt:
-                    wc["disc"] = wprep.WeightCache(list(self.opt["discriminator"].params), "discriminator")
+                    wc["disc"] = wprep.WeightCache(list(self.opt["discriminator"].params), "discriminator", any_thread=True)
         return wc
 
     def _in_weight_regions(self, fn, *a, **kw):

@@ -20,6 +20,7 @@ re-materialised again after its optimiser step), and the no-grad forwards of Enc
 a backward whose time the module cannot know.
 """
 import os
+import threading
 
 import torch
 
@@ -29,7 +30,21 @@ ENABLED = os.environ.get("FAC_WEIGHT_BATCH", "1") != "0"
 KEEP_EPOCHS = 4             # an entry nobody asked for in this many regions is dropped from the batch
 
 _ACTIVE = []                # caches with an open region (module-global on purpose: autograd's worker thread must see them)
-_STACK = []                 # entries being computed; a nested call (wn_scale inside a pack) makes the outer one depend on it
+_TLS = threading.local()    # .stack: entries being computed on this thread; a nested call (wn_scale inside a pack) makes the outer
+                            # one depend on it
+
+
+def _stack():
+    st = getattr(_TLS, "stack", None)
+    if st is None:
+        st = _TLS.stack = []
+    return st
+
+
+def _visible(me):
+    """Caches whose region this thread may use: its own, and those opened for every thread (a train step: autograd's worker thread
+    runs the backward nodes).  Another thread's no-grad forward is nobody else's business -- its replay is ordered on ITS stream."""
+    return [c for c in _ACTIVE if c.owner == me or c.any_thread]
 
 
 class _Entry:
@@ -55,8 +70,10 @@ def _key_part(a):
 class WeightCache:
     """See the module docstring.  `params`: the tensors whose derived layouts this cache may own (anything else passes through)."""
 
-    def __init__(self, params, name=""):
+    def __init__(self, params, name="", any_thread=False):
         self.name = name
+        self.any_thread = any_thread      # served to every thread while the region is open (TrainStep), or to the opening thread only
+        self.owner = None
         self._params = [p for p in params]
         self.claims = None
         self.entries = {}
@@ -89,6 +106,7 @@ class WeightCache:
             for e in self.planned:
                 e.fresh = ep
         self.depth = 1
+        self.owner = threading.get_ident()
         _ACTIVE.append(self)
         return self
 
@@ -113,6 +131,12 @@ class WeightCache:
             _lib.load().fac_prep_free(self.plan)
             self.plan, self.planned = -1, []
 
+    def __deepcopy__(self, memo):
+        return WeightCache([], self.name, self.any_thread)     # a copied module starts its own cache (cached_forward rebuilds it)
+
+    def __reduce__(self):
+        return (WeightCache, ([], self.name, self.any_thread))
+
     def __del__(self):
         try:
             if self.plan >= 0:
@@ -129,8 +153,9 @@ class WeightCache:
         if e is not None and e.fresh == self.epoch:
             e.used = self.epoch
             self.stats["hits"] += 1
-            if _STACK:
-                _STACK[-1].children.append(e)
+            st = _stack()
+            if st:
+                st[-1].children.append(e)
             return e.ret
         self.stats["misses"] += 1
         if e is None:
@@ -141,19 +166,20 @@ class WeightCache:
                     if src is not None:
                         e.children.append(src)
         e.used = self.epoch
-        _STACK.append(e)
+        st = _stack()
+        st.append(e)
         try:
             ret = fn(*args, out=e.buf, **kw)                  # the single launch(es), into the entry's buffer once it has one
         finally:
-            _STACK.pop()
+            st.pop()
         if e.buf is None:
             e.ret, e.buf = ret, _buf_of(ret)
             self.entries[key] = e
             self.by_buf.setdefault(e.buf.data_ptr(), e)       # (a forwarding function returns its inner call's buffer: the inner entry keeps it)
             self.claims.add(e.buf.data_ptr())
             self.dirty = True
-        if _STACK:
-            _STACK[-1].children.append(e)
+        if st:
+            st[-1].children.append(e)
         return e.ret
 
     # ------------------------------------------------------------------------------------------ the batch
@@ -220,6 +246,8 @@ class WeightCache:
         for e in order:
             e.fresh = self.epoch                              # nested lookups must hit while recording
         was_active = self in _ACTIVE
+        self.owner = threading.get_ident()
+        st = _stack()
         if not was_active:
             _ACTIVE.append(self)
         _lib.check(lib.fac_prep_begin(), "fac_prep_begin")
@@ -227,11 +255,11 @@ class WeightCache:
             for e in order:
                 _lib.check(lib.fac_prep_set_phase(e.phase), "fac_prep_set_phase")
                 kids = e.children
-                _STACK.append(e)
+                st.append(e)
                 try:
                     e.fn(*e.args, out=e.buf, **e.kw)
                 finally:
-                    _STACK.pop()
+                    st.pop()
                 e.children = kids                             # (the recording pass re-appended them)
             plan = lib.fac_prep_end()
         except Exception:
@@ -268,8 +296,9 @@ def prepared(fn):
         if not isinstance(v, torch.Tensor) or not v.is_cuda or not v.is_contiguous() or v.dtype != torch.float32:
             return fn(*args, **kw)
         ptr = v.data_ptr()
+        me = threading.get_ident()
         for c in _ACTIVE:
-            if ptr in c.claims:
+            if ptr in c.claims and (c.owner == me or c.any_thread):
                 for a in args[1:]:
                     if isinstance(a, torch.Tensor) and (a.data_ptr() not in c.claims or not a.is_contiguous()):
                         return fn(*args, **kw)               # an operand the cache does not own (a temporary): its address means nothing
@@ -291,7 +320,7 @@ def cached_forward(method):
     and calls made inside somebody else's region pass through."""
 
     def forward(self, *args, **kw):
-        if (not ENABLED or _ACTIVE or torch.is_grad_enabled() or not torch.cuda.is_available()
+        if (not ENABLED or torch.is_grad_enabled() or not torch.cuda.is_available() or (_ACTIVE and _visible(threading.get_ident()))
                 or torch.cuda.is_current_stream_capturing()):
             return method(self, *args, **kw)
         cache = self.__dict__.get("_wcache")

@@ -12,13 +12,6 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module")
-def cuda():
-    if not torch.cuda.is_available():
-        pytest.skip("needs a GPU")
-    return torch.device("cuda:0")
-
-
 def _weights(cuda, seed=0):
     g = torch.Generator().manual_seed(seed)
     mk = lambda *s: torch.randn(*s, generator=g).to(cuda)       # noqa: E731
@@ -147,7 +140,7 @@ def test_forward_with_the_batch_equals_the_per_layer_launches(cuda):
         wprep.ENABLED = saved
 
 
-def test_train_steps_identical_with_and_without_the_batch():
+def test_train_steps_identical_with_and_without_the_batch(cuda):
     """configs[2] at its real size, three seeded iterations with the optimisers on: losses, gradient norms and every parameter arena
     after the last step agree to the last bit between FAC_WEIGHT_BATCH=0 and the default, and the default's steady-state step
     re-materialises its ~1 000 weight layouts with at most 12 launches per region.  Separate processes: the switch is read once."""
@@ -163,3 +156,33 @@ def test_train_steps_identical_with_and_without_the_batch():
     assert infos[0] == {} and set(infos[1]) == {"gen", "disc"}, infos
     for k, i in infos[1].items():
         assert i["hits"] > 0 and 0 < i["launches"] <= 12 and i["rebuilds"] <= 3, (k, i)
+
+
+def test_regions_belong_to_their_thread_and_copies_start_over(cuda):
+    """A no-grad forward's region is served to the thread that opened it only (its replay is ordered on that thread's stream); a
+    region opened for every thread (a train step: autograd's worker runs the backward nodes) is served to all; a deep-copied module
+    does not inherit the plan of the original."""
+    import copy
+    import threading
+    from facodec_amd import ops, wprep
+    w = _weights(cuda, seed=2)
+    seen = {}
+
+    def other(tag):
+        seen[tag] = ops.pack_conv_weight_split(w["v7"], w["g7"]).data_ptr()
+
+    for any_thread in (False, True):
+        cache = wprep.WeightCache(list(w.values()), "test", any_thread=any_thread)
+        for _ in range(2):
+            with cache:
+                mine = ops.pack_conv_weight_split(w["v7"], w["g7"]).data_ptr()
+        with cache:
+            assert ops.pack_conv_weight_split(w["v7"], w["g7"]).data_ptr() == mine
+            t = threading.Thread(target=other, args=(any_thread,))
+            t.start()
+            t.join()
+        assert (seen[any_thread] == mine) == any_thread
+        clone = copy.deepcopy(cache)
+        assert clone.plan == -1 and not clone.entries and cache.plan >= 0
+        torch.cuda.synchronize()
+        cache.close()
