@@ -13,7 +13,7 @@ TAG = os.environ.get("FAC_BUILD_TAG", "")
 LIB = os.path.join(HERE, "libfacodec_hip%s.so" % ("_" + TAG if TAG else ""))
 OBJDIR = "build" + ("_" + TAG if TAG else "")
 SOURCES = ["conv1d_api.hip", "conv1d_tile_128x128.hip", "conv1d_tile_96x128.hip", "conv1d_tile_64x128.hip",
-           "conv1d_tile_32x256.hip", "conv1d_tile_128x32.hip", "conv1d_tile_128x256.hip", "conv1d_fused_ru.hip", "conv1d_narrow.hip", "conv1d_pw.hip", "conv1d_pw_split.hip", "conv1d_skinny.hip", "conv1d_bsplit.hip", "conv1d_gemm_split.hip", "conv1d_bsplit2.hip", "conv1d_bwd.hip", "conv1d_wgrad_split.hip", "train_misc.hip", "optim.hip", "train_quant.hip", "train_pred.hip", "train_disc.hip", "pack.hip", "prep_batch.hip", "lstm.hip", "lstm_persist.hip", "vq.hip", "misc.hip", "rccl_arena.hip"]
+           "conv1d_tile_32x256.hip", "conv1d_tile_128x32.hip", "conv1d_tile_128x256.hip", "conv1d_fused_ru.hip", "conv1d_narrow.hip", "conv1d_pw.hip", "conv1d_pw_split.hip", "conv1d_skinny.hip", "conv1d_bsplit.hip", "conv1d_gemm_split.hip", "conv1d_bsplit2.hip", "conv1d_bwd.hip", "conv1d_wgrad_split.hip", "conv1d_wgrad_k1.hip", "train_misc.hip", "optim.hip", "train_quant.hip", "train_pred.hip", "train_disc.hip", "pack.hip", "prep_batch.hip", "lstm.hip", "lstm_persist.hip", "vq.hip", "misc.hip", "rccl_arena.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
          "-Wno-unused-result"] + os.environ.get("FAC_EXTRA_FLAGS", "").split()
 

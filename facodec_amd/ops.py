@@ -1275,6 +1275,7 @@ def conv1d_bwd_weight(x, dy, k, stride=1, dilation=1, pad_mode=PAD_REFLECT, caus
 # launch goes to torch's current stream in program order, so consecutive layers can share it -- no per-layer allocation of
 # hundreds of MB, and its size shows up once in peak_mem instead of as allocator churn.  FAC_WGRAD_WS_GB caps it.
 _WGRAD_WS = {}
+WGRAD_K1_STREAM = os.environ.get("FAC_WGRAD_K1_STREAM", "1") != "0"      # k = 1 tails with few channels on conv1d_wgrad_k1.hip
 WGRAD_WS_CAP = int(float(os.environ.get("FAC_WGRAD_WS_GB", "6")) * (1 << 30))
 
 
@@ -1314,6 +1315,15 @@ def _bwd_weight_launch_inner(x, dy, dw, B, c_in, t_in, c_out, t_out, k, stride, 
     FAC_BF16_SPLIT is on, else on the fp32 MFMA kernel.  db: optional (C_out) buffer for the bias gradient; returns True when the
     launch filled it."""
     lib = _lib.load()
+    if WGRAD_K1_STREAM and BF16_SPLIT and k == 1 and stride == 1 and pad_left == 0 and t_in == t_out and k1 in (0, 1):
+        # few channels, long signal (the ResidualUnit tails at C = 64 / 96 / 192): both tensors once through the fp32 matrix pipe
+        # instead of two operand-split passes + plane reads (conv1d_wgrad_k1.hip); the caller takes the bias gradient from fac_bias_grad
+        nb = lib.fac_conv1d_bwd_weight_k1_ws_bytes(B, c_in, c_out, t_in)
+        if nb > 0:
+            ws = _wgrad_workspace(x.device, nb)
+            _lib.check(lib.fac_conv1d_bwd_weight_k1(_ptr(x), _ptr(dy), _ptr(dw), _ptr(ws), nb, B, c_in, c_out, t_in, _stream()),
+                       "fac_conv1d_bwd_weight_k1")
+            return False
     nbytes = lib.fac_conv1d_bwd_weight_split_ws_bytes(B, c_in, t_in, c_out, t_out, k, stride, dilation, k1, dilation2) if BF16_SPLIT else -1
     if nbytes > WGRAD_WS_CAP:       # beyond the workspace budget: the fp32 kernel (no operand planes) takes the layer
         nbytes = -1

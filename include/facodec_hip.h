@@ -463,6 +463,14 @@ int64_t fac_conv1d_bwd_weight_ws_bytes(int B, int C_in, int C_out, int T_out, in
 int fac_conv1d_bwd_weight(const float* x, const float* dy, float* dw, void* ws, int64_t ws_bytes, int B, int C_in,
                           int T_in, int C_out, int T_out, int K, int stride, int dilation, int pad_left, int pad_mode,
                           int K1, int dilation2, fac_stream_t stream);
+/* The k = 1, stride-1 case with few channels and long signals (the ResidualUnit tails of dac/model/dac.py:25-42 at C = 64 / 96 / 192:
+ * dW[co][ci] = sum over (b, t) of dy[b][co][t] * x[b][ci][t]) straight from the fp32 tensors on the fp32 matrix pipe
+ * (conv1d_wgrad_k1.hip): both tensors are read once, no operand planes.  The query returns the workspace size (partial sums of the
+ * workgroups, added in a fixed order) or -1 when the shape does not run here (channel counts: multiples of 32 in [64, 192];
+ * T >= 4096, T % 4 == 0). */
+int64_t fac_conv1d_bwd_weight_k1_ws_bytes(int B, int C_in, int C_out, int T);
+int fac_conv1d_bwd_weight_k1(const float* x, const float* dy, float* dw, void* ws, int64_t ws_bytes, int B, int C_in, int C_out, int T,
+                             fac_stream_t stream);
 /* The same gradient on the bf16 matrix pipe with fp32-grade operand splitting (conv1d_wgrad_split.hip; same arguments
  * and result layout as fac_conv1d_bwd_weight, error vs fp64 no larger than the fp32 MFMA's).  The workspace query
  * returns -1 for a (K, stride, dilation) the kernel does not cover: use fac_conv1d_bwd_weight then.  K1 / dilation2:

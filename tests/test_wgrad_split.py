@@ -68,6 +68,15 @@ CASES = [
     (2, 64, 64, 900, 1, 1, 1, 0, ops.PAD_ZERO),
     (2, 96, 96, 900, 1, 1, 1, 0, ops.PAD_ZERO),
     (2, 64, 224, 640, 4, 2, 1, 2, ops.PAD_REFLECT),
+    # round 6: k = 1, 64 .. 192 channels, T >= 4096: straight from the fp32 tensors on the fp32 matrix pipe (conv1d_wgrad_k1.hip);
+    # window tails (T % 32 != 0), 2 / 3 / 4 / 6 roles per workgroup, unequal channel counts
+    (2, 64, 64, 4800, 1, 1, 1, 0, ops.PAD_ZERO),
+    (2, 96, 96, 4100, 1, 1, 1, 0, ops.PAD_ZERO),
+    (1, 192, 192, 8192, 1, 1, 1, 0, ops.PAD_ZERO),
+    (2, 128, 128, 5004, 1, 1, 1, 0, ops.PAD_ZERO),
+    (3, 64, 192, 4096, 1, 1, 1, 0, ops.PAD_ZERO),
+    (2, 192, 96, 4444, 1, 1, 1, 0, ops.PAD_ZERO),
+    (5, 160, 64, 4112, 1, 1, 1, 0, ops.PAD_ZERO),
 ]
 
 
@@ -248,3 +257,30 @@ def test_column_split_wave_layouts_are_bit_identical_to_the_row_split():
         assert r.returncode == 0, r.stderr[-2000:]
         outs.append(json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("WGN ")][-1][4:]))
     assert outs[0] == outs[1] and len(outs[0]) == 9, outs
+
+
+def test_k1_tails_with_few_channels_run_on_the_fp32_streaming_kernel(cuda):
+    """The shapes above really take conv1d_wgrad_k1.hip (the query says so), the kernel is deterministic, and FAC_WGRAD_K1_STREAM=0
+    (module switch) gives the split kernel's result within the fp32 grade."""
+    lib = ops._lib.load()
+    assert lib.fac_conv1d_bwd_weight_k1_ws_bytes(16, 96, 96, 48000) > 0 and lib.fac_conv1d_bwd_weight_k1_ws_bytes(16, 192, 192, 24000) > 0
+    assert lib.fac_conv1d_bwd_weight_k1_ws_bytes(16, 64, 64, 48000) > 0
+    assert lib.fac_conv1d_bwd_weight_k1_ws_bytes(16, 256, 256, 4800) < 0 and lib.fac_conv1d_bwd_weight_k1_ws_bytes(16, 96, 96, 960) < 0
+    assert lib.fac_conv1d_bwd_weight_k1_ws_bytes(2, 96, 96, 4101) < 0 and lib.fac_conv1d_bwd_weight_k1_ws_bytes(2, 80, 96, 8192) < 0
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(4, 96, 12000, generator=g).to(cuda)
+    dy = torch.randn(4, 96, 12000, generator=g).to(cuda)
+    prev = ops.WGRAD_K1_STREAM
+    try:
+        ops.WGRAD_K1_STREAM = True
+        a = ops.conv1d_bwd_weight(x, dy, 1, pad_mode=ops.PAD_ZERO, pad_left=0)
+        b = ops.conv1d_bwd_weight(x, dy, 1, pad_mode=ops.PAD_ZERO, pad_left=0)
+        ops.WGRAD_K1_STREAM = False
+        c = ops.conv1d_bwd_weight(x, dy, 1, pad_mode=ops.PAD_ZERO, pad_left=0)
+    finally:
+        ops.WGRAD_K1_STREAM = prev
+    assert torch.equal(a, b)
+    ref = torch.einsum("bot,bit->oi", dy.double(), x.double()).unsqueeze(-1)
+    scale = float(ref.abs().max())
+    ea, ec = float((a.double() - ref).abs().max()) / scale, float((c.double() - ref).abs().max()) / scale
+    assert ea < 2e-6 and ec < 2e-6, (ea, ec)
