@@ -11,70 +11,73 @@
 // 32-step window takes steps [16 h, 16 h + 16), so a lane loads 16 CONSECUTIVE floats of its row (64 bytes, four 16-byte loads: a
 // wave instruction covers 32 full 128-byte lines) and MFMA j of the window multiplies register j of both operands.
 //
-// A wave owns RB row blocks (32 output channels each) x ONE column block (32 input channels); a workgroup holds one wave per (row
-// group, column block) "role" of its column-block set, WPR times over: waves of the same role take alternate windows of the
-// workgroup's range of (clip, window) pairs and are added in a fixed order through LDS at the end; the workgroups' partial sums
-// [S][C_out][C_in] are added by a second launch in a fixed order (eight interleaved chains).  Deterministic; fp32 products and sums
-// (no operand split: the error against fp64 is the fp32 kernels').  The next window's fragments are requested before the current
-// window's 16 RB MFMAs are issued (two register sets).  [Second form: twelve waves per workgroup, three per SIMD, ONE register set --
-// the waves of a SIMD cover each other's loads, every SIMD carries the same matrix work (six waves left two SIMDs with half of it),
-// and all roles of a C = 192 layer fit one workgroup, so dy is read once: 0.25 -> MEASURED_96 ms at C = 96, 0.43 -> MEASURED_192 at C = 192.]
+// A wave owns a QUADRANT of RB x CB blocks of 32 x 32 (2 x 2: C = 64 / 128; 3 x 3: C = 96 / 192): RB + CB fragment loads per window for
+// RB x CB blocks of matrix work, accumulators in registers (one wave per SIMD: the 512-entry register file is the wave's), the next
+// window's fragments requested before the current window's MFMAs (two register sets).  A fragment load touches 32 cache lines (one
+// per row, 16 bytes of each) and the texture path takes them a line at a time, so loads per MFMA are what bounds this kernel: with
+// one column block per wave (first form: every dy fragment fetched by three or six waves) it ran at a third of the fp32 pipe
+// (0.25 / 0.46 ms at C = 96 / 192); quadrants: 0.205 / 0.292 ms (62 % of the pipe at C = 192), C = 64 0.125 ms (3.1 TB/s).
+// A workgroup is four waves: the quadrants of the matrix ("roles"; one, two or four of them), WPR = 4 / roles times over; the waves
+// of a role take alternate windows; workgroup g takes the window units g, g + S, g + 2 S, ... so that the workgroups running side by
+// side read adjacent pieces of the same rows.  Every wave stores its own partial sums; [S x WPR][C_out][C_in] partial matrices are
+// added by a second launch in a fixed order (eight interleaved chains).  Deterministic; fp32 products and sums (no operand split:
+// the error against fp64 is the fp32 kernels').
 #include "common.h"
 
 namespace fac {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int WK1_WAVES = 12;
+constexpr int WK1_WAVES = 4;      // one per SIMD: a wave holds a whole RB x CB quadrant (up to 144 accumulator + 192 fragment registers)
 
 struct Wk1Args {
   const float* x;
   const float* dy;
-  float* part;             // [S][C_out][C_in]
+  float* part;             // [S * WPR][C_out * C_in (+ C_out row sums of dy when with_db)]
+  int with_db;
   int B, C_in, C_out, T;
   int wins_per_clip;       // ceil(T / 32)
   int n_win;               // B * wins_per_clip
-  int win_per_wg;          // windows per workgroup (a multiple of WPR)
-  int n_rg;                // row groups of RB blocks
-  int cb_per_wg;           // column blocks per workgroup (grid.y sets of them)
+  int n_cg;                // column groups of CB blocks (roles = row groups x column groups)
+  int roles;
   int wpr;                 // waves per role
 };
 
-template <int RB>
-__global__ __launch_bounds__(768) void wgrad_k1_kernel(Wk1Args a) {
-  extern __shared__ __attribute__((aligned(16))) float red[];      // [wave][RB][16][64] for the end-of-range exchange
+template <int RB, int CB>
+__global__ __launch_bounds__(64 * WK1_WAVES) void wgrad_k1_kernel(Wk1Args a) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int roles = a.n_rg * a.cb_per_wg;
-  const int role = wave % roles, slot = wave / roles;
-  const int rg = role / a.cb_per_wg;
-  const int cb = blockIdx.y * a.cb_per_wg + role % a.cb_per_wg;
+  const int role = wave % a.roles, slot = wave / a.roles;
+  const int rg = role / a.n_cg, cg = role - rg * a.n_cg;
   const int r = lane & 31, h = lane >> 5;
   // Workgroup g takes the window units g, g + S, g + 2 S, ... (a unit = WPR consecutive windows, one per wave of a role): the
-  // workgroups that run side by side read ADJACENT 128-byte pieces of the same rows at about the same time -- DRAM pages and TLB
-  // entries are shared across the chip -- where contiguous ranges per workgroup made 49 000 concurrent 128-byte streams.
+  // workgroups that run side by side read adjacent pieces of the same rows at about the same time.
   const int unit_stride = gridDim.x * a.wpr;
+  if (wave >= a.roles * a.wpr) return;
 
-  f32x16 acc[RB];
+  f32x16 acc[RB][CB];
 #pragma unroll
   for (int m = 0; m < RB; ++m)
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc[m][i] = 0.f;
+    for (int n = 0; n < CB; ++n)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[m][n][i] = 0.f;
 
-  float4 A[RB][4], Bv[4];
-  auto load = [&](int w, float4 (&Ad)[RB][4], float4 (&Bd)[4]) {
+  float4 A[2][RB][4], Bv[2][CB][4];
+  auto load = [&](int w, float4 (&Ad)[RB][4], float4 (&Bd)[CB][4]) {
     const int b = w / a.wins_per_clip;
     const int t = (w - b * a.wins_per_clip) * 32 + 16 * h;
-    const float* px = a.x + ((long long)b * a.C_in + cb * 32 + r) * a.T + t;
+    const float* pd = a.dy + ((long long)b * a.C_out + rg * RB * 32 + r) * a.T + t;
+    const float* px = a.x + ((long long)b * a.C_in + cg * CB * 32 + r) * a.T + t;
     if (t + 16 <= a.T) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) Bd[q] = *reinterpret_cast<const float4*>(px + 4 * q);
+      for (int m = 0; m < RB; ++m)
 #pragma unroll
-      for (int m = 0; m < RB; ++m) {
-        const float* pd = a.dy + ((long long)b * a.C_out + (rg * RB + m) * 32 + r) * a.T + t;
+        for (int q = 0; q < 4; ++q) Ad[m][q] = *reinterpret_cast<const float4*>(pd + (long long)m * 32 * a.T + 4 * q);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) Ad[m][q] = *reinterpret_cast<const float4*>(pd + 4 * q);
-      }
+      for (int n = 0; n < CB; ++n)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) Bd[n][q] = *reinterpret_cast<const float4*>(px + (long long)n * 32 * a.T + 4 * q);
     } else {                                             // the last window of a clip: steps beyond T contribute zeros
       auto guarded = [&](const float* p, float4 (&d)[4]) {
 #pragma unroll
@@ -85,60 +88,85 @@ __global__ __launch_bounds__(768) void wgrad_k1_kernel(Wk1Args a) {
           d[q].w = t + 4 * q + 3 < a.T ? p[4 * q + 3] : 0.f;
         }
       };
-      guarded(px, Bd);
 #pragma unroll
-      for (int m = 0; m < RB; ++m) guarded(a.dy + ((long long)b * a.C_out + (rg * RB + m) * 32 + r) * a.T + t, Ad[m]);
+      for (int m = 0; m < RB; ++m) guarded(pd + (long long)m * 32 * a.T, Ad[m]);
+#pragma unroll
+      for (int n = 0; n < CB; ++n) guarded(px + (long long)n * 32 * a.T, Bd[n]);
     }
   };
-  auto mma = [&](const float4 (&Ac)[RB][4], const float4 (&Bc)[4]) {
+  auto mma = [&](const float4 (&Ac)[RB][4], const float4 (&Bc)[CB][4]) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
 #pragma unroll
-      for (int m = 0; m < RB; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(Ac[m][q].x, Bc[q].x, acc[m], 0, 0, 0);
+      for (int m = 0; m < RB; ++m)
 #pragma unroll
-      for (int m = 0; m < RB; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(Ac[m][q].y, Bc[q].y, acc[m], 0, 0, 0);
+        for (int n = 0; n < CB; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(Ac[m][q].x, Bc[n][q].x, acc[m][n], 0, 0, 0);
 #pragma unroll
-      for (int m = 0; m < RB; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(Ac[m][q].z, Bc[q].z, acc[m], 0, 0, 0);
+      for (int m = 0; m < RB; ++m)
 #pragma unroll
-      for (int m = 0; m < RB; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(Ac[m][q].w, Bc[q].w, acc[m], 0, 0, 0);
+        for (int n = 0; n < CB; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(Ac[m][q].y, Bc[n][q].y, acc[m][n], 0, 0, 0);
+#pragma unroll
+      for (int m = 0; m < RB; ++m)
+#pragma unroll
+        for (int n = 0; n < CB; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(Ac[m][q].z, Bc[n][q].z, acc[m][n], 0, 0, 0);
+#pragma unroll
+      for (int m = 0; m < RB; ++m)
+#pragma unroll
+        for (int n = 0; n < CB; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(Ac[m][q].w, Bc[n][q].w, acc[m][n], 0, 0, 0);
     }
   };
 
-  const bool active = wave < roles * a.wpr;            // (8 roles: four of the twelve waves have nothing to do)
-  // One register set: the three waves of a SIMD cover each other's loads (12 waves x 16 KB in flight per CU).
-  for (int w = active ? blockIdx.x * a.wpr + slot : a.n_win; w < a.n_win; w += unit_stride) {
-    load(w, A, Bv);
-    mma(A, Bv);
+  // bias gradient (train.py:361's db = sum over (b, t) of dy): the column-group-0 waves add up the dy fragments they hold anyway
+  float rs[RB];
+#pragma unroll
+  for (int m = 0; m < RB; ++m) rs[m] = 0.f;
+  const bool sums = a.with_db && cg == 0;
+  auto rowsum = [&](const float4 (&Ac)[RB][4]) {
+#pragma unroll
+    for (int m = 0; m < RB; ++m) {
+      const float s0 = (Ac[m][0].x + Ac[m][0].y) + (Ac[m][0].z + Ac[m][0].w), s1 = (Ac[m][1].x + Ac[m][1].y) + (Ac[m][1].z + Ac[m][1].w);
+      const float s2 = (Ac[m][2].x + Ac[m][2].y) + (Ac[m][2].z + Ac[m][2].w), s3 = (Ac[m][3].x + Ac[m][3].y) + (Ac[m][3].z + Ac[m][3].w);
+      rs[m] += (s0 + s1) + (s2 + s3);
+    }
+  };
+  int w = blockIdx.x * a.wpr + slot;
+  if (w < a.n_win) load(w, A[0], Bv[0]);
+  for (; w < a.n_win; w += 2 * unit_stride) {            // two windows per trip: the register sets alternate statically
+    const int w1 = w + unit_stride, w2 = w + 2 * unit_stride;
+    if (w1 < a.n_win) load(w1, A[1], Bv[1]);
+    if (sums) rowsum(A[0]);
+    mma(A[0], Bv[0]);
+    if (w1 < a.n_win) {
+      if (sums) rowsum(A[1]);                            // (before set 0 is requested again: the sums read registers, not memory)
+      if (w2 < a.n_win) load(w2, A[0], Bv[0]);
+      mma(A[1], Bv[1]);
+    }
   }
 
-  // waves of one role: slot 0 adds slots 1 .. WPR - 1 in that order, then stores the workgroup's partial sums
-  if (active && slot != 0) {
+  // this wave's quadrant of partial-sum matrix (workgroup, slot); the other quadrants come from the other roles of the slot
+  const long long pn = (long long)a.C_out * a.C_in + (a.with_db ? a.C_out : 0);
+  float* pz = a.part + ((long long)blockIdx.x * a.wpr + slot) * pn;
+  if (sums) {
 #pragma unroll
-    for (int m = 0; m < RB; ++m)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) red[((wave * RB + m) * 16 + i) * 64 + lane] = acc[m][i];
+    for (int m = 0; m < RB; ++m) {
+      const float tot = rs[m] + __shfl_xor(rs[m], 32, 64);             // the two halves of a row's window
+      if (h == 0) pz[(long long)a.C_out * a.C_in + (rg * RB + m) * 32 + r] = tot;
+    }
   }
-  __syncthreads();
-  if (!active || slot != 0) return;
-  for (int s = 1; s < a.wpr; ++s) {
-    const int other = s * roles + role;
-#pragma unroll
-    for (int m = 0; m < RB; ++m)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) acc[m][i] += red[((other * RB + m) * 16 + i) * 64 + lane];
-  }
-  float* pz = a.part + (long long)blockIdx.x * a.C_out * a.C_in;
 #pragma unroll
   for (int m = 0; m < RB; ++m)
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int co = (rg * RB + m) * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-      pz[(long long)co * a.C_in + cb * 32 + r] = acc[m][i];
-    }
+    for (int n = 0; n < CB; ++n)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int co = (rg * RB + m) * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+        pz[(long long)co * a.C_in + (cg * CB + n) * 32 + r] = acc[m][n][i];
+      }
 }
 
 // dw[i] = sum over the S workgroups' partial sums, eight interleaved chains in a fixed order
-__global__ __launch_bounds__(256) void wgrad_k1_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int S, long long n) {
+__global__ __launch_bounds__(256) void wgrad_k1_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, float* __restrict__ db,
+                                                              int S, long long n, long long n_dw) {
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
     float c[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     const float* p = part + i;
@@ -148,53 +176,32 @@ __global__ __launch_bounds__(256) void wgrad_k1_reduce_kernel(const float* __res
       for (int j = 0; j < 8; ++j) c[j] += p[(long long)(z + j) * n];
     }
     for (int j = 0; z + j < S; ++j) c[j] += p[(long long)(z + j) * n];
-    dw[i] = ((c[0] + c[1]) + (c[2] + c[3])) + ((c[4] + c[5]) + (c[6] + c[7]));
+    const float v = ((c[0] + c[1]) + (c[2] + c[3])) + ((c[4] + c[5]) + (c[6] + c[7]));
+    if (i < n_dw) dw[i] = v; else db[i - n_dw] = v;
   }
 }
 
-template <int RB> __global__ void wgrad_k1_kernel(Wk1Args a);
-
-static int wk1_occupancy(int RB) {       // resident workgroups per CU (registers / LDS decide: 1 or 2)
-  static int occ[4] = {0, 0, 0, 0};
-  if (occ[RB] == 0) {
-    int n = 0;
-    const size_t lds = (size_t)WK1_WAVES * RB * 16 * 64 * 4;
-    const hipError_t e = RB == 3 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wgrad_k1_kernel<3>, 64 * WK1_WAVES, lds)
-                                 : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wgrad_k1_kernel<2>, 64 * WK1_WAVES, lds);
-    occ[RB] = (e == hipSuccess && n >= 1) ? (n > 4 ? 4 : n) : 1;
-  }
-  return occ[RB];
-}
-
-// Geometry; returns the number of workgroup ranges S (0: the shape does not run here).  Few channels, long signals: both channel
-// counts multiples of 32, at most 6 roles per workgroup, rows dividing into groups of 2 or 3 blocks, 16-byte aligned rows.
-static int wk1_geometry(int B, int C_in, int C_out, int T, Wk1Args* a, int* RBo, int* gy) {
-  if (B <= 0 || T < 4096 || T % 4 != 0 || C_in % 32 != 0 || C_out % 32 != 0 || C_in > 192 || C_out > 192 || C_in < 64 || C_out < 64) return 0;
-  const int nrb = C_out / 32, ncb = C_in / 32;
-  const int RB = nrb % 3 == 0 ? 3 : (nrb % 2 == 0 ? 2 : 0);
-  if (RB == 0) return 0;
-  const int n_rg = nrb / RB;
-  if (n_rg > 2) return 0;
-  int cbw = 0;
-  for (int c = 6; c >= 1; --c)
-    if (ncb % c == 0 && n_rg * c <= WK1_WAVES) { cbw = c; break; }
-  if (cbw == 0) return 0;
-  const int roles = n_rg * cbw, wpr = WK1_WAVES / roles;
+// Geometry; returns the number of workgroups S (0: the shape does not run here).  Few channels, long signals: both channel counts
+// multiples of 64 or of 96 (quadrants of 2 x 2 or 3 x 3 blocks), at most four quadrants, 16-byte aligned rows.
+static int wk1_geometry(int B, int C_in, int C_out, int T, Wk1Args* a, int* Qo) {
+  if (B <= 0 || T < 4096 || T % 4 != 0 || C_in > 192 || C_out > 192 || C_in < 64 || C_out < 64) return 0;
+  int Q = 0;
+  if (C_in % 96 == 0 && C_out % 96 == 0) Q = 3;
+  else if (C_in % 64 == 0 && C_out % 64 == 0) Q = 2;
+  if (Q == 0) return 0;
+  const int n_rg = C_out / (32 * Q), n_cg = C_in / (32 * Q);
+  const int roles = n_rg * n_cg;
+  if (roles > WK1_WAVES) return 0;
   a->B = B; a->C_in = C_in; a->C_out = C_out; a->T = T;
   a->wins_per_clip = (T + 31) / 32;
   a->n_win = B * a->wins_per_clip;
-  a->n_rg = n_rg; a->cb_per_wg = cbw; a->wpr = wpr;
-  *gy = ncb / cbw;
-  // as many workgroups as are resident at once (one round: no tail), at least 8 windows per wave
-  long long S = (long long)256 * wk1_occupancy(RB) / *gy;
-  const long long max_s = a->n_win / (8ll * wpr);
+  a->n_cg = n_cg; a->roles = roles; a->wpr = WK1_WAVES / roles;
+  // one workgroup per CU (one wave per SIMD: the register file is the wave's), at least 8 windows per wave
+  long long S = 256;
+  const long long max_s = a->n_win / (8ll * a->wpr);
   if (S > max_s) S = max_s;
   if (S < 1) S = 1;
-  long long per = (a->n_win + S - 1) / S;
-  per = (per + wpr - 1) / wpr * wpr;
-  a->win_per_wg = (int)per;
-  S = (a->n_win + per - 1) / per;
-  *RBo = RB;
+  *Qo = Q;
   return (int)S;
 }
 
@@ -203,31 +210,24 @@ static int wk1_geometry(int B, int C_in, int C_out, int T, Wk1Args* a, int* RBo,
 extern "C" int64_t fac_conv1d_bwd_weight_k1_ws_bytes(int B, int C_in, int C_out, int T) {
   using namespace fac;
   Wk1Args a;
-  int RB, gy;
-  const int S = wk1_geometry(B, C_in, C_out, T, &a, &RB, &gy);
-  return S > 0 ? (int64_t)S * C_out * C_in * 4 : -1;
+  int Q;
+  const int S = wk1_geometry(B, C_in, C_out, T, &a, &Q);
+  return S > 0 ? (int64_t)S * a.wpr * ((int64_t)C_out * C_in + C_out) * 4 : -1;
 }
 
-extern "C" int fac_conv1d_bwd_weight_k1(const float* x, const float* dy, float* dw, void* ws, int64_t ws_bytes, int B, int C_in,
-                                        int C_out, int T, fac_stream_t stream) {
+extern "C" int fac_conv1d_bwd_weight_k1(const float* x, const float* dy, float* dw, float* db, void* ws, int64_t ws_bytes, int B,
+                                        int C_in, int C_out, int T, fac_stream_t stream) {
   using namespace fac;
   Wk1Args a;
-  int RB, gy;
-  const int S = wk1_geometry(B, C_in, C_out, T, &a, &RB, &gy);
+  int Q;
+  const int S = wk1_geometry(B, C_in, C_out, T, &a, &Q);
   FAC_REQUIRE(x && dy && dw && ws && S > 0, "conv1d_bwd_weight_k1: shape not supported (query fac_conv1d_bwd_weight_k1_ws_bytes)");
-  FAC_REQUIRE(ws_bytes >= (int64_t)S * C_out * C_in * 4, "conv1d_bwd_weight_k1: workspace too small");
-  a.x = x; a.dy = dy; a.part = reinterpret_cast<float*>(ws);
+  FAC_REQUIRE(ws_bytes >= (int64_t)S * a.wpr * ((int64_t)C_out * C_in + C_out) * 4, "conv1d_bwd_weight_k1: workspace too small");
+  a.x = x; a.dy = dy; a.part = reinterpret_cast<float*>(ws); a.with_db = db != nullptr ? 1 : 0;
   hipStream_t st = (hipStream_t)stream;
-  const size_t lds = (size_t)WK1_WAVES * RB * 16 * 64 * 4;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_k1_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_k1_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
-  }
-  if (RB == 3) hipLaunchKernelGGL(wgrad_k1_kernel<3>, dim3(S, gy), dim3(64 * WK1_WAVES), lds, st, a);
-  else hipLaunchKernelGGL(wgrad_k1_kernel<2>, dim3(S, gy), dim3(64 * WK1_WAVES), lds, st, a);
-  const long long n = (long long)C_out * C_in;
-  hipLaunchKernelGGL(wgrad_k1_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a.part, dw, S, n);
+  if (Q == 3) hipLaunchKernelGGL((wgrad_k1_kernel<3, 3>), dim3(S), dim3(64 * WK1_WAVES), 0, st, a);
+  else hipLaunchKernelGGL((wgrad_k1_kernel<2, 2>), dim3(S), dim3(64 * WK1_WAVES), 0, st, a);
+  const long long n_dw = (long long)C_out * C_in, n = n_dw + (db != nullptr ? C_out : 0);
+  hipLaunchKernelGGL(wgrad_k1_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a.part, dw, db, S * a.wpr, n, n_dw);
   return check_launch("conv1d_bwd_weight_k1");
 }

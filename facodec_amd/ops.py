@@ -1317,13 +1317,13 @@ def _bwd_weight_launch_inner(x, dy, dw, B, c_in, t_in, c_out, t_out, k, stride, 
     lib = _lib.load()
     if WGRAD_K1_STREAM and BF16_SPLIT and k == 1 and stride == 1 and pad_left == 0 and t_in == t_out and k1 in (0, 1):
         # few channels, long signal (the ResidualUnit tails at C = 64 / 96 / 192): both tensors once through the fp32 matrix pipe
-        # instead of two operand-split passes + plane reads (conv1d_wgrad_k1.hip); the caller takes the bias gradient from fac_bias_grad
+        # instead of two operand-split passes + plane reads (conv1d_wgrad_k1.hip); the bias gradient rides on the dy fragments
         nb = lib.fac_conv1d_bwd_weight_k1_ws_bytes(B, c_in, c_out, t_in)
         if nb > 0:
             ws = _wgrad_workspace(x.device, nb)
-            _lib.check(lib.fac_conv1d_bwd_weight_k1(_ptr(x), _ptr(dy), _ptr(dw), _ptr(ws), nb, B, c_in, c_out, t_in, _stream()),
+            _lib.check(lib.fac_conv1d_bwd_weight_k1(_ptr(x), _ptr(dy), _ptr(dw), _ptr(db), _ptr(ws), nb, B, c_in, c_out, t_in, _stream()),
                        "fac_conv1d_bwd_weight_k1")
-            return False
+            return db is not None
     nbytes = lib.fac_conv1d_bwd_weight_split_ws_bytes(B, c_in, t_in, c_out, t_out, k, stride, dilation, k1, dilation2) if BF16_SPLIT else -1
     if nbytes > WGRAD_WS_CAP:       # beyond the workspace budget: the fp32 kernel (no operand planes) takes the layer
         nbytes = -1

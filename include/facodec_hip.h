@@ -469,8 +469,8 @@ int fac_conv1d_bwd_weight(const float* x, const float* dy, float* dw, void* ws, 
  * workgroups, added in a fixed order) or -1 when the shape does not run here (channel counts: multiples of 32 in [64, 192];
  * T >= 4096, T % 4 == 0). */
 int64_t fac_conv1d_bwd_weight_k1_ws_bytes(int B, int C_in, int C_out, int T);
-int fac_conv1d_bwd_weight_k1(const float* x, const float* dy, float* dw, void* ws, int64_t ws_bytes, int B, int C_in, int C_out, int T,
-                             fac_stream_t stream);
+int fac_conv1d_bwd_weight_k1(const float* x, const float* dy, float* dw, float* db, void* ws, int64_t ws_bytes, int B, int C_in, int C_out,
+                             int T, fac_stream_t stream);   /* db: (C_out) bias gradient sum over (b, t) of dy, or NULL */
 /* The same gradient on the bf16 matrix pipe with fp32-grade operand splitting (conv1d_wgrad_split.hip; same arguments
  * and result layout as fac_conv1d_bwd_weight, error vs fp64 no larger than the fp32 MFMA's).  The workspace query
  * returns -1 for a (K, stride, dilation) the kernel does not cover: use fac_conv1d_bwd_weight then.  K1 / dilation2:

@@ -7,7 +7,7 @@ for v in 0 1; do
   echo "FAC_WGRAD_K1_STREAM=$v" | tee -a $O/wgrad_bench.log
   FAC_WGRAD_K1_STREAM=$v timeout 600 python tools/wgrad_bench.py 2>>$O/err.log | grep "k1" | tee -a $O/wgrad_bench.log
 done
-for i in 1 2 3; do
+for i in 1 2; do
   for v in 0 1; do
     FAC_WGRAD_K1_STREAM=$v python tools/train_bench.py --batch 16 --steps 6 --warmup 3 --predictors 2>>$O/err.log | tail -1 | python -c "
 import json,sys; d=json.loads(sys.stdin.readline()); print('train FAC_WGRAD_K1_STREAM=$v', d.get('ms_per_step'), d.get('loss'))" | tee -a $O/ab.log
