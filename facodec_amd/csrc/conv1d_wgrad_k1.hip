@@ -70,14 +70,15 @@ __global__ __launch_bounds__(64 * WK1_WAVES) void wgrad_k1_kernel(Wk1Args a) {
     const float* pd = a.dy + ((long long)b * a.C_out + rg * RB * 32 + r) * a.T + t;
     const float* px = a.x + ((long long)b * a.C_in + cg * CB * 32 + r) * a.T + t;
     if (t + 16 <= a.T) {
+      // piece q of every fragment, then piece q + 1: the four accesses to a 128-byte line are RB + CB instructions apart (the fill is
+      // back before the next one asks: C = 192 0.33 -> 0.30 ms against fragment-by-fragment order)
 #pragma unroll
-      for (int m = 0; m < RB; ++m)
+      for (int q = 0; q < 4; ++q) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) Ad[m][q] = *reinterpret_cast<const float4*>(pd + (long long)m * 32 * a.T + 4 * q);
+        for (int m = 0; m < RB; ++m) Ad[m][q] = *reinterpret_cast<const float4*>(pd + (long long)m * 32 * a.T + 4 * q);
 #pragma unroll
-      for (int n = 0; n < CB; ++n)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) Bd[n][q] = *reinterpret_cast<const float4*>(px + (long long)n * 32 * a.T + 4 * q);
+        for (int n = 0; n < CB; ++n) Bd[n][q] = *reinterpret_cast<const float4*>(px + (long long)n * 32 * a.T + 4 * q);
+      }
     } else {                                             // the last window of a clip: steps beyond T contribute zeros
       auto guarded = [&](const float* p, float4 (&d)[4]) {
 #pragma unroll
