@@ -507,7 +507,8 @@ struct WkArgs {
   int n_tt, tiles_per_split;
   int MT;                    // 128-row tiles per workgroup (1 or 2)
   int gx, gy, gz, per_xcd;   // logical grid (row tiles, column-block quads, (b, t) slices) and workgroups per XCD (0: plain 3-D grid)
-  int narrow_rows;           // 1: a row tile with <= 32 real output channels runs the one-row-block wave layout (FAC_WGRAD_NARROW=0: off)
+  int narrow_rows;           // bit 0: row tiles with <= 96 real output channels run the column-split wave layouts (FAC_WGRAD_NARROW=0: off);
+                             // bit 1: their clamped duplicate rows are not staged (FAC_WGRAD_SKIP_DUP=0: staged as before)
 };
 
 __device__ __forceinline__ void wk_barrier() {
@@ -585,6 +586,25 @@ __global__ __launch_bounds__((4 * MT + 4) * 64, MT == 1 ? 2 : 1) void conv1d_wgr
       b_off[j] = (unsigned)(plane * a.b_plane_bytes + ((long long)(ci * s + ph) * a.UB + shift + k2 * a.dil2s + 8 * piece) * 2);
     }
     constexpr int LPT = PA + PB;                  // DMA instructions per lane and stage
+    // Round 6: a row tile whose upper row blocks are clamped duplicates (the column-split wave layouts below read rows
+    // [0, 32 / 64 / 96) only) does not stage them: 18 / 12 / 6 of the stage's 48 KB stay in the L2s.  These launches are bound by the
+    // traffic into LDS (32 real rows: 12 MFMAs per wave and 48 KB stage), not by the matrix pipe.  Block j of this wave is 16 rows
+    // of one plane; which blocks it skips is wave-uniform, and so is the number n_a it issues per stage (0, 3 or 6).
+    int need_rows = 128 * MT;
+    if (MT == 1 && (a.narrow_rows & 2)) {
+      const int real = a.C_out - co0;
+      if (KSP) need_rows = real <= 64 ? 64 : (real <= 96 ? 96 : 128);        // (the k-split layout reads at least two row blocks)
+      else need_rows = real <= 32 ? 32 : (real <= 64 ? 64 : (real <= 96 ? 96 : 128));
+    }
+    bool need_a[PA];
+    int n_a = 0;
+#pragma unroll
+    for (int j = 0; j < PA; ++j) {
+      const int blk = j * 4 + lw;
+      const int plane = blk / (8 * MT);
+      need_a[j] = (blk - plane * 8 * MT) * 16 < need_rows;
+      n_a += need_a[j] ? 1 : 0;
+    }
     auto issue = [&](int chunk, int buf) {
       const int tile = tile_lo + (chunk < n_chunks ? chunk : n_chunks - 1);     // past the end: reload the last tile (keeps LPT)
       const int b = tile / a.n_tt;
@@ -594,14 +614,17 @@ __global__ __launch_bounds__((4 * MT + 4) * 64, MT == 1 ? 2 : 1) void conv1d_wgr
       unsigned char* st = sm + buf * STAGE;
 #pragma unroll
       for (int j = 0; j < PA; ++j)
-        __builtin_amdgcn_global_load_lds((glb_void_t*)(ab + a_off[j]), (lds_void_t*)(st + (j * 4 + lw) * 1024), 16, 0, 0);
+        if (need_a[j]) __builtin_amdgcn_global_load_lds((glb_void_t*)(ab + a_off[j]), (lds_void_t*)(st + (j * 4 + lw) * 1024), 16, 0, 0);
 #pragma unroll
       for (int j = 0; j < PB; ++j)
         __builtin_amdgcn_global_load_lds((glb_void_t*)(bb + b_off[j]), (lds_void_t*)(st + A_OPND + (j * 4 + lw) * 1024), 16, 0, 0);
     };
     // everything but the youngest stage's loads has landed (loads return in order)
     auto landed = [&](bool younger_in_flight) {
-      if (younger_in_flight) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(LPT) : "memory");
+      if (!younger_in_flight) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      else if (n_a == PA) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(LPT) : "memory");
+      else if (n_a == 3) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(PB + 3) : "memory");
+      else if (n_a == 0) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(PB) : "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     };
     issue(0, 0);
@@ -1153,7 +1176,8 @@ static int bwd_weight_split_impl(const float* x, const float* dy, float* dw, flo
       const bool ksplit = k.MT == 1 && (ksp_env >= 0 ? ksp_env == 1
                                                      : (k.K == 7 && k.K2 == 1 && stride == 1 && (long long)grid.x * grid.y <= 256 && S >= 4));
       static const bool narrow_on = !(getenv("FAC_WGRAD_NARROW") && getenv("FAC_WGRAD_NARROW")[0] == '0');
-      k.narrow_rows = narrow_on ? 1 : 0;
+      static const bool skip_dup = !(getenv("FAC_WGRAD_SKIP_DUP") && getenv("FAC_WGRAD_SKIP_DUP")[0] == '0');
+      k.narrow_rows = narrow_on ? (skip_dup ? 3 : 1) : 0;      // bit 0: column-split layouts; bit 1: their duplicate rows are not staged
       k.gx = (int)grid.x; k.gy = (int)grid.y; k.gz = (int)grid.z; k.per_xcd = 0;
       if (xcd_order) {
         const long long total = (long long)grid.x * grid.y * grid.z;
