@@ -71,6 +71,9 @@ SIGNATURES = {
     "fac_conv1d_bwd_weight": (_i, [_p, _p, _p, _p, _i64, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
     "fac_conv1d_bwd_weight_split_ws_bytes": (_i64, [_i, _i, _i, _i, _i, _i, _i, _i, _i, _i]),
     "fac_conv1d_bwd_weight_k1_ws_bytes": (_i64, [_i, _i, _i, _i]),
+    "fac_conv1d_bwd_weight_taps_tx": (_i64, [_i, _i, _i, _i, _i]),
+    "fac_conv1d_bwd_weight_taps_ws_bytes": (_i64, [_i, _i, _i, _i, _i, _i, _i, _i]),
+    "fac_conv1d_bwd_weight_taps": (_i, [_p, _p, _p, _p, _p, _i64, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
     "fac_conv1d_bwd_weight_k1": (_i, [_p, _p, _p, _p, _p, _i64, _i, _i, _i, _i, _p]),
     "fac_conv1d_bwd_weight_split": (_i, [_p, _p, _p, _p, _i64, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
     "fac_conv1d_bwd_weight_split_db_ok": (_i, [_i, _i, _i, _i, _i, _i, _i, _i, _i, _i]),

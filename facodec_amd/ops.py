@@ -1324,6 +1324,26 @@ def _bwd_weight_launch_inner(x, dy, dw, B, c_in, t_in, c_out, t_out, k, stride, 
             _lib.check(lib.fac_conv1d_bwd_weight_k1(_ptr(x), _ptr(dy), _ptr(dw), _ptr(db), _ptr(ws), nb, B, c_in, c_out, t_in, _stream()),
                        "fac_conv1d_bwd_weight_k1")
             return db is not None
+    if WGRAD_K1_STREAM and BF16_SPLIT and k > 1 and stride == 1 and c_in * k <= 64 and c_out in (32, 64) and t_out >= 4096:
+        # first layers (1 -> 64 k = 7 of the encoder, 2 -> 32 (3, 9) of the multi-resolution discriminator): the C_in * K columns of dW
+        # are shifted views of one or two input rows -- the same kernel with virtual rows (fac_conv1d_bwd_weight_taps) on the padded input
+        kk1 = k1 if 0 < k1 < k else k
+        d2 = dilation2 if 0 < k1 < k else 0
+        nb = lib.fac_conv1d_bwd_weight_taps_ws_bytes(B, c_in, c_out, t_out, k, kk1, dilation, d2)
+        if nb > 0:
+            tx = lib.fac_conv1d_bwd_weight_taps_tx(t_out, k, kk1, dilation, d2)
+            need = (t_out - 1) + (k // kk1 - 1) * d2 + (kk1 - 1) * dilation + 1          # positions of the padded input the outputs read
+            right = max(0, need - pad_left - t_in)
+            if pad_mode == PAD_REFLECT and max(pad_left, right) > 0:
+                xp = torch.nn.functional.pad(x, (pad_left, right), mode="reflect")         # data movement only (a 1- / 2-channel signal)
+            else:
+                xp = torch.nn.functional.pad(x, (pad_left, right))
+            if xp.shape[-1] < tx:
+                xp = torch.nn.functional.pad(xp, (0, tx - xp.shape[-1]))
+            ws = _wgrad_workspace(x.device, nb)
+            _lib.check(lib.fac_conv1d_bwd_weight_taps(_ptr(xp), _ptr(dy), _ptr(dw), _ptr(db), _ptr(ws), nb, B, c_in, xp.shape[-1], c_out,
+                                                      t_out, k, kk1, dilation, d2, _stream()), "fac_conv1d_bwd_weight_taps")
+            return db is not None
     nbytes = lib.fac_conv1d_bwd_weight_split_ws_bytes(B, c_in, t_in, c_out, t_out, k, stride, dilation, k1, dilation2) if BF16_SPLIT else -1
     if nbytes > WGRAD_WS_CAP:       # beyond the workspace budget: the fp32 kernel (no operand planes) takes the layer
         nbytes = -1

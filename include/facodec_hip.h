@@ -471,6 +471,16 @@ int fac_conv1d_bwd_weight(const float* x, const float* dy, float* dw, void* ws, 
 int64_t fac_conv1d_bwd_weight_k1_ws_bytes(int B, int C_in, int C_out, int T);
 int fac_conv1d_bwd_weight_k1(const float* x, const float* dy, float* dw, float* db, void* ws, int64_t ws_bytes, int B, int C_in, int C_out,
                              int T, fac_stream_t stream);   /* db: (C_out) bias gradient sum over (b, t) of dy, or NULL */
+/* The same kernel for stride-1 convs with few input channels and taps (first layers: the encoder's 1 -> 64 k = 7 conv,
+ * dac/model/dac.py:82; the multi-resolution discriminator's 2 -> 32 (3, 9) convs, dac/model/discriminator.py:101-130): the C_in * K
+ * columns of dW are shifted views of the input rows.  xpad (B, C_in, Tx) is the conv's PADDED input (the caller pads: left padding,
+ * right padding, then zeros up to Tx >= fac_conv1d_bwd_weight_taps_tx);
+ * dW (C_out, C_in, K)[co][ci][k] = sum over (b, t < T_out) of dy[b][co][t] * xpad[b][ci][t + (k / K1) * dilation2 + (k % K1) * dilation]
+ * (K1 = K: plain taps).  C_out = 32 or 64, C_in * K <= 64, T_out >= 4096; the query returns -1 otherwise.  db as above. */
+int64_t fac_conv1d_bwd_weight_taps_tx(int T_out, int K, int K1, int dilation, int dilation2);
+int64_t fac_conv1d_bwd_weight_taps_ws_bytes(int B, int C_in, int C_out, int T_out, int K, int K1, int dilation, int dilation2);
+int fac_conv1d_bwd_weight_taps(const float* xpad, const float* dy, float* dw, float* db, void* ws, int64_t ws_bytes, int B, int C_in, int Tx,
+                               int C_out, int T_out, int K, int K1, int dilation, int dilation2, fac_stream_t stream);
 /* The same gradient on the bf16 matrix pipe with fp32-grade operand splitting (conv1d_wgrad_split.hip; same arguments
  * and result layout as fac_conv1d_bwd_weight, error vs fp64 no larger than the fp32 MFMA's).  The workspace query
  * returns -1 for a (K, stride, dilation) the kernel does not cover: use fac_conv1d_bwd_weight then.  K1 / dilation2:

@@ -77,6 +77,12 @@ CASES = [
     (3, 64, 192, 4096, 1, 1, 1, 0, ops.PAD_ZERO),
     (2, 192, 96, 4444, 1, 1, 1, 0, ops.PAD_ZERO),
     (5, 160, 64, 4112, 1, 1, 1, 0, ops.PAD_ZERO),
+    # first layers on the same kernel with virtual rows (fac_conv1d_bwd_weight_taps): reflect / zero padding, window tails
+    (2, 1, 64, 4800, 7, 1, 1, 6, ops.PAD_REFLECT),
+    (3, 1, 64, 4099, 7, 1, 1, 6, ops.PAD_REFLECT),
+    (2, 2, 32, 5000, 9, 1, 1, 4, ops.PAD_ZERO),
+    (1, 6, 32, 8192, 9, 1, 1, 4, ops.PAD_ZERO),
+    (2, 1, 32, 4500, 5, 1, 2, 4, ops.PAD_ZERO),
 ]
 
 
